@@ -1,0 +1,172 @@
+/*
+ * fpng_amd.h -- C ABI of the MI355X-native fpng encode hot path (libfpng_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types, no exceptions.
+ * The reference has no FFI of its own -- its operator boundary is the nine free functions of
+ * `namespace fpng` (reference src/fpng.h:17-111).  Each entry point below names the reference
+ * interface it replaces or the part of it that it carries; the `fpng::` C++ drop-in
+ * (include/fpng.h + fpng_amd/csrc/fpng_dropin.cpp) is a thin wrapper over exactly these calls, and
+ * INTEGRATION.md shows the binding a maintainer of the reference (or of its Python/other
+ * bindings) would add.
+ *
+ * All encode entry points produce output that is BYTE-IDENTICAL to the reference's
+ * fpng_encode_image_to_memory() (reference src/fpng.cpp:1662-1803) for the same pixels and flags.
+ *
+ * Return convention: 0 = success, negative = FPNG_AMD_ERR_*.  fpng_amd_last_error() gives text.
+ * There is NO CPU fallback: without a usable HIP device every encode call fails with
+ * FPNG_AMD_ERR_NO_DEVICE.
+ */
+#ifndef FPNG_AMD_H
+#define FPNG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPNG_AMD_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define FPNG_AMD_OK 0
+#define FPNG_AMD_ERR_INVALID_ARG (-1)      /* the conditions of reference src/fpng.cpp:1670-1680 */
+#define FPNG_AMD_ERR_NO_DEVICE (-2)
+#define FPNG_AMD_ERR_HIP (-3)
+#define FPNG_AMD_ERR_BUFFER_TOO_SMALL (-4)
+#define FPNG_AMD_ERR_OUT_OF_MEMORY (-5)
+#define FPNG_AMD_ERR_UNSUPPORTED (-6)      /* > 4 GiB of filtered bytes: undefined in the reference (src/fpng.cpp:1682-1705) */
+
+/* ---- encode flags: same bit values as reference src/fpng.h:34-42 ---- */
+#define FPNG_AMD_ENCODE_SLOWER 1u      /* 2-pass: per-image dynamic Huffman table */
+#define FPNG_AMD_FORCE_UNCOMPRESSED 2u /* stored Deflate blocks only */
+
+/* ---- how an image ended up encoded (informational; the reference decides this silently) ---- */
+#define FPNG_AMD_MODE_COMPRESSED 0u /* one dynamic-Huffman block */
+#define FPNG_AMD_MODE_STORED 1u     /* raw fallback, reference src/fpng.cpp:1728-1758 */
+
+/* ---- library ---- */
+
+/* Replaces fpng_init() (reference src/fpng.h:17): there it probes CPUID for SSE4.1, here it binds
+ * the calling thread's default context to HIP device `device` (-1 = current device) and uploads
+ * the format tables.  Optional, like the original: every other call self-initialises lazily and
+ * outputs never depend on whether it ran. */
+int fpng_amd_init(int device);
+
+/* Replaces fpng_cpu_supports_sse41() (reference src/fpng.h:23): 1 if a gfx950-capable HIP device
+ * is usable by this library, else 0. */
+int fpng_amd_device_available(void);
+int fpng_amd_device_count(void);
+const char *fpng_amd_last_error(void);
+int fpng_amd_abi_version(void);
+
+/* fpng_crc32 / fpng_adler32 (reference src/fpng.h:26-31), host buffers, same calling convention
+ * (prev = finished checksum of the preceding bytes; init 0 / 1). */
+uint32_t fpng_amd_crc32(const void *data, size_t size, uint32_t prev_crc32);
+uint32_t fpng_amd_adler32(const void *data, size_t size, uint32_t adler);
+/* checksum of X||Y from the checksums of X and Y and |Y| -- what makes the path shardable */
+uint32_t fpng_amd_crc32_combine(uint32_t crc_x, uint32_t crc_y, uint64_t len_y);
+uint32_t fpng_amd_adler32_combine(uint32_t adler_x, uint32_t adler_y, uint64_t len_y);
+
+/* Largest possible output of any encode call for these dimensions (= the stored-block size,
+ * reference src/fpng.cpp:1747, + container).  d_out capacities must be >= this. */
+size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
+
+/* ---- encoder object: a HIP stream + reusable device scratch.  Not thread-safe; create one
+ *      per thread (the reference is re-entrant, reference src/fpng.cpp:371 note in SURVEY 8b). ---- */
+typedef struct fpng_amd_encoder fpng_amd_encoder;
+
+/* hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let the
+ * encoder create its own non-blocking stream. */
+int fpng_amd_encoder_create(fpng_amd_encoder **enc, int device, void *hip_stream);
+void fpng_amd_encoder_destroy(fpng_amd_encoder *enc);
+void *fpng_amd_encoder_stream(fpng_amd_encoder *enc);
+
+typedef struct fpng_amd_image {
+    const void *d_pixels; /* DEVICE pointer, R first, pitch = w*num_chans (reference src/fpng.h:44-47) */
+    uint32_t w, h, num_chans;
+    uint8_t *d_out;  /* DEVICE pointer, receives the whole .png file */
+    size_t out_cap;  /* >= fpng_amd_max_encoded_size(w,h,num_chans) */
+} fpng_amd_image;
+
+typedef struct fpng_amd_result {
+    uint64_t png_size; /* bytes written to d_out */
+    uint32_t mode;     /* FPNG_AMD_MODE_* */
+    uint32_t status;   /* 0 = ok */
+} fpng_amd_result;
+
+/*
+ * THE HOT PATH.  fpng_encode_image_to_memory() (reference src/fpng.h:48, src/fpng.cpp:1662-1803)
+ * for `n` device-resident images in one submission.  Enqueues all kernels on the encoder's stream
+ * and returns without waiting; nothing is copied to the host except the n result records, which
+ * are delivered by fpng_amd_encode_finish().
+ */
+int fpng_amd_encode_batch_async(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t flags);
+
+/* Waits for the last fpng_amd_encode_batch_async() of this encoder and copies out its n result
+ * records (results may be NULL to just wait). */
+int fpng_amd_encode_finish(fpng_amd_encoder *enc, fpng_amd_result *results, uint32_t n);
+
+/* Convenience: fpng_encode_image_to_memory() on HOST buffers (H2D + encode + D2H, synchronous).
+ * This is what the fpng:: C++ drop-in calls. */
+int fpng_amd_encode_host(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
+                         uint32_t flags, uint8_t *out, size_t out_cap, size_t *out_size);
+
+/* ---- row-band interface: one image sharded by rows over several GPUs.
+ *      The stream stays ONE IDAT / ONE Deflate block; bands are stitched at bit granularity. ---- */
+
+typedef struct fpng_amd_band_stats {
+    uint64_t token_bits;  /* bits of all tokens of the band's rows */
+    uint32_t adler_s1;    /* raw byte sum of the band's filtered bytes mod 65521 */
+    uint32_t adler_s2;    /* raw position-weighted sum mod 65521 */
+    uint64_t adler_len;   /* filtered bytes in the band = (w*c+1)*rows */
+    uint32_t last_unit_bits; /* size of the band's final flush unit (failure rule) */
+    uint32_t reserved;
+} fpng_amd_band_stats;
+
+/* Phase 1: count.  d_rows points at row y0 of the image, d_row_above at row y0-1 (ignored when
+ * y0 == 0).  Synchronous (returns the band's stats to the host). */
+int fpng_amd_band_count(fpng_amd_encoder *enc, const void *d_rows, const void *d_row_above, uint32_t w,
+                        uint32_t num_chans, uint32_t y0, uint32_t y1, fpng_amd_band_stats *stats);
+
+/* Phase 2: emit the band's tokens at absolute stream bit `start_bit` into d_band_out, which
+ * represents stream bytes [start_bit/8, ...).  Bits outside the band are written as zero so
+ * neighbouring bands can be OR-merged.  If is_first, the 1-pass prefix is written too (start_bit
+ * must then equal the table's first token bit and d_band_out starts at stream byte 0).  If is_last,
+ * EOB + padding + the big-endian `adler` are appended.  *out_bytes = bytes of d_band_out used.
+ * Must follow fpng_amd_band_count() on the same encoder with the same rows. */
+int fpng_amd_band_emit(fpng_amd_encoder *enc, const void *d_rows, const void *d_row_above, uint32_t w,
+                       uint32_t num_chans, uint32_t y0, uint32_t y1, uint64_t start_bit, int is_first, int is_last,
+                       uint32_t adler, uint8_t *d_band_out, size_t out_cap, size_t *out_bytes);
+
+/* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
+ * and the EOB length (12) -- what the host needs to lay out bands and evaluate the failure rule. */
+int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
+
+/* Wrap an assembled zlib stream (device memory, at d_png + 58) into the PNG container: 58-byte
+ * header, IDAT CRC-32, IEND (reference src/fpng.cpp:1764-1800).  Synchronous. */
+int fpng_amd_wrap_png(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t w, uint32_t h,
+                      uint32_t num_chans, size_t *png_size);
+
+/* ---- synthetic inputs for tests/bench, host memory ---- */
+#define FPNG_AMD_SYNTH_NOISE 0
+#define FPNG_AMD_SYNTH_SOLID 1
+#define FPNG_AMD_SYNTH_GRAD 2
+#define FPNG_AMD_SYNTH_BLOCKS 3
+int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32_t num_chans, uint8_t *out);
+
+/* ---- instrumentation for bench.py: time of the last batch's kernels measured with HIP events
+ *      on the encoder's own stream (ms); per-phase breakdown when profiling is enabled. ---- */
+#define FPNG_AMD_PHASE_COUNT 0
+#define FPNG_AMD_PHASE_SCAN 1
+#define FPNG_AMD_PHASE_EMIT 2
+#define FPNG_AMD_PHASE_CRC 3
+#define FPNG_AMD_PHASE_FINAL 4
+#define FPNG_AMD_NUM_PHASES 8
+int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
+int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPNG_AMD_H */

@@ -1,0 +1,90 @@
+"""ctypes loader for libfpng_amd.so (the C ABI in include/fpng_amd.h).
+
+torch is imported first ON PURPOSE: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7; loading
+it first makes our library (DT_NEEDED libamdhip64.so.7) bind to the same HIP runtime instance
+instead of pulling in a second one from /opt/rocm.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfpng_amd.so")
+
+NUM_PHASES = 8
+
+
+class Image(C.Structure):
+    _fields_ = [("d_pixels", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("num_chans", C.c_uint32),
+                ("d_out", C.c_void_p), ("out_cap", C.c_size_t)]
+
+
+class Result(C.Structure):
+    _fields_ = [("png_size", C.c_uint64), ("mode", C.c_uint32), ("status", C.c_uint32)]
+
+
+class BandStats(C.Structure):
+    _fields_ = [("token_bits", C.c_uint64), ("adler_s1", C.c_uint32), ("adler_s2", C.c_uint32),
+                ("adler_len", C.c_uint64), ("last_unit_bits", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/fpng_amd.h declares: (restype, argtypes)
+_u32, _u64, _sz, _vp, _int = C.c_uint32, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int
+SIGNATURES = {
+    "fpng_amd_init": (_int, [_int]),
+    "fpng_amd_device_available": (_int, []),
+    "fpng_amd_device_count": (_int, []),
+    "fpng_amd_last_error": (C.c_char_p, []),
+    "fpng_amd_abi_version": (_int, []),
+    "fpng_amd_crc32": (_u32, [_vp, _sz, _u32]),
+    "fpng_amd_adler32": (_u32, [_vp, _sz, _u32]),
+    "fpng_amd_crc32_combine": (_u32, [_u32, _u32, _u64]),
+    "fpng_amd_adler32_combine": (_u32, [_u32, _u32, _u64]),
+    "fpng_amd_max_encoded_size": (_sz, [_u32, _u32, _u32]),
+    "fpng_amd_encoder_create": (_int, [C.POINTER(_vp), _int, _vp]),
+    "fpng_amd_encoder_destroy": (None, [_vp]),
+    "fpng_amd_encoder_stream": (_vp, [_vp]),
+    "fpng_amd_encode_batch_async": (_int, [_vp, C.POINTER(Image), _u32, _u32]),
+    "fpng_amd_encode_finish": (_int, [_vp, C.POINTER(Result), _u32]),
+    "fpng_amd_encode_host": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, C.POINTER(_sz)]),
+    "fpng_amd_band_count": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(BandStats)]),
+    "fpng_amd_band_emit": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _int, _int, _u32, _vp, _sz,
+                                  C.POINTER(_sz)]),
+    "fpng_amd_1pass_layout": (_int, [_u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "fpng_amd_wrap_png": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, C.POINTER(_sz)]),
+    "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
+    "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
+    "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (built by `python -m fpng_amd.build` / __graft_entry__.build()).
+    Fails loudly if it is missing: there is no Python or CPU fallback for the encode path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -m fpng_amd.build` "
+                          "(fpng_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class FpngAmdError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"fpng_amd error {code}: {what}")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise FpngAmdError(rc, load().fpng_amd_last_error().decode("utf-8", "replace"))

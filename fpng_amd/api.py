@@ -1,0 +1,221 @@
+"""Host-side mirror of the reference's `namespace fpng` encode interface (reference src/fpng.h:17-52)
+on top of the C ABI, plus the device-resident batch / row-band entry points the MI355X path adds.
+
+Names, argument meaning and error behaviour follow the reference:
+
+    fpng_init()                                           src/fpng.h:17
+    fpng_cpu_supports_sse41()  -> "is the accelerator usable"   src/fpng.h:23
+    fpng_crc32(data, prev=0) / fpng_adler32(data, prev=1)        src/fpng.h:26-31
+    fpng_encode_image_to_memory(image, w, h, num_chans, flags) -> (ok, bytes)   src/fpng.h:48
+    fpng_encode_image_to_file(filename, image, w, h, num_chans, flags) -> ok    src/fpng.h:52
+
+torch is only plumbing here (device memory + streams).  There is no CPU fallback: if the HIP library
+or a GPU is missing, encode calls raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BandStats, FpngAmdError, Image, Result, check
+
+FPNG_ENCODE_SLOWER = 1        # reference src/fpng.h:38
+FPNG_FORCE_UNCOMPRESSED = 2   # reference src/fpng.h:41
+FPNG_CRC32_INIT = 0           # reference src/fpng.h:26
+FPNG_ADLER32_INIT = 1         # reference src/fpng.h:30
+
+MODE_COMPRESSED, MODE_STORED = 0, 1
+SYNTH_KINDS = {"noise": 0, "solid": 1, "grad": 2, "blocks": 3}
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def fpng_init(device=-1):
+    check(_lib.load().fpng_amd_init(device))
+
+
+def fpng_cpu_supports_sse41():
+    """Kept for source compatibility; answers "is the MI355X path usable"."""
+    return bool(_lib.load().fpng_amd_device_available())
+
+
+def fpng_crc32(data, prev_crc32=FPNG_CRC32_INIT):
+    b = _as_u8(data)
+    return _lib.load().fpng_amd_crc32(b.ctypes.data, b.size, prev_crc32)
+
+
+def fpng_adler32(data, adler=FPNG_ADLER32_INIT):
+    b = _as_u8(data)
+    return _lib.load().fpng_amd_adler32(b.ctypes.data, b.size, adler)
+
+
+def crc32_combine(crc_x, crc_y, len_y):
+    return _lib.load().fpng_amd_crc32_combine(crc_x, crc_y, len_y)
+
+
+def adler32_combine(adler_x, adler_y, len_y):
+    return _lib.load().fpng_amd_adler32_combine(adler_x, adler_y, len_y)
+
+
+def max_encoded_size(w, h, num_chans):
+    return _lib.load().fpng_amd_max_encoded_size(w, h, num_chans)
+
+
+def layout_1pass(num_chans):
+    a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    check(_lib.load().fpng_amd_1pass_layout(num_chans, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def synth_image(kind, w, h, num_chans, seed=12345):
+    """Deterministic test image as a uint8 array of shape (h, w, num_chans)."""
+    out = np.empty(w * h * num_chans, dtype=np.uint8)
+    check(_lib.load().fpng_amd_synth_image(SYNTH_KINDS[kind], seed, w, h, num_chans, out.ctypes.data))
+    return out.reshape(h, w, num_chans)
+
+
+class Encoder:
+    """A HIP stream + reusable device scratch (one per thread).  `stream="torch"` enqueues on torch's
+    current stream of `device` so that it orders naturally with torch copies."""
+
+    def __init__(self, device=0, stream="torch"):
+        self.lib = _lib.load()
+        self.device = device
+        h = C.c_void_p()
+        if stream == "torch":
+            with torch.cuda.device(device):
+                sptr = torch.cuda.current_stream().cuda_stream
+            sp = C.c_void_p(sptr) if sptr else None
+        elif stream is None or stream == "own":
+            sp = None
+        else:
+            sp = C.c_void_p(int(stream))
+        check(self.lib.fpng_amd_encoder_create(C.byref(h), device, sp))
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fpng_amd_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- device-resident batch: the hot path ----
+    def submit(self, images, outs, flags=0):
+        """images: list of uint8 CUDA tensors shaped (h, w, c), contiguous.  outs: list of uint8 CUDA
+        tensors with >= max_encoded_size bytes.  Asynchronous; call finish() for the sizes."""
+        n = len(images)
+        arr = (Image * n)()
+        for i, (im, out) in enumerate(zip(images, outs)):
+            assert im.is_cuda and im.dtype == torch.uint8 and im.is_contiguous() and im.dim() == 3
+            h, w, c = im.shape
+            arr[i].d_pixels = im.data_ptr()
+            arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
+            arr[i].d_out = out.data_ptr()
+            arr[i].out_cap = out.numel()
+        self._keep = (images, outs, arr)
+        check(self.lib.fpng_amd_encode_batch_async(self.h, arr, n, flags))
+        return n
+
+    def finish(self, n):
+        res = (Result * n)()
+        check(self.lib.fpng_amd_encode_finish(self.h, res, n))
+        return [(r.png_size, r.mode, r.status) for r in res]
+
+    def encode_tensors(self, images, flags=0):
+        """Convenience: allocate outputs, encode, return list of PNG byte strings."""
+        outs = [torch.empty(max_encoded_size(im.shape[1], im.shape[0], im.shape[2]) + 64, dtype=torch.uint8,
+                            device=im.device) for im in images]
+        n = self.submit(images, outs, flags)
+        res = self.finish(n)
+        pngs = []
+        for out, (size, mode, status) in zip(outs, res):
+            if status:
+                raise FpngAmdError(status, "device reported an encode failure")
+            pngs.append(bytes(out[:size].cpu().numpy()))
+        return pngs, [m for _, m, _ in res]
+
+    # ---- host buffers: what fpng_encode_image_to_memory() does ----
+    def encode_host(self, image, w, h, num_chans, flags=0):
+        b = _as_u8(image)
+        if b.size < w * h * num_chans:
+            raise ValueError("image buffer smaller than w*h*num_chans")
+        cap = max_encoded_size(w, h, num_chans) if (w and h and num_chans in (3, 4)) else 64
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        check(self.lib.fpng_amd_encode_host(self.h, b.ctypes.data, w, h, num_chans, flags, out.ctypes.data, cap,
+                                            C.byref(n)))
+        return out[: n.value].tobytes()
+
+    # ---- row bands (multi-GPU, one image) ----
+    def band_count(self, rows, row_above, w, num_chans, y0, y1):
+        st = BandStats()
+        ra = row_above.data_ptr() if row_above is not None else None
+        check(self.lib.fpng_amd_band_count(self.h, rows.data_ptr(), ra, w, num_chans, y0, y1, C.byref(st)))
+        return st
+
+    def band_emit(self, rows, row_above, w, num_chans, y0, y1, start_bit, is_first, is_last, adler, out):
+        n = C.c_size_t(0)
+        ra = row_above.data_ptr() if row_above is not None else None
+        check(self.lib.fpng_amd_band_emit(self.h, rows.data_ptr(), ra, w, num_chans, y0, y1, start_bit, int(is_first),
+                                          int(is_last), adler, out.data_ptr(), out.numel(), C.byref(n)))
+        return n.value
+
+    def wrap_png(self, png_buf, zlib_size, w, h, num_chans):
+        n = C.c_size_t(0)
+        check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, w, h, num_chans, C.byref(n)))
+        return n.value
+
+    # ---- instrumentation ----
+    def set_profiling(self, on=True):
+        check(self.lib.fpng_amd_encoder_set_profiling(self.h, int(on)))
+
+    def last_phase_ms(self):
+        arr = (C.c_float * _lib.NUM_PHASES)()
+        check(self.lib.fpng_amd_encoder_last_phase_ms(self.h, C.byref(arr)))
+        return list(arr)
+
+
+_default_encoder = None
+
+
+def _encoder():
+    global _default_encoder
+    if _default_encoder is None:
+        _default_encoder = Encoder(device=torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return _default_encoder
+
+
+def fpng_encode_image_to_memory(image, w, h, num_chans, flags=0):
+    """Reference src/fpng.h:48.  Returns (ok, png_bytes); ok is False exactly where the reference
+    returns false (bad dimensions / channel count, src/fpng.cpp:1670-1680).  Everything else
+    (missing GPU, HIP errors) raises: it is not silently papered over."""
+    try:
+        return True, _encoder().encode_host(image, w, h, num_chans, flags)
+    except FpngAmdError as e:
+        if e.code == -1:  # FPNG_AMD_ERR_INVALID_ARG
+            return False, b""
+        raise
+
+
+def fpng_encode_image_to_file(filename, image, w, h, num_chans, flags=0):
+    """Reference src/fpng.h:52 / src/fpng.cpp:1806-1828."""
+    ok, png = fpng_encode_image_to_memory(image, w, h, num_chans, flags)
+    if not ok:
+        return False
+    try:
+        with open(filename, "wb") as f:
+            f.write(png)
+    except OSError:
+        return False
+    return True

@@ -1,0 +1,62 @@
+"""Build libfpng_amd.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m fpng_amd.build            # rebuild if sources are newer than the library
+    python -m fpng_amd.build --force
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only dev container.  The .so is
+git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libfpng_amd.so")
+DROPIN_LIB = os.path.join(LIB_DIR, "libfpng.so")
+SOURCES = ["kernels.hip", "api.cpp", "format.cpp", "synth.cpp"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(ROOT, "include", "fpng_amd.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if force or _stale(LIB, srcs + HEADERS):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+               "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB]
+        for s in srcs:
+            cmd += ["-x", "hip", s]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    dropin_src = os.path.join(CSRC, "fpng_dropin.cpp")
+    if os.path.exists(dropin_src) and (force or _stale(DROPIN_LIB, [dropin_src, LIB, os.path.join(ROOT, "include", "fpng.h")])):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), dropin_src, "-o", DROPIN_LIB,
+               "-L", LIB_DIR, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

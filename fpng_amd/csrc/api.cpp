@@ -1,0 +1,633 @@
+// api.cpp -- the C ABI of libfpng_amd.so (see include/fpng_amd.h) on top of the HIP kernels.
+//
+// Host-side orchestration only: argument rules of the reference's fpng_encode_image_to_memory
+// (reference src/fpng.cpp:1662-1680), job descriptors, scratch management, kernel launches on one
+// stream.  There is no CPU implementation of the encode path in this library.
+#include "fpng_amd.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace fpng_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                      \
+    do {                                                                   \
+        hipError_t e_ = (expr);                                            \
+        if (e_ != hipSuccess) return fail(FPNG_AMD_ERR_HIP, #expr, e_);    \
+    } while (0)
+
+// per-device immutable tables
+struct DeviceTables {
+    TokenTable *one_pass[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // index by num_chans
+    TokenTable *symbols[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // histogram pass: chunk[q] = length symbol - 256
+    CrcDeviceTables *crc = nullptr;
+    bool ready = false;
+};
+constexpr int kMaxDevices = 64;
+DeviceTables g_dev[kMaxDevices];
+TokenTable g_host_1pass[5];
+std::mutex g_mu;
+bool g_host_ready = false;
+
+bool host_tables()
+{
+    if (g_host_ready) return true;
+    if (!build_1pass_tables(&g_host_1pass[3], &g_host_1pass[4])) return false;
+    g_host_ready = true;
+    return true;
+}
+
+int ensure_device_tables(int dev)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (dev < 0 || dev >= kMaxDevices) return fail(FPNG_AMD_ERR_INVALID_ARG, "device index out of range");
+    if (g_dev[dev].ready) return FPNG_AMD_OK;
+    if (!host_tables()) return fail(FPNG_AMD_ERR_UNSUPPORTED, "format tables failed self-check");
+    DeviceTables &d = g_dev[dev];
+    for (int c = 3; c <= 4; c++) {
+        HIP_TRY(hipMalloc(&d.one_pass[c], sizeof(TokenTable)));
+        HIP_TRY(hipMemcpy(d.one_pass[c], &g_host_1pass[c], sizeof(TokenTable), hipMemcpyHostToDevice));
+        TokenTable sym;
+        std::memset(&sym, 0, sizeof sym);
+        const uint32_t cap = (c == 3) ? kMaxChunkPixels3 : kMaxChunkPixels4;
+        for (uint32_t q = 1; q <= cap; q++) {
+            uint32_t s, e;
+            deflate_length_symbol(q * c - 3, &s, &e);
+            sym.chunk[q] = s - 256;
+        }
+        HIP_TRY(hipMalloc(&d.symbols[c], sizeof(TokenTable)));
+        HIP_TRY(hipMemcpy(d.symbols[c], &sym, sizeof(TokenTable), hipMemcpyHostToDevice));
+    }
+    static CrcDeviceTables host_crc;
+    build_crc_device_tables(&host_crc);
+    HIP_TRY(hipMalloc(&d.crc, sizeof(CrcDeviceTables)));
+    HIP_TRY(hipMemcpy(d.crc, &host_crc, sizeof(CrcDeviceTables), hipMemcpyHostToDevice));
+    d.ready = true;
+    return FPNG_AMD_OK;
+}
+
+template <typename T> struct DeviceBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return FPNG_AMD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, cap * 2);
+        hipError_t e = hipMalloc(&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipMalloc scratch", e);
+        cap = want;
+        return FPNG_AMD_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+template <typename T> struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return FPNG_AMD_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        hipError_t e = hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipHostMalloc", e);
+        cap = n;
+        return FPNG_AMD_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// reference src/fpng.cpp:1670-1680 plus the 32-bit arithmetic limit of :1682-1705
+int check_dims(uint32_t w, uint32_t h, uint32_t c)
+{
+    if (w < 1 || h < 1 || (uint64_t)w * h > 0xFFFFFFFFull || w > (1u << 24) || h > (1u << 24))
+        return fail(FPNG_AMD_ERR_INVALID_ARG, "invalid image dimensions");
+    if (c != 3 && c != 4) return fail(FPNG_AMD_ERR_INVALID_ARG, "num_chans must be 3 or 4");
+    if (((uint64_t)w * c + 1) * h > 0xFFFFFF00ull)
+        return fail(FPNG_AMD_ERR_UNSUPPORTED, "more than 4 GiB of filtered bytes (undefined in the reference)");
+    return FPNG_AMD_OK;
+}
+
+void make_png_header(uint8_t *hdr, uint32_t w, uint32_t h, uint32_t c)
+{
+    // reference src/fpng.cpp:1767-1791.  Only the low 16 bits of each dimension are stored there
+    // (":1773-1774"); reproduced, not fixed.  The IDAT length (bytes 50..53) is patched on device.
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
+    static const uint8_t fdec[17] = {0, 0, 0, 5, 'f', 'd', 'E', 'C', 82, 36, 147, 227, 0, 0xE5, 0xAB, 0x62, 0x99};
+    std::memset(hdr, 0, 60);
+    std::memcpy(hdr, sig, 8);
+    hdr[11] = 13;
+    std::memcpy(hdr + 12, "IHDR", 4);
+    hdr[18] = (uint8_t)(w >> 8), hdr[19] = (uint8_t)w;
+    hdr[22] = (uint8_t)(h >> 8), hdr[23] = (uint8_t)h;
+    hdr[24] = 8;
+    hdr[25] = (c == 3) ? 2 : 6;
+    const uint32_t crc = host_crc32(hdr + 12, 17, 0);
+    hdr[29] = (uint8_t)(crc >> 24), hdr[30] = (uint8_t)(crc >> 16), hdr[31] = (uint8_t)(crc >> 8), hdr[32] = (uint8_t)crc;
+    std::memcpy(hdr + 33, fdec, 17);
+    std::memcpy(hdr + 54, "IDAT", 4);
+}
+
+} // namespace
+
+struct fpng_amd_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    hipEvent_t ev[FPNG_AMD_NUM_PHASES + 1] = {};
+    bool ev_ready = false;
+    float phase_ms[FPNG_AMD_NUM_PHASES] = {};
+    uint32_t phases_recorded = 0;
+
+    PinnedBuf<Job> h_jobs;
+    DeviceBuf<Job> d_jobs;
+    DeviceBuf<RowInfo> d_rows;
+    DeviceBuf<uint64_t> d_row_off;
+    DeviceBuf<JobState> d_states;
+    DeviceBuf<Result> d_results;
+    PinnedBuf<Result> h_results;
+    PinnedBuf<JobState> h_states;
+    DeviceBuf<uint32_t> d_partials;
+    DeviceBuf<uint32_t> d_hist;
+    DeviceBuf<TokenTable> d_dyn;
+    DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
+    uint32_t last_n = 0;
+};
+
+extern "C" {
+
+int fpng_amd_abi_version(void) { return FPNG_AMD_ABI_VERSION; }
+const char *fpng_amd_last_error(void) { return g_last_error.c_str(); }
+
+int fpng_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fpng_amd_device_available(void) { return fpng_amd_device_count() > 0 ? 1 : 0; }
+
+int fpng_amd_init(int device)
+{
+    if (!host_tables()) return fail(FPNG_AMD_ERR_UNSUPPORTED, "format tables failed self-check");
+    if (fpng_amd_device_count() <= 0) return fail(FPNG_AMD_ERR_NO_DEVICE, "no HIP device");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    return ensure_device_tables(cur);
+}
+
+uint32_t fpng_amd_crc32(const void *data, size_t size, uint32_t prev) { return host_crc32(data, size, prev); }
+uint32_t fpng_amd_adler32(const void *data, size_t size, uint32_t adler) { return host_adler32(data, size, adler); }
+uint32_t fpng_amd_crc32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return crc32_combine(a, b, len_b); }
+uint32_t fpng_amd_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return adler32_combine(a, b, len_b); }
+
+size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t c)
+{
+    const uint64_t n = ((uint64_t)w * c + 1) * h;
+    return (size_t)(kPngHeaderBytes + 6 + n + 5 * ((n + kStoredBlockMax - 1) / kStoredBlockMax) + kPngTrailerBytes);
+}
+
+int fpng_amd_1pass_layout(uint32_t c, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes)
+{
+    if (c != 3 && c != 4) return fail(FPNG_AMD_ERR_INVALID_ARG, "num_chans must be 3 or 4");
+    if (!host_tables()) return fail(FPNG_AMD_ERR_UNSUPPORTED, "format tables failed self-check");
+    if (first_token_bit) *first_token_bit = g_host_1pass[c].first_token_bit;
+    if (eob_bits) *eob_bits = g_host_1pass[c].lit[256] >> 16;
+    if (prefix_bytes) *prefix_bytes = g_host_1pass[c].header_bits >> 3;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream)
+{
+    if (!out) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder pointer");
+    *out = nullptr;
+    if (fpng_amd_device_count() <= 0) return fail(FPNG_AMD_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipSetDevice(device));
+    int rc = ensure_device_tables(device);
+    if (rc) return rc;
+    fpng_amd_encoder *e = new fpng_amd_encoder();
+    e->device = device;
+    if (hip_stream) {
+        e->stream = (hipStream_t)hip_stream;
+    } else {
+        hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (err != hipSuccess) {
+            delete e;
+            return fail(FPNG_AMD_ERR_HIP, "hipStreamCreate", err);
+        }
+        e->own_stream = true;
+    }
+    *out = e;
+    return FPNG_AMD_OK;
+}
+
+void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    if (e->ev_ready)
+        for (auto &ev : e->ev) (void)hipEventDestroy(ev);
+    e->h_jobs.release();
+    e->d_jobs.release();
+    e->d_rows.release();
+    e->d_row_off.release();
+    e->d_states.release();
+    e->d_results.release();
+    e->h_results.release();
+    e->h_states.release();
+    e->d_partials.release();
+    e->d_hist.release();
+    e->d_dyn.release();
+    e->d_stage_in.release();
+    e->d_stage_out.release();
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+void *fpng_amd_encoder_stream(fpng_amd_encoder *e) { return e ? (void *)e->stream : nullptr; }
+
+int fpng_amd_encoder_set_profiling(fpng_amd_encoder *e, int enabled)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    if (enabled && !e->ev_ready) {
+        HIP_TRY(hipSetDevice(e->device));
+        for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+        e->ev_ready = true;
+    }
+    e->profiling = enabled != 0;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *e, float ms[FPNG_AMD_NUM_PHASES])
+{
+    if (!e || !ms) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < FPNG_AMD_NUM_PHASES; i++) ms[i] = 0.f;
+    if (!e->profiling || !e->phases_recorded) return FPNG_AMD_OK;
+    HIP_TRY(hipEventSynchronize(e->ev[e->phases_recorded]));
+    for (uint32_t i = 0; i < e->phases_recorded; i++) HIP_TRY(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+    return FPNG_AMD_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+struct Submission {
+    uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
+    uint64_t total_rows = 0;
+};
+
+int mark(fpng_amd_encoder *e, uint32_t idx)
+{
+    if (e->profiling) {
+        HIP_TRY(hipEventRecord(e->ev[idx], e->stream));
+        e->phases_recorded = idx;
+    }
+    return FPNG_AMD_OK;
+}
+
+// Fills e->h_jobs[0..n) for whole-image jobs and sizes the scratch buffers.
+int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags, Submission &sub)
+{
+    if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
+    if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
+    int rc;
+    if ((rc = e->h_jobs.ensure(n))) return rc;
+    const DeviceTables &dt = g_dev[e->device];
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !(flags & FPNG_AMD_FORCE_UNCOMPRESSED);
+    sub = Submission();
+    sub.n = n;
+    for (uint32_t i = 0; i < n; i++) {
+        const fpng_amd_image &im = images[i];
+        if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
+        if (!im.d_pixels || !im.d_out) return fail(FPNG_AMD_ERR_INVALID_ARG, "null device pointer");
+        if (((uintptr_t)im.d_out & 15) || (im.num_chans == 4 && ((uintptr_t)im.d_pixels & 3)))
+            return fail(FPNG_AMD_ERR_INVALID_ARG, "d_out must be 16-byte aligned, RGBA d_pixels 4-byte aligned");
+        if (im.out_cap < fpng_amd_max_encoded_size(im.w, im.h, im.num_chans))
+            return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "out_cap < fpng_amd_max_encoded_size()");
+        if (sub.total_rows + im.h > 0xFFFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many rows in one batch");
+        Job &j = e->h_jobs.p[i];
+        std::memset(&j, 0, sizeof j);
+        j.rows = (const uint8_t *)im.d_pixels;
+        j.row_above = nullptr;
+        j.out = im.d_out;
+        j.out_cap = im.out_cap;
+        j.w = im.w;
+        j.c = im.num_chans;
+        j.bpl = im.w * im.num_chans;
+        j.nrows = j.h_total = im.h;
+        j.y0 = 0;
+        j.flags = flags;
+        j.row_base = (uint32_t)sub.total_rows;
+        j.one_pass = two_pass ? 0 : 1;
+        j.whole_png = j.is_first = j.is_last = 1;
+        j.bit_bias = (int64_t)kPngHeaderBytes * 8;
+        j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
+        j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
+        make_png_header(j.png_header, im.w, im.h, im.num_chans);
+        sub.total_rows += im.h;
+        sub.max_rows = std::max(sub.max_rows, im.h);
+        sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
+    }
+    if ((rc = e->d_jobs.ensure(n))) return rc;
+    if ((rc = e->d_rows.ensure(sub.total_rows))) return rc;
+    if ((rc = e->d_row_off.ensure(sub.total_rows))) return rc;
+    if ((rc = e->d_states.ensure(n))) return rc;
+    if ((rc = e->d_results.ensure(n))) return rc;
+    if ((rc = e->h_results.ensure(n))) return rc;
+    if ((rc = e->d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
+    if (two_pass) {
+        if ((rc = e->d_hist.ensure((size_t)n * 288))) return rc;
+        if ((rc = e->d_dyn.ensure(n))) return rc;
+    }
+    return FPNG_AMD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    HIP_TRY(hipSetDevice(e->device));
+    // the pinned job array of the previous submission may still be in flight
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Submission sub;
+    int rc = prepare_jobs(e, images, n, flags, sub);
+    if (rc) return rc;
+    const DeviceTables &dt = g_dev[e->device];
+    const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
+    hipStream_t s = e->stream;
+    e->phases_recorded = 0;
+
+    if (two_pass) {
+        // pass 1 works on the symbol table; the per-job dynamic table is built on device
+        for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = dt.symbols[e->h_jobs.p[i].c];
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, n * sizeof(JobState), s));
+    if ((rc = mark(e, 0))) return rc;
+    if (two_pass) {
+        HIP_TRY(hipMemsetAsync(e->d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
+        launch_hist(s, e->d_jobs.p, n, sub.max_rows, e->d_hist.p);
+        launch_build_dynamic(s, e->d_jobs.p, n, e->d_hist.p, e->d_dyn.p);
+        // second job array: same jobs, now pointing at their dynamic tables
+        HIP_TRY(hipStreamSynchronize(s)); // h_jobs is reused below
+        for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = e->d_dyn.p + i;
+        HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    }
+    if (!force_stored) launch_count(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
+    if ((rc = mark(e, 1))) return rc;
+    launch_scan(s, e->d_jobs.p, n, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+    if ((rc = mark(e, 2))) return rc;
+    launch_emit(s, e->d_jobs.p, n, sub.max_rows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
+    if ((rc = mark(e, 3))) return rc;
+    launch_crc(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_states.p, dt.crc, e->d_partials.p);
+    if ((rc = mark(e, 4))) return rc;
+    launch_finalize(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_rows.p, e->d_states.p, dt.crc, e->d_partials.p,
+                    e->d_results.p);
+    if ((rc = mark(e, 5))) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
+    e->last_n = n;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_encode_finish(fpng_amd_encoder *e, fpng_amd_result *results, uint32_t n)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (results) {
+        if (n > e->last_n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
+        for (uint32_t i = 0; i < n; i++) {
+            results[i].png_size = e->h_results.p[i].png_size;
+            results[i].mode = e->h_results.p[i].mode;
+            results[i].status = e->h_results.p[i].status;
+        }
+    }
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_encode_host(fpng_amd_encoder *e, const void *pixels, uint32_t w, uint32_t h, uint32_t c, uint32_t flags,
+                         uint8_t *out, size_t out_cap, size_t *out_size)
+{
+    if (!e || !pixels || !out_size) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    int rc = check_dims(w, h, c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)w * h * c, max_out = fpng_amd_max_encoded_size(w, h, c);
+    if ((rc = e->d_stage_in.ensure(in_bytes + 16))) return rc;
+    if ((rc = e->d_stage_out.ensure(max_out + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_stage_in.p, pixels, in_bytes, hipMemcpyHostToDevice, e->stream));
+    fpng_amd_image im;
+    im.d_pixels = e->d_stage_in.p;
+    im.w = w, im.h = h, im.num_chans = c;
+    im.d_out = e->d_stage_out.p;
+    im.out_cap = max_out + 64;
+    if ((rc = fpng_amd_encode_batch_async(e, &im, 1, flags))) return rc;
+    fpng_amd_result res;
+    if ((rc = fpng_amd_encode_finish(e, &res, 1))) return rc;
+    if (res.status) return fail(FPNG_AMD_ERR_HIP, "device reported an encode failure");
+    *out_size = (size_t)res.png_size;
+    if (!out || out_cap < res.png_size) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+    HIP_TRY(hipMemcpy(out, e->d_stage_out.p, res.png_size, hipMemcpyDeviceToHost));
+    return FPNG_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row bands
+// ------------------------------------------------------------------------------------------------
+static int band_job(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c, uint32_t y0,
+                    uint32_t y1, Job &j)
+{
+    if (!e || !d_rows) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (y1 <= y0) return fail(FPNG_AMD_ERR_INVALID_ARG, "empty band");
+    int rc = check_dims(w, y1, c);
+    if (rc) return rc;
+    if (y0 > 0 && !d_row_above) return fail(FPNG_AMD_ERR_INVALID_ARG, "band needs the row above its first row");
+    if (c == 4 && (((uintptr_t)d_rows & 3) || ((uintptr_t)d_row_above & 3)))
+        return fail(FPNG_AMD_ERR_INVALID_ARG, "RGBA rows must be 4-byte aligned");
+    std::memset(&j, 0, sizeof j);
+    j.rows = (const uint8_t *)d_rows;
+    j.row_above = (const uint8_t *)d_row_above;
+    j.w = w, j.c = c, j.bpl = w * c;
+    j.nrows = y1 - y0;
+    j.y0 = y0;
+    j.h_total = y1;
+    j.one_pass = 1;
+    j.table = g_dev[e->device].one_pass[c];
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_band_count(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c,
+                        uint32_t y0, uint32_t y1, fpng_amd_band_stats *stats)
+{
+    if (!stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null stats");
+    HIP_TRY(hipSetDevice(e ? e->device : 0));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc;
+    if ((rc = e->h_jobs.ensure(1))) return rc;
+    Job &j = e->h_jobs.p[0];
+    if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
+    j.is_first = 0; // offsets relative to start_bit = 0: only the total is used
+    j.is_last = 0;
+    j.start_bit = 0;
+    if ((rc = e->d_jobs.ensure(1)) || (rc = e->d_rows.ensure(j.nrows)) || (rc = e->d_row_off.ensure(j.nrows)) ||
+        (rc = e->d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
+        return rc;
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, sizeof(JobState), s));
+    launch_count(s, e->d_jobs.p, 1, j.nrows, e->d_rows.p, e->d_states.p);
+    launch_scan(s, e->d_jobs.p, 1, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const JobState &st = e->h_states.p[0];
+    stats->token_bits = st.token_end_bit;
+    stats->adler_s1 = st.s1;
+    stats->adler_s2 = st.s2;
+    stats->adler_len = (uint64_t)(j.bpl + 1) * j.nrows;
+    stats->last_unit_bits = st.last_unit_bits;
+    stats->reserved = 0;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_band_emit(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c,
+                       uint32_t y0, uint32_t y1, uint64_t start_bit, int is_first, int is_last, uint32_t adler,
+                       uint8_t *d_band_out, size_t out_cap, size_t *out_bytes)
+{
+    if (!d_band_out || !out_bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if ((uintptr_t)d_band_out & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_band_out must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e ? e->device : 0));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc;
+    if ((rc = e->h_jobs.ensure(1))) return rc;
+    Job &j = e->h_jobs.p[0];
+    if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
+    const TokenTable &tab = g_host_1pass[c];
+    if (is_first) start_bit = tab.first_token_bit;
+    j.is_first = is_first ? 1 : 0;
+    j.is_last = is_last ? 1 : 0;
+    j.start_bit = start_bit;
+    j.out = d_band_out;
+    j.out_cap = out_cap;
+    const uint64_t first_byte = is_first ? 0 : (start_bit >> 3);
+    j.bit_bias = -(int64_t)(first_byte * 8);
+    j.flags = 0x100; // band emit: scan_kernel prepares seams/prefix in the band window
+    if ((rc = e->d_jobs.ensure(1)) || (rc = e->d_rows.ensure(j.nrows)) || (rc = e->d_row_off.ensure(j.nrows)) ||
+        (rc = e->d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
+        return rc;
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, sizeof(JobState), s));
+    launch_count(s, e->d_jobs.p, 1, j.nrows, e->d_rows.p, e->d_states.p);
+    launch_scan(s, e->d_jobs.p, 1, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+    launch_emit(s, e->d_jobs.p, 1, j.nrows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t end_bit = e->h_states.p[0].token_end_bit;
+    uint64_t bytes;
+    if (is_last) {
+        const uint32_t eob_len = tab.lit[256] >> 16;
+        bytes = ((end_bit + eob_len + 7) >> 3) - first_byte;
+        if (bytes + 4 > out_cap) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "band buffer too small");
+        const uint8_t be[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
+        HIP_TRY(hipMemcpy(d_band_out + bytes, be, 4, hipMemcpyHostToDevice));
+        bytes += 4;
+    } else {
+        bytes = ((end_bit + 7) >> 3) - first_byte;
+    }
+    *out_bytes = (size_t)bytes;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t w, uint32_t h, uint32_t c,
+                      size_t *png_size)
+{
+    if (!e || !d_png || !png_size || zlib_size < 6) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
+    if ((uintptr_t)d_png & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_png must be 16-byte aligned");
+    int rc = check_dims(w, h, c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = e->h_jobs.ensure(1)) || (rc = e->d_jobs.ensure(1)) || (rc = e->d_states.ensure(1)) ||
+        (rc = e->h_states.ensure(1)) || (rc = e->d_results.ensure(1)) || (rc = e->h_results.ensure(1)) ||
+        (rc = e->d_rows.ensure(1)))
+        return rc;
+    Job &j = e->h_jobs.p[0];
+    std::memset(&j, 0, sizeof j);
+    j.out = d_png;
+    j.w = w, j.c = c, j.bpl = w * c, j.nrows = 0, j.h_total = h;
+    j.whole_png = j.is_first = j.is_last = 1;
+    j.crc_blocks = (uint32_t)((kPngHeaderBytes + zlib_size + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
+    make_png_header(j.png_header, w, h, c);
+    j.png_header[50] = (uint8_t)(zlib_size >> 24), j.png_header[51] = (uint8_t)(zlib_size >> 16);
+    j.png_header[52] = (uint8_t)(zlib_size >> 8), j.png_header[53] = (uint8_t)zlib_size;
+    // the stream's own Adler bytes are re-written by finalize_kernel: read them back first
+    uint8_t be[4];
+    HIP_TRY(hipMemcpy(be, d_png + kPngHeaderBytes + zlib_size - 4, 4, hipMemcpyDeviceToHost));
+    JobState &st = e->h_states.p[0];
+    std::memset(&st, 0, sizeof st);
+    st.zlib_size = zlib_size;
+    st.mode = 0;
+    st.adler = ((uint32_t)be[0] << 24) | ((uint32_t)be[1] << 16) | ((uint32_t)be[2] << 8) | be[3];
+    if ((rc = e->d_partials.ensure(j.crc_blocks))) return rc;
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_png, j.png_header, kPngHeaderBytes, hipMemcpyHostToDevice, s));
+    launch_crc(s, e->d_jobs.p, 1, j.crc_blocks, e->d_states.p, g_dev[e->device].crc, e->d_partials.p);
+    launch_finalize(s, e->d_jobs.p, 1, j.crc_blocks, e->d_rows.p, e->d_states.p, g_dev[e->device].crc, e->d_partials.p,
+                    e->d_results.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->d_results.p, sizeof(Result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *png_size = (size_t)e->h_results.p[0].png_size;
+    return FPNG_AMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,75 @@
+// kernels.h -- host/device shared structures and kernel launchers (internal).
+#pragma once
+#include "format.h"
+
+#include <hip/hip_runtime_api.h>
+
+namespace fpng_amd {
+
+// CRC work decomposition: every block owns kCrcRangeBytes of the (16-byte aligned) file span,
+// 256 lanes x 16 B = one 4 KiB block row per step.
+constexpr uint32_t kCrcRangeBytes = 1u << 16;
+constexpr uint32_t kCrcRowBytes = 4096;
+
+// One unit of work: a whole image, or a band of rows of one image (multi-GPU).
+struct Job {
+    const uint8_t *rows;      // first row of the job (row y0 of the image)
+    const uint8_t *row_above; // row y0-1, used only when y0 > 0
+    uint8_t *out;             // whole_png: start of the .png file; band: start of the band's byte window
+    const TokenTable *table;  // device table (1-pass static or per-job dynamic)
+    uint64_t out_cap;
+    uint64_t start_bit;       // band: absolute zlib bit of the band's first token (ignored if is_first)
+    int64_t bit_bias;         // destination bit = zlib bit + bit_bias  (whole_png: 58*8)
+    uint32_t w, c, bpl, nrows, y0, h_total, flags;
+    uint32_t row_base;        // index of the job's first row in the per-row scratch arrays
+    uint32_t one_pass, whole_png, is_first, is_last;
+    uint32_t crc_blocks;      // upper bound of CRC ranges for this job
+    uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
+};
+
+struct RowInfo {
+    uint32_t bits; // token bits of the row
+    uint32_t s1;   // Adler raw sums of the filtered row mod 65521
+    uint32_t s2;
+    uint32_t pad;
+};
+
+struct JobState {
+    uint64_t token_end_bit; // zlib bit position after the last token
+    uint64_t zlib_size;     // bytes of the zlib stream incl. Adler
+    uint32_t mode;          // 0 compressed, 1 stored
+    uint32_t last_unit_bits;
+    uint32_t s1, s2;        // Adler raw sums of the job's filtered bytes
+    uint32_t adler, crc;
+    uint32_t pad[2];
+};
+
+struct Result {
+    uint64_t png_size;
+    uint32_t mode;
+    uint32_t status;
+};
+
+// device-side CRC constants (superset of CrcTables in format.h)
+struct CrcDeviceTables {
+    uint32_t striped[16][256]; // raw CRC of byte b, followed by (15-k) + (kCrcRowBytes-16) zero bytes
+    uint32_t lane_fix[256];    // x^(8*(kCrcRowBytes - 16*tid)): lane stripe -> one row past the range end
+    uint32_t pow2[48];         // x^(8*2^i)
+    uint32_t inv_pad[16];      // x^(-8*p)
+    uint32_t inv_row;          // x^(-8*kCrcRowBytes)
+    uint32_t pad[15];
+};
+void build_crc_device_tables(CrcDeviceTables *t);
+
+void launch_count(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states);
+void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
+void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
+                 const JobState *states);
+void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
+                const CrcDeviceTables *tabs, uint32_t *partials);
+void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
+                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
+void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables);
+
+} // namespace fpng_amd

@@ -1,0 +1,965 @@
+// kernels.hip -- CDNA4 (gfx950, wave64) kernels of the fpng encode hot path.
+//
+// Pipeline per submission (all on one stream, no host round trip):
+//
+//   count_kernel     one wavefront per scanline: Up/None filter on the fly, RLE chunking from wave
+//                    ballots, token bit lengths from LDS tables -> bits per row; fused Adler-32
+//                    partial sums of the filtered row.            (reference fpng.cpp:1592-1660 filter,
+//                                                                  :1468-1558 / :1182-1241 token grammar, :407-487 Adler)
+//   scan_kernel      per image: exclusive scan of row bits -> absolute bit offset of every row,
+//                    Adler combine, closed-form "did the coder run out of buffer" decision
+//                    (reference fpng.cpp:567-588), PNG header + Deflate prefix, seam zeroing.
+//   emit_kernel      one wavefront per scanline again: recompute tokens, DPP prefix sum of token
+//                    lengths -> bit offsets, OR tokens into an LDS staging window, stream the
+//                    window out with coalesced stores; rows meet at bit granularity (seam dwords
+//                    are OR-merged).  Stored-block fallback rows are written by the same kernel.
+//   crc_kernel       CRC-32 of the finished IDAT bytes: 16 bytes per lane per step, slice-by-16
+//                    from LDS, lane stripes folded with GF(2) constants (reference fpng.cpp:234-292).
+//   finalize_kernel  folds the CRC partials, writes Adler / IDAT CRC / IEND and the result record
+//                    (reference fpng.cpp:1764-1800).
+//
+// Integer / byte work throughout, bounded by HBM traffic and LDS table lookups: no MFMA.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace fpng_amd {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kStageDwords = 512;          // per-wave LDS staging window of the output bit stream
+constexpr int kStageFlushAt = kStageDwords - 136; // a 64-pixel window adds at most 64*60 bits = 120 dwords
+
+// ---------------------------------------------------------------------------------------------
+// wave-level primitives (wave64, gfx9 DPP)
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_CTRL = true>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL);
+}
+
+// value of lane-1; lane 0 receives `lane0_value`
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v, uint32_t lane0_value)
+{
+    return dpp_mov<0x138, 0xF, 0xF, false>(lane0_value, v); // wave_shr:1
+}
+
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += dpp_mov<0x111>(0, v);             // row_shr:1
+    v += dpp_mov<0x112>(0, v);             // row_shr:2
+    v += dpp_mov<0x114>(0, v);             // row_shr:4
+    v += dpp_mov<0x118>(0, v);             // row_shr:8   -> scan inside each row of 16
+    v += dpp_mov<0x142, 0xA>(0, v);        // row_bcast:15 into rows 1,3
+    v += dpp_mov<0x143, 0xC>(0, v);        // row_bcast:31 into rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(v), 63);
+}
+
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
+}
+
+// LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this
+// only stops the compiler from moving them across.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Pointers that come out of a Job record are generic ("flat") to the compiler.  The hot loads and
+// stores go through explicitly global-address-space pointer types so they become global_*
+// instructions (flat_* ones also occupy the LDS counter and issue slower).
+#define FPNG_GLOBAL __attribute__((address_space(1)))
+typedef const FPNG_GLOBAL uint8_t *gptr_cu8;
+typedef const FPNG_GLOBAL uint32_t *gptr_cu32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const FPNG_GLOBAL u32x4 *gptr_cu128;
+typedef FPNG_GLOBAL uint8_t *gptr_u8;
+typedef FPNG_GLOBAL uint32_t *gptr_u32;
+template <typename G, typename T> __device__ __forceinline__ G to_global(T *p) { return (G)(uintptr_t)p; }
+
+// per-byte a-b (mod 256) on four packed bytes
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t a, uint32_t b)
+{
+    return ((a | 0x80808080u) - (b & 0x7F7F7F7Fu)) ^ ((a ^ ~b) & 0x80808080u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pixel access.  Lane i of a 64-pixel window owns pixel x0+i.
+// ---------------------------------------------------------------------------------------------
+template <int C> struct RawPixel;
+template <> struct RawPixel<4> {
+    uint32_t cur, up;
+};
+template <> struct RawPixel<3> {
+    uint32_t cur_lo, cur_hi, up_lo, up_hi, cur_sh, up_sh;
+};
+
+// 3 bytes at an arbitrary address through aligned dword loads only: an aligned dword that contains
+// at least one valid byte never leaves that byte's page, so nothing is touched outside the image.
+__device__ __forceinline__ void load3(gptr_cu8 p, uint32_t &lo, uint32_t &hi, uint32_t &sh)
+{
+    const uintptr_t a = (uintptr_t)p;
+    gptr_cu32 q = (gptr_cu32)(a & ~(uintptr_t)3);
+    sh = (uint32_t)(a & 3);
+    lo = q[0];
+    hi = (sh >= 2) ? q[1] : 0u;
+}
+
+template <int C>
+__device__ __forceinline__ RawPixel<C> load_pixel(gptr_cu8 row, gptr_cu8 up_row, uint32_t x, bool valid)
+{
+    RawPixel<C> r;
+    if constexpr (C == 4) {
+        r.cur = 0;
+        r.up = 0;
+        if (valid) {
+            r.cur = ((gptr_cu32)row)[x];
+            if (up_row) r.up = ((gptr_cu32)up_row)[x];
+        }
+    } else {
+        r.cur_lo = r.cur_hi = r.up_lo = r.up_hi = r.cur_sh = r.up_sh = 0;
+        if (valid) {
+            load3(row + 3u * x, r.cur_lo, r.cur_hi, r.cur_sh);
+            if (up_row) load3(up_row + 3u * x, r.up_lo, r.up_hi, r.up_sh);
+        }
+    }
+    return r;
+}
+
+// filtered pixel value: bytes of (cur - up) mod 256, R in bits 0..7 (reference fpng.cpp:1605-1655)
+template <int C> __device__ __forceinline__ uint32_t filtered(const RawPixel<C> &r)
+{
+    if constexpr (C == 4) {
+        return sub_bytes(r.cur, r.up);
+    } else {
+        const uint32_t c = __builtin_amdgcn_alignbyte(r.cur_hi, r.cur_lo, r.cur_sh);
+        const uint32_t u = __builtin_amdgcn_alignbyte(r.up_hi, r.up_lo, r.up_sh);
+        return sub_bytes(c, u) & 0xFFFFFFu;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RLE structure of one 64-pixel window from the wave ballot of "equals previous pixel".
+//
+// A run of equal pixels is cut greedily from its first pixel into chunks of at most CAP pixels
+// (reference fpng.cpp:1503-1514 / :1209-1219).  We attribute every chunk to its LAST pixel:
+//   t(x)  = number of consecutive "same" pixels ending at x
+//   q(x)  = ((t-1) mod CAP) + 1        position inside the current chunk
+//   x ends a chunk iff same(x) and (q == CAP or !same(x+1))
+// which needs only look-back (a scalar carry across windows) and one pixel of look-ahead.
+// ---------------------------------------------------------------------------------------------
+template <int C> struct Rle {
+    static constexpr uint32_t CAP = (C == 4) ? kMaxChunkPixels4 : kMaxChunkPixels3;
+    uint32_t carry = 0; // t of the pixel just before the window, reduced mod CAP (wave-uniform)
+
+    // returns q (1..CAP) for lanes with same==1 (undefined otherwise); ends = chunk-end flag
+    __device__ __forceinline__ uint32_t classify(uint64_t same_mask, uint32_t next_same_bit0, uint32_t lane,
+                                                 uint64_t lane_le_mask, bool &ends) const
+    {
+        const uint64_t zeros_le = ~same_mask & lane_le_mask; // not-same pixels at or below this lane
+        uint32_t t;
+        if (zeros_le == 0)
+            t = carry + lane + 1;
+        else
+            t = lane - (63u - (uint32_t)__builtin_clzll(zeros_le));
+        uint32_t u = t - 1;
+        if (u >= CAP) u -= CAP;
+        if (C == 4 && u >= CAP) u -= CAP;
+        const uint32_t q = u + 1;
+        const uint64_t after = (same_mask >> 1) | ((uint64_t)next_same_bit0 << 63);
+        const bool same = (same_mask >> lane) & 1;
+        ends = same && (q == CAP || !((after >> lane) & 1));
+        return q;
+    }
+
+    // advance the carry past a full window
+    __device__ __forceinline__ void advance(uint64_t same_mask)
+    {
+        uint32_t t;
+        if (same_mask == ~0ull)
+            t = carry + 64;
+        else
+            t = (uint32_t)__builtin_clzll(~same_mask); // leading ones
+        while (t >= CAP) t -= CAP;
+        carry = t;
+    }
+};
+
+// LDS copy of the job's token table
+struct LdsTables {
+    uint32_t lit[288];
+    uint32_t chunk[96];
+};
+
+__device__ __forceinline__ void stage_tables(LdsTables &dst, const TokenTable *src)
+{
+    for (int i = threadIdx.x; i < 288; i += kBlock) dst.lit[i] = src->lit[i];
+    for (int i = threadIdx.x; i < 96; i += kBlock) dst.chunk[i] = src->chunk[i];
+}
+
+template <int C> __device__ __forceinline__ uint32_t literal_bits(const LdsTables &T, uint32_t f)
+{
+    uint32_t n = (T.lit[f & 0xFF] >> 16) + (T.lit[(f >> 8) & 0xFF] >> 16) + (T.lit[(f >> 16) & 0xFF] >> 16);
+    if (C == 4) n += T.lit[f >> 24] >> 16;
+    return n;
+}
+
+// all literals of one pixel as a single token (<= 48 bits)
+template <int C> __device__ __forceinline__ uint64_t literal_token(const LdsTables &T, uint32_t f, uint32_t &nbits)
+{
+    const uint32_t e0 = T.lit[f & 0xFF], e1 = T.lit[(f >> 8) & 0xFF], e2 = T.lit[(f >> 16) & 0xFF];
+    const uint32_t l0 = e0 >> 16, l1 = e1 >> 16, l2 = e2 >> 16;
+    const uint32_t lo = (e0 & 0xFFFF) | ((e1 & 0xFFFF) << l0); // <= 24 bits
+    uint32_t hi = e2 & 0xFFFF, lh = l2;
+    if (C == 4) {
+        const uint32_t e3 = T.lit[f >> 24];
+        hi |= (e3 & 0xFFFF) << l2;
+        lh += e3 >> 16;
+    }
+    nbits = l0 + l1 + lh;
+    return (uint64_t)lo | ((uint64_t)hi << (l0 + l1));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row walker shared by the count / histogram / emit kernels.
+// ---------------------------------------------------------------------------------------------
+enum class Pass { Count, Hist, Emit };
+
+struct EmitSink {
+    uint32_t *stage;     // this wave's LDS window
+    gptr_u32 out32;      // dword view of the destination (bit 0 of dword 0 = destination bit 0)
+    uint64_t base_dw;    // destination dword index of stage[0]
+    uint32_t fill;       // bits used in the window
+    bool first_flush;
+};
+
+__device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t ndw)
+{
+    for (uint32_t j = lane; j < ndw; j += kWave) s.stage[j] = 0;
+}
+
+// OR a token of nbits (<= 60) at window bit position pos
+__device__ __forceinline__ void sink_put(EmitSink &s, uint64_t code, uint32_t nbits, uint32_t pos)
+{
+    const uint32_t d = pos >> 5, sh = pos & 31;
+    const uint64_t lo64 = code << sh;
+    atomicOr(&s.stage[d], (uint32_t)lo64);
+    if (sh + nbits > 32) atomicOr(&s.stage[d + 1], (uint32_t)(lo64 >> 32));
+    if (sh + nbits > 64) atomicOr(&s.stage[d + 2], (uint32_t)(code >> (64 - sh)));
+}
+
+// Write out the complete dwords of the window (all of them when `final`), keep the partial one.
+// The first and the last dword of a row's span may be shared with the neighbouring rows (or with
+// header bytes): those two are OR-merged into memory that scan_kernel zeroed; everything in
+// between belongs to this row alone and is stored plainly, 256 B per wave store.
+__device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool final)
+{
+    wave_lds_fence();
+    const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5);
+    for (uint32_t j = lane; j < ndw; j += kWave) {
+        const uint32_t v = s.stage[j];
+        gptr_u32 dst = s.out32 + s.base_dw + j;
+        const bool shared = (j == 0 && s.first_flush) || (final && j == ndw - 1);
+        if (shared) {
+            if (v) __hip_atomic_fetch_or(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
+            *dst = v;
+    }
+    if (!final) {
+        const uint32_t rem = s.stage[ndw]; // partial dword, uniform address
+        wave_lds_fence();
+        sink_zero(s, lane, ndw + 1);
+        wave_lds_fence();
+        if (lane == 0) s.stage[0] = rem;
+        s.base_dw += ndw;
+        s.fill &= 31;
+        s.first_flush = s.first_flush && (ndw == 0);
+        wave_lds_fence();
+    }
+}
+
+struct RowResult {
+    uint32_t bits;           // token bits of the row
+    uint32_t last_unit_bits; // bits of the row's final flush unit (see scan_kernel)
+    uint32_t s1, s2;         // Adler raw sums of the filtered row, mod 65521
+};
+
+template <int C, Pass PASS>
+__device__ __forceinline__ RowResult walk_row(const Job &job, const LdsTables &T, uint32_t *hist, uint32_t r,
+                                              uint32_t lane, EmitSink *sink)
+{
+    const uint32_t w = job.w, bpl = job.bpl;
+    gptr_cu8 row = to_global<gptr_cu8>(job.rows) + (size_t)r * bpl;
+    const bool filter_up = (job.y0 + r) != 0;
+    gptr_cu8 up_row = filter_up ? (r ? row - bpl : to_global<gptr_cu8>(job.row_above)) : (gptr_cu8)0;
+    const uint32_t filter_byte = filter_up ? 2u : 0u;
+    const bool lit_test = (C == 4) && job.one_pass; // reference fpng.cpp:1520-1528
+    const uint64_t lane_le_mask = (2ull << lane) - 1ull;
+
+    Rle<C> rle;
+    uint32_t row_bits = 0, last_unit = 0;
+    uint32_t acc_a = 0, acc_j = 0; // Adler: per-lane sum of bytes, sum of (byte index in pixel)*byte
+    uint64_t acc_w = 0;            //        per-lane sum of (weight of the pixel's first byte)*(pixel byte sum)
+
+    // software pipeline: raw pixels are fetched two windows ahead, filtered one window ahead
+    RawPixel<C> raw_n1 = load_pixel<C>(row, up_row, lane, lane < w);
+    RawPixel<C> raw_n2 = load_pixel<C>(row, up_row, 64 + lane, 64 + lane < w);
+    uint32_t f_cur = filtered<C>(raw_n1);
+    uint64_t m_cur;
+    {
+        const uint32_t prev = lane_prev(f_cur, 0);
+        m_cur = __ballot(lane < w && lane > 0 && f_cur == prev);
+    }
+
+    for (uint32_t x0 = 0; x0 < w; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        const bool valid = x < w;
+        // next window: filter + same-mask (needed for this window's last lane), prefetch the one after
+        const RawPixel<C> raw_next = raw_n2;
+        raw_n2 = load_pixel<C>(row, up_row, x + 128, x + 128 < w);
+        const uint32_t f_next = filtered<C>(raw_next);
+        uint64_t m_next = 0;
+        if (x0 + 64 < w) {
+            const uint32_t last_cur = (uint32_t)__builtin_amdgcn_readlane((int)f_cur, 63);
+            const uint32_t prev = lane_prev(f_next, last_cur);
+            m_next = __ballot(x + 64 < w && f_next == prev);
+        }
+
+        bool ends;
+        const uint32_t q = rle.classify(m_cur, (uint32_t)(m_next & 1), lane, lane_le_mask, ends);
+        const bool same = (m_cur >> lane) & 1;
+        const bool lits_needed = valid && (!same || (lit_test && ends && q == 1));
+
+        uint32_t nbits = 0;
+        uint64_t code = 0;
+        bool as_lits = valid && !same;
+        if (PASS == Pass::Hist) {
+            if (as_lits) {
+                atomicAdd(&hist[f_cur & 0xFF], 1u);
+                atomicAdd(&hist[(f_cur >> 8) & 0xFF], 1u);
+                atomicAdd(&hist[(f_cur >> 16) & 0xFF], 1u);
+                if (C == 4) atomicAdd(&hist[f_cur >> 24], 1u);
+            } else if (ends) {
+                atomicAdd(&hist[256 + (T.chunk[q] & 0xFF)], 1u); // chunk[] holds length-symbol-256 in Hist mode
+            }
+        } else {
+            uint32_t lbits = 0;
+            uint64_t lcode = 0;
+            if (lits_needed) {
+                if (PASS == Pass::Emit)
+                    lcode = literal_token<C>(T, f_cur, lbits);
+                else
+                    lbits = literal_bits<C>(T, f_cur);
+            }
+            if (ends) {
+                const uint32_t ce = T.chunk[q];
+                nbits = ce >> 24;
+                code = ce & 0xFFFFFFu;
+                if (lit_test && q == 1 && nbits > lbits) as_lits = true;
+            }
+            if (as_lits) {
+                nbits = lbits;
+                code = lcode;
+            }
+            // size of the final flush unit of the row = token of its last pixel; when the row is a
+            // single pixel, 1-pass RGB flushes the filter literal together with it
+            // (reference fpng.cpp:1186-1203 vs :1473-1497)
+            const uint32_t fl = T.lit[filter_byte];
+            if (x == w - 1) last_unit = nbits + ((C == 3 && job.one_pass && w == 1) ? (fl >> 16) : 0u);
+            if (x == 0) { // filter-type literal goes in front of pixel 0
+                code = (code << (fl >> 16)) | (fl & 0xFFFF);
+                nbits += fl >> 16;
+            }
+        }
+
+        if (PASS == Pass::Count) {
+            row_bits += nbits; // per lane, reduced after the loop
+            if (valid) {
+                // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially)
+                const uint32_t a = (C == 4) ? __builtin_amdgcn_sad_u8(f_cur, 0u, 0u)
+                                            : (f_cur & 0xFF) + ((f_cur >> 8) & 0xFF) + (f_cur >> 16);
+                const uint32_t jsum = ((f_cur >> 8) & 0xFF) + 2u * ((f_cur >> 16) & 0xFF) + ((C == 4) ? 3u * (f_cur >> 24) : 0u);
+                acc_a += a;
+                acc_j += jsum;
+                acc_w += (uint64_t)(bpl - (uint32_t)C * x) * a;
+            }
+        } else if (PASS == Pass::Emit) {
+            const uint32_t incl = wave_inclusive_sum(nbits);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (nbits) sink_put(*sink, code, nbits, sink->fill + incl - nbits);
+            sink->fill += total;
+            row_bits += total;
+            if (sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false);
+        }
+
+        rle.advance(m_cur);
+        f_cur = f_next;
+        m_cur = m_next;
+    }
+
+    RowResult res;
+    res.bits = 0;
+    res.last_unit_bits = 0;
+    res.s1 = res.s2 = 0;
+    if (PASS == Pass::Count) {
+        res.bits = wave_sum(row_bits);
+        res.last_unit_bits = wave_sum(last_unit); // exactly one lane set it
+        const uint32_t la = acc_a % kAdlerMod;
+        const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod);
+        const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
+        res.s1 = (wave_sum(la) + filter_byte) % kAdlerMod;
+        res.s2 = (wave_sum(lw) + n_mod * filter_byte) % kAdlerMod;
+    } else if (PASS == Pass::Emit) {
+        res.bits = row_bits;
+    }
+    return res;
+}
+
+__device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return jobs[blockIdx.y]; }
+
+// ---------------------------------------------------------------------------------------------
+// count_kernel: grid (ceil(max_rows/4), n_jobs), block 256 = 4 rows
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
+{
+    __shared__ LdsTables T;
+    const Job &job = job_of_block(jobs);
+    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    stage_tables(T, job.table);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= job.nrows) return;
+    RowResult res = (job.c == 4) ? walk_row<4, Pass::Count>(job, T, nullptr, r, lane, nullptr)
+                                 : walk_row<3, Pass::Count>(job, T, nullptr, r, lane, nullptr);
+    if (lane == 0) {
+        RowInfo ri;
+        ri.bits = res.bits;
+        ri.s1 = res.s1;
+        ri.s2 = res.s2;
+        ri.pad = 0;
+        rows_out[job.row_base + r] = ri;
+        if (r == job.nrows - 1) states[blockIdx.y].last_unit_bits = res.last_unit_bits;
+    }
+}
+
+// hist_kernel (2-pass, pass 1): literal / length-symbol histogram of the whole image
+// (reference fpng.cpp:1021-1084 / :1299-1363).  job.table here is the "symbol" table whose
+// chunk[q] holds (length symbol - 256).
+__global__ __launch_bounds__(kBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+{
+    __shared__ LdsTables T;
+    __shared__ uint32_t hist[288];
+    const Job &job = job_of_block(jobs);
+    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    stage_tables(T, job.table);
+    for (int i = threadIdx.x; i < 288; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r < job.nrows) {
+        if (job.c == 4)
+            walk_row<4, Pass::Hist>(job, T, hist, r, lane, nullptr);
+        else
+            walk_row<3, Pass::Hist>(job, T, hist, r, lane, nullptr);
+        if (lane == 0) atomicAdd(&hist[(job.y0 + r) ? 2 : 0], 1u); // the row's filter-type literal
+    }
+    __syncthreads();
+    uint32_t *dst = hist_out + (size_t)blockIdx.y * 288;
+    for (int i = threadIdx.x; i < 288; i += kBlock)
+        if (hist[i]) atomicAdd(&dst[i], hist[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan_kernel: one block per job
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *scratch, uint64_t &total)
+{
+    // scratch: kBlock entries; simple Hillis-Steele in LDS (called O(rows/256) times per image)
+    const uint32_t t = threadIdx.x;
+    scratch[t] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < kBlock; o <<= 1) {
+        uint64_t add = (t >= o) ? scratch[t - o] : 0;
+        __syncthreads();
+        scratch[t] += add;
+        __syncthreads();
+    }
+    const uint64_t incl = scratch[t];
+    total = scratch[kBlock - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v)
+{
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off,
+                                                     JobState *states)
+{
+    __shared__ uint64_t scratch[kBlock];
+    __shared__ uint64_t s_adl[2];
+    const Job &job = jobs[blockIdx.x];
+    JobState &st = states[blockIdx.x];
+    const uint32_t t = threadIdx.x;
+    const TokenTable *tab = job.table;
+    const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
+    const bool force_stored = (job.flags & 2u) != 0;
+
+    // --- exclusive scan of row bits (absolute zlib bit positions), Adler combine ---
+    const uint64_t first_bit = job.is_first ? tab->first_token_bit : job.start_bit;
+    uint64_t carry = first_bit;
+    uint64_t a_s1 = 0, a_s2 = 0;
+    const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
+    if (!force_stored) {
+        for (uint32_t base = 0; base < job.nrows; base += kBlock) {
+            const uint32_t r = base + t;
+            uint64_t bits = 0;
+            if (r < job.nrows) {
+                const RowInfo ri = rows[job.row_base + r];
+                bits = ri.bits;
+                // S2 of the concatenation: every byte of this row is followed by the later rows
+                const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+                a_s1 += ri.s1;
+                a_s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
+            }
+            uint64_t total;
+            const uint64_t excl = block_exclusive_scan_u64(bits, scratch, total);
+            if (r < job.nrows) row_off[job.row_base + r] = carry + excl;
+            carry += total;
+        }
+    }
+    const uint64_t s_last = carry; // zlib bit position after the last token
+    // block-reduce the Adler sums
+    a_s1 %= kAdlerMod;
+    a_s2 %= kAdlerMod;
+    {
+        uint64_t tot;
+        block_exclusive_scan_u64(a_s1, scratch, tot);
+        if (t == 0) s_adl[0] = tot % kAdlerMod;
+        block_exclusive_scan_u64(a_s2, scratch, tot);
+        if (t == 0) s_adl[1] = tot % kAdlerMod;
+        __syncthreads();
+    }
+
+    // --- compressed or stored?  (closed form of reference fpng.cpp:567-588) ---
+    const uint32_t eob = tab->lit[256];
+    const uint32_t eob_len = eob >> 16;
+    // byte budget the reference hands to the coder (fpng.cpp:1705): whole image only
+    const uint64_t n_total = (uint64_t)(job.bpl + 1) * job.h_total;
+    const uint64_t D = ((58 + n_total + 7) & ~7ull) - 58;
+    bool stored = force_stored;
+    if (job.whole_png && !force_stored) {
+        if (job.one_pass && D < tab->header_bits / 8) stored = true;                 // fpng.cpp:1169, :1455
+        if (((s_last - st.last_unit_bits) >> 3) + 8 > D) stored = true;              // last PUT_BITS_FLUSH
+        if (((s_last + eob_len + 7) >> 3) + 4 > D) stored = true;                    // EOB + Adler
+    }
+    const uint64_t zlib_bytes_no_adler = stored ? (2 + n_filtered + 5 * ((n_filtered + kStoredBlockMax - 1) / kStoredBlockMax))
+                                                : ((s_last + eob_len + 7) >> 3);
+    const uint64_t zlib_size = zlib_bytes_no_adler + 4;
+
+    if (t == 0) {
+        st.token_end_bit = s_last;
+        st.mode = stored ? 1u : 0u;
+        st.zlib_size = zlib_size;
+        st.s1 = (uint32_t)s_adl[0];
+        st.s2 = (uint32_t)s_adl[1];
+        const uint32_t a1 = (uint32_t)((1 + s_adl[0]) % kAdlerMod);
+        const uint32_t a2 = (uint32_t)((n_filtered % kAdlerMod + s_adl[1]) % kAdlerMod);
+        st.adler = (a2 << 16) | a1; // Adler-32 of the Up/None-filtered stream (compressed mode)
+    }
+    // band count (multi-GPU phase 1) stops here; whole images and band emits prepare the output window
+    if (!job.whole_png && !(job.flags & 0x100u)) return;
+
+    // --- zero the seam dwords, then write PNG header + Deflate prefix ---
+    gptr_u32 out32 = to_global<gptr_u32>(job.out);
+    const int64_t bias = job.bit_bias;
+    if (!stored) {
+        for (uint32_t r = t; r < job.nrows; r += kBlock) {
+            const uint64_t o = row_off[job.row_base + r] + bias;
+            out32[o >> 5] = 0; // dword holding the first bit of row r (and the last bits of row r-1)
+        }
+        if (t == 0) {
+            // last bit written by this job: after EOB + byte padding for the final band
+            const uint64_t end_bit = (job.is_last ? ((s_last + eob_len + 7) & ~7ull) : s_last) + bias;
+            out32[(end_bit - 1) >> 5] = 0;
+            if (job.is_last) out32[(s_last + bias) >> 5] = 0;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    gptr_u8 out = to_global<gptr_u8>(job.out);
+    if (job.whole_png)
+        for (uint32_t i = t; i < kPngHeaderBytes; i += kBlock) out[i] = job.png_header[i];
+    gptr_u8 zl = out + (bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
+    if (!stored && job.is_first) {
+        // whole prefix bytes; the pending tail bits are OR-ed into the (zeroed) seam byte below
+        const uint32_t whole = tab->header_bits >> 3;
+        for (uint32_t i = t; i < whole; i += kBlock) zl[i] = tab->header[i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
+        if (!stored && job.is_first && (tab->header_bits & 7)) zl[tab->header_bits >> 3] |= tab->header[tab->header_bits >> 3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// emit_kernel: grid (ceil(max_rows/4), n_jobs)
+// ---------------------------------------------------------------------------------------------
+// Stored-block fallback, one row per wave (reference fpng.cpp:818-866 over the filter-0 stream,
+// :1728-1758).  Stream byte s of the filter-0 image sits at zlib offset 2 + 5*(s/65535+1) + s.
+__device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *rows_out)
+{
+    const uint32_t bpl = job.bpl, n_row = bpl + 1;
+    gptr_cu8 src = to_global<gptr_cu8>(job.rows) + (size_t)r * bpl;
+    gptr_u8 z = to_global<gptr_u8>(job.out) + kPngHeaderBytes;
+    const uint64_t n_filtered = (uint64_t)n_row * job.nrows;
+    const uint64_t s0 = (uint64_t)r * n_row;
+    if (r == 0 && lane == 0) {
+        z[0] = 0x78;
+        z[1] = 0x01;
+    }
+    uint32_t acc_a = 0;
+    uint64_t acc_w = 0;
+    for (uint32_t i = lane; i < n_row; i += kWave) {
+        const uint64_t s = s0 + i;
+        const uint64_t blk = s / kStoredBlockMax;
+        const uint64_t pos = 2 + 5 * (blk + 1) + s;
+        const uint32_t v = i ? src[i - 1] : 0u;
+        z[pos] = (uint8_t)v;
+        if (s % kStoredBlockMax == 0) { // first byte of a stored block: write its 5-byte header
+            const uint64_t remaining = n_filtered - s;
+            const uint32_t len = remaining < kStoredBlockMax ? (uint32_t)remaining : kStoredBlockMax;
+            gptr_u8 h = z + pos - 5;
+            h[0] = (remaining <= kStoredBlockMax) ? 1 : 0;
+            h[1] = (uint8_t)len;
+            h[2] = (uint8_t)(len >> 8);
+            h[3] = (uint8_t)~len;
+            h[4] = (uint8_t)(~len >> 8);
+        }
+        acc_a += v;
+        acc_w += (uint64_t)(n_row - i) * v;
+    }
+    const uint32_t s1 = wave_sum(acc_a % kAdlerMod) % kAdlerMod;
+    const uint32_t s2 = wave_sum((uint32_t)(acc_w % kAdlerMod)) % kAdlerMod;
+    if (lane == 0) {
+        RowInfo ri;
+        ri.bits = 0;
+        ri.s1 = s1;
+        ri.s2 = s2;
+        ri.pad = 0;
+        rows_out[job.row_base + r] = ri; // overwrites the compressed-mode partials: finalize recombines
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
+                                                     const JobState *states)
+{
+    __shared__ LdsTables T;
+    __shared__ uint32_t stage[kWavesPerBlock][kStageDwords];
+    const Job &job = job_of_block(jobs);
+    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    const JobState &st = states[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = blockIdx.x * kWavesPerBlock + wv;
+    if (st.mode == 1u) {
+        if (r < job.nrows) stored_row(job, r, lane, rows_io);
+        return;
+    }
+    stage_tables(T, job.table);
+    __syncthreads();
+    if (r >= job.nrows) return;
+
+    EmitSink sink;
+    sink.stage = stage[wv];
+    sink.out32 = to_global<gptr_u32>(job.out);
+    const uint64_t off = row_off[job.row_base + r] + job.bit_bias;
+    sink.base_dw = off >> 5;
+    sink.fill = (uint32_t)(off & 31);
+    sink.first_flush = true;
+    sink_zero(sink, lane, kStageDwords);
+    wave_lds_fence();
+
+    if (job.c == 4)
+        walk_row<4, Pass::Emit>(job, T, nullptr, r, lane, &sink);
+    else
+        walk_row<3, Pass::Emit>(job, T, nullptr, r, lane, &sink);
+
+    if (r == job.nrows - 1 && job.is_last) {
+        // end of block symbol; zero bits up to the byte boundary follow implicitly
+        // (reference fpng.cpp:1564-1567)
+        const uint32_t eob = T.lit[256];
+        if (lane == 0) sink_put(sink, eob & 0xFFFF, eob >> 16, sink.fill);
+        sink.fill += eob >> 16;
+    }
+    sink_flush(sink, lane, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// crc_kernel: raw (init 0, no final xor) CRC-32 partials of the zlib bytes except the 4 Adler
+// bytes (reference fpng.cpp:234-292 computes the same function serially / with pclmul).
+//
+// grid (max_crc_blocks, n_jobs).  Block j owns the 64 KiB range that ENDS j*64 KiB before the
+// 16-byte-aligned end of the data, so every lane does aligned 16-byte loads and the only padding
+// is < 16 zero bytes at the very end (undone with one constant in finalize_kernel); bytes in front
+// of the data count as zero, which a raw CRC ignores.  Per step the 256 lanes cover one 4 KiB block
+// row; each lane keeps the CRC of its own 16-byte stripe with slice-by-16 tables that already
+// contain the 4080-byte jump to its next piece.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dev_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll 8
+    for (int i = 31; i >= 0; i--) {
+        r ^= b & (0u - ((a >> i) & 1u));
+        b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobState *states, const CrcDeviceTables *tabs,
+                                                    uint32_t *partials, uint32_t max_crc_blocks)
+{
+    __shared__ uint32_t tab[16][256];
+    __shared__ uint32_t red[kWavesPerBlock];
+    const Job &job = job_of_block(jobs);
+    const JobState &st = states[blockIdx.y];
+    if (!job.whole_png) return;
+    const int64_t data_begin = kPngHeaderBytes, data_end = (int64_t)(kPngHeaderBytes + st.zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * kCrcRangeBytes;
+    if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
+    for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
+    __syncthreads();
+    gptr_cu8 base = to_global<gptr_cu8>(job.out);
+    const uint32_t tid = threadIdx.x;
+    uint32_t c = 0;
+    for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
+        const int64_t o = range_end - kCrcRangeBytes + (int64_t)row * kCrcRowBytes + tid * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (o + 16 > data_begin && o < data_end) {
+            const u32x4 d = *(gptr_cu128)(base + o);
+            w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
+            if (o < data_begin || o + 16 > data_end) { // zero the bytes outside [data_begin, data_end)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int64_t pos = o + 4 * k + b;
+                        if (pos >= data_begin && pos < data_end) m |= 0xFFu << (8 * b);
+                    }
+                    w[k] &= m;
+                }
+            }
+        }
+        w[0] ^= c;
+        uint32_t n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            n ^= tab[4 * k + 0][w[k] & 0xFF] ^ tab[4 * k + 1][(w[k] >> 8) & 0xFF] ^ tab[4 * k + 2][(w[k] >> 16) & 0xFF] ^
+                 tab[4 * k + 3][w[k] >> 24];
+        c = n;
+    }
+    // lane stripes now sit at range_end + 16*tid: move them all to range_end + one block row, fold
+    c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) partials[(size_t)blockIdx.y * max_crc_blocks + blockIdx.x] = red[0] ^ red[1] ^ red[2] ^ red[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize_kernel: one block per job
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dev_crc_byte(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    return c;
+}
+
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *red64)
+{
+    const uint32_t t = threadIdx.x;
+    red64[t] = v;
+    __syncthreads();
+    for (uint32_t o = kBlock / 2; o > 0; o >>= 1) {
+        if (t < o) red64[t] += red64[t + o];
+        __syncthreads();
+    }
+    const uint64_t r = red64[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const RowInfo *rows, JobState *states,
+                                                         const CrcDeviceTables *tabs, const uint32_t *partials,
+                                                         uint32_t max_crc_blocks, Result *results)
+{
+    __shared__ uint32_t red[kBlock];
+    __shared__ uint64_t red64[kBlock];
+    const Job &job = jobs[blockIdx.x];
+    JobState &st = states[blockIdx.x];
+    const uint32_t t = threadIdx.x;
+    if (!job.whole_png) {
+        if (t == 0) {
+            results[blockIdx.x].png_size = 0;
+            results[blockIdx.x].mode = st.mode;
+            results[blockIdx.x].status = 0;
+        }
+        return;
+    }
+    uint32_t adler = st.adler;
+    if (st.mode == 1u) {
+        // stored mode: Adler of the filter-0 stream from the per-row partials written by stored_row
+        const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
+        uint64_t s1 = 0, s2 = 0;
+        for (uint32_t r = t; r < job.nrows; r += kBlock) {
+            const RowInfo ri = rows[job.row_base + r];
+            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+            s1 += ri.s1;
+            s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
+        }
+        const uint64_t S1 = block_sum_u64(s1 % kAdlerMod, red64) % kAdlerMod;
+        const uint64_t S2 = block_sum_u64(s2 % kAdlerMod, red64) % kAdlerMod;
+        const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
+        adler = (uint32_t)(((n_filtered % kAdlerMod + S2) % kAdlerMod) << 16) | (uint32_t)((1 + S1) % kAdlerMod);
+    }
+
+    // ---- fold the CRC partials.  Partial j sits (j ranges + one block row) before the common end
+    //      point, so  T = XOR_j p_j * X^j  with X = x^(8*64Ki); all needed constants are x^(8*2^i). ----
+    const uint64_t zlib_size = st.zlib_size;
+    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + kCrcRangeBytes - 1) / kCrcRangeBytes);
+    uint32_t g = 0; // each thread folds G = 2^g consecutive partials
+    while (((uint64_t)kBlock << g) < n_ranges) g++;
+    const uint32_t G = 1u << g;
+    const uint32_t *pj = partials + (size_t)blockIdx.x * max_crc_blocks;
+    uint32_t v = 0;
+    {
+        const uint32_t X = tabs->pow2[16]; // x^(8*2^16)
+        for (int i = (int)G - 1; i >= 0; i--) {
+            const uint32_t j = t * G + (uint32_t)i;
+            if (v) v = dev_mulmod(v, X);
+            if (j < n_ranges) v ^= pj[j];
+        }
+    }
+    red[t] = v;
+    __syncthreads();
+    for (uint32_t l = 0; (1u << l) < kBlock; l++) {
+        if ((t & ((2u << l) - 1u)) == 0) {
+            const uint32_t other = red[t + (1u << l)];
+            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[16 + g + l]);
+        }
+        __syncthreads();
+    }
+    const uint32_t folded = red[0];
+    __syncthreads();
+    // x^(8*(zlib_size-4)) as a product over the set bits of the exponent, multiplied as a tree
+    {
+        const uint64_t e = zlib_size - 4;
+        uint32_t f = 0x80000000u; // 1
+        if (t < 48 && ((e >> t) & 1)) f = tabs->pow2[t];
+        red[t] = f;
+        __syncthreads();
+        for (uint32_t o = 32; o > 0; o >>= 1) {
+            if (t < o) red[t] = dev_mulmod(red[t], red[t + o]);
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        gptr_u8 out = to_global<gptr_u8>(job.out);
+        const uint32_t pad = (uint32_t)(end_aligned - data_end);
+        const uint32_t raw_data = dev_mulmod(dev_mulmod(folded, tabs->inv_row), tabs->inv_pad[pad]);
+        // running CRC state (init ~0) after "IDAT", advanced over the data, then the 4 Adler bytes
+        uint32_t s = 0xFFFFFFFFu;
+        s = dev_crc_byte(s, 'I');
+        s = dev_crc_byte(s, 'D');
+        s = dev_crc_byte(s, 'A');
+        s = dev_crc_byte(s, 'T');
+        s = dev_mulmod(s, red[0]) ^ raw_data;
+        gptr_u8 tail = out + kPngHeaderBytes + zlib_size - 4;
+        store_be32(tail, adler); // reference fpng.cpp:1569-1577 / :851-863
+        s = dev_crc_byte(s, adler >> 24);
+        s = dev_crc_byte(s, (adler >> 16) & 0xFF);
+        s = dev_crc_byte(s, (adler >> 8) & 0xFF);
+        s = dev_crc_byte(s, adler & 0xFF);
+        const uint32_t crc = ~s;
+        store_be32(tail + 4, crc); // reference fpng.cpp:1797-1800
+        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+        for (int i = 0; i < 12; i++) tail[8 + i] = iend[i];
+        st.adler = adler;
+        st.crc = crc;
+        results[blockIdx.x].png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes;
+        results[blockIdx.x].mode = st.mode;
+        results[blockIdx.x].status = 0;
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static dim3 row_grid(uint32_t max_rows, uint32_t n_jobs)
+{
+    return dim3((max_rows + kWavesPerBlock - 1) / kWavesPerBlock, n_jobs, 1);
+}
+
+void launch_count(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states)
+{
+    hipLaunchKernelGGL(count_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, rows, states);
+}
+void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist)
+{
+    hipLaunchKernelGGL(hist_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, hist);
+}
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, row_off, states);
+}
+void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
+                 const JobState *states)
+{
+    hipLaunchKernelGGL(emit_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, row_off, rows, states);
+}
+void launch_build_dynamic(hipStream_t, const Job *, uint32_t, const uint32_t *, TokenTable *) {}
+void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
+                const CrcDeviceTables *tabs, uint32_t *partials)
+{
+    hipLaunchKernelGGL(crc_kernel, dim3(max_crc_blocks, n_jobs), dim3(kBlock), 0, s, jobs, states, tabs, partials,
+                       max_crc_blocks);
+}
+void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
+                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, states, tabs, partials, max_crc_blocks,
+                       results);
+}
+
+} // namespace fpng_amd

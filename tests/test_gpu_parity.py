@@ -1,0 +1,187 @@
+"""GPU parity tests (-m gpu): the HIP encoder, called through the C ABI, against the oracle, the
+committed golden vectors and size-independent properties.  Bit-exact is the bar."""
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from cpu_ref import ROOT, fuzz_image, have_ref, oracle, ref
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def enc(built_lib):
+    import torch
+    import fpng_amd
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    e = fpng_amd.Encoder(device=0)
+    yield e
+    e.close()
+
+
+def _gpu_encode(enc, imgs, flags=0):
+    import torch
+    ts = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    pngs, modes = enc.encode_tensors(ts, flags)
+    return pngs, modes
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    x = np.frombuffer(a[:n], dtype=np.uint8) != np.frombuffer(b[:n], dtype=np.uint8)
+    return int(np.argmax(x)) if x.any() else n
+
+
+def _assert_same(png, exp, what):
+    if png != exp:
+        d = _first_diff(png, exp)
+        raise AssertionError(f"{what}: sizes {len(png)} vs {len(exp)}, first difference at byte {d}: "
+                             f"{png[d:d+8].hex()} vs {exp[d:d+8].hex()}")
+
+
+def _kat():
+    with open(os.path.join(GOLD, "kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("entry", _kat(), ids=lambda e: f'{e["kind"]}_{e["w"]}x{e["h"]}x{e["c"]}')
+@pytest.mark.parametrize("flags", [0, 2])
+def test_golden_kat(enc, entry, flags):
+    """Known answers produced by the unmodified reference (tests/golden/kat.json), up to 8K RGBA."""
+    import fpng_amd
+    w, h, c = entry["w"], entry["h"], entry["c"]
+    img = fpng_amd.synth_image(entry["kind"], w, h, c)
+    (png,), (mode,) = _gpu_encode(enc, [img], flags)
+    exp = entry["flags"][str(flags)]
+    assert len(png) == exp["size"]
+    assert hashlib.sha256(png).hexdigest() == exp["sha256"]
+    assert mode == (1 if exp["btype"] == 0 else 0)
+
+
+def test_golden_small_files(enc):
+    import fpng_amd
+    for name in sorted(os.listdir(os.path.join(GOLD, "small"))):
+        kind, dims, fl = name[:-4].split("_")
+        if fl == "f1":
+            continue
+        w, h, c = (int(v) for v in dims.split("x"))
+        with open(os.path.join(GOLD, "small", name), "rb") as f:
+            exp = f.read()
+        (png,), _ = _gpu_encode(enc, [fpng_amd.synth_image(kind, w, h, c)], int(fl[1:]))
+        _assert_same(png, exp, name)
+
+
+def test_golden_fuzz_cases(enc):
+    z = np.load(os.path.join(GOLD, "fuzz_cases.npz"))
+    imgs, exps = [], []
+    for i, (w, h, c) in enumerate(z["meta"]):
+        imgs.append(z["img"][z["img_off"][i]:z["img_off"][i + 1]].reshape(int(h), int(w), int(c)))
+        exps.append(z["o0"][z["o0_off"][i]:z["o0_off"][i + 1]].tobytes())
+    pngs, _ = _gpu_encode(enc, imgs, 0)
+    for i, (p, e) in enumerate(zip(pngs, exps)):
+        _assert_same(p, e, f"fuzz case {i} {tuple(z['meta'][i])}")
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_fuzz_vs_oracle_batched(enc, flags):
+    """2000 edge-case images (SURVEY B.3 recipe), encoded as batches in single submissions."""
+    rng = np.random.default_rng(100 + flags)
+    stored = 0
+    for _ in range(10):
+        cases = [fuzz_image(rng) for _ in range(200)]
+        pngs, modes = _gpu_encode(enc, [c[0] for c in cases], flags)
+        for (img, w, h, c), p in zip(cases, pngs):
+            _assert_same(p, oracle().encode(img, w, h, c, flags), f"fuzz {w}x{h}x{c}")
+        stored += sum(modes)
+    assert stored > 100
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_widths_around_window_and_chunk_limits(enc, c):
+    """Window (64 px) and chunk-cap (63 / 85 px) boundaries, runs crossing windows."""
+    rng = np.random.default_rng(7 + c)
+    imgs, dims = [], []
+    for w in [1, 2, 3, 62, 63, 64, 65, 66, 84, 85, 86, 87, 126, 127, 128, 129, 130, 170, 171, 172, 191, 192, 193, 255, 256,
+              257, 500, 1000, 4099]:
+        for h in (1, 2, 5):
+            for kind in range(4):
+                if kind == 0:      # solid
+                    img = np.full((h, w, c), 77, dtype=np.uint8)
+                elif kind == 1:    # long runs with random breaks
+                    img = np.repeat(rng.integers(0, 256, (h, (w + 39) // 40, c), dtype=np.uint8), 40, axis=1)[:, :w]
+                elif kind == 2:    # runs of random length 1..200 on the FILTERED rows: make rows identical so Up gives zeros after row 0
+                    row = np.repeat(rng.integers(0, 256, (1, w, c), dtype=np.uint8), h, axis=0)
+                    brk = rng.random((1, w)) < 0.03
+                    row[:, ~brk[0]] = 0
+                    row = np.maximum.accumulate(row, axis=1)
+                    img = row
+                else:              # two-pixel alternation (1-pixel matches -> literal-vs-match rule)
+                    a = rng.integers(0, 256, (h, 1, c), dtype=np.uint8)
+                    img = np.repeat(a, w, axis=1).copy()
+                    img[:, 2::3] = rng.integers(0, 256, (h, len(range(2, w, 3)), c), dtype=np.uint8)
+                imgs.append(np.ascontiguousarray(img))
+                dims.append((w, h, c))
+    pngs, _ = _gpu_encode(enc, imgs, 0)
+    for img, (w, h, c_), p in zip(imgs, dims, pngs):
+        _assert_same(p, oracle().encode(img, w, h, c_, 0), f"{w}x{h}x{c_}")
+
+
+def test_mixed_batch_shapes_and_channels(enc):
+    import fpng_amd
+    imgs = [fpng_amd.synth_image(k, w, h, c) for (k, w, h, c) in
+            [("grad", 640, 480, 3), ("blocks", 333, 77, 4), ("noise", 50, 50, 4), ("solid", 1, 1, 3), ("grad", 1921, 3, 4),
+             ("noise", 7, 300, 3), ("blocks", 1024, 1024, 3), ("grad", 2, 2, 4)]]
+    pngs, _ = _gpu_encode(enc, imgs, 0)
+    for img, p in zip(imgs, pngs):
+        h, w, c = img.shape
+        _assert_same(p, oracle().encode(img, w, h, c, 0), f"{w}x{h}x{c}")
+
+
+def test_full_size_properties_8k(enc):
+    """BASELINE north-star size: checks that do not need a CPU encode of the full image.
+    zlib inflates the payload to exactly the Up-filtered image; CRC and Adler verify."""
+    import fpng_amd
+    w, h, c = 7680, 4320, 4
+    img = fpng_amd.synth_image("grad", w, h, c, seed=4242)
+    (png,), (mode,) = _gpu_encode(enc, [img], 0)
+    assert mode == 0 and png[:8] == b"\x89PNG\r\n\x1a\n"
+    idat = int.from_bytes(png[50:54], "big")
+    assert len(png) == 58 + idat + 16
+    raw = np.frombuffer(zlib.decompress(png[58:58 + idat]), dtype=np.uint8).reshape(h, w * c + 1)
+    src = img.reshape(h, w * c)
+    assert (raw[0, 1:] == src[0]).all() and raw[0, 0] == 0 and (raw[1:, 0] == 2).all()
+    assert (raw[1:, 1:] == (src[1:] - src[:-1])).all()
+    assert zlib.crc32(png[54:58 + idat]) == int.from_bytes(png[58 + idat:62 + idat], "big")
+    assert png[-12:] == bytes([0, 0, 0, 0, 73, 69, 78, 68, 0xAE, 0x42, 0x60, 0x82])
+    if have_ref():
+        st, out, ww, hh, cc = ref().decode(png, 4)
+        assert st == 0 and (out == img.reshape(-1)).all()
+
+
+def test_host_buffer_entry_point(enc):
+    """fpng_amd_encode_host: what the fpng:: drop-in calls."""
+    import fpng_amd
+    for (k, w, h, c) in [("grad", 300, 200, 3), ("noise", 64, 64, 4), ("blocks", 777, 33, 4)]:
+        img = fpng_amd.synth_image(k, w, h, c)
+        for fl in (0, 2):
+            ok, png = fpng_amd.fpng_encode_image_to_memory(img, w, h, c, fl)
+            assert ok
+            _assert_same(png, oracle().encode(img, w, h, c, fl), f"{k} {w}x{h}x{c} f{fl}")
+    ok, png = fpng_amd.fpng_encode_image_to_memory(np.zeros(16, dtype=np.uint8), 0, 4, 3)
+    assert not ok                                           # reference fpng.cpp:1670-1674
+    ok, png = fpng_amd.fpng_encode_image_to_memory(np.zeros(16, dtype=np.uint8), 2, 2, 2)
+    assert not ok                                           # reference fpng.cpp:1676-1680
+
+
+def test_repeated_submissions_reuse_scratch(enc):
+    import fpng_amd
+    img = fpng_amd.synth_image("grad", 800, 600, 4)
+    exp = oracle().encode(img, 800, 600, 4, 0)
+    for _ in range(5):
+        (png,), _ = _gpu_encode(enc, [img], 0)
+        assert png == exp

@@ -280,7 +280,9 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
     for (uint32_t j = lane; j < ndw; j += kWave) {
         const uint32_t v = s.stage[j];
         gptr_u32 dst = s.out32 + s.base_dw + j;
-        const bool shared = (j == 0 && s.first_flush) || (final && j == ndw - 1);
+        // the last dword is shared only when the row ends inside it (then it holds the next row's
+        // first bit, or the job's end, both of which scan_kernel zeroed)
+        const bool shared = (j == 0 && s.first_flush) || (final && j == ndw - 1 && (s.fill & 31u));
         if (shared) {
             if (v) __hip_atomic_fetch_or(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the fpng encode hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|4k|1080p] [--batch B] [--flags F]
+
+A "step" is one submission of the hot path (fpng_encode_image_to_memory semantics, 1-pass) over a
+batch of B synthetic device-resident images; inputs and outputs live in HBM for the whole timed
+region (no PCIe).  Default workload: the configuration BASELINE.json's metric is quoted on --
+7680x4320 RGBA `grad` frames, B distinct frames per step so the working set
+(B x 133 MB in + PNG out) is far larger than the 256 MiB Infinity Cache.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes its own
+batch (images are independent objects: no data-path collective), time is max over ranks,
+value = all ranks' pixels / that time, scaling = weak.
+
+Rank 0 prints ONE JSON line, including
+  roofline     : dominant kernel's algorithmic bytes / its HIP-event-measured duration vs 8 TB/s
+  cpu_baseline : the reference's own SSE4.1 encoder (oracle/_ref) timed on one host core on a
+                 bounded sample of the same workload (falls back to the C port in oracle/)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {"8k": (7680, 4320, 4), "4k": (3840, 2160, 4), "1080p": (1920, 1080, 3), "512": (512, 512, 3)}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--kind", default="grad")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(w, h, c, kind, flags, reps):
+    """The reference's CPU path on ONE host core (rank 0, N=1 only).  Checker-side code: this is the
+    only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ref
+    import fpng_amd
+    img = fpng_amd.synth_image(kind, w, h, c)
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+    mp = w * h / 1e6
+    if cpu_ref.have_ref():
+        r = cpu_ref.ref()
+        secs, size = r.time_encode(img, w, h, c, flags, reps)
+        return {"value": round(mp / secs, 2), "unit": "MP/s", "cores": 1, "kind": "reference",
+                "sample": f"1 image {w}x{h}x{c} {kind}, best of {reps}, fpng.cpp SSE4.1+PCLMUL build (sse41={r.L.ref_supports_sse41()})",
+                "png_bytes": size}
+    o = cpu_ref.oracle()
+    best = 1e30
+    for _ in range(max(1, reps // 2)):
+        t0 = time.perf_counter()
+        png = o.encode(img, w, h, c, flags)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(mp / best, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": f"1 image {w}x{h}x{c} {kind}, best of {max(1, reps // 2)}, scalar C port", "png_bytes": len(png)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import fpng_amd
+    w, h, c = WORKLOADS[args.workload]
+    B = args.batch
+    # B distinct frames per rank (seed varies per image and per rank)
+    imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]
+    cap = fpng_amd.max_encoded_size(w, h, c) + 64
+    outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)]
+    enc = fpng_amd.Encoder(device=local_rank, stream="own")
+
+    def step():
+        enc.submit(imgs, outs, args.flags)
+        return enc.finish(B)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    png_bytes = sum(r[0] for r in res)
+    assert all(r[2] == 0 for r in res)
+    pixels_per_step = B * w * h
+    value = world * pixels_per_step * args.steps / elapsed / 1e6
+
+    # ---- per-kernel durations with HIP events on the encoder's own stream (untimed extra steps) ----
+    enc.set_profiling(True)
+    phases = np.zeros(8)
+    reps = 5
+    for _ in range(reps):
+        step()
+        phases += np.array(enc.last_phase_ms())
+    phases /= reps
+    enc.set_profiling(False)
+    names = ["count", "scan", "emit", "crc", "finalize"]
+    phase_ms = {n: round(float(phases[i]), 4) for i, n in enumerate(names)}
+    alg_bytes = B * w * h * c + png_bytes  # input read once + PNG written once
+    dom = max(("count", "emit", "crc"), key=lambda k: phase_ms[k])
+    dom_s = phase_ms[dom] / 1e3
+    achieved = alg_bytes / dom_s / 1e9
+    kernels_s = sum(phase_ms[k] for k in ("count", "scan", "emit", "crc", "finalize")) / 1e3
+    roofline = {"bound": "hbm", "kernel": f"{dom}_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": phase_ms[dom],
+                "all_kernels_ms": round(kernels_s * 1e3, 4),
+                "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": phase_ms}
+
+    line = {
+        "metric": "encode megapixels/sec (whole node), 1-pass, device-resident",
+        "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{B} x {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' frames per GPU per step, "
+                               f"flags={args.flags}, bit-exact fpng PNG output", "batch_per_gpu": B,
+                   "width": w, "height": h, "channels": c, "png_bytes_per_step_per_gpu": png_bytes,
+                   "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(w, h, c, args.kind, args.flags, args.cpu_reps)
+        line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(line))
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,7 +75,7 @@ int ensure_device_tables(int dev)
         for (uint32_t q = 1; q <= cap; q++) {
             uint32_t s, e;
             deflate_length_symbol(q * c - 3, &s, &e);
-            sym.chunk[q] = s - 256;
+            sym.chunk[q] = (s - 256) | (e << 8) | (((q * c - 3) & ((1u << e) - 1u)) << 16);
         }
         HIP_TRY(hipMalloc(&d.symbols[c], sizeof(TokenTable)));
         HIP_TRY(hipMemcpy(d.symbols[c], &sym, sizeof(TokenTable), hipMemcpyHostToDevice));

@@ -923,6 +923,288 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// build_dynamic_kernel (2-pass): histogram -> per-image Huffman table + Deflate dynamic block
+// header, one wave per image, everything in LDS.
+//
+// The table must be THE table the reference builds, not merely an optimal one: code lengths depend
+// on its tie-breaking (reference fpng.cpp:868-907 adjust_freq32, :622-709 sort / minimum redundancy /
+// length limit / canonical codes, :746-816 header).  Restated here as: stable rank sort (parallel),
+// two-queue Huffman merge that prefers the leaf on ties with 16-bit node weights, leaf depths by
+// parent walking (parallel), Kraft repair, shortest codes to the heaviest symbols, canonical
+// bit-reversed codes, run-length packing of the code lengths with symbols 16/17/18.
+// ---------------------------------------------------------------------------------------------
+struct BuilderLds {
+    uint32_t count[288];            // 16-bit symbol counts
+    uint32_t skey[288], ssym[288];  // used symbols sorted by (count, symbol)
+    uint32_t iw[288];               // internal node weights (mod 2^16)
+    int iparent[288], lparent[288];
+    int num_codes[40];
+    uint32_t len[288], code[288];   // result of the last build_table call
+    uint32_t lit_len[288], lit_code[288];
+    uint32_t seq[320], packed[640], npacked;
+    uint32_t c2[19], cl_len[19], cl_code[19];
+    uint32_t hdr[100];              // header bits, LSB-first
+    uint32_t used, tmp;
+};
+
+__device__ __forceinline__ uint32_t dev_bitrev(uint32_t v, uint32_t n)
+{
+    return n ? (__brev(v) >> (32 - n)) : 0u;
+}
+
+// Code lengths (<= max_len) and canonical codes for n symbols with counts L.count[0..n).
+__device__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uint32_t lane)
+{
+    // ---- stable sort of the used symbols by count: every element computes its own rank ----
+    if (lane == 0) L.used = 0;
+    wave_lds_fence();
+    for (uint32_t i = lane; i < n; i += kWave) {
+        const uint32_t k = L.count[i];
+        if (k) {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t kj = L.count[j];
+                rank += (kj != 0) && (kj < k || (kj == k && j < i));
+            }
+            L.skey[rank] = k;
+            L.ssym[rank] = i;
+            atomicAdd(&L.used, 1u);
+        }
+    }
+    for (uint32_t i = lane; i < 40; i += kWave) L.num_codes[i] = 0;
+    for (uint32_t i = lane; i < n; i += kWave) L.len[i] = 0, L.code[i] = 0;
+    wave_lds_fence();
+    const uint32_t used = L.used;
+    if (used == 1) {
+        if (lane == 0) L.num_codes[1] = 1;
+    } else if (used >= 2) {
+        if (lane == 0) {
+            // two-queue merge: leaves ascending, internal nodes in creation order; an internal node is
+            // taken only when strictly lighter than the next leaf (reference fpng.cpp:645-651)
+            uint32_t leaf = 0, root = 0, made = 0;
+            while (made < used - 1) {
+                uint32_t wsum = 0;
+                for (int k = 0; k < 2; k++) {
+                    if (leaf >= used || (root < made && L.iw[root] < L.skey[leaf])) {
+                        wsum += L.iw[root];
+                        L.iparent[root++] = (int)made;
+                    } else {
+                        wsum += L.skey[leaf];
+                        L.lparent[leaf++] = (int)made;
+                    }
+                }
+                L.iw[made++] = wsum & 0xFFFFu;
+            }
+        }
+        wave_lds_fence();
+        // leaf depth = number of parent hops to the root (the last internal node)
+        for (uint32_t i = lane; i < used; i += kWave) {
+            int node = L.lparent[i], d = 1;
+            while (node != (int)used - 2) {
+                node = L.iparent[node];
+                d++;
+            }
+            atomicAdd(&L.num_codes[d > 39 ? 39 : d], 1);
+        }
+        wave_lds_fence();
+        if (lane == 0) {
+            // Kraft repair (reference fpng.cpp:663-674)
+            for (uint32_t l = max_len + 1; l < 40; l++) {
+                L.num_codes[max_len] += L.num_codes[l];
+                L.num_codes[l] = 0;
+            }
+            uint32_t total = 0;
+            for (uint32_t l = max_len; l > 0; l--) total += (uint32_t)L.num_codes[l] << (max_len - l);
+            while (total != (1u << max_len)) {
+                L.num_codes[max_len]--;
+                for (uint32_t l = max_len - 1; l > 0; l--)
+                    if (L.num_codes[l]) {
+                        L.num_codes[l]--;
+                        L.num_codes[l + 1] += 2;
+                        break;
+                    }
+                total--;
+            }
+        }
+    }
+    wave_lds_fence();
+    // shortest codes to the END of the sorted order (reference fpng.cpp:697-698)
+    for (uint32_t i = lane; i < used; i += kWave) {
+        const uint32_t from_end = used - 1 - i;
+        uint32_t acc = 0, l = 1;
+        for (; l <= max_len; l++) {
+            acc += (uint32_t)L.num_codes[l];
+            if (acc > from_end) break;
+        }
+        L.len[L.ssym[i]] = l;
+    }
+    wave_lds_fence();
+    // canonical codes in symbol order, bit-reversed (reference fpng.cpp:699-708)
+    for (uint32_t i = lane; i < n; i += kWave) {
+        const uint32_t l = L.len[i];
+        if (!l) continue;
+        uint32_t first = 0;
+        for (uint32_t k = 1; k < l; k++) first = (first + (uint32_t)L.num_codes[k]) << 1;
+        uint32_t before = 0;
+        for (uint32_t j = 0; j < i; j++) before += (L.len[j] == l);
+        L.code[i] = dev_bitrev(first + before, l);
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ void hdr_put(BuilderLds &L, uint32_t &pos, uint32_t v, uint32_t nbits)
+{
+    const uint32_t d = pos >> 5, sh = pos & 31;
+    L.hdr[d] |= v << sh;
+    if (sh + nbits > 32) L.hdr[d + 1] |= v >> (32 - sh);
+    pos += nbits;
+}
+
+__global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, const uint32_t *hist_all, TokenTable *tables)
+{
+    __shared__ BuilderLds L;
+    const Job &job = jobs[blockIdx.x];
+    const uint32_t lane = threadIdx.x, c = job.c;
+    const uint32_t *hist = hist_all + (size_t)blockIdx.x * 288;
+    const TokenTable *symtab = job.table; // chunk[q] = (length symbol - 256) | extra_bits << 8 | extra_value << 16
+    TokenTable *out = tables + blockIdx.x;
+
+    // ---- adjust_freq32 (reference fpng.cpp:868-907): scale to 16 bits, never to zero.  Its
+    //      ">65535" repair loop only rewrites the 32-bit input, which nothing reads afterwards. ----
+    uint32_t part = 0;
+    for (uint32_t i = lane; i < 288; i += kWave) part += (i == 256) ? 1u : hist[i];
+    const uint32_t total = wave_sum(part); // uint32 wrap-around like the reference's total_freq
+    for (uint32_t i = lane; i < 288; i += kWave) {
+        const uint32_t f = (i == 256) ? 1u : hist[i];
+        uint32_t v = 0;
+        if (f && total) {
+            v = (uint32_t)(((uint64_t)f * 65535ull) / total);
+            if (!v) v = 1;
+        }
+        if (i == 256) v = 1; // reference fpng.cpp:757
+        L.count[i] = v;
+    }
+    for (uint32_t i = lane; i < 100; i += kWave) L.hdr[i] = 0;
+    wave_lds_fence();
+    dev_build_table(L, 288, 12, lane);
+    for (uint32_t i = lane; i < 288; i += kWave) L.lit_len[i] = L.len[i], L.lit_code[i] = L.code[i];
+    wave_lds_fence();
+
+    // distance tree: exactly two used symbols (c-1 and c), both get 1-bit codes, the real one code 0
+    // (reference fpng.cpp:1095-1099 / :1375-1377)
+    uint32_t n_lit = 286, n_dist = c + 1;
+    while (n_lit > 257 && !L.lit_len[n_lit - 1]) n_lit--;
+    const uint32_t n_seq = n_lit + n_dist;
+    for (uint32_t i = lane; i < n_seq; i += kWave)
+        L.seq[i] = (i < n_lit) ? L.lit_len[i] : ((i - n_lit == c - 1 || i - n_lit == c) ? 1u : 0u);
+    for (uint32_t i = lane; i < 19; i += kWave) L.c2[i] = 0;
+    wave_lds_fence();
+
+    // ---- run-length packing of the code lengths (reference fpng.cpp:711-726, :770-794) ----
+    if (lane == 0) {
+        uint32_t np = 0, zrun = 0, rep = 0, prev = 0xFF;
+        auto flush_rep = [&]() {
+            if (!rep) return;
+            if (rep < 3) {
+                L.c2[prev] += rep;
+                while (rep--) L.packed[np++] = prev;
+            } else {
+                L.c2[16]++;
+                L.packed[np++] = 16;
+                L.packed[np++] = rep - 3;
+            }
+            rep = 0;
+        };
+        auto flush_zero = [&]() {
+            if (!zrun) return;
+            if (zrun < 3) {
+                L.c2[0] += zrun;
+                while (zrun--) L.packed[np++] = 0;
+            } else if (zrun <= 10) {
+                L.c2[17]++;
+                L.packed[np++] = 17;
+                L.packed[np++] = zrun - 3;
+            } else {
+                L.c2[18]++;
+                L.packed[np++] = 18;
+                L.packed[np++] = zrun - 11;
+            }
+            zrun = 0;
+        };
+        for (uint32_t i = 0; i < n_seq; i++) {
+            const uint32_t cs = L.seq[i];
+            if (!cs) {
+                flush_rep();
+                if (++zrun == 138) flush_zero();
+            } else {
+                flush_zero();
+                if (cs != prev) {
+                    flush_rep();
+                    L.c2[cs]++;
+                    L.packed[np++] = cs;
+                } else if (++rep == 6)
+                    flush_rep();
+            }
+            prev = cs;
+        }
+        if (rep)
+            flush_rep();
+        else
+            flush_zero();
+        L.npacked = np;
+    }
+    wave_lds_fence();
+    for (uint32_t i = lane; i < 288; i += kWave) L.count[i] = (i < 19) ? (L.c2[i] & 0xFFFFu) : 0u;
+    wave_lds_fence();
+    dev_build_table(L, 19, 7, lane);
+    for (uint32_t i = lane; i < 19; i += kWave) L.cl_len[i] = L.len[i], L.cl_code[i] = L.code[i];
+    wave_lds_fence();
+
+    // ---- header bits (reference fpng.cpp:1279-1283 zlib header + BFINAL, :796-813 block header) ----
+    if (lane == 0) {
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint32_t pos = 0;
+        hdr_put(L, pos, 0x78, 8);
+        hdr_put(L, pos, 0x01, 8);
+        hdr_put(L, pos, 1, 1);
+        hdr_put(L, pos, 2, 2);
+        hdr_put(L, pos, n_lit - 257, 5);
+        hdr_put(L, pos, n_dist - 1, 5);
+        int nbl = 18;
+        while (nbl >= 0 && !L.cl_len[order[nbl]]) nbl--;
+        nbl = (nbl + 1 < 4) ? 4 : nbl + 1;
+        hdr_put(L, pos, (uint32_t)nbl - 4, 4);
+        for (int i = 0; i < nbl; i++) hdr_put(L, pos, L.cl_len[order[i]], 3);
+        const uint32_t np = L.npacked;
+        for (uint32_t i = 0; i < np;) {
+            const uint32_t sy = L.packed[i++];
+            hdr_put(L, pos, L.cl_code[sy], L.cl_len[sy]);
+            if (sy >= 16) hdr_put(L, pos, L.packed[i++], sy == 16 ? 2u : (sy == 17 ? 3u : 7u));
+        }
+        L.tmp = pos;
+    }
+    wave_lds_fence();
+
+    // ---- publish the table in the layout the row kernels consume ----
+    const uint32_t hbits = L.tmp;
+    for (uint32_t i = lane; i < 288; i += kWave) out->lit[i] = L.lit_code[i] | (L.lit_len[i] << 16);
+    const uint32_t cap = (c == 4) ? kMaxChunkPixels4 : kMaxChunkPixels3;
+    for (uint32_t q = lane; q < 96; q += kWave) {
+        uint32_t v = 0;
+        if (q >= 1 && q <= cap) {
+            const uint32_t e = symtab->chunk[q], sy = 256 + (e & 0xFF), extra = (e >> 8) & 0xFF, ev = e >> 16;
+            v = (L.lit_code[sy] | (ev << L.lit_len[sy])) | ((L.lit_len[sy] + extra + 1u) << 24);
+        }
+        out->chunk[q] = v;
+    }
+    for (uint32_t i = lane; i < 100; i += kWave) ((uint32_t *)out->header)[i] = L.hdr[i];
+    if (lane == 0) {
+        out->first_token_bit = hbits;
+        out->header_bits = hbits;
+    }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -950,7 +1232,10 @@ void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 {
     hipLaunchKernelGGL(emit_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, row_off, rows, states);
 }
-void launch_build_dynamic(hipStream_t, const Job *, uint32_t, const uint32_t *, TokenTable *) {}
+void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
+{
+    hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, hist, tables);
+}
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials)
 {

@@ -50,7 +50,7 @@ def _kat():
 
 
 @pytest.mark.parametrize("entry", _kat(), ids=lambda e: f'{e["kind"]}_{e["w"]}x{e["h"]}x{e["c"]}')
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 1, 2])
 def test_golden_kat(enc, entry, flags):
     """Known answers produced by the unmodified reference (tests/golden/kat.json), up to 8K RGBA."""
     import fpng_amd
@@ -67,8 +67,6 @@ def test_golden_small_files(enc):
     import fpng_amd
     for name in sorted(os.listdir(os.path.join(GOLD, "small"))):
         kind, dims, fl = name[:-4].split("_")
-        if fl == "f1":
-            continue
         w, h, c = (int(v) for v in dims.split("x"))
         with open(os.path.join(GOLD, "small", name), "rb") as f:
             exp = f.read()
@@ -85,9 +83,12 @@ def test_golden_fuzz_cases(enc):
     pngs, _ = _gpu_encode(enc, imgs, 0)
     for i, (p, e) in enumerate(zip(pngs, exps)):
         _assert_same(p, e, f"fuzz case {i} {tuple(z['meta'][i])}")
+    pngs, _ = _gpu_encode(enc, imgs, 1)
+    for i, p in enumerate(pngs):
+        _assert_same(p, z["o1"][z["o1_off"][i]:z["o1_off"][i + 1]].tobytes(), f"2-pass fuzz case {i} {tuple(z['meta'][i])}")
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 1, 2])
 def test_fuzz_vs_oracle_batched(enc, flags):
     """2000 edge-case images (SURVEY B.3 recipe), encoded as batches in single submissions."""
     rng = np.random.default_rng(100 + flags)
@@ -126,9 +127,10 @@ def test_widths_around_window_and_chunk_limits(enc, c):
                     img[:, 2::3] = rng.integers(0, 256, (h, len(range(2, w, 3)), c), dtype=np.uint8)
                 imgs.append(np.ascontiguousarray(img))
                 dims.append((w, h, c))
-    pngs, _ = _gpu_encode(enc, imgs, 0)
-    for img, (w, h, c_), p in zip(imgs, dims, pngs):
-        _assert_same(p, oracle().encode(img, w, h, c_, 0), f"{w}x{h}x{c_}")
+    for fl in (0, 1):
+        pngs, _ = _gpu_encode(enc, imgs, fl)
+        for img, (w, h, c_), p in zip(imgs, dims, pngs):
+            _assert_same(p, oracle().encode(img, w, h, c_, fl), f"{w}x{h}x{c_} flags={fl}")
 
 
 def test_mixed_batch_shapes_and_channels(enc):
@@ -168,7 +170,7 @@ def test_host_buffer_entry_point(enc):
     import fpng_amd
     for (k, w, h, c) in [("grad", 300, 200, 3), ("noise", 64, 64, 4), ("blocks", 777, 33, 4)]:
         img = fpng_amd.synth_image(k, w, h, c)
-        for fl in (0, 2):
+        for fl in (0, 1, 2):
             ok, png = fpng_amd.fpng_encode_image_to_memory(img, w, h, c, fl)
             assert ok
             _assert_same(png, oracle().encode(img, w, h, c, fl), f"{k} {w}x{h}x{c} f{fl}")
@@ -185,3 +187,16 @@ def test_repeated_submissions_reuse_scratch(enc):
     for _ in range(5):
         (png,), _ = _gpu_encode(enc, [img], 0)
         assert png == exp
+
+
+def test_two_pass_skewed_histogram_quirk(enc):
+    """adjust_freq32 with a large skewed histogram: vertical deltas in {0,+1,-1} plus
+    ~200 singleton outlier byte values; the 16-bit scaled counts sum past 65535 here."""
+    rng = np.random.default_rng(12)
+    w, h, c = 1024, 256, 3
+    d = rng.choice(np.array([0, 1, 255], dtype=np.uint8), size=(h, w * c), p=[0.9, 0.05, 0.05])
+    pos = rng.choice(h * w * c, size=200, replace=False)
+    d.reshape(-1)[pos] = rng.choice(np.arange(3, 250), size=200, replace=False).astype(np.uint8)
+    img = np.cumsum(d.astype(np.int64), axis=0).astype(np.uint8).reshape(h, w, c)
+    (png,), _ = _gpu_encode(enc, [img], 1)
+    _assert_same(png, oracle().encode(img, w, h, c, 1), "skewed 2-pass")

@@ -768,7 +768,7 @@ int fpo_encode(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, ui
 
 uint64_t fpo_encode_band_1pass(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t y0, uint32_t y1,
                                uint8_t *out, size_t out_cap, uint32_t *adler_s1, uint32_t *adler_s2,
-                               uint64_t *adler_len)
+                               uint64_t *adler_len, uint32_t *last_unit_bits)
 {
     ensure_init();
     bitw bw = {out, out_cap, 0, 0};
@@ -786,5 +786,6 @@ uint64_t fpo_encode_band_1pass(const void *image, uint32_t w, uint32_t h, uint32
     if (adler_s1) *adler_s1 = (uint32_t)k.s1;
     if (adler_s2) *adler_s2 = (uint32_t)k.s2;
     if (adler_len) *adler_len = k.nbytes;
+    if (last_unit_bits) *last_unit_bits = k.last_unit_bits;
     return bw.overflow ? 0 : bw.pos;
 }

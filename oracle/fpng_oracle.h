@@ -49,7 +49,8 @@ int fpo_encode(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, ui
  */
 uint64_t fpo_encode_band_1pass(const void *image, uint32_t w, uint32_t h, uint32_t num_chans,
                                uint32_t y0, uint32_t y1, uint8_t *out, size_t out_cap,
-                               uint32_t *adler_s1, uint32_t *adler_s2, uint64_t *adler_len);
+                               uint32_t *adler_s1, uint32_t *adler_s2, uint64_t *adler_len,
+                               uint32_t *last_unit_bits);
 
 /* Exposed for unit tests of the derived format tables. */
 void fpo_get_1pass_table(uint32_t num_chans, uint8_t len_out[288], uint16_t code_out[288],

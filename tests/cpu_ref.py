@@ -38,7 +38,7 @@ class _Oracle:
         L.fpo_encode_band_1pass.restype = C.c_uint64
         L.fpo_encode_band_1pass.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
-                                            C.POINTER(C.c_uint64)]
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.fpo_get_1pass_table.restype = None
         L.fpo_get_1pass_table.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -72,9 +72,10 @@ class _Oracle:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         cap = ((w * c + 1) * (y1 - y0) * 12 + 7) // 8 + 64
         out = np.zeros(cap, dtype=np.uint8)
-        s1, s2, ln = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        s1, s2, ln, lu = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
         bits = self.L.fpo_encode_band_1pass(img.ctypes.data, w, h, c, y0, y1, out.ctypes.data, cap, C.byref(s1),
-                                            C.byref(s2), C.byref(ln))
+                                            C.byref(s2), C.byref(ln), C.byref(lu))
+        self.last_unit_bits = lu.value
         return bits, out[: (bits + 7) // 8].copy(), s1.value, s2.value, ln.value
 
     def table_1pass(self, c):

@@ -47,10 +47,11 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    dropin_src = os.path.join(CSRC, "fpng_dropin.cpp")
-    if os.path.exists(dropin_src) and (force or _stale(DROPIN_LIB, [dropin_src, LIB, os.path.join(ROOT, "include", "fpng.h")])):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), dropin_src, "-o", DROPIN_LIB,
-               "-L", LIB_DIR, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"]
+    dropin_srcs = [os.path.join(CSRC, "fpng_dropin.cpp"), os.path.join(CSRC, "fpng_decode.cpp")]
+    if force or _stale(DROPIN_LIB, dropin_srcs + [LIB, os.path.join(ROOT, "include", "fpng.h")]):
+        # the `namespace fpng` drop-in: plain C++ over the C ABI, no HIP in it
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include")] + dropin_srcs + [
+            "-o", DROPIN_LIB, "-L", LIB_DIR, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,0 +1,78 @@
+// fpng_dropin.cpp -- `namespace fpng` (include/fpng.h) on top of the C ABI of libfpng_amd.so.
+//
+// Built by g++ into libfpng.so; it contains no HIP code and no encoder of its own: every encode call
+// goes through fpng_amd_encode_host() (H2D copy -> HIP kernels -> D2H copy).  Each thread gets its own
+// encoder object, so the functions stay re-entrant like the reference's.
+//
+// Decoding (fpng_get_info / fpng_decode_memory / fpng_decode_file) is a serial Huffman stream and
+// stays on the CPU: see fpng_decode.cpp.
+#include "fpng.h"
+
+#include "fpng_amd.h"
+
+#include <stdio.h>
+
+namespace fpng {
+
+namespace {
+struct ThreadEncoder {
+    fpng_amd_encoder *enc = nullptr;
+    ~ThreadEncoder()
+    {
+        if (enc) fpng_amd_encoder_destroy(enc);
+    }
+    fpng_amd_encoder *get()
+    {
+        if (!enc && fpng_amd_encoder_create(&enc, -1, nullptr) != FPNG_AMD_OK) enc = nullptr;
+        return enc;
+    }
+};
+thread_local ThreadEncoder t_encoder;
+} // namespace
+
+void fpng_init() { (void)fpng_amd_init(-1); }
+
+bool fpng_cpu_supports_sse41() { return fpng_amd_device_available() != 0; }
+
+uint32_t fpng_crc32(const void *pData, size_t size, uint32_t prev_crc32) { return fpng_amd_crc32(pData, size, prev_crc32); }
+
+uint32_t fpng_adler32(const void *pData, size_t size, uint32_t adler) { return fpng_amd_adler32(pData, size, adler); }
+
+// reference src/fpng.cpp:1662-1803: returns false on bad arguments; "does not compress" is not an
+// error (stored-block fallback happens on the device exactly where the reference would fall back).
+bool fpng_encode_image_to_memory(const void *pImage, uint32_t w, uint32_t h, uint32_t num_chans, std::vector<uint8_t> &out_buf,
+                                 uint32_t flags)
+{
+    if (!pImage) return false;
+    if ((w < 1) || (h < 1) || ((uint64_t)w * h > UINT32_MAX) || (w > (1u << 24)) || (h > (1u << 24))) return false;
+    if ((num_chans != 3) && (num_chans != 4)) return false;
+    fpng_amd_encoder *enc = t_encoder.get();
+    if (!enc) return false;
+    const size_t cap = fpng_amd_max_encoded_size(w, h, num_chans);
+    out_buf.resize(cap);
+    size_t size = 0;
+    if (fpng_amd_encode_host(enc, pImage, w, h, num_chans, flags, out_buf.data(), cap, &size) != FPNG_AMD_OK) {
+        out_buf.resize(0);
+        return false;
+    }
+    out_buf.resize(size);
+    return true;
+}
+
+#ifndef FPNG_NO_STDIO
+// reference src/fpng.cpp:1806-1828
+bool fpng_encode_image_to_file(const char *pFilename, const void *pImage, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t flags)
+{
+    std::vector<uint8_t> out_buf;
+    if (!fpng_encode_image_to_memory(pImage, w, h, num_chans, out_buf, flags)) return false;
+    FILE *f = fopen(pFilename, "wb");
+    if (!f) return false;
+    if (fwrite(out_buf.data(), 1, out_buf.size(), f) != out_buf.size()) {
+        fclose(f);
+        return false;
+    }
+    return fclose(f) != EOF;
+}
+#endif
+
+} // namespace fpng

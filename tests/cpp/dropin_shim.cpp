@@ -1,0 +1,40 @@
+// Test-only C shim so Python can call the `namespace fpng` drop-in (std::vector API) via ctypes.
+#include "fpng.h"
+#include <string.h>
+extern "C" {
+int shim_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, uint8_t *out, size_t cap, size_t *size)
+{
+    std::vector<uint8_t> v;
+    if (!fpng::fpng_encode_image_to_memory(img, w, h, c, v, flags)) return 0;
+    *size = v.size();
+    if (v.size() > cap) return 0;
+    memcpy(out, v.data(), v.size());
+    return 1;
+}
+int shim_encode_file(const char *name, const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags)
+{
+    return fpng::fpng_encode_image_to_file(name, img, w, h, c, flags) ? 1 : 0;
+}
+int shim_get_info(const void *png, uint32_t size, uint32_t *w, uint32_t *h, uint32_t *c) { return fpng::fpng_get_info(png, size, *w, *h, *c); }
+int shim_decode(const void *png, uint32_t size, uint8_t *out, size_t cap, uint32_t *w, uint32_t *h, uint32_t *c, uint32_t desired)
+{
+    std::vector<uint8_t> v;
+    int st = fpng::fpng_decode_memory(png, size, v, *w, *h, *c, desired);
+    if (st == 0) {
+        if (v.size() > cap) return -1;
+        memcpy(out, v.data(), v.size());
+    }
+    return st;
+}
+int shim_decode_file(const char *name, uint8_t *out, size_t cap, uint32_t *w, uint32_t *h, uint32_t *c, uint32_t desired)
+{
+    std::vector<uint8_t> v;
+    int st = fpng::fpng_decode_file(name, v, *w, *h, *c, desired);
+    if (st == 0 && v.size() <= cap) memcpy(out, v.data(), v.size());
+    return st;
+}
+void shim_init() { fpng::fpng_init(); }
+int shim_supported() { return fpng::fpng_cpu_supports_sse41() ? 1 : 0; }
+uint32_t shim_crc32(const void *p, size_t n, uint32_t prev) { return fpng::fpng_crc32(p, n, prev); }
+uint32_t shim_adler32(const void *p, size_t n, uint32_t prev) { return fpng::fpng_adler32(p, n, prev); }
+}

@@ -1,0 +1,70 @@
+"""Loads the `namespace fpng` C++ drop-in (fpng_amd/lib/libfpng.so) through a tiny test-only C shim."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import torch  # noqa: F401  keep one HIP runtime in the process (see fpng_amd/_lib.py)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_shim = None
+
+
+def shim():
+    global _shim
+    if _shim is not None:
+        return _shim
+    from fpng_amd import build
+    build.build()
+    lib_dir = os.path.join(ROOT, "fpng_amd", "lib")
+    src = os.path.join(ROOT, "tests", "cpp", "dropin_shim.cpp")
+    so = os.path.join(lib_dir, "libfpng_test_shim.so")
+    deps = [src, os.path.join(lib_dir, "libfpng.so")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), src, "-o", so,
+                               "-L", lib_dir, "-lfpng", "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
+    L = C.CDLL(so)
+    L.shim_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.shim_encode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.shim_get_info.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.shim_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
+    L.shim_decode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
+    L.shim_crc32.restype = C.c_uint32
+    L.shim_crc32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    L.shim_adler32.restype = C.c_uint32
+    L.shim_adler32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    _shim = L
+    return L
+
+
+def decode(png, desired):
+    L = shim()
+    b = np.frombuffer(bytes(png), dtype=np.uint8)
+    w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    cap = max(1 << 16, 4 * len(png) * 64)
+    st = L.shim_get_info(b.ctypes.data, b.size, C.byref(w), C.byref(h), C.byref(c))
+    if st == 0:
+        cap = w.value * h.value * desired + 16
+    out = np.zeros(cap, dtype=np.uint8)
+    st = L.shim_decode(b.ctypes.data, b.size, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), desired)
+    return st, (out[: w.value * h.value * desired] if st == 0 else None), w.value, h.value, c.value
+
+
+def get_info(png):
+    L = shim()
+    b = np.frombuffer(bytes(png), dtype=np.uint8)
+    w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    st = L.shim_get_info(b.ctypes.data, b.size, C.byref(w), C.byref(h), C.byref(c))
+    return st, w.value, h.value, c.value
+
+
+def encode(img, w, h, c, flags=0):
+    L = shim()
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    n_f = (w * c + 1) * h
+    cap = 58 + 6 + n_f + 5 * ((n_f + 65534) // 65535) + 16 + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    ok = L.shim_encode(a.ctypes.data, w, h, c, flags, out.ctypes.data, cap, C.byref(n))
+    return out[: n.value].tobytes() if ok else None

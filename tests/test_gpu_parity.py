@@ -231,3 +231,25 @@ def test_row_bands_4k_eight_bands(enc):
     cuts = [b[0] for b in sharded.split_rows(2160, 8)] + [2160]
     png = sharded.encode_image_bands_local(sharded.GpuBandBackend(enc), torch.from_numpy(img).cuda(), cuts)
     assert hashlib.sha256(png).hexdigest() == "d0f30341ef67c6ea2f67fdb6d6892d493e77999a70b1b0415e16eb81ea653d33"
+
+
+def test_cpp_dropin_namespace_fpng(enc, tmp_path):
+    """include/fpng.h + libfpng.so: the reference's own C++ signatures (std::vector out_buf) end to end."""
+    import dropin
+    import fpng_amd
+    L = dropin.shim()
+    assert L.shim_supported() == 1
+    for (k, w, h, c) in [("grad", 640, 480, 3), ("blocks", 200, 100, 4), ("noise", 31, 17, 4), ("solid", 1, 1, 3)]:
+        img = fpng_amd.synth_image(k, w, h, c)
+        for fl in (0, 1, 2):
+            png = dropin.encode(img, w, h, c, fl)
+            _assert_same(png, oracle().encode(img, w, h, c, fl), f"dropin {k} {w}x{h}x{c} f{fl}")
+            st, out, *_ = dropin.decode(png, c)
+            assert st == 0 and (out == img.reshape(-1)).all()
+    assert dropin.encode(np.zeros(12, dtype=np.uint8), 0, 1, 3) is None      # reference fpng.cpp:1670
+    assert dropin.encode(np.zeros(12, dtype=np.uint8), 2, 2, 5) is None      # reference fpng.cpp:1676
+    img = fpng_amd.synth_image("grad", 100, 50, 4)
+    path = str(tmp_path / "x.png").encode()
+    assert L.shim_encode_file(path, img.ctypes.data, 100, 50, 4, 0) == 1
+    with open(path, "rb") as f:
+        assert f.read() == oracle().encode(img, 100, 50, 4, 0)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),
+    "fpng_amd_calibration_stream": (_int, [_vp, _int, _u32, _vp, _sz]),
 }
 
 _lib = None

@@ -630,4 +630,17 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     return FPNG_AMD_OK;
 }
 
+int fpng_amd_calibration_stream(fpng_amd_encoder *e, int write, uint32_t lane_bytes, void *d_buf, size_t bytes)
+{
+    if (!e || !d_buf || (lane_bytes != 4 && lane_bytes != 16) || ((uintptr_t)d_buf & 15))
+        return fail(FPNG_AMD_ERR_INVALID_ARG, "bad calibration arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->d_hist.ensure(288))) return rc;
+    launch_calibration(e->stream, write, lane_bytes, d_buf, bytes, e->d_hist.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FPNG_AMD_OK;
+}
+
 } // extern "C"

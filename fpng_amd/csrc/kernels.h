@@ -70,6 +70,7 @@ void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_cr
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
                      JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
+void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables);
 
 } // namespace fpng_amd

@@ -1205,6 +1205,32 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PMC calibration kernels (instrumentation only): stream a buffer of known size with the access
+// widths the encoder uses, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be converted to bytes
+// on gfx950 (MI355X_MICROARCH.md, HBM section: the counters are not in bytes for every width).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(kBlock) void calib_read_kernel(const T *src, size_t n, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (sizeof(T) == 16)
+            acc ^= src[i].x ^ src[i].w;
+        else
+            acc ^= (uint32_t)src[i];
+    }
+    if (acc == 0x12345678u) *sink = acc; // keep the loads alive
+}
+template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kernel(T *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (sizeof(T) == 16)
+            dst[i] = make_uint4((uint32_t)i, 1, 2, 3);
+        else
+            dst[i] = (T)i;
+    }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1247,6 +1273,15 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, states, tabs, partials, max_crc_blocks,
                        results);
+}
+
+void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
+{
+    const dim3 grid(256 * 8), block(kBlock);
+    if (!write && width == 4) hipLaunchKernelGGL(calib_read_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)buf, bytes / 4, sink);
+    if (!write && width == 16) hipLaunchKernelGGL(calib_read_kernel<uint4>, grid, block, 0, s, (const uint4 *)buf, bytes / 16, sink);
+    if (write && width == 4) hipLaunchKernelGGL(calib_write_kernel<uint32_t>, grid, block, 0, s, (uint32_t *)buf, bytes / 4);
+    if (write && width == 16) hipLaunchKernelGGL(calib_write_kernel<uint4>, grid, block, 0, s, (uint4 *)buf, bytes / 16);
 }
 
 } // namespace fpng_amd

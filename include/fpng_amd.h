@@ -166,6 +166,10 @@ int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
 
+/* PMC calibration (instrumentation): stream `bytes` of d_buf once with 4- or 16-byte lanes, reading
+ * (write=0) or writing (write=1), so rocprofv3 FETCH_SIZE/WRITE_SIZE can be converted to bytes. */
+int fpng_amd_calibration_stream(fpng_amd_encoder *enc, int write, uint32_t lane_bytes, void *d_buf, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

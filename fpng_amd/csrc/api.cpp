@@ -186,6 +186,10 @@ struct fpng_amd_encoder {
     DeviceBuf<uint32_t> d_hist;
     DeviceBuf<TokenTable> d_dyn;
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
+    // fused single-pass encoder scratch: [ticket | status words] are cleared together before each launch
+    DeviceBuf<uint64_t> d_status;   // element 0 holds the ticket counter, unit u is element 1+u
+    DeviceBuf<uint2> d_seams, d_unit_adler;
+    uint32_t grid_blocks = 0;       // persistent grid of encode_kernel
     uint32_t last_n = 0;
 };
 
@@ -245,6 +249,11 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
     if (rc) return rc;
     fpng_amd_encoder *e = new fpng_amd_encoder();
     e->device = device;
+    {
+        hipDeviceProp_t prop;
+        // encode_kernel is persistent: 6 blocks of 27 KB LDS fit a CU (160 KB), 5 leave headroom
+        e->grid_blocks = (hipGetDeviceProperties(&prop, device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u) * 5u;
+    }
     if (hip_stream) {
         e->stream = (hipStream_t)hip_stream;
     } else {
@@ -279,6 +288,9 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->d_dyn.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
+    e->d_status.release();
+    e->d_seams.release();
+    e->d_unit_adler.release();
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -313,8 +325,28 @@ namespace {
 
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
-    uint64_t total_rows = 0;
+    uint64_t total_rows = 0, total_units = 0, total_tickets = 0;
 };
+
+constexpr uint32_t kSegPixelsHost = 1024; // must match kSegPixels in fused_kernels.inc
+
+// unit / ticket geometry of the fused encoder for one job
+int set_units(Job &j, Submission &sub)
+{
+    j.nseg = (j.w + kSegPixelsHost - 1) / kSegPixelsHost;
+    const uint64_t units = (uint64_t)j.nrows * j.nseg;
+    if (sub.total_units + units > 0x7FFFFFF0ull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many row segments in one submission");
+    j.n_units = (uint32_t)units;
+    j.unit_base = (uint32_t)sub.total_units;
+    j.ticket_base = (uint32_t)sub.total_tickets;
+    // 4 vertically adjacent units per ticket keep the Up row in L1/L2; with very wide rows fall back to
+    // stream order so that a ticket never waits for more than `grid` later tickets
+    j.rows_per_ticket = (j.nseg <= 256) ? 4 : 1;
+    const uint64_t tickets = (j.rows_per_ticket == 4) ? (uint64_t)((j.nrows + 3) / 4) * j.nseg : (units + 3) / 4;
+    sub.total_units += units;
+    sub.total_tickets += tickets;
+    return FPNG_AMD_OK;
+}
 
 int mark(fpng_amd_encoder *e, uint32_t idx)
 {
@@ -364,6 +396,7 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
+        if ((rc = set_units(j, sub))) return rc;
         sub.total_rows += im.h;
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
@@ -375,6 +408,9 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
     if ((rc = e->d_results.ensure(n))) return rc;
     if ((rc = e->h_results.ensure(n))) return rc;
     if ((rc = e->d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
+    if ((rc = e->d_status.ensure(sub.total_units + 2))) return rc;
+    if ((rc = e->d_seams.ensure(sub.total_units + 1))) return rc;
+    if ((rc = e->d_unit_adler.ensure(sub.total_units + 1))) return rc;
     if (two_pass) {
         if ((rc = e->d_hist.ensure((size_t)n * 288))) return rc;
         if ((rc = e->d_dyn.ensure(n))) return rc;
@@ -417,11 +453,16 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = e->d_dyn.p + i;
         HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
-    if (!force_stored) launch_count(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
+    FusedBuffers fb{e->d_status.p + 1, e->d_seams.p, e->d_unit_adler.p, (uint32_t *)e->d_status.p};
+    if (!force_stored) {
+        HIP_TRY(hipMemsetAsync(e->d_status.p, 0, (sub.total_units + 2) * sizeof(uint64_t), s));
+        launch_encode(s, e->d_jobs.p, n, (uint32_t)sub.total_tickets, std::min<uint32_t>(e->grid_blocks, (uint32_t)sub.total_tickets), fb,
+                      e->d_states.p);
+    }
     if ((rc = mark(e, 1))) return rc;
-    launch_scan(s, e->d_jobs.p, n, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+    launch_seal(s, e->d_jobs.p, n, fb, e->d_states.p);
     if ((rc = mark(e, 2))) return rc;
-    launch_emit(s, e->d_jobs.p, n, sub.max_rows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
+    launch_stored(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
     if ((rc = mark(e, 3))) return rc;
     launch_crc(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_states.p, dt.crc, e->d_partials.p);
     if ((rc = mark(e, 4))) return rc;

@@ -24,6 +24,12 @@ struct Job {
     uint32_t row_base;        // index of the job's first row in the per-row scratch arrays
     uint32_t one_pass, whole_png, is_first, is_last;
     uint32_t crc_blocks;      // upper bound of CRC ranges for this job
+    // fused single-pass encoder: a unit = one 1024-pixel segment of one row
+    uint32_t nseg;            // units per row
+    uint32_t n_units;         // nrows * nseg
+    uint32_t unit_base;       // index of the job's first unit in the per-unit scratch arrays
+    uint32_t ticket_base;     // first ticket (a ticket = 4 units) of the job
+    uint32_t rows_per_ticket; // 4: vertically adjacent units per ticket; 1: 4 consecutive units of the stream
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
 
@@ -70,6 +76,16 @@ void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_cr
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
                      JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
+struct FusedBuffers {
+    uint64_t *status;
+    void *seams;      // uint2 per unit
+    void *unit_adler; // uint2 per unit
+    uint32_t *ticket;
+};
+void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_tickets, uint32_t grid_blocks,
+                   const FusedBuffers &fb, JobState *states);
+void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, const FusedBuffers &fb, JobState *states);
+void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states);
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables);
 

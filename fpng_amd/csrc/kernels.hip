@@ -1231,6 +1231,8 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
     }
 }
 
+#include "fused_kernels.inc"
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1275,6 +1277,21 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
                        results);
 }
 
+void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_tickets, uint32_t grid_blocks,
+                   const FusedBuffers &fb, JobState *states)
+{
+    FusedScratch sc{fb.status, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
+    hipLaunchKernelGGL(encode_kernel, dim3(grid_blocks), dim3(kBlock), 0, s, jobs, n_jobs, total_tickets, fb.ticket, sc);
+}
+void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, const FusedBuffers &fb, JobState *states)
+{
+    FusedScratch sc{fb.status, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
+    hipLaunchKernelGGL(seal_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, sc);
+}
+void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
+{
+    hipLaunchKernelGGL(stored_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, rows, states);
+}
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
 {
     const dim3 grid(256 * 8), block(kBlock);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -186,8 +187,9 @@ struct fpng_amd_encoder {
     DeviceBuf<uint32_t> d_hist;
     DeviceBuf<TokenTable> d_dyn;
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
-    // fused single-pass encoder scratch: [ticket | status words] are cleared together before each launch
-    DeviceBuf<uint64_t> d_status;   // element 0 holds the ticket counter, unit u is element 1+u
+    // fused single-pass encoder scratch.  d_sync = [ticket | group_acc[G] | group_state[G] | unit_bits[U]] is
+    // cleared with one memset before each launch; unit_start / seams are fully rewritten by the kernel.
+    DeviceBuf<uint64_t> d_sync, d_unit_start;
     DeviceBuf<uint2> d_seams, d_unit_adler;
     uint32_t grid_blocks = 0;       // persistent grid of encode_kernel
     uint32_t last_n = 0;
@@ -252,7 +254,7 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
     {
         hipDeviceProp_t prop;
         // encode_kernel is persistent: 6 blocks of 27 KB LDS fit a CU (160 KB), 5 leave headroom
-        e->grid_blocks = (hipGetDeviceProperties(&prop, device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u) * 5u;
+        e->grid_blocks = (hipGetDeviceProperties(&prop, device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u) * 8u;
     }
     if (hip_stream) {
         e->stream = (hipStream_t)hip_stream;
@@ -288,7 +290,8 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->d_dyn.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
-    e->d_status.release();
+    e->d_sync.release();
+    e->d_unit_start.release();
     e->d_seams.release();
     e->d_unit_adler.release();
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -325,7 +328,9 @@ namespace {
 
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
-    uint64_t total_rows = 0, total_units = 0, total_tickets = 0;
+    uint64_t total_rows = 0, total_units = 0, total_tickets = 0, total_groups = 0;
+    uint32_t max_units = 0, max_tickets = 0;
+    size_t sync_words() const { return 1 + 2 * total_groups + (total_units + 1) / 2 + 1; }
 };
 
 constexpr uint32_t kSegPixelsHost = 1024; // must match kSegPixels in fused_kernels.inc
@@ -343,10 +348,25 @@ int set_units(Job &j, Submission &sub)
     // stream order so that a ticket never waits for more than `grid` later tickets
     j.rows_per_ticket = (j.nseg <= 256) ? 4 : 1;
     const uint64_t tickets = (j.rows_per_ticket == 4) ? (uint64_t)((j.nrows + 3) / 4) * j.nseg : (units + 3) / 4;
+    // placement groups: ~64 stream-consecutive units (whole rows, a multiple of the 4-row ticket height)
+    if (j.rows_per_ticket == 4) {
+        uint32_t k = (16 + j.nseg - 1) / j.nseg;
+        k = std::max(1u, std::min(16u, k));
+        j.group_rows = 4 * k;
+    } else
+        j.group_rows = 1;
+    j.n_groups = (j.nrows + j.group_rows - 1) / j.group_rows;
+    j.group_base = (uint32_t)sub.total_groups;
+    sub.total_groups += j.n_groups;
+    j.ticket_count = (uint32_t)tickets;
     sub.total_units += units;
     sub.total_tickets += tickets;
+    sub.max_units = std::max(sub.max_units, j.n_units);
+    sub.max_tickets = std::max(sub.max_tickets, j.ticket_count);
     return FPNG_AMD_OK;
 }
+
+FusedBuffers fused_buffers(fpng_amd_encoder *e, const Submission &sub);
 
 int mark(fpng_amd_encoder *e, uint32_t idx)
 {
@@ -408,7 +428,8 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
     if ((rc = e->d_results.ensure(n))) return rc;
     if ((rc = e->h_results.ensure(n))) return rc;
     if ((rc = e->d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
-    if ((rc = e->d_status.ensure(sub.total_units + 2))) return rc;
+    if ((rc = e->d_sync.ensure(sub.sync_words()))) return rc;
+    if ((rc = e->d_unit_start.ensure(sub.total_units + 1))) return rc;
     if ((rc = e->d_seams.ensure(sub.total_units + 1))) return rc;
     if ((rc = e->d_unit_adler.ensure(sub.total_units + 1))) return rc;
     if (two_pass) {
@@ -416,6 +437,20 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
         if ((rc = e->d_dyn.ensure(n))) return rc;
     }
     return FPNG_AMD_OK;
+}
+
+FusedBuffers fused_buffers(fpng_amd_encoder *e, const Submission &sub)
+{
+    FusedBuffers fb;
+    uint64_t *p = e->d_sync.p;
+    fb.ticket = (uint32_t *)p;
+    fb.group_acc = p + 1;
+    fb.group_state = p + 1 + sub.total_groups;
+    fb.unit_bits = (uint32_t *)(p + 1 + 2 * sub.total_groups);
+    fb.unit_start = e->d_unit_start.p;
+    fb.seams = e->d_seams.p;
+    fb.unit_adler = e->d_unit_adler.p;
+    return fb;
 }
 
 } // namespace
@@ -453,17 +488,32 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = e->d_dyn.p + i;
         HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
-    FusedBuffers fb{e->d_status.p + 1, e->d_seams.p, e->d_unit_adler.p, (uint32_t *)e->d_status.p};
-    if (!force_stored) {
-        HIP_TRY(hipMemsetAsync(e->d_status.p, 0, (sub.total_units + 2) * sizeof(uint64_t), s));
-        launch_encode(s, e->d_jobs.p, n, (uint32_t)sub.total_tickets, std::min<uint32_t>(e->grid_blocks, (uint32_t)sub.total_tickets), fb,
-                      e->d_states.p);
+    // Two pipelines produce the same bytes.  Default: two passes over the image (count -> scan -> emit),
+    // the faster one on MI355X today (profiles/).  FPNG_AMD_FUSED=1 selects the experimental single-pass
+    // encoder (encode -> seam/seal -> stored) kept for A/B measurements, see DESIGN.md.
+    static const bool use_fused = [] {
+        const char *v = getenv("FPNG_AMD_FUSED");
+        return v && v[0] == '1';
+    }();
+    if (use_fused) {
+        const FusedBuffers fb = fused_buffers(e, sub);
+        if (!force_stored) {
+            HIP_TRY(hipMemsetAsync(e->d_sync.p, 0, sub.sync_words() * sizeof(uint64_t), s));
+            launch_encode(s, e->d_jobs.p, n, sub.max_tickets, fb, e->d_states.p);
+        }
+        if ((rc = mark(e, 1))) return rc;
+        launch_seal(s, e->d_jobs.p, n, sub.max_units, fb, e->d_states.p);
+        if ((rc = mark(e, 2))) return rc;
+        launch_stored(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
+        if ((rc = mark(e, 3))) return rc;
+    } else {
+        if (!force_stored) launch_count(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
+        if ((rc = mark(e, 1))) return rc;
+        launch_scan(s, e->d_jobs.p, n, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+        if ((rc = mark(e, 2))) return rc;
+        launch_emit(s, e->d_jobs.p, n, sub.max_rows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
+        if ((rc = mark(e, 3))) return rc;
     }
-    if ((rc = mark(e, 1))) return rc;
-    launch_seal(s, e->d_jobs.p, n, fb, e->d_states.p);
-    if ((rc = mark(e, 2))) return rc;
-    launch_stored(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
-    if ((rc = mark(e, 3))) return rc;
     launch_crc(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_states.p, dt.crc, e->d_partials.p);
     if ((rc = mark(e, 4))) return rc;
     launch_finalize(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_rows.p, e->d_states.p, dt.crc, e->d_partials.p,

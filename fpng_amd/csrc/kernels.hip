@@ -1277,16 +1277,19 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
                        results);
 }
 
-void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_tickets, uint32_t grid_blocks,
-                   const FusedBuffers &fb, JobState *states)
+static FusedScratch fused_scratch(const FusedBuffers &fb, JobState *states)
 {
-    FusedScratch sc{fb.status, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
-    hipLaunchKernelGGL(encode_kernel, dim3(grid_blocks), dim3(kBlock), 0, s, jobs, n_jobs, total_tickets, fb.ticket, sc);
+    return FusedScratch{fb.unit_bits, fb.unit_start, fb.group_acc, fb.group_state, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
 }
-void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, const FusedBuffers &fb, JobState *states)
+void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_tickets, const FusedBuffers &fb, JobState *states)
 {
-    FusedScratch sc{fb.status, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
-    hipLaunchKernelGGL(seal_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, sc);
+    hipLaunchKernelGGL(encode_kernel, dim3(max_tickets, n_jobs), dim3(kBlock), 0, s, jobs, fused_scratch(fb, states));
+}
+void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_units, const FusedBuffers &fb, JobState *states)
+{
+    hipLaunchKernelGGL(seam_kernel, dim3((max_units + 1 + kBlock - 1) / kBlock, n_jobs), dim3(kBlock), 0, s, jobs,
+                       fused_scratch(fb, states));
+    hipLaunchKernelGGL(seal_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, fused_scratch(fb, states));
 }
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
 {

@@ -23,6 +23,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace fpng_amd {
 
 namespace {
@@ -206,43 +208,146 @@ template <int C> struct Rle {
     }
 };
 
-// LDS copy of the job's token table
-struct LdsTables {
+// LDS table layout of the row walkers: len in bits 0..3 (bits 4..7 zero), code from bit 8.  A
+// packed entry can be used directly as a shift amount and lengths add up in the low byte.
+struct PackedTables {
     uint32_t lit[288];
     uint32_t chunk[96];
 };
 
-__device__ __forceinline__ void stage_tables(LdsTables &dst, const TokenTable *src)
+__device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const TokenTable *src)
 {
-    for (int i = threadIdx.x; i < 288; i += kBlock) dst.lit[i] = src->lit[i];
-    for (int i = threadIdx.x; i < 96; i += kBlock) dst.chunk[i] = src->chunk[i];
+    for (int i = threadIdx.x; i < 288; i += kBlock) {
+        const uint32_t e = src->lit[i];
+        dst.lit[i] = (e >> 16) | ((e & 0xFFFFu) << 8);
+    }
+    for (int i = threadIdx.x; i < 96; i += kBlock) {
+        const uint32_t e = src->chunk[i];
+        dst.chunk[i] = (e >> 24) | ((e & 0xFFFFFFu) << 8);
+    }
 }
 
-template <int C> __device__ __forceinline__ uint32_t literal_bits(const LdsTables &T, uint32_t f)
-{
-    uint32_t n = (T.lit[f & 0xFF] >> 16) + (T.lit[(f >> 8) & 0xFF] >> 16) + (T.lit[(f >> 16) & 0xFF] >> 16);
-    if (C == 4) n += T.lit[f >> 24] >> 16;
-    return n;
-}
-
-// all literals of one pixel as a single token (<= 48 bits)
-template <int C> __device__ __forceinline__ uint64_t literal_token(const LdsTables &T, uint32_t f, uint32_t &nbits)
+// all literals of one pixel as one token; entries are packed (see PackedTables)
+template <int C> __device__ __forceinline__ uint64_t packed_literal_token(const PackedTables &T, uint32_t f, uint32_t &nbits)
 {
     const uint32_t e0 = T.lit[f & 0xFF], e1 = T.lit[(f >> 8) & 0xFF], e2 = T.lit[(f >> 16) & 0xFF];
-    const uint32_t l0 = e0 >> 16, l1 = e1 >> 16, l2 = e2 >> 16;
-    const uint32_t lo = (e0 & 0xFFFF) | ((e1 & 0xFFFF) << l0); // <= 24 bits
-    uint32_t hi = e2 & 0xFFFF, lh = l2;
+    const uint32_t lo = ((e1 >> 8) << (e0 & 31)) | (e0 >> 8);
+    const uint32_t s01 = e0 + e1; // low byte = len0 + len1
+    uint32_t hi, sum;
     if (C == 4) {
         const uint32_t e3 = T.lit[f >> 24];
-        hi |= (e3 & 0xFFFF) << l2;
-        lh += e3 >> 16;
+        hi = ((e3 >> 8) << (e2 & 31)) | (e2 >> 8);
+        sum = s01 + e2 + e3;
+    } else {
+        hi = e2 >> 8;
+        sum = s01 + e2;
     }
-    nbits = l0 + l1 + lh;
-    return (uint64_t)lo | ((uint64_t)hi << (l0 + l1));
+    nbits = sum & 0xFF;
+    return (uint64_t)lo | ((uint64_t)hi << (s01 & 63));
 }
 
+template <int C> __device__ __forceinline__ uint32_t packed_literal_bits(const PackedTables &T, uint32_t f)
+{
+    uint32_t s = T.lit[f & 0xFF] + T.lit[(f >> 8) & 0xFF] + T.lit[(f >> 16) & 0xFF];
+    if (C == 4) s += T.lit[f >> 24];
+    return s & 0xFF;
+}
+
+// ---- pixel windows through buffer resources: out-of-range lanes read 0, no exec masking ----
+// The descriptor must live in SGPRs; whenever the compiler cannot prove base/size wave-uniform it wraps
+// EVERY load through it in a waterfall loop (cdna_hip_programming.md T20), so force them uniform here.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    const uint64_t p = uniform64((uint64_t)(uintptr_t)base);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)p, 0, (int)uniform(bytes), 0x00020000);
+}
+
+template <int C> struct RowWindows {
+    __amdgpu_buffer_rsrc_t cur, up;
+    uint32_t voff; // per-lane byte offset of its pixel inside window 0 of the row (RGB: aligned down)
+    uint32_t sh;   // RGB: byte phase of the pixel inside its aligned dword
+
+    __device__ __forceinline__ void init(const uint8_t *row, const uint8_t *up_row, uint32_t bpl, uint32_t lane)
+    {
+        if (C == 4) {
+            cur = make_rsrc(row, bpl);
+            up = make_rsrc(up_row ? up_row : row, up_row ? bpl : 0);
+            voff = lane * 4;
+            sh = 0;
+        } else {
+            // base pointers aligned down to 4 so that every load is an aligned dword; the row then
+            // starts `a` bytes into the resource.  Up row has its own phase.
+            const uint32_t a = (uint32_t)((uintptr_t)row & 3);
+            cur = make_rsrc(row - a, (a + bpl + 3) & ~3u);
+            voff = (3 * lane + a) & ~3u;
+            sh = (3 * lane + a) & 3u;
+            // branch-free: a descriptor chosen by a branch ends up in VGPRs and every load through it
+            // in a waterfall loop.  No Up row -> zero-sized resource (reads return 0).
+            const uint8_t *ub = up_row ? up_row : row;
+            const uint32_t b = (uint32_t)((uintptr_t)ub & 3);
+            up = make_rsrc(ub - b, up_row ? ((b + bpl + 3) & ~3u) : 0u);
+            up_voff = (3 * lane + b) & ~3u;
+            up_sh = (3 * lane + b) & 3u;
+        }
+    }
+    uint32_t up_voff = 0, up_sh = 0;
+
+    // Raw dwords of this lane's pixel in the 64-pixel window starting at pixel x0 (multiple of 64).
+    // Loading and filtering are split so that several windows can be in flight (the walk keeps a
+    // 4-deep ring of Raw values: HBM latency is covered by the ring, not only by other waves).
+    struct Raw {
+        uint32_t c_lo, c_hi, u_lo, u_hi;
+    };
+    __device__ __forceinline__ Raw load_raw(uint32_t x0) const
+    {
+        Raw q;
+        if (C == 4) {
+            q.c_lo = __builtin_amdgcn_raw_buffer_load_b32(cur, voff, x0 * 4, 0);
+            q.u_lo = __builtin_amdgcn_raw_buffer_load_b32(up, voff, x0 * 4, 0);
+            q.c_hi = q.u_hi = 0;
+        } else {
+            const uint32_t so = x0 * 3; // 192-byte steps keep the dword phase of every lane
+            q.c_lo = __builtin_amdgcn_raw_buffer_load_b32(cur, voff, so, 0);
+            q.c_hi = __builtin_amdgcn_raw_buffer_load_b32(cur, voff + 4, so, 0);
+            q.u_lo = __builtin_amdgcn_raw_buffer_load_b32(up, up_voff, so, 0);
+            q.u_hi = __builtin_amdgcn_raw_buffer_load_b32(up, up_voff + 4, so, 0);
+        }
+        return q;
+    }
+    // filtered pixel: bytes of (cur - up) mod 256 (reference fpng.cpp:1605-1655)
+    __device__ __forceinline__ uint32_t filter(const Raw &q) const
+    {
+        if (C == 4) return sub_bytes(q.c_lo, q.u_lo);
+        const uint32_t c = __builtin_amdgcn_alignbyte(q.c_hi, q.c_lo, sh);
+        const uint32_t u = __builtin_amdgcn_alignbyte(q.u_hi, q.u_lo, up_sh);
+        return sub_bytes(c, u) & 0xFFFFFFu;
+    }
+    __device__ __forceinline__ uint32_t filtered_at(uint32_t x0) const { return filter(load_raw(x0)); }
+};
+
+// 64-bit mask of lanes whose pixel index x0+lane is below `limit`
+__device__ __forceinline__ uint64_t valid_mask(uint32_t x0, uint32_t limit)
+{
+    if (limit >= x0 + 64) return ~0ull;
+    if (limit <= x0) return 0ull;
+    return (1ull << (limit - x0)) - 1ull;
+}
+
+
 // ---------------------------------------------------------------------------------------------
-// Row walker shared by the count / histogram / emit kernels.
+// Row walker shared by the count / histogram / emit kernels: one wavefront walks one scanline in
+// 64-pixel windows.
+//
+// Instruction count is what bounds these kernels (VALU issue, not HBM), so the walk is organised
+// around the common cases:
+//   * raw pixel loads go through buffer resources (hardware bounds check, SGPR base + lane offset)
+//     and a 4-deep register ring, so nothing in the loop waits for memory it just asked for;
+//   * interior windows (this one and the next are completely inside the row) carry no validity
+//     masks at all; only the last two windows of a row run the masked "tail" body;
+//   * a window whose `same` mask is zero (no pixel repeats its left neighbour) skips the whole RLE
+//     classification: every lane is a literal pixel;
+//   * table entries are packed so that code lengths add up in the low byte and an entry can be used
+//     directly as a shift amount.
 // ---------------------------------------------------------------------------------------------
 enum class Pass { Count, Hist, Emit };
 
@@ -259,14 +364,15 @@ __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t n
     for (uint32_t j = lane; j < ndw; j += kWave) s.stage[j] = 0;
 }
 
-// OR a token of nbits (<= 60) at window bit position pos
+// OR a token of nbits (<= 60) at window bit position pos.  Lanes without a token pass code == 0:
+// the two unconditional ds_or are cheaper than the exec juggling of conditional ones.
 __device__ __forceinline__ void sink_put(EmitSink &s, uint64_t code, uint32_t nbits, uint32_t pos)
 {
     const uint32_t d = pos >> 5, sh = pos & 31;
-    const uint64_t lo64 = code << sh;
-    atomicOr(&s.stage[d], (uint32_t)lo64);
-    if (sh + nbits > 32) atomicOr(&s.stage[d + 1], (uint32_t)(lo64 >> 32));
-    if (sh + nbits > 64) atomicOr(&s.stage[d + 2], (uint32_t)(code >> (64 - sh)));
+    const uint64_t v = code << sh;
+    atomicOr(&s.stage[d], (uint32_t)v);
+    atomicOr(&s.stage[d + 1], (uint32_t)(v >> 32));
+    if (__ballot(sh + nbits > 64)) atomicOr(&s.stage[d + 2], (uint32_t)((code >> 1) >> (63 - sh)));
 }
 
 // Write out the complete dwords of the window (all of them when `final`), keep the partial one.
@@ -291,7 +397,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
     if (!final) {
         const uint32_t rem = s.stage[ndw]; // partial dword, uniform address
         wave_lds_fence();
-        sink_zero(s, lane, ndw + 1);
+        sink_zero(s, lane, ndw + 3);
         wave_lds_fence();
         if (lane == 0) s.stage[0] = rem;
         s.base_dw += ndw;
@@ -308,127 +414,167 @@ struct RowResult {
 };
 
 template <int C, Pass PASS>
-__device__ __forceinline__ RowResult walk_row(const Job &job, const LdsTables &T, uint32_t *hist, uint32_t r,
+__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r,
                                               uint32_t lane, EmitSink *sink)
 {
-    const uint32_t w = job.w, bpl = job.bpl;
-    gptr_cu8 row = to_global<gptr_cu8>(job.rows) + (size_t)r * bpl;
-    const bool filter_up = (job.y0 + r) != 0;
-    gptr_cu8 up_row = filter_up ? (r ? row - bpl : to_global<gptr_cu8>(job.row_above)) : (gptr_cu8)0;
+    using Raw = typename RowWindows<C>::Raw;
+    constexpr int PF = 4; // windows in flight ahead of the one being processed
+    const uint32_t w = uniform(job.w), bpl = uniform(job.bpl);
+    const uint8_t *row = job.rows + (size_t)r * bpl;
+    const bool filter_up = (uniform(job.y0) + r) != 0;
+    const uint8_t *up_row = filter_up ? (r ? row - bpl : job.row_above) : nullptr;
     const uint32_t filter_byte = filter_up ? 2u : 0u;
-    const bool lit_test = (C == 4) && job.one_pass; // reference fpng.cpp:1520-1528
+    const bool one_pass = uniform(job.one_pass) != 0;
+    const bool lit_test = (C == 4) && one_pass; // reference fpng.cpp:1520-1528
     const uint64_t lane_le_mask = (2ull << lane) - 1ull;
+    const uint32_t nwin = (w + 63) >> 6;
+    const uint32_t n_interior = (w >= 128) ? (w >> 6) - 1 : 0; // windows k with (k+2)*64 <= w
+
+    RowWindows<C> px;
+    px.init(row, up_row, bpl, lane);
+    const Raw raw0 = px.load_raw(0);
+    Raw ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) ring[j] = px.load_raw(64u * (uint32_t)(j + 1));
 
     Rle<C> rle;
     uint32_t row_bits = 0, last_unit = 0;
-    uint32_t acc_a = 0, acc_j = 0; // Adler: per-lane sum of bytes, sum of (byte index in pixel)*byte
-    uint64_t acc_w = 0;            //        per-lane sum of (weight of the pixel's first byte)*(pixel byte sum)
-
-    // software pipeline: raw pixels are fetched two windows ahead, filtered one window ahead
-    RawPixel<C> raw_n1 = load_pixel<C>(row, up_row, lane, lane < w);
-    RawPixel<C> raw_n2 = load_pixel<C>(row, up_row, 64 + lane, 64 + lane < w);
-    uint32_t f_cur = filtered<C>(raw_n1);
-    uint64_t m_cur;
-    {
-        const uint32_t prev = lane_prev(f_cur, 0);
-        m_cur = __ballot(lane < w && lane > 0 && f_cur == prev);
+    uint32_t a1 = 0, a2 = 0, aj = 0; // Adler per-lane: byte sum, sum of sums, intra-pixel weights (this fold chunk)
+    uint32_t acc_a = 0;              // folded byte sum
+    int64_t acc_w = 0;               // folded position-weighted sum (relative to the row end)
+    const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
+    if (PASS == Pass::Emit) {
+        if (lane == 0) atomicOr(&sink->stage[sink->fill >> 5], (fl >> 8) << (sink->fill & 31)), atomicOr(&sink->stage[(sink->fill >> 5) + 1], (uint32_t)(((uint64_t)(fl >> 8) << (sink->fill & 31)) >> 32));
+        sink->fill += fl & 0xFF;
     }
 
-    for (uint32_t x0 = 0; x0 < w; x0 += 64) {
-        const uint32_t x = x0 + lane;
-        const bool valid = x < w;
-        // next window: filter + same-mask (needed for this window's last lane), prefetch the one after
-        const RawPixel<C> raw_next = raw_n2;
-        raw_n2 = load_pixel<C>(row, up_row, x + 128, x + 128 < w);
-        const uint32_t f_next = filtered<C>(raw_next);
-        uint64_t m_next = 0;
-        if (x0 + 64 < w) {
-            const uint32_t last_cur = (uint32_t)__builtin_amdgcn_readlane((int)f_cur, 63);
-            const uint32_t prev = lane_prev(f_next, last_cur);
-            m_next = __ballot(x + 64 < w && f_next == prev);
+    uint32_t f_cur = px.filter(raw0);
+    uint64_t m_cur = __ballot(f_cur == lane_prev(f_cur, 0)) & valid_mask(0, w) & ~1ull;
+
+    // Adler: fold the per-lane chunk accumulators after window k_end (see DESIGN.md for the weights)
+    auto fold_adler = [&](uint32_t k_end) {
+        const int64_t tail = (int64_t)w - 64 * (int64_t)(k_end + 1) - (int64_t)lane; // pixels after this lane's pixel of window k_end+1
+        acc_w += (int64_t)(64u * C) * a2 + (int64_t)C * tail * (int64_t)a1 - (int64_t)aj;
+        acc_a += a1;
+        a1 = a2 = aj = 0;
+    };
+
+    auto step = [&](auto tail_tag, uint32_t k, uint32_t f_next) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const uint32_t x0 = k << 6;
+        const uint32_t last_cur = (uint32_t)__builtin_amdgcn_readlane((int)f_cur, 63);
+        uint64_t m_next = __ballot(f_next == lane_prev(f_next, last_cur));
+        bool valid = true;
+        if (TAIL) {
+            m_next &= valid_mask(x0 + 64, w);
+            valid = (valid_mask(x0, w) >> lane) & 1;
         }
-
-        bool ends;
-        const uint32_t q = rle.classify(m_cur, (uint32_t)(m_next & 1), lane, lane_le_mask, ends);
-        const bool same = (m_cur >> lane) & 1;
-        const bool lits_needed = valid && (!same || (lit_test && ends && q == 1));
-
         uint32_t nbits = 0;
         uint64_t code = 0;
-        bool as_lits = valid && !same;
-        if (PASS == Pass::Hist) {
-            if (as_lits) {
+        if (m_cur == 0) {
+            // no pixel of this window repeats its left neighbour: every lane is a literal pixel
+            if (PASS == Pass::Emit)
+                code = packed_literal_token<C>(T, f_cur, nbits);
+            else if (PASS == Pass::Count)
+                nbits = packed_literal_bits<C>(T, f_cur);
+            else if (valid) {
                 atomicAdd(&hist[f_cur & 0xFF], 1u);
                 atomicAdd(&hist[(f_cur >> 8) & 0xFF], 1u);
                 atomicAdd(&hist[(f_cur >> 16) & 0xFF], 1u);
                 if (C == 4) atomicAdd(&hist[f_cur >> 24], 1u);
-            } else if (ends) {
-                atomicAdd(&hist[256 + (T.chunk[q] & 0xFF)], 1u); // chunk[] holds length-symbol-256 in Hist mode
             }
+            rle.carry = 0;
         } else {
-            uint32_t lbits = 0;
-            uint64_t lcode = 0;
-            if (lits_needed) {
-                if (PASS == Pass::Emit)
-                    lcode = literal_token<C>(T, f_cur, lbits);
-                else
-                    lbits = literal_bits<C>(T, f_cur);
+            bool ends;
+            const uint32_t q = rle.classify(m_cur, (uint32_t)(m_next & 1), lane, lane_le_mask, ends);
+            const bool same = (m_cur >> lane) & 1;
+            if (PASS == Pass::Hist) {
+                if (valid && !same) {
+                    atomicAdd(&hist[f_cur & 0xFF], 1u);
+                    atomicAdd(&hist[(f_cur >> 8) & 0xFF], 1u);
+                    atomicAdd(&hist[(f_cur >> 16) & 0xFF], 1u);
+                    if (C == 4) atomicAdd(&hist[f_cur >> 24], 1u);
+                } else if (ends)
+                    atomicAdd(&hist[256 + ((T.chunk[q] >> 8) & 0xFF)], 1u); // symbols table: length symbol - 256
+            } else {
+                uint32_t lbits = 0;
+                uint64_t lcode = 0;
+                if (!same || (lit_test && ends && q == 1)) {
+                    if (PASS == Pass::Emit)
+                        lcode = packed_literal_token<C>(T, f_cur, lbits);
+                    else
+                        lbits = packed_literal_bits<C>(T, f_cur);
+                }
+                bool as_lits = !same;
+                if (ends) {
+                    const uint32_t ce = T.chunk[q];
+                    nbits = ce & 0xFF;
+                    code = ce >> 8;
+                    if (lit_test && q == 1 && nbits > lbits) as_lits = true;
+                }
+                if (as_lits) {
+                    nbits = lbits;
+                    code = lcode;
+                }
             }
-            if (ends) {
-                const uint32_t ce = T.chunk[q];
-                nbits = ce >> 24;
-                code = ce & 0xFFFFFFu;
-                if (lit_test && q == 1 && nbits > lbits) as_lits = true;
-            }
-            if (as_lits) {
-                nbits = lbits;
-                code = lcode;
-            }
-            // size of the final flush unit of the row = token of its last pixel; when the row is a
-            // single pixel, 1-pass RGB flushes the filter literal together with it
-            // (reference fpng.cpp:1186-1203 vs :1473-1497)
-            const uint32_t fl = T.lit[filter_byte];
-            if (x == w - 1) last_unit = nbits + ((C == 3 && job.one_pass && w == 1) ? (fl >> 16) : 0u);
-            if (x == 0) { // filter-type literal goes in front of pixel 0
-                code = (code << (fl >> 16)) | (fl & 0xFFFF);
-                nbits += fl >> 16;
-            }
+            rle.advance(m_cur);
         }
-
+        if (TAIL) {
+            if (!valid) {
+                nbits = 0;
+                code = 0;
+            }
+            // size of the final flush unit of the row = token of its last pixel (scan_kernel's failure rule)
+            if (PASS != Pass::Hist && x0 + 64 >= w) last_unit = (uint32_t)__builtin_amdgcn_readlane((int)nbits, (w - 1) & 63);
+        }
         if (PASS == Pass::Count) {
             row_bits += nbits; // per lane, reduced after the loop
-            if (valid) {
-                // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially)
-                const uint32_t a = (C == 4) ? __builtin_amdgcn_sad_u8(f_cur, 0u, 0u)
-                                            : (f_cur & 0xFF) + ((f_cur >> 8) & 0xFF) + (f_cur >> 16);
-                const uint32_t jsum = ((f_cur >> 8) & 0xFF) + 2u * ((f_cur >> 16) & 0xFF) + ((C == 4) ? 3u * (f_cur >> 24) : 0u);
-                acc_a += a;
-                acc_j += jsum;
-                acc_w += (uint64_t)(bpl - (uint32_t)C * x) * a;
-            }
+            // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially).  Lanes
+            // past the row end read 0 (RGBA) or are masked (RGB shares an aligned dword with real bytes).
+            const uint32_t fa = (!TAIL || C == 4 || valid) ? f_cur : 0u;
+            a1 += __builtin_amdgcn_sad_u8(fa, 0u, 0u);
+            a2 += a1;
+            aj = __builtin_amdgcn_udot4(fa, 0x03020100u, aj, false);
         } else if (PASS == Pass::Emit) {
             const uint32_t incl = wave_inclusive_sum(nbits);
+            sink_put(*sink, code, nbits, sink->fill + incl - nbits);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (nbits) sink_put(*sink, code, nbits, sink->fill + incl - nbits);
             sink->fill += total;
             row_bits += total;
             if (sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false);
         }
-
-        rle.advance(m_cur);
         f_cur = f_next;
         m_cur = m_next;
+    };
+
+    // interior windows: ring-fed, unmasked
+    for (uint32_t kb = 0; kb < n_interior; kb += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const uint32_t k = kb + (uint32_t)j;
+            if (k >= n_interior) break;
+            const uint32_t f_next = px.filter(ring[j]);                           // window k+1
+            if (k + 1 + PF < nwin) ring[j] = px.load_raw((k + 1 + PF) << 6);      // refill the slot
+            step(std::false_type{}, k, f_next);
+            if (PASS == Pass::Count && (k & 1023u) == 1023u) fold_adler(k);       // keeps a2 inside 32 bits
+        }
     }
+    // the last one or two windows of the row: masked body, look-ahead loaded directly
+    for (uint32_t k = n_interior; k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
 
     RowResult res;
     res.bits = 0;
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
     if (PASS == Pass::Count) {
-        res.bits = wave_sum(row_bits);
-        res.last_unit_bits = wave_sum(last_unit); // exactly one lane set it
+        fold_adler(nwin - 1);
+        const uint32_t fl_bits = fl & 0xFF;
+        res.bits = wave_sum(row_bits) + fl_bits;
+        // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
+        // (reference fpng.cpp:1186-1203 vs :1473-1497)
+        res.last_unit_bits = last_unit + ((C == 3 && one_pass && w == 1) ? fl_bits : 0u);
         const uint32_t la = acc_a % kAdlerMod;
-        const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod);
+        const uint32_t lw = (uint32_t)(acc_w % (int64_t)kAdlerMod); // acc_w >= 0: every pixel weight is positive
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
         res.s1 = (wave_sum(la) + filter_byte) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * filter_byte) % kAdlerMod;
@@ -445,12 +591,12 @@ __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return job
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
 {
-    __shared__ LdsTables T;
+    __shared__ PackedTables T;
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
-    stage_tables(T, job.table);
+    stage_packed_tables(T, job.table);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + uniform(threadIdx.x >> 6);
     if (r >= job.nrows) return;
     RowResult res = (job.c == 4) ? walk_row<4, Pass::Count>(job, T, nullptr, r, lane, nullptr)
                                  : walk_row<3, Pass::Count>(job, T, nullptr, r, lane, nullptr);
@@ -470,14 +616,14 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const Job *jobs, RowInfo 
 // chunk[q] holds (length symbol - 256).
 __global__ __launch_bounds__(kBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
 {
-    __shared__ LdsTables T;
+    __shared__ PackedTables T;
     __shared__ uint32_t hist[288];
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
-    stage_tables(T, job.table);
+    stage_packed_tables(T, job.table);
     for (int i = threadIdx.x; i < 288; i += kBlock) hist[i] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + uniform(threadIdx.x >> 6);
     if (r < job.nrows) {
         if (job.c == 4)
             walk_row<4, Pass::Hist>(job, T, hist, r, lane, nullptr);
@@ -682,17 +828,17 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
 __global__ __launch_bounds__(kBlock) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
                                                      const JobState *states)
 {
-    __shared__ LdsTables T;
+    __shared__ PackedTables T;
     __shared__ uint32_t stage[kWavesPerBlock][kStageDwords];
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
     const JobState &st = states[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = blockIdx.x * kWavesPerBlock + wv;
+    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kWavesPerBlock + wv;
     if (st.mode == 1u) {
         if (r < job.nrows) stored_row(job, r, lane, rows_io);
         return;
     }
-    stage_tables(T, job.table);
+    stage_packed_tables(T, job.table);
     __syncthreads();
     if (r >= job.nrows) return;
 
@@ -714,9 +860,9 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const Job *jobs, const uin
     if (r == job.nrows - 1 && job.is_last) {
         // end of block symbol; zero bits up to the byte boundary follow implicitly
         // (reference fpng.cpp:1564-1567)
-        const uint32_t eob = T.lit[256];
-        if (lane == 0) sink_put(sink, eob & 0xFFFF, eob >> 16, sink.fill);
-        sink.fill += eob >> 16;
+        const uint32_t eob = T.lit[256]; // packed: len in the low byte, code above
+        sink_put(sink, lane == 0 ? (uint64_t)(eob >> 8) : 0ull, eob & 0xFF, sink.fill);
+        sink.fill += eob & 0xFF;
     }
     sink_flush(sink, lane, true);
 }

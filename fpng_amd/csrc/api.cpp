@@ -191,8 +191,20 @@ struct fpng_amd_encoder {
     // cleared with one memset before each launch; unit_start / seams are fully rewritten by the kernel.
     DeviceBuf<uint64_t> d_sync, d_unit_start;
     DeviceBuf<uint2> d_seams, d_unit_adler;
-    uint32_t grid_blocks = 0;       // persistent grid of encode_kernel
+    uint32_t grid_blocks = 0;       // (unused by the current kernels; kept for the experimental path)
     uint32_t last_n = 0;
+    // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
+    // records coming back) guarded by an event, so fpng_amd_encode_batch_async() never waits for the GPU
+    // unless all slots are in flight.  Device scratch is shared: the stream executes submissions in order.
+    static constexpr int kSlots = 4;
+    struct Slot {
+        PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
+        PinnedBuf<Result> results;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+        uint32_t n = 0;
+    } slots[kSlots];
+    int cur_slot = 0;
 };
 
 extern "C" {
@@ -278,6 +290,12 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     if (e->ev_ready)
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
     e->h_jobs.release();
+    for (auto &sl : e->slots) {
+        sl.jobs.release();
+        sl.jobs2.release();
+        sl.results.release();
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     e->d_jobs.release();
     e->d_rows.release();
     e->d_row_off.release();
@@ -377,13 +395,14 @@ int mark(fpng_amd_encoder *e, uint32_t idx)
     return FPNG_AMD_OK;
 }
 
-// Fills e->h_jobs[0..n) for whole-image jobs and sizes the scratch buffers.
-int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags, Submission &sub)
+// Fills slot.jobs[0..n) for whole-image jobs and sizes the scratch buffers.
+int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, const fpng_amd_image *images, uint32_t n, uint32_t flags,
+                 Submission &sub)
 {
     if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
     int rc;
-    if ((rc = e->h_jobs.ensure(n))) return rc;
+    if ((rc = slot.jobs.ensure(n)) || (rc = slot.results.ensure(n))) return rc;
     const DeviceTables &dt = g_dev[e->device];
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !(flags & FPNG_AMD_FORCE_UNCOMPRESSED);
     sub = Submission();
@@ -397,7 +416,7 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
         if (im.out_cap < fpng_amd_max_encoded_size(im.w, im.h, im.num_chans))
             return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "out_cap < fpng_amd_max_encoded_size()");
         if (sub.total_rows + im.h > 0xFFFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many rows in one batch");
-        Job &j = e->h_jobs.p[i];
+        Job &j = slot.jobs.p[i];
         std::memset(&j, 0, sizeof j);
         j.rows = (const uint8_t *)im.d_pixels;
         j.row_above = nullptr;
@@ -426,7 +445,6 @@ int prepare_jobs(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, 
     if ((rc = e->d_row_off.ensure(sub.total_rows))) return rc;
     if ((rc = e->d_states.ensure(n))) return rc;
     if ((rc = e->d_results.ensure(n))) return rc;
-    if ((rc = e->h_results.ensure(n))) return rc;
     if ((rc = e->d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
     if ((rc = e->d_sync.ensure(sub.sync_words()))) return rc;
     if ((rc = e->d_unit_start.ensure(sub.total_units + 1))) return rc;
@@ -461,10 +479,16 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
 {
     if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
     HIP_TRY(hipSetDevice(e->device));
-    // the pinned job array of the previous submission may still be in flight
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    // next slot of the ring; wait only if the submission that used it is still running
+    e->cur_slot = (e->cur_slot + 1) % fpng_amd_encoder::kSlots;
+    fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (slot.in_flight) {
+        HIP_TRY(hipEventSynchronize(slot.done));
+        slot.in_flight = false;
+    }
     Submission sub;
-    int rc = prepare_jobs(e, images, n, flags, sub);
+    int rc = prepare_jobs(e, slot, images, n, flags, sub);
     if (rc) return rc;
     const DeviceTables &dt = g_dev[e->device];
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
@@ -473,20 +497,23 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     e->phases_recorded = 0;
 
     if (two_pass) {
-        // pass 1 works on the symbol table; the per-job dynamic table is built on device
-        for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = dt.symbols[e->h_jobs.p[i].c];
+        // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
+        // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
+        if ((rc = slot.jobs2.ensure(n))) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            slot.jobs2.p[i] = slot.jobs.p[i];
+            slot.jobs2.p[i].table = e->d_dyn.p + i;
+            slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
+        }
     }
-    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(e->d_states.p, 0, n * sizeof(JobState), s));
     if ((rc = mark(e, 0))) return rc;
     if (two_pass) {
         HIP_TRY(hipMemsetAsync(e->d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
         launch_hist(s, e->d_jobs.p, n, sub.max_rows, e->d_hist.p);
         launch_build_dynamic(s, e->d_jobs.p, n, e->d_hist.p, e->d_dyn.p);
-        // second job array: same jobs, now pointing at their dynamic tables
-        HIP_TRY(hipStreamSynchronize(s)); // h_jobs is reused below
-        for (uint32_t i = 0; i < n; i++) e->h_jobs.p[i].table = e->d_dyn.p + i;
-        HIP_TRY(hipMemcpyAsync(e->d_jobs.p, e->h_jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
     // Two pipelines produce the same bytes.  Default: two passes over the image (count -> scan -> emit),
     // the faster one on MI355X today (profiles/).  FPNG_AMD_FUSED=1 selects the experimental single-pass
@@ -520,7 +547,10 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
                     e->d_results.p);
     if ((rc = mark(e, 5))) return rc;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(slot.results.p, e->d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(slot.done, s));
+    slot.in_flight = true;
+    slot.n = n;
     e->last_n = n;
     return FPNG_AMD_OK;
 }
@@ -529,13 +559,15 @@ int fpng_amd_encode_finish(fpng_amd_encoder *e, fpng_amd_result *results, uint32
 {
     if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream)); // every outstanding submission is done after this
+    for (auto &sl : e->slots) sl.in_flight = false;
     if (results) {
-        if (n > e->last_n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
+        const fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
+        if (n > slot.n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
         for (uint32_t i = 0; i < n; i++) {
-            results[i].png_size = e->h_results.p[i].png_size;
-            results[i].mode = e->h_results.p[i].mode;
-            results[i].status = e->h_results.p[i].status;
+            results[i].png_size = slot.results.p[i].png_size;
+            results[i].mode = slot.results.p[i].mode;
+            results[i].status = slot.results.p[i].status;
         }
     }
     return FPNG_AMD_OK;

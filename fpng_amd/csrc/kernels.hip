@@ -32,7 +32,9 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kStageDwords = 512;          // per-wave LDS staging window of the output bit stream
+constexpr int kRowWaves = 8;               // rows (waves) per block of the row kernels: 7 of 8 Up rows are L1/L2-hot
+constexpr int kRowBlock = kWave * kRowWaves;
+constexpr int kStageDwords = 1024;         // per-wave LDS staging window of the output bit stream
 constexpr int kStageFlushAt = kStageDwords - 136; // a 64-pixel window adds at most 64*60 bits = 120 dwords
 
 // ---------------------------------------------------------------------------------------------
@@ -217,11 +219,11 @@ struct PackedTables {
 
 __device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const TokenTable *src)
 {
-    for (int i = threadIdx.x; i < 288; i += kBlock) {
+    for (int i = threadIdx.x; i < 288; i += blockDim.x) {
         const uint32_t e = src->lit[i];
         dst.lit[i] = (e >> 16) | ((e & 0xFFFFu) << 8);
     }
-    for (int i = threadIdx.x; i < 96; i += kBlock) {
+    for (int i = threadIdx.x; i < 96; i += blockDim.x) {
         const uint32_t e = src->chunk[i];
         dst.chunk[i] = (e >> 24) | ((e & 0xFFFFFFu) << 8);
     }
@@ -407,6 +409,16 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
     }
 }
 
+// 2-pass histogram in LDS.  Filtered bytes of real images concentrate on a handful of values, and
+// LDS atomics from many lanes to ONE address serialise; so the block histogram is replicated 32 times
+// with the replica chosen by lane: bank = replica, i.e. every lane owns a bank and at most two lanes
+// (l and l+32) ever meet on an address.
+constexpr int kHistReplicas = 32;
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, uint32_t lane)
+{
+    atomicAdd(&hist[bin * kHistReplicas + (lane & (kHistReplicas - 1))], 1u);
+}
+
 struct RowResult {
     uint32_t bits;           // token bits of the row
     uint32_t last_unit_bits; // bits of the row's final flush unit (see scan_kernel)
@@ -478,10 +490,10 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             else if (PASS == Pass::Count)
                 nbits = packed_literal_bits<C>(T, f_cur);
             else if (valid) {
-                atomicAdd(&hist[f_cur & 0xFF], 1u);
-                atomicAdd(&hist[(f_cur >> 8) & 0xFF], 1u);
-                atomicAdd(&hist[(f_cur >> 16) & 0xFF], 1u);
-                if (C == 4) atomicAdd(&hist[f_cur >> 24], 1u);
+                hist_add(hist, f_cur & 0xFF, lane);
+                hist_add(hist, (f_cur >> 8) & 0xFF, lane);
+                hist_add(hist, (f_cur >> 16) & 0xFF, lane);
+                if (C == 4) hist_add(hist, f_cur >> 24, lane);
             }
             rle.carry = 0;
         } else {
@@ -490,12 +502,12 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             const bool same = (m_cur >> lane) & 1;
             if (PASS == Pass::Hist) {
                 if (valid && !same) {
-                    atomicAdd(&hist[f_cur & 0xFF], 1u);
-                    atomicAdd(&hist[(f_cur >> 8) & 0xFF], 1u);
-                    atomicAdd(&hist[(f_cur >> 16) & 0xFF], 1u);
-                    if (C == 4) atomicAdd(&hist[f_cur >> 24], 1u);
+                    hist_add(hist, f_cur & 0xFF, lane);
+                    hist_add(hist, (f_cur >> 8) & 0xFF, lane);
+                    hist_add(hist, (f_cur >> 16) & 0xFF, lane);
+                    if (C == 4) hist_add(hist, f_cur >> 24, lane);
                 } else if (ends)
-                    atomicAdd(&hist[256 + ((T.chunk[q] >> 8) & 0xFF)], 1u); // symbols table: length symbol - 256
+                    hist_add(hist, 256 + ((T.chunk[q] >> 8) & 0xFF), lane); // symbols table: length symbol - 256
             } else {
                 uint32_t lbits = 0;
                 uint64_t lcode = 0;
@@ -589,14 +601,14 @@ __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return job
 // ---------------------------------------------------------------------------------------------
 // count_kernel: grid (ceil(max_rows/4), n_jobs), block 256 = 4 rows
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
+__global__ __launch_bounds__(kRowBlock) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
 {
     __shared__ PackedTables T;
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    if (blockIdx.x * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + uniform(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + uniform(threadIdx.x >> 6);
     if (r >= job.nrows) return;
     RowResult res = (job.c == 4) ? walk_row<4, Pass::Count>(job, T, nullptr, r, lane, nullptr)
                                  : walk_row<3, Pass::Count>(job, T, nullptr, r, lane, nullptr);
@@ -614,27 +626,30 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const Job *jobs, RowInfo 
 // hist_kernel (2-pass, pass 1): literal / length-symbol histogram of the whole image
 // (reference fpng.cpp:1021-1084 / :1299-1363).  job.table here is the "symbol" table whose
 // chunk[q] holds (length symbol - 256).
-__global__ __launch_bounds__(kBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+__global__ __launch_bounds__(kRowBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t hist[288];
+    __shared__ uint32_t hist[288 * kHistReplicas];
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    if (blockIdx.x * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
-    for (int i = threadIdx.x; i < 288; i += kBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < 288 * kHistReplicas; i += kRowBlock) hist[i] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kWavesPerBlock + uniform(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + uniform(threadIdx.x >> 6);
     if (r < job.nrows) {
         if (job.c == 4)
             walk_row<4, Pass::Hist>(job, T, hist, r, lane, nullptr);
         else
             walk_row<3, Pass::Hist>(job, T, hist, r, lane, nullptr);
-        if (lane == 0) atomicAdd(&hist[(job.y0 + r) ? 2 : 0], 1u); // the row's filter-type literal
+        if (lane == 0) hist_add(hist, (job.y0 + r) ? 2 : 0, r); // the row's filter-type literal
     }
     __syncthreads();
     uint32_t *dst = hist_out + (size_t)blockIdx.y * 288;
-    for (int i = threadIdx.x; i < 288; i += kBlock)
-        if (hist[i]) atomicAdd(&dst[i], hist[i]);
+    for (int i = threadIdx.x; i < 288; i += kRowBlock) {
+        uint32_t s = 0;
+        for (int rep = 0; rep < kHistReplicas; rep++) s += hist[i * kHistReplicas + ((rep + i) & (kHistReplicas - 1))];
+        if (s) atomicAdd(&dst[i], s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,15 +840,15 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
+__global__ __launch_bounds__(kRowBlock) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
                                                      const JobState *states)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t stage[kWavesPerBlock][kStageDwords];
+    __shared__ uint32_t stage[kRowWaves][kStageDwords];
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kWavesPerBlock >= job.nrows) return;
+    if (blockIdx.x * kRowWaves >= job.nrows) return;
     const JobState &st = states[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kWavesPerBlock + wv;
+    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kRowWaves + wv;
     if (st.mode == 1u) {
         if (r < job.nrows) stored_row(job, r, lane, rows_io);
         return;
@@ -1386,16 +1401,16 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
 // ---------------------------------------------------------------------------------------------
 static dim3 row_grid(uint32_t max_rows, uint32_t n_jobs)
 {
-    return dim3((max_rows + kWavesPerBlock - 1) / kWavesPerBlock, n_jobs, 1);
+    return dim3((max_rows + kRowWaves - 1) / kRowWaves, n_jobs, 1);
 }
 
 void launch_count(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states)
 {
-    hipLaunchKernelGGL(count_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, rows, states);
+    hipLaunchKernelGGL(count_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
 }
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist)
 {
-    hipLaunchKernelGGL(hist_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, hist);
+    hipLaunchKernelGGL(hist_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, hist);
 }
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
@@ -1404,7 +1419,7 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
                  const JobState *states)
 {
-    hipLaunchKernelGGL(emit_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, row_off, rows, states);
+    hipLaunchKernelGGL(emit_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, row_off, rows, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {
@@ -1439,7 +1454,7 @@ void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_u
 }
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
 {
-    hipLaunchKernelGGL(stored_kernel, row_grid(max_rows, n_jobs), dim3(kBlock), 0, s, jobs, rows, states);
+    hipLaunchKernelGGL(stored_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
 }
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
 {

@@ -699,22 +699,26 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
     uint64_t a_s1 = 0, a_s2 = 0;
     const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
     if (!force_stored) {
-        for (uint32_t base = 0; base < job.nrows; base += kBlock) {
-            const uint32_t r = base + t;
-            uint64_t bits = 0;
-            if (r < job.nrows) {
-                const RowInfo ri = rows[job.row_base + r];
-                bits = ri.bits;
-                // S2 of the concatenation: every byte of this row is followed by the later rows
-                const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
-                a_s1 += ri.s1;
-                a_s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
-            }
-            uint64_t total;
-            const uint64_t excl = block_exclusive_scan_u64(bits, scratch, total);
-            if (r < job.nrows) row_off[job.row_base + r] = carry + excl;
-            carry += total;
+        // every thread owns a contiguous chunk of rows: local sums, ONE block scan of the 256 chunk
+        // totals, then the chunk is walked again to hand out the row offsets
+        const uint32_t per = (job.nrows + kBlock - 1) / kBlock;
+        const uint32_t r0 = t * per, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
+        uint64_t local = 0;
+        for (uint32_t r = r0; r < r1; r++) {
+            const RowInfo ri = rows[job.row_base + r];
+            local += ri.bits;
+            // S2 of the concatenation: every byte of this row is followed by the later rows
+            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+            a_s1 += ri.s1;
+            a_s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
         }
+        uint64_t total;
+        uint64_t pos = first_bit + block_exclusive_scan_u64(local, scratch, total);
+        for (uint32_t r = r0; r < r1; r++) {
+            row_off[job.row_base + r] = pos;
+            pos += rows[job.row_base + r].bits;
+        }
+        carry += total;
     }
     const uint64_t s_last = carry; // zlib bit position after the last token
     // block-reduce the Adler sums

@@ -253,3 +253,51 @@ def test_cpp_dropin_namespace_fpng(enc, tmp_path):
     assert L.shim_encode_file(path, img.ctypes.data, 100, 50, 4, 0) == 1
     with open(path, "rb") as f:
         assert f.read() == oracle().encode(img, 100, 50, 4, 0)
+
+
+def test_pipelined_submissions_without_intermediate_finish(enc):
+    """fpng_amd_encode_batch_async() may be called repeatedly before fpng_amd_encode_finish(): submissions
+    go through a ring of pinned slots and share device scratch in stream order."""
+    import torch
+    import fpng_amd
+    rng = np.random.default_rng(55)
+    batches, outs_all = [], []
+    for b in range(7):   # more than the 4 slots of the ring
+        imgs = [fpng_amd.synth_image(k, w, h, c, seed=100 + b) for (k, w, h, c) in
+                [("grad", 320 + 16 * b, 200, 4), ("blocks", 257, 64 + b, 3), ("noise", 40, 30, 4)]]
+        ts = [torch.from_numpy(i).cuda() for i in imgs]
+        outs = [torch.empty(fpng_amd.max_encoded_size(t.shape[1], t.shape[0], t.shape[2]) + 64, dtype=torch.uint8, device="cuda") for t in ts]
+        enc.submit(ts, outs, b % 2)      # alternate 1-pass / 2-pass
+        batches.append((imgs, ts, b % 2))
+        outs_all.append(outs)
+    enc.finish(3)
+    for (imgs, ts, fl), outs in zip(batches, outs_all):
+        for img, out in zip(imgs, outs):
+            h, w, c = img.shape
+            exp = oracle().encode(img, w, h, c, fl)
+            got = bytes(out[:len(exp)].cpu().numpy())
+            _assert_same(got, exp, f"pipelined {w}x{h}x{c} flags={fl}")
+
+
+def test_experimental_fused_pipeline_same_bytes():
+    """FPNG_AMD_FUSED=1 selects the single-pass encoder; it must produce the same files."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(os.environ["FPNG_ROOT"], "tests")); sys.path.insert(0, os.environ["FPNG_ROOT"])
+import numpy as np, torch, fpng_amd
+from cpu_ref import oracle, fuzz_image
+enc = fpng_amd.Encoder(device=0)
+rng = np.random.default_rng(9)
+cases = [fuzz_image(rng) for _ in range(150)]
+cases += [(fpng_amd.synth_image(k, w, h, c), w, h, c) for (k, w, h, c) in [("grad", 2100, 37, 4), ("blocks", 3000, 20, 3), ("grad", 1025, 9, 3), ("noise", 300, 40, 4), ("solid", 5000, 6, 4)]]
+for fl in (0, 1, 2):
+    pngs, _ = enc.encode_tensors([torch.from_numpy(np.ascontiguousarray(c[0])).cuda() for c in cases], fl)
+    for (img, w, h, c), p in zip(cases, pngs):
+        assert p == oracle().encode(img, w, h, c, fl), (w, h, c, fl)
+print("fused ok")
+'''
+    env = dict(os.environ, FPNG_AMD_FUSED="1", FPNG_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stderr[-2000:]

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Turn a gpurun_out/prof_<tag>/ directory (tools/gpu_profile_round.sh) into the committed summaries:
+profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and profiles/<tag>_pmc_traffic.txt."""
+import collections, csv, json, shutil, sys, os
+
+tag = sys.argv[1]
+alg = int(sys.argv[2]) if len(sys.argv) > 2 else None
+base = f"gpurun_out/prof_{tag}"
+shutil.copy(f"{base}/trace/trace_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"].replace("fpng_amd::(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+cal_f, cal_w = load(f"{base}/cal_FETCH_SIZE/cal_counter_collection.csv"), load(f"{base}/cal_WRITE_SIZE/cal_counter_collection.csv")
+f, w = load(f"{base}/pmc_FETCH_SIZE/pmc_counter_collection.csv"), load(f"{base}/pmc_WRITE_SIZE/pmc_counter_collection.csv")
+GiB = 1 << 30
+fscale = GiB / [v for k, v in cal_f.items() if "calib_read_kernel<unsigned int>" in k][0]
+wscale = GiB / [v for k, v in cal_w.items() if "calib_write_kernel<unsigned int>" in k][0]
+lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+         f"# calibration (tools/pmc_calibrate.py, 1 GiB streams with 4-byte lanes): FETCH_SIZE unit = {fscale:.1f} B, WRITE_SIZE unit = {wscale:.1f} B",
+         f"{'kernel':<22} {'FETCH_SIZE':>12} {'fetch_MB':>10} {'WRITE_SIZE':>12} {'write_MB':>10}"]
+tot = 0
+kernels = [k for k in f if k.endswith("_kernel") and "calib" not in k]
+for k in sorted(kernels, key=lambda k: -(f.get(k, 0) * fscale + w.get(k, 0) * wscale)):
+    fb, wb = f.get(k, 0) * fscale, w.get(k, 0) * wscale
+    tot += fb + wb
+    lines.append(f"{k:<22} {f.get(k,0):>12.1f} {fb/1e6:>10.1f} {w.get(k,0):>12.1f} {wb/1e6:>10.1f}")
+lines.append(f"total HBM-side traffic per launch: {tot/1e6:.1f} MB" + (f"  ({tot/alg:.2f} x the {alg} algorithmic bytes)" if alg else ""))
+open(f"profiles/{tag}_pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
+    print(r["Name"].replace("fpng_amd::(anonymous namespace)::", "").split("(")[0][:28], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")

@@ -370,7 +370,11 @@ __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t n
 // the two unconditional ds_or are cheaper than the exec juggling of conditional ones.
 __device__ __forceinline__ void sink_put(EmitSink &s, uint64_t code, uint32_t nbits, uint32_t pos)
 {
-    const uint32_t d = pos >> 5, sh = pos & 31;
+    // Token-less lanes all share one bit position; atomics from many lanes to ONE LDS address
+    // serialise (64-way in run-length-heavy windows), so each of them ORs its zero into a private
+    // dump slot behind the window instead.
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t d = nbits ? (pos >> 5) : ((uint32_t)kStageDwords + 2u * lane), sh = pos & 31;
     const uint64_t v = code << sh;
     atomicOr(&s.stage[d], (uint32_t)v);
     atomicOr(&s.stage[d + 1], (uint32_t)(v >> 32));
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(kRowBlock) void emit_kernel(const Job *jobs, const 
                                                      const JobState *states)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t stage[kRowWaves][kStageDwords];
+    __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kRowWaves >= job.nrows) return;
     const JobState &st = states[blockIdx.y];

@@ -367,14 +367,17 @@ __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t n
 }
 
 // OR a token of nbits (<= 60) at window bit position pos.  Lanes without a token pass code == 0:
-// the two unconditional ds_or are cheaper than the exec juggling of conditional ones.
+// two unconditional ds_or are cheaper than the exec juggling of conditional ones.
+// ALL_TOKENS: every lane is known to carry a token (all-literal window), no dump slots needed.
+template <bool ALL_TOKENS>
 __device__ __forceinline__ void sink_put(EmitSink &s, uint64_t code, uint32_t nbits, uint32_t pos)
 {
     // Token-less lanes all share one bit position; atomics from many lanes to ONE LDS address
     // serialise (64-way in run-length-heavy windows), so each of them ORs its zero into a private
     // dump slot behind the window instead.
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t d = nbits ? (pos >> 5) : ((uint32_t)kStageDwords + 2u * lane), sh = pos & 31;
+    uint32_t d = pos >> 5;
+    const uint32_t sh = pos & 31;
+    if (!ALL_TOKENS) d = nbits ? d : ((uint32_t)kStageDwords + 2u * (threadIdx.x & 63));
     const uint64_t v = code << sh;
     atomicOr(&s.stage[d], (uint32_t)v);
     atomicOr(&s.stage[d + 1], (uint32_t)(v >> 32));
@@ -487,7 +490,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         }
         uint32_t nbits = 0;
         uint64_t code = 0;
-        if (m_cur == 0) {
+        const bool all_lits = (m_cur == 0); // wave-uniform
+        if (all_lits) {
             // no pixel of this window repeats its left neighbour: every lane is a literal pixel
             if (PASS == Pass::Emit)
                 code = packed_literal_token<C>(T, f_cur, nbits);
@@ -553,7 +557,10 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             aj = __builtin_amdgcn_udot4(fa, 0x03020100u, aj, false);
         } else if (PASS == Pass::Emit) {
             const uint32_t incl = wave_inclusive_sum(nbits);
-            sink_put(*sink, code, nbits, sink->fill + incl - nbits);
+            if (!TAIL && all_lits)
+                sink_put<true>(*sink, code, nbits, sink->fill + incl - nbits);
+            else
+                sink_put<false>(*sink, code, nbits, sink->fill + incl - nbits);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             sink->fill += total;
             row_bits += total;
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(kRowBlock) void emit_kernel(const Job *jobs, const 
         // end of block symbol; zero bits up to the byte boundary follow implicitly
         // (reference fpng.cpp:1564-1567)
         const uint32_t eob = T.lit[256]; // packed: len in the low byte, code above
-        sink_put(sink, lane == 0 ? (uint64_t)(eob >> 8) : 0ull, eob & 0xFF, sink.fill);
+        sink_put<false>(sink, lane == 0 ? (uint64_t)(eob >> 8) : 0ull, lane == 0 ? (eob & 0xFF) : 0u, sink.fill);
         sink.fill += eob & 0xFF;
     }
     sink_flush(sink, lane, true);

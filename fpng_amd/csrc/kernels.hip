@@ -210,8 +210,9 @@ template <int C> struct Rle {
     }
 };
 
-// LDS table layout of the row walkers: len in bits 0..3 (bits 4..7 zero), code from bit 8.  A
-// packed entry can be used directly as a shift amount and lengths add up in the low byte.
+// LDS table layout of the row walkers.  lit[s]: code in bits 0..15, code length in bits 24..31 (field
+// extraction folds into SDWA operand selects; four entries can be added and the top byte is the sum of
+// the lengths).  chunk[q]: total bit count in bits 0..7, token bits from bit 8.
 struct PackedTables {
     uint32_t lit[288];
     uint32_t chunk[96];
@@ -221,7 +222,7 @@ __device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const Tok
 {
     for (int i = threadIdx.x; i < 288; i += blockDim.x) {
         const uint32_t e = src->lit[i];
-        dst.lit[i] = (e >> 16) | ((e & 0xFFFFu) << 8);
+        dst.lit[i] = (e & 0xFFFFu) | ((e >> 16) << 24);
     }
     for (int i = threadIdx.x; i < 96; i += blockDim.x) {
         const uint32_t e = src->chunk[i];
@@ -229,30 +230,35 @@ __device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const Tok
     }
 }
 
+// packed literal entry: code in the low word, length in the top byte (both are SDWA operand selects)
+__device__ __forceinline__ uint32_t plit_code(uint32_t e) { return e & 0xFFFFu; }
+__device__ __forceinline__ uint32_t plit_len(uint32_t e) { return e >> 24; }
+
 // all literals of one pixel as one token; entries are packed (see PackedTables)
 template <int C> __device__ __forceinline__ uint64_t packed_literal_token(const PackedTables &T, uint32_t f, uint32_t &nbits)
 {
     const uint32_t e0 = T.lit[f & 0xFF], e1 = T.lit[(f >> 8) & 0xFF], e2 = T.lit[(f >> 16) & 0xFF];
-    const uint32_t lo = ((e1 >> 8) << (e0 & 31)) | (e0 >> 8);
-    const uint32_t s01 = e0 + e1; // low byte = len0 + len1
+    const uint32_t lo = (plit_code(e1) << plit_len(e0)) | plit_code(e0);
+    const uint32_t s01 = plit_len(e0) + plit_len(e1);
     uint32_t hi, sum;
     if (C == 4) {
         const uint32_t e3 = T.lit[f >> 24];
-        hi = ((e3 >> 8) << (e2 & 31)) | (e2 >> 8);
-        sum = s01 + e2 + e3;
+        hi = (plit_code(e3) << plit_len(e2)) | plit_code(e2);
+        sum = s01 + plit_len(e2) + plit_len(e3);
     } else {
-        hi = e2 >> 8;
-        sum = s01 + e2;
+        hi = plit_code(e2);
+        sum = s01 + plit_len(e2);
     }
-    nbits = sum & 0xFF;
-    return (uint64_t)lo | ((uint64_t)hi << (s01 & 63));
+    nbits = sum;
+    return (uint64_t)lo | ((uint64_t)hi << s01);
 }
 
 template <int C> __device__ __forceinline__ uint32_t packed_literal_bits(const PackedTables &T, uint32_t f)
 {
+    // the four codes (16 bits each) cannot carry into bit 24: the top byte of the sum is the sum of the lengths
     uint32_t s = T.lit[f & 0xFF] + T.lit[(f >> 8) & 0xFF] + T.lit[(f >> 16) & 0xFF];
     if (C == 4) s += T.lit[f >> 24];
-    return s & 0xFF;
+    return s >> 24;
 }
 
 // ---- pixel windows through buffer resources: out-of-range lanes read 0, no exec masking ----
@@ -462,9 +468,14 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     uint32_t acc_a = 0;              // folded byte sum
     int64_t acc_w = 0;               // folded position-weighted sum (relative to the row end)
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
+    const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
     if (PASS == Pass::Emit) {
-        if (lane == 0) atomicOr(&sink->stage[sink->fill >> 5], (fl >> 8) << (sink->fill & 31)), atomicOr(&sink->stage[(sink->fill >> 5) + 1], (uint32_t)(((uint64_t)(fl >> 8) << (sink->fill & 31)) >> 32));
-        sink->fill += fl & 0xFF;
+        if (lane == 0) {
+            const uint64_t v = (uint64_t)plit_code(fl) << (sink->fill & 31);
+            atomicOr(&sink->stage[sink->fill >> 5], (uint32_t)v);
+            atomicOr(&sink->stage[(sink->fill >> 5) + 1], (uint32_t)(v >> 32));
+        }
+        sink->fill += plit_len(fl);
     }
 
     uint32_t f_cur = px.filter(raw0);
@@ -491,6 +502,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         uint32_t nbits = 0;
         uint64_t code = 0;
         const bool all_lits = (m_cur == 0); // wave-uniform
+        bool every_lane_has_token = all_lits;
         if (all_lits) {
             // no pixel of this window repeats its left neighbour: every lane is a literal pixel
             if (PASS == Pass::Emit)
@@ -504,6 +516,61 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 if (C == 4) hist_add(hist, f_cur >> 24, lane);
             }
             rle.carry = 0;
+        } else if (!TAIL && rle.carry == 0 && (m_cur & (m_cur >> 1)) == 0 && !((m_cur >> 63) & m_next & 1)) {
+            // SPARSE tier: every repeated pixel of this window is an isolated 1-pixel run (no two adjacent
+            // mask bits, none continuing into or out of the window).  All lanes build their literal token;
+            // the repeated ones swap it for the 1-pixel chunk token (unless the 1-pass RGBA cost rule
+            // keeps the literals, reference fpng.cpp:1520-1528).  Typical for photographic content, where
+            // the general classification below would otherwise run for one or two lanes' benefit.
+            const bool same = (m_cur >> lane) & 1;
+            every_lane_has_token = true;
+            if (PASS == Pass::Hist) {
+                if (same)
+                    hist_add(hist, 256 + ((chunk1 >> 8) & 0xFF), lane);
+                else {
+                    hist_add(hist, f_cur & 0xFF, lane);
+                    hist_add(hist, (f_cur >> 8) & 0xFF, lane);
+                    hist_add(hist, (f_cur >> 16) & 0xFF, lane);
+                    if (C == 4) hist_add(hist, f_cur >> 24, lane);
+                }
+            } else {
+                if (PASS == Pass::Emit)
+                    code = packed_literal_token<C>(T, f_cur, nbits);
+                else
+                    nbits = packed_literal_bits<C>(T, f_cur);
+                const uint32_t c1_bits = chunk1 & 0xFF;
+                if (same && !(lit_test && c1_bits > nbits)) {
+                    nbits = c1_bits;
+                    code = chunk1 >> 8;
+                }
+            }
+            rle.carry = (uint32_t)(m_cur >> 63); // a run may start on the last lane
+        } else if (!TAIL && m_cur == ~0ull) {
+            // RUN tier: the whole window lies inside one run.  Chunk boundaries follow from the carry alone.
+            uint32_t u = rle.carry + lane; // t - 1
+            if (u >= Rle<C>::CAP) u -= Rle<C>::CAP;
+            if (C == 4 && u >= Rle<C>::CAP) u -= Rle<C>::CAP;
+            const uint32_t q = u + 1;
+            const bool ends = (q == Rle<C>::CAP) || (lane == 63 && !(m_next & 1));
+            if (ends) {
+                if (PASS == Pass::Hist)
+                    hist_add(hist, 256 + ((T.chunk[q] >> 8) & 0xFF), lane);
+                else {
+                    const uint32_t ce = T.chunk[q];
+                    nbits = ce & 0xFF;
+                    code = ce >> 8;
+                    if (lit_test && q == 1) { // a 1-pixel chunk can only be the run's last pixel here
+                        uint32_t lbits = 0;
+                        const uint64_t lcode = (PASS == Pass::Emit) ? packed_literal_token<C>(T, f_cur, lbits) : 0ull;
+                        if (PASS == Pass::Count) lbits = packed_literal_bits<C>(T, f_cur);
+                        if (nbits > lbits) {
+                            nbits = lbits;
+                            code = lcode;
+                        }
+                    }
+                }
+            }
+            rle.advance(m_cur);
         } else {
             bool ends;
             const uint32_t q = rle.classify(m_cur, (uint32_t)(m_next & 1), lane, lane_le_mask, ends);
@@ -557,7 +624,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             aj = __builtin_amdgcn_udot4(fa, 0x03020100u, aj, false);
         } else if (PASS == Pass::Emit) {
             const uint32_t incl = wave_inclusive_sum(nbits);
-            if (!TAIL && all_lits)
+            if (!TAIL && every_lane_has_token)
                 sink_put<true>(*sink, code, nbits, sink->fill + incl - nbits);
             else
                 sink_put<false>(*sink, code, nbits, sink->fill + incl - nbits);
@@ -591,7 +658,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.s1 = res.s2 = 0;
     if (PASS == Pass::Count) {
         fold_adler(nwin - 1);
-        const uint32_t fl_bits = fl & 0xFF;
+        const uint32_t fl_bits = plit_len(fl);
         res.bits = wave_sum(row_bits) + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
@@ -890,9 +957,9 @@ __global__ __launch_bounds__(kRowBlock) void emit_kernel(const Job *jobs, const 
     if (r == job.nrows - 1 && job.is_last) {
         // end of block symbol; zero bits up to the byte boundary follow implicitly
         // (reference fpng.cpp:1564-1567)
-        const uint32_t eob = T.lit[256]; // packed: len in the low byte, code above
-        sink_put<false>(sink, lane == 0 ? (uint64_t)(eob >> 8) : 0ull, lane == 0 ? (eob & 0xFF) : 0u, sink.fill);
-        sink.fill += eob & 0xFF;
+        const uint32_t eob = T.lit[256];
+        sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
+        sink.fill += plit_len(eob);
     }
     sink_flush(sink, lane, true);
 }

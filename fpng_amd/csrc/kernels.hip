@@ -390,6 +390,16 @@ __device__ __forceinline__ void sink_put(EmitSink &s, uint64_t code, uint32_t nb
     if (__ballot(sh + nbits > 64)) atomicOr(&s.stage[d + 2], (uint32_t)((code >> 1) >> (63 - sh)));
 }
 
+// a token of up to 64 bits (two pixels' literals merged in the lane); the third dword is common here
+__device__ __forceinline__ void sink_put_wide(EmitSink &s, uint64_t code, uint32_t pos)
+{
+    const uint32_t d = pos >> 5, sh = pos & 31;
+    const uint64_t v = code << sh;
+    atomicOr(&s.stage[d], (uint32_t)v);
+    atomicOr(&s.stage[d + 1], (uint32_t)(v >> 32));
+    atomicOr(&s.stage[d + 2], (uint32_t)((code >> 1) >> (63 - sh)));
+}
+
 // Write out the complete dwords of the window (all of them when `final`), keep the partial one.
 // The first and the last dword of a row's span may be shared with the neighbouring rows (or with
 // header bytes): those two are OR-merged into memory that scan_kernel zeroed; everything in
@@ -457,16 +467,13 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
 
     RowWindows<C> px;
     px.init(row, up_row, bpl, lane);
-    const Raw raw0 = px.load_raw(0);
-    Raw ring[PF];
-#pragma unroll
-    for (int j = 0; j < PF; j++) ring[j] = px.load_raw(64u * (uint32_t)(j + 1));
 
     Rle<C> rle;
     uint32_t row_bits = 0, last_unit = 0;
-    uint32_t a1 = 0, a2 = 0, aj = 0; // Adler per-lane: byte sum, sum of sums, intra-pixel weights (this fold chunk)
-    uint32_t acc_a = 0;              // folded byte sum
-    int64_t acc_w = 0;               // folded position-weighted sum (relative to the row end)
+    // Adler per-lane accumulators: byte sum, sum of (bytes from the pixel's first byte to the row end) x
+    // (pixel byte sum), sum of (byte index inside the pixel) x byte.  s2(row) = acc_w - acc_j.
+    uint32_t acc_a = 0, acc_j = 0;
+    uint64_t acc_w = 0;
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
     const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
     if (PASS == Pass::Emit) {
@@ -478,16 +485,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         sink->fill += plit_len(fl);
     }
 
-    uint32_t f_cur = px.filter(raw0);
-    uint64_t m_cur = __ballot(f_cur == lane_prev(f_cur, 0)) & valid_mask(0, w) & ~1ull;
-
-    // Adler: fold the per-lane chunk accumulators after window k_end (see DESIGN.md for the weights)
-    auto fold_adler = [&](uint32_t k_end) {
-        const int64_t tail = (int64_t)w - 64 * (int64_t)(k_end + 1) - (int64_t)lane; // pixels after this lane's pixel of window k_end+1
-        acc_w += (int64_t)(64u * C) * a2 + (int64_t)C * tail * (int64_t)a1 - (int64_t)aj;
-        acc_a += a1;
-        a1 = a2 = aj = 0;
-    };
+    uint32_t f_cur = 0; // state of the per-pixel walk (phase B): filtered pixels and `same` mask of window k
+    uint64_t m_cur = 0;
 
     auto step = [&](auto tail_tag, uint32_t k, uint32_t f_next) {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -619,9 +618,10 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially).  Lanes
             // past the row end read 0 (RGBA) or are masked (RGB shares an aligned dword with real bytes).
             const uint32_t fa = (!TAIL || C == 4 || valid) ? f_cur : 0u;
-            a1 += __builtin_amdgcn_sad_u8(fa, 0u, 0u);
-            a2 += a1;
-            aj = __builtin_amdgcn_udot4(fa, 0x03020100u, aj, false);
+            const uint32_t a = __builtin_amdgcn_sad_u8(fa, 0u, 0u);
+            acc_a += a;
+            acc_w += (uint64_t)(bpl - (uint32_t)C * (x0 + lane)) * a; // invalid lanes: a == 0
+            acc_j = __builtin_amdgcn_udot4(fa, 0x03020100u, acc_j, false);
         } else if (PASS == Pass::Emit) {
             const uint32_t incl = wave_inclusive_sum(nbits);
             if (!TAIL && every_lane_has_token)
@@ -637,34 +637,202 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         m_cur = m_next;
     };
 
-    // interior windows: ring-fed, unmasked
-    for (uint32_t kb = 0; kb < n_interior; kb += PF) {
+    // =====================================================================================
+    // Phase A (RGBA): 256-pixel super-windows with FOUR consecutive pixels per lane (one
+    // buffer_load_dwordx4 per lane for the row and one for the Up row).  The per-window overheads --
+    // neighbour compare across lanes, DPP prefix sum, LDS puts, loop -- are paid once per 256 pixels.
+    // Only the two cheap tiers are done in this layout (all literal / isolated 1-pixel runs, together
+    // ~all of photographic content); any other super-window is replayed through the per-pixel walk
+    // below with ds_bpermute gathers.  Super-windows S with 256*(S+2) <= w qualify (full look-ahead).
+    // =====================================================================================
+    uint32_t k0 = 0;      // first 64-pixel window left for phase B
+    uint32_t carry_f = 0; // filtered value of the pixel just before window k0
+    if constexpr (C == 4) {
+        const uint32_t NS = (w >= 512) ? (w >> 8) - 1 : 0;
+        if (NS) {
+            const uint32_t voff4 = lane * 16;
+            auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
+                c4 = __builtin_amdgcn_raw_buffer_load_b128(px.cur, voff4, S << 10, 0);
+                u4 = __builtin_amdgcn_raw_buffer_load_b128(px.up, voff4, S << 10, 0);
+            };
+            constexpr int PF4 = 2; // super-windows in flight ahead of the look-ahead one
+            u32x4 c_first, u_first, rc[PF4], ru[PF4];
+            load4(0, c_first, u_first);
 #pragma unroll
-        for (int j = 0; j < PF; j++) {
-            const uint32_t k = kb + (uint32_t)j;
-            if (k >= n_interior) break;
-            const uint32_t f_next = px.filter(ring[j]);                           // window k+1
-            if (k + 1 + PF < nwin) ring[j] = px.load_raw((k + 1 + PF) << 6);      // refill the slot
-            step(std::false_type{}, k, f_next);
-            if (PASS == Pass::Count && (k & 1023u) == 1023u) fold_adler(k);       // keeps a2 inside 32 bits
+            for (int j = 0; j < PF4; j++) load4((uint32_t)j + 1, rc[j], ru[j]);
+            uint32_t f[4] = {sub_bytes(c_first.x, u_first.x), sub_bytes(c_first.y, u_first.y), sub_bytes(c_first.z, u_first.z),
+                             sub_bytes(c_first.w, u_first.w)};
+            uint32_t last_f = 0;                                     // pixel just before the super-window
+            uint32_t wgt = bpl - 16u * lane;                         // bytes from this lane's first byte to the row end
+            const uint32_t c1_bits = chunk1 & 0xFF;
+            // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
+            auto gather = [&](uint32_t jw, const uint32_t (&src)[4]) {
+                const int sl = (int)((16u * jw + (lane >> 2)) << 2);
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)src[0]);
+                const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)src[1]);
+                const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)src[2]);
+                const uint32_t t3 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)src[3]);
+                const uint32_t comp = lane & 3;
+                return comp == 0 ? t0 : (comp == 1 ? t1 : (comp == 2 ? t2 : t3));
+            };
+            uint32_t gen_streak = 0, done = 0, limit = NS;
+            for (uint32_t Sb = 0; Sb < limit; Sb += PF4) {
+#pragma unroll
+                for (int js = 0; js < PF4; js++) {
+                    const uint32_t S = Sb + (uint32_t)js;
+                    if (S >= limit) break;
+                    // look-ahead super-window S+1 (always completely inside the row) out of the ring
+                    const uint32_t fn[4] = {sub_bytes(rc[js].x, ru[js].x), sub_bytes(rc[js].y, ru[js].y),
+                                            sub_bytes(rc[js].z, ru[js].z), sub_bytes(rc[js].w, ru[js].w)};
+                    if (S + 1 + PF4 <= NS) load4(S + 1 + PF4, rc[js], ru[js]);
+                    // `same` masks of the four pixel slots
+                    // per-lane "equals its left neighbour" predicates (their SGPR form is the wave ballot)
+                    const bool s0 = (f[0] == lane_prev(f[3], last_f)) && !(S == 0 && lane == 0);
+                    const bool s1 = f[1] == f[0], s2 = f[2] == f[1], s3 = f[3] == f[2];
+                    const uint64_t M0 = __ballot(s0), M1 = __ballot(s1), M2 = __ballot(s2), M3 = __ballot(s3);
+                    const uint32_t last3 = (uint32_t)__builtin_amdgcn_readlane((int)f[3], 63);
+                    const bool next0 = uniform(fn[0]) == last3; // does the next super-window start by repeating this one's last pixel?
+                    const uint64_t any = M0 | M1 | M2 | M3;
+                    const bool all_lits = (any == 0);
+                    const bool sparse = !all_lits && rle.carry == 0 &&
+                                        (((M0 & M1) | (M1 & M2) | (M2 & M3) | (M3 & (M0 >> 1))) == 0) && !((M3 >> 63) && next0);
+                    if (all_lits || sparse) {
+                        gen_streak = 0;
+                        if (PASS == Pass::Hist) {
+                            const bool ss[4] = {s0, s1, s2, s3};
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                if (sparse && ss[j])
+                                    hist_add(hist, 256 + ((chunk1 >> 8) & 0xFF), lane);
+                                else {
+                                    hist_add(hist, f[j] & 0xFF, lane);
+                                    hist_add(hist, (f[j] >> 8) & 0xFF, lane);
+                                    hist_add(hist, (f[j] >> 16) & 0xFF, lane);
+                                    hist_add(hist, f[j] >> 24, lane);
+                                }
+                            }
+                        } else if (PASS == Pass::Count) {
+                            uint32_t n[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) n[j] = packed_literal_bits<4>(T, f[j]);
+                            if (sparse) { // repeats are rare: only the pixel slots that have one are touched (uniform tests)
+                                if (M0 && s0 && !(lit_test && c1_bits > n[0])) n[0] = c1_bits;
+                                if (M1 && s1 && !(lit_test && c1_bits > n[1])) n[1] = c1_bits;
+                                if (M2 && s2 && !(lit_test && c1_bits > n[2])) n[2] = c1_bits;
+                                if (M3 && s3 && !(lit_test && c1_bits > n[3])) n[3] = c1_bits;
+                            }
+                            row_bits += n[0] + n[1] + n[2] + n[3];
+                            // Adler: 16 consecutive bytes per lane
+                            uint32_t a = __builtin_amdgcn_sad_u8(f[0], 0u, 0u);
+                            a = __builtin_amdgcn_sad_u8(f[1], 0u, a);
+                            a = __builtin_amdgcn_sad_u8(f[2], 0u, a);
+                            a = __builtin_amdgcn_sad_u8(f[3], 0u, a);
+                            acc_a += a;
+                            acc_w += (uint64_t)wgt * a;
+                            acc_j = __builtin_amdgcn_udot4(f[0], 0x03020100u, acc_j, false);
+                            acc_j = __builtin_amdgcn_udot4(f[1], 0x07060504u, acc_j, false);
+                            acc_j = __builtin_amdgcn_udot4(f[2], 0x0B0A0908u, acc_j, false);
+                            acc_j = __builtin_amdgcn_udot4(f[3], 0x0F0E0D0Cu, acc_j, false);
+                        } else {
+                            // room for a whole super-window (<= 256 x 48 bits = 384 dwords) in the LDS window
+                            if (sink->fill > (uint32_t)(kStageDwords - 420) * 32u) sink_flush(*sink, lane, false);
+                            uint32_t n[4];
+                            uint64_t t[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) t[j] = packed_literal_token<4>(T, f[j], n[j]);
+                            if (sparse) {
+                                const uint64_t c1_code = chunk1 >> 8;
+                                if (M0 && s0 && !(lit_test && c1_bits > n[0])) n[0] = c1_bits, t[0] = c1_code;
+                                if (M1 && s1 && !(lit_test && c1_bits > n[1])) n[1] = c1_bits, t[1] = c1_code;
+                                if (M2 && s2 && !(lit_test && c1_bits > n[2])) n[2] = c1_bits, t[2] = c1_code;
+                                if (M3 && s3 && !(lit_test && c1_bits > n[3])) n[3] = c1_bits, t[3] = c1_code;
+                            }
+                            const uint32_t nA = n[0] + n[1], nB = n[2] + n[3], nL = nA + nB;
+                            const uint32_t incl = wave_inclusive_sum(nL);
+                            const uint32_t pos = sink->fill + incl - nL;
+                            if (__ballot(nA > 64 || nB > 64)) {
+                                // noisy pixels: a pair does not fit 64 bits, put the four tokens one by one
+                                sink_put<true>(*sink, t[0], n[0], pos);
+                                sink_put<true>(*sink, t[1], n[1], pos + n[0]);
+                                sink_put<true>(*sink, t[2], n[2], pos + nA);
+                                sink_put<true>(*sink, t[3], n[3], pos + nA + n[2]);
+                            } else {
+                                sink_put_wide(*sink, t[0] | (t[1] << n[0]), pos);
+                                sink_put_wide(*sink, t[2] | (t[3] << n[2]), pos + nA);
+                            }
+                            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            sink->fill += total;
+                            row_bits += total;
+                        }
+                        rle.carry = sparse ? (uint32_t)(M3 >> 63) : 0u;
+                    } else {
+                        // general case: replay the super-window as four 64-pixel windows of the per-pixel walk
+                        gen_streak++;
+                        uint32_t fw = gather(0, f);
+                        uint32_t carry_px = last_f;
+#pragma unroll 1
+                        for (uint32_t jw = 0; jw < 4; jw++) {
+                            f_cur = fw;
+                            m_cur = __ballot(f_cur == lane_prev(f_cur, carry_px));
+                            if (S == 0 && jw == 0) m_cur &= ~1ull;
+                            carry_px = (uint32_t)__builtin_amdgcn_readlane((int)f_cur, 63);
+                            // look-ahead: next window of this super-window, or (only bit 0 is used) the next super-window
+                            fw = (jw < 3) ? gather(jw + 1, f) : uniform(fn[0]);
+                            step(std::false_type{}, 4 * S + jw, fw);
+                        }
+                    }
+                    last_f = last3;
+                    wgt -= 1024;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) f[j] = fn[j];
+                    done = S + 1;
+                    // run-length-heavy rows gain nothing from this layout: hand the rest of the row to phase B
+                    if (gen_streak >= 2) limit = done;
+                }
+            }
+            k0 = 4 * done;
+            carry_f = last_f;
         }
     }
-    // the last one or two windows of the row: masked body, look-ahead loaded directly
-    for (uint32_t k = n_interior; k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
+
+    // =====================================================================================
+    // Phase B: per-pixel walk (lane = pixel) of windows k0 .. nwin-1: everything for RGB, the row tail for RGBA
+    // =====================================================================================
+    {
+        Raw ring[PF];
+        const Raw raw0 = px.load_raw(k0 << 6);
+#pragma unroll
+        for (int j = 0; j < PF; j++) ring[j] = px.load_raw((k0 + (uint32_t)j + 1) << 6);
+        f_cur = px.filter(raw0);
+        m_cur = __ballot(f_cur == lane_prev(f_cur, carry_f)) & valid_mask(k0 << 6, w);
+        if (k0 == 0) m_cur &= ~1ull;
+        // interior windows: ring-fed, unmasked
+        for (uint32_t kb = k0; kb < n_interior; kb += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const uint32_t k = kb + (uint32_t)j;
+                if (k >= n_interior) break;
+                const uint32_t f_next = px.filter(ring[j]);                      // window k+1
+                if (k + 1 + PF < nwin) ring[j] = px.load_raw((k + 1 + PF) << 6); // refill the slot
+                step(std::false_type{}, k, f_next);
+            }
+        }
+        // the last one or two windows of the row: masked body, look-ahead loaded directly
+        for (uint32_t k = (k0 > n_interior ? k0 : n_interior); k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
+    }
 
     RowResult res;
     res.bits = 0;
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
     if (PASS == Pass::Count) {
-        fold_adler(nwin - 1);
         const uint32_t fl_bits = plit_len(fl);
         res.bits = wave_sum(row_bits) + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
         res.last_unit_bits = last_unit + ((C == 3 && one_pass && w == 1) ? fl_bits : 0u);
         const uint32_t la = acc_a % kAdlerMod;
-        const uint32_t lw = (uint32_t)(acc_w % (int64_t)kAdlerMod); // acc_w >= 0: every pixel weight is positive
+        const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod); // every byte weight is positive
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
         res.s1 = (wave_sum(la) + filter_byte) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * filter_byte) % kAdlerMod;

@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfpng_amd.so")
+# FPNG_AMD_LIB: developer override for A/B-timing two builds on the same GPU box
+LIB_PATH = os.environ.get("FPNG_AMD_LIB") or os.path.join(_HERE, "lib", "libfpng_amd.so")
 
 NUM_PHASES = 8
 

@@ -675,7 +675,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 const uint32_t comp = lane & 3;
                 return comp == 0 ? t0 : (comp == 1 ? t1 : (comp == 2 ? t2 : t3));
             };
-            uint32_t gen_streak = 0, done = 0, limit = NS;
+            uint32_t gen_streak = 1, done = 0, limit = NS; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
             for (uint32_t Sb = 0; Sb < limit; Sb += PF4) {
 #pragma unroll
                 for (int js = 0; js < PF4; js++) {
@@ -847,7 +847,7 @@ __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return job
 // ---------------------------------------------------------------------------------------------
 // count_kernel: grid (ceil(max_rows/4), n_jobs), block 256 = 4 rows
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRowBlock) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
 {
     __shared__ PackedTables T;
     const Job &job = job_of_block(jobs);
@@ -1090,7 +1090,7 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
     }
 }
 
-__global__ __launch_bounds__(kRowBlock) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
                                                      const JobState *states)
 {
     __shared__ PackedTables T;

@@ -133,6 +133,49 @@ def test_widths_around_window_and_chunk_limits(enc, c):
             _assert_same(p, oracle().encode(img, w, h, c_, fl), f"{w}x{h}x{c_} flags={fl}")
 
 
+def _tier_pattern(rng, kind, w, c):
+    """One FILTERED row exercising a particular mix of the row walker's super-window (256 px) tiers."""
+    row = rng.integers(0, 256, (w, c), dtype=np.uint8)
+    x = np.arange(w)
+    if kind == "sparse":           # isolated repeats, some of them straddling 4-pixel lane groups and super-window seams
+        rep = rng.random(w) < 0.01
+        rep[[i for i in (1, 3, 4, 255, 256, 257, 511, 512) if i < w]] = True
+        rep[0] = False
+        for i in np.flatnonzero(rep):
+            row[i] = row[i - 1]
+    elif kind == "lit_then_runs":  # literal super-windows, then run-heavy ones (walker hands the row over mid-way)
+        row[x >= (w // 2)] = row[w // 2]
+    elif kind == "runs_then_lit":
+        row[x < (w // 2)] = 9
+    elif kind == "alternate":      # general and literal super-windows alternate: the hand-over streak must reset
+        for s in range(0, w, 512):
+            row[s:s + 200] = row[s]
+    elif kind == "pairs":          # every second pixel repeats: 1-pixel matches everywhere (literal-vs-match rule)
+        row[1::2] = row[0:w - (w % 2):2][: len(row[1::2])]
+    elif kind == "long_run_mid":   # a run longer than the chunk cap crossing several super-windows
+        a, b = w // 5, w - w // 7
+        row[a:b] = row[a]
+    return row
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_super_window_tiers(enc, c):
+    """Widths around the 256-pixel super-window and its 4-pixel lane groups, with content that steers each tier."""
+    rng = np.random.default_rng(40 + c)
+    imgs, dims = [], []
+    for w in [252, 256, 257, 259, 260, 511, 512, 513, 516, 768, 1023, 1024, 1025, 1300, 2065]:
+        for kind in ("sparse", "lit_then_runs", "runs_then_lit", "alternate", "pairs", "long_run_mid"):
+            r0 = _tier_pattern(rng, kind, w, c)
+            r1 = (r0.astype(np.uint16) + _tier_pattern(rng, kind, w, c)).astype(np.uint8)   # Up-filtered row 1 = second pattern
+            r2 = (r1.astype(np.uint16) + _tier_pattern(rng, "sparse", w, c)).astype(np.uint8)
+            imgs.append(np.ascontiguousarray(np.stack([r0, r1, r2])))
+            dims.append((w, 3, c))
+    for fl in (0, 1):
+        pngs, _ = _gpu_encode(enc, imgs, fl)
+        for img, (w, h, c_), p in zip(imgs, dims, pngs):
+            _assert_same(p, oracle().encode(img, w, h, c_, fl), f"tiers {w}x{h}x{c_} flags={fl}")
+
+
 def test_mixed_batch_shapes_and_channels(enc):
     import fpng_amd
     imgs = [fpng_amd.synth_image(k, w, h, c) for (k, w, h, c) in

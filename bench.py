@@ -96,7 +96,9 @@ def main():
     # B distinct frames per rank (seed varies per image and per rank)
     imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]
     cap = fpng_amd.max_encoded_size(w, h, c) + 64
-    outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)]
+    # consecutive submissions overlap on the GPU (two encoder lanes): each gets its own set of output buffers
+    out_sets = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(4)]
+    outs = out_sets[0]
     enc = fpng_amd.Encoder(device=local_rank, stream="own")
 
     def step():
@@ -115,8 +117,8 @@ def main():
     t0 = time.perf_counter()
     # K steps are enqueued back to back (the encoder pipelines submissions through a ring of pinned
     # slots); the closing finish()/barrier waits for all of them, so exactly K steps are timed.
-    for _ in range(args.steps):
-        enc.submit(imgs, outs, args.flags)
+    for i in range(args.steps):
+        enc.submit(imgs, out_sets[i & 3], args.flags)
     res = enc.finish(B)
     barrier()
     elapsed = time.perf_counter() - t0

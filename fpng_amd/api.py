@@ -97,7 +97,7 @@ class Encoder:
             sp = C.c_void_p(int(stream))
         check(self.lib.fpng_amd_encoder_create(C.byref(h), device, sp))
         self.h = h
-        self._keep = None
+        self._keep = []
 
     def close(self):
         if getattr(self, "h", None):
@@ -123,13 +123,19 @@ class Encoder:
             arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
             arr[i].d_out = out.data_ptr()
             arr[i].out_cap = out.numel()
-        self._keep = (images, outs, arr)
+        self._keep.append((images, outs, arr))  # buffers of submissions in flight stay alive until finish()
         check(self.lib.fpng_amd_encode_batch_async(self.h, arr, n, flags))
         return n
 
+    def join(self):
+        """Device-side join: the encoder's stream waits for every submission made so far (no host wait)."""
+        check(self.lib.fpng_amd_encoder_join(self.h))
+
     def finish(self, n):
+        """Waits for ALL submissions in flight; returns (png_size, mode, status) of the last one's n images."""
         res = (Result * n)()
         check(self.lib.fpng_amd_encode_finish(self.h, res, n))
+        self._keep = []
         return [(r.png_size, r.mode, r.status) for r in res]
 
     def encode_tensors(self, images, flags=0):

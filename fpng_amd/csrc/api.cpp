@@ -176,16 +176,31 @@ struct fpng_amd_encoder {
     uint32_t phases_recorded = 0;
 
     PinnedBuf<Job> h_jobs;
-    DeviceBuf<Job> d_jobs;
-    DeviceBuf<RowInfo> d_rows;
-    DeviceBuf<uint64_t> d_row_off;
-    DeviceBuf<JobState> d_states;
-    DeviceBuf<Result> d_results;
     PinnedBuf<Result> h_results;
     PinnedBuf<JobState> h_states;
-    DeviceBuf<uint32_t> d_partials;
-    DeviceBuf<uint32_t> d_hist;
-    DeviceBuf<TokenTable> d_dyn;
+    // Device scratch of one submission.  Batch submissions alternate between kLanes internal streams, each
+    // with its own scratch, so that the latency-bound tail of one submission (row scan, CRC fold, trailer)
+    // and its LDS-bound CRC kernel overlap the VALU-bound row walkers of the next one.  Set 0 also serves
+    // the synchronous entry points (bands, wrap_png), which drain the lanes first.
+    struct Scratch {
+        DeviceBuf<Job> d_jobs;
+        DeviceBuf<RowInfo> d_rows;
+        DeviceBuf<uint64_t> d_row_off;
+        DeviceBuf<JobState> d_states;
+        DeviceBuf<Result> d_results;
+        DeviceBuf<uint32_t> d_partials;
+        DeviceBuf<uint32_t> d_hist;
+        DeviceBuf<TokenTable> d_dyn;
+        void release()
+        {
+            d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
+            d_partials.release(), d_hist.release(), d_dyn.release();
+        }
+    };
+    static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
+    Scratch sc[kLanes];
+    hipStream_t lane_stream[kLanes] = {};
+    uint32_t submit_count = 0;
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
     // fused single-pass encoder scratch.  d_sync = [ticket | group_acc[G] | group_state[G] | unit_bits[U]] is
     // cleared with one memset before each launch; unit_start / seams are fully rewritten by the kernel.
@@ -195,12 +210,13 @@ struct fpng_amd_encoder {
     uint32_t last_n = 0;
     // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
     // records coming back) guarded by an event, so fpng_amd_encode_batch_async() never waits for the GPU
-    // unless all slots are in flight.  Device scratch is shared: the stream executes submissions in order.
+    // unless all slots are in flight.
     static constexpr int kSlots = 4;
     struct Slot {
         PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
         PinnedBuf<Result> results;
-        hipEvent_t done = nullptr;
+        hipEvent_t in = nullptr;   // recorded on the caller's stream: the inputs are ready
+        hipEvent_t done = nullptr; // recorded on the lane: PNGs and result records are complete
         bool in_flight = false;
         uint32_t n = 0;
     } slots[kSlots];
@@ -278,6 +294,13 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
         }
         e->own_stream = true;
     }
+    for (auto &ls : e->lane_stream) {
+        hipError_t err = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
+        if (err != hipSuccess) {
+            fpng_amd_encoder_destroy(e);
+            return fail(FPNG_AMD_ERR_HIP, "hipStreamCreate (lane)", err);
+        }
+    }
     *out = e;
     return FPNG_AMD_OK;
 }
@@ -286,6 +309,8 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    for (auto &ls : e->lane_stream)
+        if (ls) (void)hipStreamSynchronize(ls);
     (void)hipStreamSynchronize(e->stream);
     if (e->ev_ready)
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
@@ -295,17 +320,13 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
         sl.jobs2.release();
         sl.results.release();
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.in) (void)hipEventDestroy(sl.in);
     }
-    e->d_jobs.release();
-    e->d_rows.release();
-    e->d_row_off.release();
-    e->d_states.release();
-    e->d_results.release();
+    for (auto &ls : e->lane_stream)
+        if (ls) (void)hipStreamDestroy(ls);
+    for (auto &s : e->sc) s.release();
     e->h_results.release();
     e->h_states.release();
-    e->d_partials.release();
-    e->d_hist.release();
-    e->d_dyn.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
     e->d_sync.release();
@@ -386,18 +407,29 @@ int set_units(Job &j, Submission &sub)
 
 FusedBuffers fused_buffers(fpng_amd_encoder *e, const Submission &sub);
 
-int mark(fpng_amd_encoder *e, uint32_t idx)
+int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
 {
     if (e->profiling) {
-        HIP_TRY(hipEventRecord(e->ev[idx], e->stream));
+        HIP_TRY(hipEventRecord(e->ev[idx], s));
         e->phases_recorded = idx;
     }
     return FPNG_AMD_OK;
 }
 
+// Host-side wait for every submission in flight on the lanes.
+int drain(fpng_amd_encoder *e)
+{
+    for (auto &sl : e->slots)
+        if (sl.in_flight) {
+            HIP_TRY(hipEventSynchronize(sl.done));
+            sl.in_flight = false;
+        }
+    return FPNG_AMD_OK;
+}
+
 // Fills slot.jobs[0..n) for whole-image jobs and sizes the scratch buffers.
-int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, const fpng_amd_image *images, uint32_t n, uint32_t flags,
-                 Submission &sub)
+int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_encoder::Scratch &sc, const fpng_amd_image *images,
+                 uint32_t n, uint32_t flags, Submission &sub)
 {
     if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
@@ -440,19 +472,19 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, const fpng_a
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
     }
-    if ((rc = e->d_jobs.ensure(n))) return rc;
-    if ((rc = e->d_rows.ensure(sub.total_rows))) return rc;
-    if ((rc = e->d_row_off.ensure(sub.total_rows))) return rc;
-    if ((rc = e->d_states.ensure(n))) return rc;
-    if ((rc = e->d_results.ensure(n))) return rc;
-    if ((rc = e->d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
+    if ((rc = sc.d_jobs.ensure(n))) return rc;
+    if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
+    if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
+    if ((rc = sc.d_states.ensure(n))) return rc;
+    if ((rc = sc.d_results.ensure(n))) return rc;
+    if ((rc = sc.d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
     if ((rc = e->d_sync.ensure(sub.sync_words()))) return rc;
     if ((rc = e->d_unit_start.ensure(sub.total_units + 1))) return rc;
     if ((rc = e->d_seams.ensure(sub.total_units + 1))) return rc;
     if ((rc = e->d_unit_adler.ensure(sub.total_units + 1))) return rc;
     if (two_pass) {
-        if ((rc = e->d_hist.ensure((size_t)n * 288))) return rc;
-        if ((rc = e->d_dyn.ensure(n))) return rc;
+        if ((rc = sc.d_hist.ensure((size_t)n * 288))) return rc;
+        if ((rc = sc.d_dyn.ensure(n))) return rc;
     }
     return FPNG_AMD_OK;
 }
@@ -483,37 +515,10 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     e->cur_slot = (e->cur_slot + 1) % fpng_amd_encoder::kSlots;
     fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (!slot.in) HIP_TRY(hipEventCreateWithFlags(&slot.in, hipEventDisableTiming));
     if (slot.in_flight) {
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
-    }
-    Submission sub;
-    int rc = prepare_jobs(e, slot, images, n, flags, sub);
-    if (rc) return rc;
-    const DeviceTables &dt = g_dev[e->device];
-    const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
-    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
-    hipStream_t s = e->stream;
-    e->phases_recorded = 0;
-
-    if (two_pass) {
-        // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
-        // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
-        if ((rc = slot.jobs2.ensure(n))) return rc;
-        for (uint32_t i = 0; i < n; i++) {
-            slot.jobs2.p[i] = slot.jobs.p[i];
-            slot.jobs2.p[i].table = e->d_dyn.p + i;
-            slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
-        }
-    }
-    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, n * sizeof(JobState), s));
-    if ((rc = mark(e, 0))) return rc;
-    if (two_pass) {
-        HIP_TRY(hipMemsetAsync(e->d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
-        launch_hist(s, e->d_jobs.p, n, sub.max_rows, e->d_hist.p);
-        launch_build_dynamic(s, e->d_jobs.p, n, e->d_hist.p, e->d_dyn.p);
-        HIP_TRY(hipMemcpyAsync(e->d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
     // Two pipelines produce the same bytes.  Default: two passes over the image (count -> scan -> emit),
     // the faster one on MI355X today (profiles/).  FPNG_AMD_FUSED=1 selects the experimental single-pass
@@ -522,32 +527,72 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         const char *v = getenv("FPNG_AMD_FUSED");
         return v && v[0] == '1';
     }();
+    static const uint32_t n_lanes = [] {
+        const char *v = getenv("FPNG_AMD_LANES");
+        const int n = v ? atoi(v) : 2;
+        return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
+    }();
+    // lane = internal stream + scratch set.  Per-kernel profiling and the experimental pipeline (shared
+    // scratch) stay on lane 0, which serialises them.
+    const int lane = (use_fused || e->profiling) ? 0 : (int)(e->submit_count++ % n_lanes);
+    fpng_amd_encoder::Scratch &sc = e->sc[lane];
+    hipStream_t s = e->lane_stream[lane];
+    Submission sub;
+    int rc = prepare_jobs(e, slot, sc, images, n, flags, sub);
+    if (rc) return rc;
+    // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
+    HIP_TRY(hipEventRecord(slot.in, e->stream));
+    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
+    const DeviceTables &dt = g_dev[e->device];
+    const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
+    e->phases_recorded = 0;
+
+    if (two_pass) {
+        // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
+        // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
+        if ((rc = slot.jobs2.ensure(n))) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            slot.jobs2.p[i] = slot.jobs.p[i];
+            slot.jobs2.p[i].table = sc.d_dyn.p + i;
+            slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, n * sizeof(JobState), s));
+    if ((rc = mark(e, s, 0))) return rc;
+    if (two_pass) {
+        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
+        launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
+        launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
+        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    }
     if (use_fused) {
         const FusedBuffers fb = fused_buffers(e, sub);
         if (!force_stored) {
             HIP_TRY(hipMemsetAsync(e->d_sync.p, 0, sub.sync_words() * sizeof(uint64_t), s));
-            launch_encode(s, e->d_jobs.p, n, sub.max_tickets, fb, e->d_states.p);
+            launch_encode(s, sc.d_jobs.p, n, sub.max_tickets, fb, sc.d_states.p);
         }
-        if ((rc = mark(e, 1))) return rc;
-        launch_seal(s, e->d_jobs.p, n, sub.max_units, fb, e->d_states.p);
-        if ((rc = mark(e, 2))) return rc;
-        launch_stored(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
-        if ((rc = mark(e, 3))) return rc;
+        if ((rc = mark(e, s, 1))) return rc;
+        launch_seal(s, sc.d_jobs.p, n, sub.max_units, fb, sc.d_states.p);
+        if ((rc = mark(e, s, 2))) return rc;
+        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
+        if ((rc = mark(e, s, 3))) return rc;
     } else {
-        if (!force_stored) launch_count(s, e->d_jobs.p, n, sub.max_rows, e->d_rows.p, e->d_states.p);
-        if ((rc = mark(e, 1))) return rc;
-        launch_scan(s, e->d_jobs.p, n, e->d_rows.p, e->d_row_off.p, e->d_states.p);
-        if ((rc = mark(e, 2))) return rc;
-        launch_emit(s, e->d_jobs.p, n, sub.max_rows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
-        if ((rc = mark(e, 3))) return rc;
+        if (!force_stored) launch_count(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
+        if ((rc = mark(e, s, 1))) return rc;
+        launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+        if ((rc = mark(e, s, 2))) return rc;
+        launch_emit(s, sc.d_jobs.p, n, sub.max_rows, sc.d_row_off.p, sc.d_rows.p, sc.d_states.p);
+        if ((rc = mark(e, s, 3))) return rc;
     }
-    launch_crc(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_states.p, dt.crc, e->d_partials.p);
-    if ((rc = mark(e, 4))) return rc;
-    launch_finalize(s, e->d_jobs.p, n, sub.max_crc_blocks, e->d_rows.p, e->d_states.p, dt.crc, e->d_partials.p,
-                    e->d_results.p);
-    if ((rc = mark(e, 5))) return rc;
+    launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
+    if ((rc = mark(e, s, 4))) return rc;
+    launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p,
+                    sc.d_results.p);
+    if ((rc = mark(e, s, 5))) return rc;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(slot.results.p, e->d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(slot.results.p, sc.d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(slot.done, s));
     slot.in_flight = true;
     slot.n = n;
@@ -555,12 +600,21 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     return FPNG_AMD_OK;
 }
 
+int fpng_amd_encoder_join(fpng_amd_encoder *e)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    HIP_TRY(hipSetDevice(e->device));
+    for (auto &sl : e->slots)
+        if (sl.in_flight) HIP_TRY(hipStreamWaitEvent(e->stream, sl.done, 0));
+    return FPNG_AMD_OK;
+}
+
 int fpng_amd_encode_finish(fpng_amd_encoder *e, fpng_amd_result *results, uint32_t n)
 {
     if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream)); // every outstanding submission is done after this
-    for (auto &sl : e->slots) sl.in_flight = false;
+    int rc0 = drain(e); // every outstanding submission is done after this
+    if (rc0) return rc0;
     if (results) {
         const fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
         if (n > slot.n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
@@ -629,24 +683,25 @@ int fpng_amd_band_count(fpng_amd_encoder *e, const void *d_rows, const void *d_r
 {
     if (!stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null stats");
     HIP_TRY(hipSetDevice(e ? e->device : 0));
-    HIP_TRY(hipStreamSynchronize(e->stream));
     int rc;
+    if ((rc = drain(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     if ((rc = e->h_jobs.ensure(1))) return rc;
     Job &j = e->h_jobs.p[0];
     if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
     j.is_first = 0; // offsets relative to start_bit = 0: only the total is used
     j.is_last = 0;
     j.start_bit = 0;
-    if ((rc = e->d_jobs.ensure(1)) || (rc = e->d_rows.ensure(j.nrows)) || (rc = e->d_row_off.ensure(j.nrows)) ||
-        (rc = e->d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
+    if ((rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_rows.ensure(j.nrows)) || (rc = e->sc[0].d_row_off.ensure(j.nrows)) ||
+        (rc = e->sc[0].d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
         return rc;
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, sizeof(JobState), s));
-    launch_count(s, e->d_jobs.p, 1, j.nrows, e->d_rows.p, e->d_states.p);
-    launch_scan(s, e->d_jobs.p, 1, e->d_rows.p, e->d_row_off.p, e->d_states.p);
+    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->sc[0].d_states.p, 0, sizeof(JobState), s));
+    launch_count(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_rows.p, e->sc[0].d_states.p);
+    launch_scan(s, e->sc[0].d_jobs.p, 1, e->sc[0].d_rows.p, e->sc[0].d_row_off.p, e->sc[0].d_states.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->sc[0].d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const JobState &st = e->h_states.p[0];
     stats->token_bits = st.token_end_bit;
@@ -665,8 +720,9 @@ int fpng_amd_band_emit(fpng_amd_encoder *e, const void *d_rows, const void *d_ro
     if (!d_band_out || !out_bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
     if ((uintptr_t)d_band_out & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_band_out must be 16-byte aligned");
     HIP_TRY(hipSetDevice(e ? e->device : 0));
-    HIP_TRY(hipStreamSynchronize(e->stream));
     int rc;
+    if ((rc = drain(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     if ((rc = e->h_jobs.ensure(1))) return rc;
     Job &j = e->h_jobs.p[0];
     if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
@@ -680,17 +736,17 @@ int fpng_amd_band_emit(fpng_amd_encoder *e, const void *d_rows, const void *d_ro
     const uint64_t first_byte = is_first ? 0 : (start_bit >> 3);
     j.bit_bias = -(int64_t)(first_byte * 8);
     j.flags = 0x100; // band emit: scan_kernel prepares seams/prefix in the band window
-    if ((rc = e->d_jobs.ensure(1)) || (rc = e->d_rows.ensure(j.nrows)) || (rc = e->d_row_off.ensure(j.nrows)) ||
-        (rc = e->d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
+    if ((rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_rows.ensure(j.nrows)) || (rc = e->sc[0].d_row_off.ensure(j.nrows)) ||
+        (rc = e->sc[0].d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
         return rc;
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->d_states.p, 0, sizeof(JobState), s));
-    launch_count(s, e->d_jobs.p, 1, j.nrows, e->d_rows.p, e->d_states.p);
-    launch_scan(s, e->d_jobs.p, 1, e->d_rows.p, e->d_row_off.p, e->d_states.p);
-    launch_emit(s, e->d_jobs.p, 1, j.nrows, e->d_row_off.p, e->d_rows.p, e->d_states.p);
+    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->sc[0].d_states.p, 0, sizeof(JobState), s));
+    launch_count(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_rows.p, e->sc[0].d_states.p);
+    launch_scan(s, e->sc[0].d_jobs.p, 1, e->sc[0].d_rows.p, e->sc[0].d_row_off.p, e->sc[0].d_states.p);
+    launch_emit(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_row_off.p, e->sc[0].d_rows.p, e->sc[0].d_states.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->sc[0].d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint64_t end_bit = e->h_states.p[0].token_end_bit;
     uint64_t bytes;
@@ -716,10 +772,11 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     int rc = check_dims(w, h, c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
+    if ((rc = drain(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if ((rc = e->h_jobs.ensure(1)) || (rc = e->d_jobs.ensure(1)) || (rc = e->d_states.ensure(1)) ||
-        (rc = e->h_states.ensure(1)) || (rc = e->d_results.ensure(1)) || (rc = e->h_results.ensure(1)) ||
-        (rc = e->d_rows.ensure(1)))
+    if ((rc = e->h_jobs.ensure(1)) || (rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_states.ensure(1)) ||
+        (rc = e->h_states.ensure(1)) || (rc = e->sc[0].d_results.ensure(1)) || (rc = e->h_results.ensure(1)) ||
+        (rc = e->sc[0].d_rows.ensure(1)))
         return rc;
     Job &j = e->h_jobs.p[0];
     std::memset(&j, 0, sizeof j);
@@ -738,16 +795,16 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     st.zlib_size = zlib_size;
     st.mode = 0;
     st.adler = ((uint32_t)be[0] << 24) | ((uint32_t)be[1] << 16) | ((uint32_t)be[2] << 8) | be[3];
-    if ((rc = e->d_partials.ensure(j.crc_blocks))) return rc;
+    if ((rc = e->sc[0].d_partials.ensure(j.crc_blocks))) return rc;
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->sc[0].d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_png, j.png_header, kPngHeaderBytes, hipMemcpyHostToDevice, s));
-    launch_crc(s, e->d_jobs.p, 1, j.crc_blocks, e->d_states.p, g_dev[e->device].crc, e->d_partials.p);
-    launch_finalize(s, e->d_jobs.p, 1, j.crc_blocks, e->d_rows.p, e->d_states.p, g_dev[e->device].crc, e->d_partials.p,
-                    e->d_results.p);
+    launch_crc(s, e->sc[0].d_jobs.p, 1, j.crc_blocks, e->sc[0].d_states.p, g_dev[e->device].crc, e->sc[0].d_partials.p);
+    launch_finalize(s, e->sc[0].d_jobs.p, 1, j.crc_blocks, e->sc[0].d_rows.p, e->sc[0].d_states.p, g_dev[e->device].crc, e->sc[0].d_partials.p,
+                    e->sc[0].d_results.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->d_results.p, sizeof(Result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->sc[0].d_results.p, sizeof(Result), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *png_size = (size_t)e->h_results.p[0].png_size;
     return FPNG_AMD_OK;
@@ -759,8 +816,8 @@ int fpng_amd_calibration_stream(fpng_amd_encoder *e, int write, uint32_t lane_by
         return fail(FPNG_AMD_ERR_INVALID_ARG, "bad calibration arguments");
     HIP_TRY(hipSetDevice(e->device));
     int rc;
-    if ((rc = e->d_hist.ensure(288))) return rc;
-    launch_calibration(e->stream, write, lane_bytes, d_buf, bytes, e->d_hist.p);
+    if ((rc = e->sc[0].d_hist.ensure(288))) return rc;
+    launch_calibration(e->stream, write, lane_bytes, d_buf, bytes, e->sc[0].d_hist.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     return FPNG_AMD_OK;

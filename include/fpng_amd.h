@@ -72,12 +72,13 @@ uint32_t fpng_amd_adler32_combine(uint32_t adler_x, uint32_t adler_y, uint64_t l
  * reference src/fpng.cpp:1747, + container).  d_out capacities must be >= this. */
 size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
 
-/* ---- encoder object: a HIP stream + reusable device scratch.  Not thread-safe; create one
- *      per thread (the reference is re-entrant, reference src/fpng.cpp:371 note in SURVEY 8b). ---- */
+/* ---- encoder object: the caller's HIP stream (ordering point) + two internal streams ("lanes") with
+ *      reusable device scratch.  Not thread-safe; create one per thread (the reference is re-entrant,
+ *      reference src/fpng.cpp:371 note in SURVEY 8b). ---- */
 typedef struct fpng_amd_encoder fpng_amd_encoder;
 
-/* hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let the
- * encoder create its own non-blocking stream. */
+/* hip_stream: the hipStream_t submissions are ordered against (e.g. torch's current stream: the producer
+ * of the pixels), or NULL to let the encoder create its own non-blocking stream. */
 int fpng_amd_encoder_create(fpng_amd_encoder **enc, int device, void *hip_stream);
 void fpng_amd_encoder_destroy(fpng_amd_encoder *enc);
 void *fpng_amd_encoder_stream(fpng_amd_encoder *enc);
@@ -97,14 +98,22 @@ typedef struct fpng_amd_result {
 
 /*
  * THE HOT PATH.  fpng_encode_image_to_memory() (reference src/fpng.h:48, src/fpng.cpp:1662-1803)
- * for `n` device-resident images in one submission.  Enqueues all kernels on the encoder's stream
- * and returns without waiting; nothing is copied to the host except the n result records, which
- * are delivered by fpng_amd_encode_finish().
+ * for `n` device-resident images in one submission.  Returns without waiting; nothing is copied to the
+ * host except the n result records, which are delivered by fpng_amd_encode_finish().
+ *
+ * Ordering: the kernels start after everything enqueued on the encoder's stream before this call, and run
+ * on one of the encoder's two internal lanes, so consecutive submissions OVERLAP on the GPU (the serial
+ * tail and the LDS-bound CRC of one under the row walkers of the next).  Outputs are complete after
+ * fpng_amd_encode_finish() (host side) or, for work enqueued on the encoder's stream, after
+ * fpng_amd_encoder_join().  The pixel and output buffers of submissions in flight must not alias.
  */
 int fpng_amd_encode_batch_async(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t flags);
 
-/* Waits for the last fpng_amd_encode_batch_async() of this encoder and copies out its n result
- * records (results may be NULL to just wait). */
+/* Device-side join: the encoder's stream waits (no host wait) for every submission made so far. */
+int fpng_amd_encoder_join(fpng_amd_encoder *enc);
+
+/* Waits for ALL outstanding fpng_amd_encode_batch_async() submissions of this encoder and copies out the
+ * n result records of the last one (results may be NULL to just wait). */
 int fpng_amd_encode_finish(fpng_amd_encoder *enc, fpng_amd_result *results, uint32_t n);
 
 /* Convenience: fpng_encode_image_to_memory() on HOST buffers (H2D + encode + D2H, synchronous).

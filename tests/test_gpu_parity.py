@@ -300,7 +300,7 @@ def test_cpp_dropin_namespace_fpng(enc, tmp_path):
 
 def test_pipelined_submissions_without_intermediate_finish(enc):
     """fpng_amd_encode_batch_async() may be called repeatedly before fpng_amd_encode_finish(): submissions
-    go through a ring of pinned slots and share device scratch in stream order."""
+    go through a ring of pinned slots and alternate between the encoder's two lanes."""
     import torch
     import fpng_amd
     rng = np.random.default_rng(55)
@@ -320,6 +320,30 @@ def test_pipelined_submissions_without_intermediate_finish(enc):
             exp = oracle().encode(img, w, h, c, fl)
             got = bytes(out[:len(exp)].cpu().numpy())
             _assert_same(got, exp, f"pipelined {w}x{h}x{c} flags={fl}")
+
+
+def test_overlapping_submissions_large_enough_to_run_concurrently(enc):
+    """Consecutive submissions run on two internal lanes with separate scratch: make them long enough to
+    really overlap on the GPU (several ms each) and check every PNG of every submission."""
+    import torch
+    import fpng_amd
+    subs = []
+    for b in range(6):
+        c = 4 if b % 3 else 3
+        imgs = [fpng_amd.synth_image(kind, 2048, 768 + 64 * b, c, seed=900 + 10 * b + i) for i, kind in enumerate(("grad", "blocks", "noise"))]
+        ts = [torch.from_numpy(i).cuda() for i in imgs]
+        outs = [torch.empty(fpng_amd.max_encoded_size(t.shape[1], t.shape[0], t.shape[2]) + 64, dtype=torch.uint8, device="cuda") for t in ts]
+        subs.append((imgs, ts, outs, 1 if b in (2, 3) else 0))
+    torch.cuda.synchronize()
+    for imgs, ts, outs, fl in subs:
+        enc.submit(ts, outs, fl)
+    enc.join()        # device-side join on the encoder's stream, then the host-side wait
+    enc.finish(3)
+    for imgs, ts, outs, fl in subs:
+        for img, out in zip(imgs, outs):
+            h, w, c = img.shape
+            exp = oracle().encode(img, w, h, c, fl)
+            _assert_same(bytes(out[:len(exp)].cpu().numpy()), exp, f"overlapped {w}x{h}x{c} flags={fl}")
 
 
 def test_experimental_fused_pipeline_same_bytes():

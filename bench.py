@@ -141,10 +141,10 @@ def main():
         phases += np.array(enc.last_phase_ms())
     phases /= reps
     enc.set_profiling(False)
-    names = ["encode", "seal", "stored", "crc", "finalize"] if os.environ.get("FPNG_AMD_FUSED") == "1" else ["count", "scan", "emit", "crc", "finalize"]
+    names = enc.phase_names()
     phase_ms = {n: round(float(phases[i]), 4) for i, n in enumerate(names)}
     alg_bytes = B * w * h * c + png_bytes  # input read once + PNG written once
-    dom = max((k for k in names if k in ("encode", "count", "emit", "crc")), key=lambda k: phase_ms[k])
+    dom = max((k for k in names if k in ("encode_rows", "assemble", "encode", "count", "emit", "crc")), key=lambda k: phase_ms[k])
     dom_s = phase_ms[dom] / 1e3
     achieved = alg_bytes / dom_s / 1e9
     kernels_s = sum(phase_ms[k] for k in names) / 1e3

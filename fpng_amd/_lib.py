@@ -47,6 +47,7 @@ SIGNATURES = {
     "fpng_amd_encoder_destroy": (None, [_vp]),
     "fpng_amd_encoder_stream": (_vp, [_vp]),
     "fpng_amd_encoder_join": (_int, [_vp]),
+    "fpng_amd_encoder_phase_names": (C.c_char_p, [_vp]),
     "fpng_amd_encode_batch_async": (_int, [_vp, C.POINTER(Image), _u32, _u32]),
     "fpng_amd_encode_finish": (_int, [_vp, C.POINTER(Result), _u32]),
     "fpng_amd_encode_host": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, C.POINTER(_sz)]),

@@ -127,6 +127,10 @@ class Encoder:
         check(self.lib.fpng_amd_encode_batch_async(self.h, arr, n, flags))
         return n
 
+    def phase_names(self):
+        """Names of the kernels/phases of the last submission's pipeline (see last_phase_ms)."""
+        return self.lib.fpng_amd_encoder_phase_names(self.h).decode().split(",")
+
     def join(self):
         """Device-side join: the encoder's stream waits for every submission made so far (no host wait)."""
         check(self.lib.fpng_amd_encoder_join(self.h))

@@ -191,16 +191,18 @@ struct fpng_amd_encoder {
         DeviceBuf<uint32_t> d_partials;
         DeviceBuf<uint32_t> d_hist;
         DeviceBuf<TokenTable> d_dyn;
+        DeviceBuf<uint32_t> d_local; // the rows' local streams (Job::local_base / local_stride)
         void release()
         {
             d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
-            d_partials.release(), d_hist.release(), d_dyn.release();
+            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
         }
     };
     static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
     uint32_t submit_count = 0;
+    int pipeline = 0; // of the last submission: 0 rows+assemble, 1 count/scan/emit, 2 experimental fused
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
     // fused single-pass encoder scratch.  d_sync = [ticket | group_acc[G] | group_state[G] | unit_bits[U]] is
     // cleared with one memset before each launch; unit_start / seams are fully rewritten by the kernel.
@@ -369,6 +371,7 @@ struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
     uint64_t total_rows = 0, total_units = 0, total_tickets = 0, total_groups = 0;
     uint32_t max_units = 0, max_tickets = 0;
+    uint64_t local_dwords = 0; // scratch for the rows' local streams
     size_t sync_words() const { return 1 + 2 * total_groups + (total_units + 1) / 2 + 1; }
 };
 
@@ -468,6 +471,11 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
         if ((rc = set_units(j, sub))) return rc;
+        // a row's local stream: no Deflate code is longer than 15 bits -> < 2 bytes per filtered byte; rows start
+        // 16-byte aligned and assemble_kernel may read one dword past the stream
+        j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * 16 + 64 + 31) / 32 + 4 + 3) & ~3ull);
+        j.local_base = sub.local_dwords;
+        sub.local_dwords += (uint64_t)j.local_stride * im.h;
         sub.total_rows += im.h;
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
@@ -547,6 +555,24 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     e->phases_recorded = 0;
+    // Default pipeline: ONE walk over the pixels (encode_rows: every row into its local stream), then the
+    // streams are shifted into place while the IDAT CRC is taken (assemble).  Images whose local streams would
+    // not fit the scratch budget, and FPNG_AMD_PIPELINE=count, use the older count -> scan -> emit -> crc
+    // kernels (two walks over the pixels, no scratch), which the row-band entry points need anyway.
+    static const bool prefer_count = [] {
+        const char *v = getenv("FPNG_AMD_PIPELINE");
+        return v && !strcmp(v, "count");
+    }();
+    static const uint64_t local_limit = [] {
+        const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
+        return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
+    }();
+    const bool use_rows = !use_fused && !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
+    e->pipeline = use_fused ? 2 : (use_rows ? 0 : 1);
+    if (use_rows) {
+        if ((rc = sc.d_local.ensure(sub.local_dwords + 16))) return rc;
+        for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
+    }
 
     if (two_pass) {
         // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
@@ -578,6 +604,13 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         if ((rc = mark(e, s, 2))) return rc;
         launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 3))) return rc;
+    } else if (use_rows) {
+        if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+        if ((rc = mark(e, s, 1))) return rc;
+        launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+        if ((rc = mark(e, s, 2))) return rc;
+        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+        if ((rc = mark(e, s, 3))) return rc;
     } else {
         if (!force_stored) launch_count(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 1))) return rc;
@@ -586,7 +619,10 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         launch_emit(s, sc.d_jobs.p, n, sub.max_rows, sc.d_row_off.p, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 3))) return rc;
     }
-    launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
+    if (use_rows)
+        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
+    else
+        launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
     if ((rc = mark(e, s, 4))) return rc;
     launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p,
                     sc.d_results.p);
@@ -598,6 +634,13 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     slot.n = n;
     e->last_n = n;
     return FPNG_AMD_OK;
+}
+
+const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
+{
+    static const char *names[3] = {"encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize",
+                                   "encode,seal,stored,crc,finalize"};
+    return names[e ? e->pipeline : 0];
 }
 
 int fpng_amd_encoder_join(fpng_amd_encoder *e)

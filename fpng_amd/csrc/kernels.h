@@ -24,6 +24,11 @@ struct Job {
     uint32_t row_base;        // index of the job's first row in the per-row scratch arrays
     uint32_t one_pass, whole_png, is_first, is_last;
     uint32_t crc_blocks;      // upper bound of CRC ranges for this job
+    // whole images: every row is first encoded into its own dword-aligned stream in scratch ("local stream"),
+    // assemble_kernel then shifts the streams into place.  Row r lives at local + local_base + r*local_stride.
+    uint64_t local_base;      // dwords
+    uint32_t local_stride;    // dwords per row (worst-case token bits of a row + slack)
+    uint32_t local_pad;
     // fused single-pass encoder: a unit = one 1024-pixel segment of one row
     uint32_t nseg;            // units per row
     uint32_t n_units;         // nrows * nseg
@@ -78,6 +83,10 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
 void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
                  const JobState *states);
+void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states,
+                        uint32_t *local);
+void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,

@@ -357,7 +357,10 @@ __device__ __forceinline__ uint64_t valid_mask(uint32_t x0, uint32_t limit)
 //   * table entries are packed so that code lengths add up in the low byte and an entry can be used
 //     directly as a shift amount.
 // ---------------------------------------------------------------------------------------------
-enum class Pass { Count, Hist, Emit };
+// Count: token lengths + Adler sums of a row.  Hist: symbol histogram (2-pass).  Emit: tokens at their final
+// bit position (row bands).  Encode: tokens into the row's private scratch stream AND the sums of Count, so
+// that a whole image needs one walk over its pixels.
+enum class Pass { Count, Hist, Emit, Encode };
 
 struct EmitSink {
     uint32_t *stage;     // this wave's LDS window
@@ -365,6 +368,7 @@ struct EmitSink {
     uint64_t base_dw;    // destination dword index of stage[0]
     uint32_t fill;       // bits used in the window
     bool first_flush;
+    bool exclusive;      // the destination belongs to this row alone (local stream): no shared dwords
 };
 
 __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t ndw)
@@ -413,7 +417,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
         gptr_u32 dst = s.out32 + s.base_dw + j;
         // the last dword is shared only when the row ends inside it (then it holds the next row's
         // first bit, or the job's end, both of which scan_kernel zeroed)
-        const bool shared = (j == 0 && s.first_flush) || (final && j == ndw - 1 && (s.fill & 31u));
+        const bool shared = !s.exclusive && ((j == 0 && s.first_flush) || (final && j == ndw - 1 && (s.fill & 31u)));
         if (shared) {
             if (v) __hip_atomic_fetch_or(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else
@@ -454,6 +458,9 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
+    constexpr bool kEmit = PASS == Pass::Emit || PASS == Pass::Encode;  // builds and stages the token bits
+    constexpr bool kCount = PASS == Pass::Count;                        // token lengths only
+    constexpr bool kSums = PASS == Pass::Count || PASS == Pass::Encode; // Adler sums, final flush unit
     const uint32_t w = uniform(job.w), bpl = uniform(job.bpl);
     const uint8_t *row = job.rows + (size_t)r * bpl;
     const bool filter_up = (uniform(job.y0) + r) != 0;
@@ -476,7 +483,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     uint64_t acc_w = 0;
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
     const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
-    if (PASS == Pass::Emit) {
+    if (kEmit) {
         if (lane == 0) {
             const uint64_t v = (uint64_t)plit_code(fl) << (sink->fill & 31);
             atomicOr(&sink->stage[sink->fill >> 5], (uint32_t)v);
@@ -504,9 +511,9 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         bool every_lane_has_token = all_lits;
         if (all_lits) {
             // no pixel of this window repeats its left neighbour: every lane is a literal pixel
-            if (PASS == Pass::Emit)
+            if (kEmit)
                 code = packed_literal_token<C>(T, f_cur, nbits);
-            else if (PASS == Pass::Count)
+            else if (kCount)
                 nbits = packed_literal_bits<C>(T, f_cur);
             else if (valid) {
                 hist_add(hist, f_cur & 0xFF, lane);
@@ -533,7 +540,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     if (C == 4) hist_add(hist, f_cur >> 24, lane);
                 }
             } else {
-                if (PASS == Pass::Emit)
+                if (kEmit)
                     code = packed_literal_token<C>(T, f_cur, nbits);
                 else
                     nbits = packed_literal_bits<C>(T, f_cur);
@@ -560,8 +567,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     code = ce >> 8;
                     if (lit_test && q == 1) { // a 1-pixel chunk can only be the run's last pixel here
                         uint32_t lbits = 0;
-                        const uint64_t lcode = (PASS == Pass::Emit) ? packed_literal_token<C>(T, f_cur, lbits) : 0ull;
-                        if (PASS == Pass::Count) lbits = packed_literal_bits<C>(T, f_cur);
+                        const uint64_t lcode = kEmit ? packed_literal_token<C>(T, f_cur, lbits) : 0ull;
+                        if (kCount) lbits = packed_literal_bits<C>(T, f_cur);
                         if (nbits > lbits) {
                             nbits = lbits;
                             code = lcode;
@@ -586,7 +593,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 uint32_t lbits = 0;
                 uint64_t lcode = 0;
                 if (!same || (lit_test && ends && q == 1)) {
-                    if (PASS == Pass::Emit)
+                    if (kEmit)
                         lcode = packed_literal_token<C>(T, f_cur, lbits);
                     else
                         lbits = packed_literal_bits<C>(T, f_cur);
@@ -613,8 +620,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             // size of the final flush unit of the row = token of its last pixel (scan_kernel's failure rule)
             if (PASS != Pass::Hist && x0 + 64 >= w) last_unit = (uint32_t)__builtin_amdgcn_readlane((int)nbits, (w - 1) & 63);
         }
-        if (PASS == Pass::Count) {
-            row_bits += nbits; // per lane, reduced after the loop
+        if (kCount) row_bits += nbits; // per lane, reduced after the loop
+        if (kSums) {
             // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially).  Lanes
             // past the row end read 0 (RGBA) or are masked (RGB shares an aligned dword with real bytes).
             const uint32_t fa = (!TAIL || C == 4 || valid) ? f_cur : 0u;
@@ -622,7 +629,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             acc_a += a;
             acc_w += (uint64_t)(bpl - (uint32_t)C * (x0 + lane)) * a; // invalid lanes: a == 0
             acc_j = __builtin_amdgcn_udot4(fa, 0x03020100u, acc_j, false);
-        } else if (PASS == Pass::Emit) {
+        }
+        if (kEmit) {
             const uint32_t incl = wave_inclusive_sum(nbits);
             if (!TAIL && every_lane_has_token)
                 sink_put<true>(*sink, code, nbits, sink->fill + incl - nbits);
@@ -711,7 +719,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                     hist_add(hist, f[j] >> 24, lane);
                                 }
                             }
-                        } else if (PASS == Pass::Count) {
+                        } else {
+                          if (kCount) {
                             uint32_t n[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) n[j] = packed_literal_bits<4>(T, f[j]);
@@ -722,6 +731,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                 if (M3 && s3 && !(lit_test && c1_bits > n[3])) n[3] = c1_bits;
                             }
                             row_bits += n[0] + n[1] + n[2] + n[3];
+                          }
+                          if (kSums) {
                             // Adler: 16 consecutive bytes per lane
                             uint32_t a = __builtin_amdgcn_sad_u8(f[0], 0u, 0u);
                             a = __builtin_amdgcn_sad_u8(f[1], 0u, a);
@@ -733,7 +744,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             acc_j = __builtin_amdgcn_udot4(f[1], 0x07060504u, acc_j, false);
                             acc_j = __builtin_amdgcn_udot4(f[2], 0x0B0A0908u, acc_j, false);
                             acc_j = __builtin_amdgcn_udot4(f[3], 0x0F0E0D0Cu, acc_j, false);
-                        } else {
+                          }
+                          if (kEmit) {
                             // room for a whole super-window (<= 256 x 48 bits = 384 dwords) in the LDS window
                             if (sink->fill > (uint32_t)(kStageDwords - 420) * 32u) sink_flush(*sink, lane, false);
                             uint32_t n[4];
@@ -763,6 +775,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                             sink->fill += total;
                             row_bits += total;
+                          }
                         }
                         rle.carry = sparse ? (uint32_t)(M3 >> 63) : 0u;
                     } else {
@@ -825,9 +838,9 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.bits = 0;
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
-    if (PASS == Pass::Count) {
+    if (kSums) {
         const uint32_t fl_bits = plit_len(fl);
-        res.bits = wave_sum(row_bits) + fl_bits;
+        res.bits = (kCount ? wave_sum(row_bits) : row_bits) + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
         res.last_unit_bits = last_unit + ((C == 3 && one_pass && w == 1) ? fl_bits : 0u);
@@ -836,7 +849,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
         res.s1 = (wave_sum(la) + filter_byte) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * filter_byte) % kAdlerMod;
-    } else if (PASS == Pass::Emit) {
+    } else if (kEmit) {
         res.bits = row_bits;
     }
     return res;
@@ -1009,9 +1022,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
     if (!job.whole_png && !(job.flags & 0x100u)) return;
 
     // --- zero the seam dwords, then write PNG header + Deflate prefix ---
+    // (flag 0x200: the rows sit in local streams and assemble_kernel places them; it wants the head followed
+    // by zeros up to the next 16-byte boundary and needs no zeroed seams)
+    const bool assemble = (job.flags & 0x200u) != 0;
     gptr_u32 out32 = to_global<gptr_u32>(job.out);
     const int64_t bias = job.bit_bias;
-    if (!stored) {
+    if (!stored && !assemble) {
         for (uint32_t r = t; r < job.nrows; r += kBlock) {
             const uint64_t o = row_off[job.row_base + r] + bias;
             out32[o >> 5] = 0; // dword holding the first bit of row r (and the last bits of row r-1)
@@ -1037,7 +1053,16 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
     __syncthreads();
     if (t == 0) {
         if (job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
-        if (!stored && job.is_first && (tab->header_bits & 7)) zl[tab->header_bits >> 3] |= tab->header[tab->header_bits >> 3];
+        if (!stored && job.is_first && (tab->header_bits & 7)) {
+            if (assemble)
+                zl[tab->header_bits >> 3] = tab->header[tab->header_bits >> 3];
+            else
+                zl[tab->header_bits >> 3] |= tab->header[tab->header_bits >> 3];
+        }
+    }
+    if (assemble && !stored) {
+        const uint32_t head_end = kPngHeaderBytes + ((tab->header_bits + 7) >> 3);
+        for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
     }
 }
 
@@ -1114,6 +1139,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     sink.base_dw = off >> 5;
     sink.fill = (uint32_t)(off & 31);
     sink.first_flush = true;
+    sink.exclusive = false;
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
@@ -1130,6 +1156,53 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
         sink.fill += plit_len(eob);
     }
     sink_flush(sink, lane, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode_rows_kernel: grid (ceil(max_rows/8), n_jobs).  ONE walk over the pixels of a whole image: each wave
+// encodes its row into the row's private, dword-aligned local stream (plain coalesced stores, nothing is
+// shared between rows) and records the row's token bits and Adler sums for scan_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
+                                                                                                      JobState *states, uint32_t *local)
+{
+    __shared__ PackedTables T;
+    __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
+    const Job &job = job_of_block(jobs);
+    if (blockIdx.x * kRowWaves >= job.nrows) return;
+    stage_packed_tables(T, job.table);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kRowWaves + wv;
+    if (r >= job.nrows) return;
+
+    EmitSink sink;
+    sink.stage = stage[wv];
+    sink.out32 = to_global<gptr_u32>(local + job.local_base + (uint64_t)r * job.local_stride);
+    sink.base_dw = 0;
+    sink.fill = 0;
+    sink.first_flush = false;
+    sink.exclusive = true;
+    sink_zero(sink, lane, kStageDwords);
+    wave_lds_fence();
+
+    const RowResult res = (job.c == 4) ? walk_row<4, Pass::Encode>(job, T, nullptr, r, lane, &sink)
+                                       : walk_row<3, Pass::Encode>(job, T, nullptr, r, lane, &sink);
+    if (r == job.nrows - 1) {
+        // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of ri.bits
+        const uint32_t eob = T.lit[256];
+        sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
+        sink.fill += plit_len(eob);
+    }
+    sink_flush(sink, lane, true);
+    if (lane == 0) {
+        RowInfo ri;
+        ri.bits = res.bits;
+        ri.s1 = res.s1;
+        ri.s2 = res.s2;
+        ri.pad = 0;
+        rows_out[job.row_base + r] = ri;
+        if (r == job.nrows - 1) states[blockIdx.y].last_unit_bits = res.last_unit_bits;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1199,6 +1272,163 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
         c = n;
     }
     // lane stripes now sit at range_end + 16*tid: move them all to range_end + one block row, fold
+    c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) partials[(size_t)blockIdx.y * max_crc_blocks + blockIdx.x] = red[0] ^ red[1] ^ red[2] ^ red[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// assemble_kernel: same geometry and CRC arithmetic as crc_kernel, but the 16 bytes a lane feeds to its CRC
+// stripe are ASSEMBLED here from the rows' local streams and stored to the file: row r's stream is shifted
+// to file bit row_off[r] + bias, neighbouring rows meet inside a dword.  Nothing is read back from the file
+// except the head (PNG header + Deflate prefix, written by scan_kernel), and no destination dword is
+// written twice, so the rows need no atomics and no zeroed seams.  Stored-mode jobs only take the CRC.
+// ---------------------------------------------------------------------------------------------
+typedef FPNG_GLOBAL u32x4 *gptr_u128;
+
+// up to 32 bits of a local stream of `nbits` bits, starting at its bit p
+__device__ __forceinline__ uint32_t local_bits(gptr_cu32 src, uint64_t p, uint64_t nbits)
+{
+    const uint64_t i = p >> 5;
+    const uint32_t sh = (uint32_t)p & 31u;
+    const uint32_t lo = src[i];
+    const uint32_t hi = (sh && ((i + 1) << 5) < nbits) ? src[i + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+__global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const JobState *states, const uint64_t *row_off,
+                                                         const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
+                                                         uint32_t max_crc_blocks)
+{
+    __shared__ uint32_t tab[16][256];
+    __shared__ uint32_t red[kWavesPerBlock];
+    const Job &job = job_of_block(jobs);
+    const JobState &st = states[blockIdx.y];
+    if (!job.whole_png) return;
+    const int64_t data_begin = kPngHeaderBytes, data_end = (int64_t)(kPngHeaderBytes + st.zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * kCrcRangeBytes;
+    if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
+    for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
+    __syncthreads();
+    gptr_cu8 base = to_global<gptr_cu8>(job.out);
+    const uint32_t tid = threadIdx.x;
+
+    const bool gather = st.mode == 0u;
+    const int64_t bias = job.bit_bias;
+    const uint32_t R = job.nrows;
+    gptr_cu32 loc = to_global<gptr_cu32>(local) + job.local_base;
+    const uint32_t stride = job.local_stride;
+    gptr_cu32 src = loc;
+    const FPNG_GLOBAL uint64_t *offs = (const FPNG_GLOBAL uint64_t *)(uintptr_t)(row_off + job.row_base);
+    // file bit positions: first token, end of the end-of-block symbol (= end of the last row's local stream)
+    int64_t tok_begin = 0, tok_end = 0;
+    // row cursor of this lane: row r spans file bits [off_r, off_next)
+    uint32_t r = 0;
+    int64_t off_r = 0, off_next = 0;
+    auto row_end = [&](uint32_t rr) { return (rr + 1 < R) ? (int64_t)offs[rr + 1] + bias : tok_end; };
+    if (gather) {
+        tok_begin = (int64_t)offs[0] + bias;
+        tok_end = (int64_t)st.token_end_bit + bias + (int64_t)(job.table->lit[256] >> 16);
+        // the row holding this lane's first position (binary search; later positions advance linearly)
+        const int64_t o0 = range_end - kCrcRangeBytes + tid * 16;
+        const int64_t p0 = (o0 * 8 > tok_begin) ? o0 * 8 : tok_begin;
+        uint32_t lo = 0, hi = R; // invariant: offs[lo] + bias <= p0, row hi (if any) starts after p0
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((int64_t)offs[mid] + bias <= p0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        r = lo;
+        off_r = (int64_t)offs[r] + bias;
+        off_next = row_end(r);
+        src = loc + (uint64_t)r * stride;
+    }
+
+    uint32_t c = 0;
+    for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
+        const int64_t o = range_end - kCrcRangeBytes + (int64_t)row * kCrcRowBytes + tid * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (o + 16 > data_begin && o < data_end) {
+            const int64_t P = o * 8;
+            if (!gather || P < tok_begin) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
+                const u32x4 d = *(gptr_cu128)(base + o);
+                w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
+            }
+            if (gather && P + 128 > tok_begin) {
+                if (P < tok_end) {
+                    const int64_t pm = P > tok_begin ? P : tok_begin;
+                    while (r + 1 < R && off_next <= pm) {
+                        r++;
+                        off_r = off_next;
+                        off_next = row_end(r);
+                        src += stride;
+                    }
+                    if (P >= off_r && P + 128 <= off_next) {
+                        // the whole piece comes from one row: five dwords, four funnel shifts
+                        const uint64_t p = (uint64_t)(P - off_r);
+                        gptr_cu32 q = src + (p >> 5);
+                        const uint32_t sh = (uint32_t)p & 31u;
+                        const uint32_t s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
+                        w[0] = __builtin_amdgcn_alignbit(s1, s0, sh);
+                        w[1] = __builtin_amdgcn_alignbit(s2, s1, sh);
+                        w[2] = __builtin_amdgcn_alignbit(s3, s2, sh);
+                        w[3] = __builtin_amdgcn_alignbit(s4, s3, sh);
+                    } else {
+                        // rows meet inside the piece (or it holds the stream's begin / end): dword by dword
+                        uint32_t r2 = r;
+                        int64_t a = off_r, n = off_next;
+                        gptr_cu32 s2p = src;
+#pragma unroll 1
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int64_t B = P + 32 * kk, E = B + 32;
+                            if (E <= tok_begin || B >= tok_end) continue;
+                            uint32_t acc = 0;
+                            for (;;) {
+                                const int64_t lo = B > a ? B : a, hi = E < n ? E : n; // [lo, hi): bits of row r2 inside the dword
+                                if (lo < hi) {
+                                    uint32_t v = local_bits(s2p, (uint64_t)(lo - a), (uint64_t)(n - a));
+                                    if (hi - lo < 32) v &= (1u << (uint32_t)(hi - lo)) - 1u;
+                                    acc |= v << (uint32_t)(lo - B);
+                                }
+                                if (n >= E || r2 + 1 >= R) break;
+                                r2++;
+                                a = n;
+                                n = row_end(r2);
+                                s2p += stride;
+                            }
+                            w[kk] |= acc;
+                        }
+                    }
+                }
+                u32x4 d;
+                d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
+                *(gptr_u128)(uintptr_t)(base + o) = d;
+            }
+            if (o < data_begin || o + 16 > data_end) { // zero the bytes outside [data_begin, data_end) for the CRC
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int64_t pos = o + 4 * kk + b;
+                        if (pos >= data_begin && pos < data_end) m |= 0xFFu << (8 * b);
+                    }
+                    w[kk] &= m;
+                }
+            }
+        }
+        w[0] ^= c;
+        uint32_t n = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            n ^= tab[4 * kk + 0][w[kk] & 0xFF] ^ tab[4 * kk + 1][(w[kk] >> 8) & 0xFF] ^ tab[4 * kk + 2][(w[kk] >> 16) & 0xFF] ^
+                 tab[4 * kk + 3][w[kk] >> 24];
+        c = n;
+    }
     c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
     if ((tid & 63) == 0) red[tid >> 6] = c;
     __syncthreads();
@@ -1674,6 +1904,17 @@ void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {
     hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, hist, tables);
+}
+void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states,
+                        uint32_t *local)
+{
+    hipLaunchKernelGGL(encode_rows_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+}
+void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials)
+{
+    hipLaunchKernelGGL(assemble_kernel, dim3(max_crc_blocks, n_jobs), dim3(kBlock), 0, s, jobs, states, row_off, local, tabs,
+                       partials, max_crc_blocks);
 }
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials)

@@ -164,16 +164,14 @@ int fpng_amd_wrap_png(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, u
 #define FPNG_AMD_SYNTH_BLOCKS 3
 int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32_t num_chans, uint8_t *out);
 
-/* ---- instrumentation for bench.py: time of the last batch's kernels measured with HIP events
- *      on the encoder's own stream (ms); per-phase breakdown when profiling is enabled. ---- */
-#define FPNG_AMD_PHASE_COUNT 0
-#define FPNG_AMD_PHASE_SCAN 1
-#define FPNG_AMD_PHASE_EMIT 2
-#define FPNG_AMD_PHASE_CRC 3
-#define FPNG_AMD_PHASE_FINAL 4
+/* ---- instrumentation for bench.py: per-kernel durations of the last submission measured with HIP
+ *      events (ms).  With profiling enabled submissions use one lane, i.e. they do not overlap.
+ *      fpng_amd_encoder_phase_names(): comma-separated names of the phases of the last submission's
+ *      pipeline, e.g. "encode_rows,scan,stored,assemble,finalize". ---- */
 #define FPNG_AMD_NUM_PHASES 8
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
+const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *enc);
 
 /* PMC calibration (instrumentation): stream `bytes` of d_buf once with 4- or 16-byte lanes, reading
  * (write=0) or writing (write=1), so rocprofv3 FETCH_SIZE/WRITE_SIZE can be converted to bytes. */

@@ -372,6 +372,7 @@ struct Submission {
     uint64_t total_rows = 0, total_units = 0, total_tickets = 0, total_groups = 0;
     uint32_t max_units = 0, max_tickets = 0;
     uint64_t local_dwords = 0; // scratch for the rows' local streams
+    uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
     size_t sync_words() const { return 1 + 2 * total_groups + (total_units + 1) / 2 + 1; }
 };
 
@@ -475,6 +476,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         // 16-byte aligned and assemble_kernel may read one dword past the stream
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * 16 + 64 + 31) / 32 + 4 + 3) & ~3ull);
         j.local_base = sub.local_dwords;
+        sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         sub.local_dwords += (uint64_t)j.local_stride * im.h;
         sub.total_rows += im.h;
         sub.max_rows = std::max(sub.max_rows, im.h);
@@ -605,7 +607,7 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 3))) return rc;
     } else if (use_rows) {
-        if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+        if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
         if ((rc = mark(e, s, 1))) return rc;
         launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
         if ((rc = mark(e, s, 2))) return rc;

@@ -83,8 +83,9 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
 void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
                  const JobState *states);
-void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states,
-                        uint32_t *local);
+// chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
+void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
+                        JobState *states, uint32_t *local);
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                      const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,

@@ -412,6 +412,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
 {
     wave_lds_fence();
     const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5);
+#pragma unroll 1
     for (uint32_t j = lane; j < ndw; j += kWave) {
         const uint32_t v = s.stage[j];
         gptr_u32 dst = s.out32 + s.base_dw + j;
@@ -1163,13 +1164,16 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // encodes its row into the row's private, dword-aligned local stream (plain coalesced stores, nothing is
 // shared between rows) and records the row's token bits and Adler sums for scan_kernel.
 // ---------------------------------------------------------------------------------------------
+// One instantiation per channel count (jobs of the other kind leave at once): the 3-channel walk needs far
+// fewer registers than the 4-pixels-per-lane RGBA one and keeps 8 waves per SIMD.
+template <int C>
 __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
                                                                                                       JobState *states, uint32_t *local)
 {
     __shared__ PackedTables T;
     __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kRowWaves >= job.nrows) return;
+    if (job.c != C || blockIdx.x * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kRowWaves + wv;
@@ -1178,15 +1182,17 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     EmitSink sink;
     sink.stage = stage[wv];
     sink.out32 = to_global<gptr_u32>(local + job.local_base + (uint64_t)r * job.local_stride);
-    sink.base_dw = 0;
-    sink.fill = 0;
+    // (a zero the compiler cannot see: with a literal 0 it specialises the walk on the known fill level and
+    // nearly doubles the register count)
+    const uint32_t zero = uniform(job.local_pad);
+    sink.base_dw = zero;
+    sink.fill = zero;
     sink.first_flush = false;
     sink.exclusive = true;
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
-    const RowResult res = (job.c == 4) ? walk_row<4, Pass::Encode>(job, T, nullptr, r, lane, &sink)
-                                       : walk_row<3, Pass::Encode>(job, T, nullptr, r, lane, &sink);
+    const RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, lane, &sink);
     if (r == job.nrows - 1) {
         // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of ri.bits
         const uint32_t eob = T.lit[256];
@@ -1287,16 +1293,6 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
 // ---------------------------------------------------------------------------------------------
 typedef FPNG_GLOBAL u32x4 *gptr_u128;
 
-// up to 32 bits of a local stream of `nbits` bits, starting at its bit p
-__device__ __forceinline__ uint32_t local_bits(gptr_cu32 src, uint64_t p, uint64_t nbits)
-{
-    const uint64_t i = p >> 5;
-    const uint32_t sh = (uint32_t)p & 31u;
-    const uint32_t lo = src[i];
-    const uint32_t hi = (sh && ((i + 1) << 5) < nbits) ? src[i + 1] : 0u;
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-}
-
 __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
                                                          uint32_t max_crc_blocks)
@@ -1312,110 +1308,110 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
     for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
     __syncthreads();
-    gptr_cu8 base = to_global<gptr_cu8>(job.out);
     const uint32_t tid = threadIdx.x;
 
+    // Everything below is relative to the first byte of the block's range, in 32-bit arithmetic: positions that
+    // matter lie within +-2^31 bits of it (a row has < 2^30 token bits), the rest saturates.
+    const int64_t range_begin = range_end - kCrcRangeBytes; // may be negative: bytes in front of the file count as absent
+    auto sat = [](int64_t v) { return (int32_t)(v > 0x7FFFFFFFll ? 0x7FFFFFFFll : (v < -0x7FFFFFFFll ? -0x7FFFFFFFll : v)); };
+    const int32_t db = sat(data_begin - range_begin), de = sat(data_end - range_begin); // bytes
+    gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
+
     const bool gather = st.mode == 0u;
-    const int64_t bias = job.bit_bias;
+    const int64_t bit0 = range_begin * 8 - job.bit_bias; // zlib bit position of relative bit 0
     const uint32_t R = job.nrows;
-    gptr_cu32 loc = to_global<gptr_cu32>(local) + job.local_base;
     const uint32_t stride = job.local_stride;
-    gptr_cu32 src = loc;
+    gptr_cu32 src = to_global<gptr_cu32>(local) + job.local_base;
     const FPNG_GLOBAL uint64_t *offs = (const FPNG_GLOBAL uint64_t *)(uintptr_t)(row_off + job.row_base);
-    // file bit positions: first token, end of the end-of-block symbol (= end of the last row's local stream)
-    int64_t tok_begin = 0, tok_end = 0;
-    // row cursor of this lane: row r spans file bits [off_r, off_next)
+    int32_t tok_begin = 0, tok_end = 0; // first token; end of the end-of-block symbol (= end of the last row's local stream)
+    // row cursor of this lane: row r spans bits [off_r, off_next), row r+1 ends at off_next2 (fetched ahead)
     uint32_t r = 0;
-    int64_t off_r = 0, off_next = 0;
-    auto row_end = [&](uint32_t rr) { return (rr + 1 < R) ? (int64_t)offs[rr + 1] + bias : tok_end; };
+    int32_t off_r = 0, off_next = 0, off_next2 = 0;
+    auto row_begin = [&](uint32_t rr) { return (rr < R) ? sat((int64_t)offs[rr] - bit0) : tok_end; };
     if (gather) {
-        tok_begin = (int64_t)offs[0] + bias;
-        tok_end = (int64_t)st.token_end_bit + bias + (int64_t)(job.table->lit[256] >> 16);
+        tok_begin = sat((int64_t)offs[0] - bit0);
+        tok_end = sat((int64_t)st.token_end_bit + (int64_t)(job.table->lit[256] >> 16) - bit0);
         // the row holding this lane's first position (binary search; later positions advance linearly)
-        const int64_t o0 = range_end - kCrcRangeBytes + tid * 16;
-        const int64_t p0 = (o0 * 8 > tok_begin) ? o0 * 8 : tok_begin;
-        uint32_t lo = 0, hi = R; // invariant: offs[lo] + bias <= p0, row hi (if any) starts after p0
+        const int32_t p0 = ((int32_t)(tid * 128) > tok_begin) ? (int32_t)(tid * 128) : tok_begin;
+        uint32_t lo = 0, hi = R; // invariant: row lo starts at or before p0, row hi (if any) after it
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if ((int64_t)offs[mid] + bias <= p0)
+            if ((int64_t)offs[mid] - bit0 <= (int64_t)p0)
                 lo = mid;
             else
                 hi = mid;
         }
         r = lo;
-        off_r = (int64_t)offs[r] + bias;
-        off_next = row_end(r);
-        src = loc + (uint64_t)r * stride;
+        off_r = row_begin(r);
+        off_next = row_begin(r + 1);
+        off_next2 = row_begin(r + 2);
+        src += (uint64_t)r * stride;
     }
 
     uint32_t c = 0;
     for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
-        const int64_t o = range_end - kCrcRangeBytes + (int64_t)row * kCrcRowBytes + tid * 16;
+        const int32_t o = (int32_t)(row * kCrcRowBytes + tid * 16); // byte, relative
         uint32_t w[4] = {0, 0, 0, 0};
-        if (o + 16 > data_begin && o < data_end) {
-            const int64_t P = o * 8;
+        if (o + 16 > db && o < de) {
+            const int32_t P = o * 8;
             if (!gather || P < tok_begin) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
                 const u32x4 d = *(gptr_cu128)(base + o);
                 w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
             }
             if (gather && P + 128 > tok_begin) {
-                if (P < tok_end) {
-                    const int64_t pm = P > tok_begin ? P : tok_begin;
-                    while (r + 1 < R && off_next <= pm) {
-                        r++;
-                        off_r = off_next;
-                        off_next = row_end(r);
-                        src += stride;
-                    }
-                    if (P >= off_r && P + 128 <= off_next) {
-                        // the whole piece comes from one row: five dwords, four funnel shifts
-                        const uint64_t p = (uint64_t)(P - off_r);
-                        gptr_cu32 q = src + (p >> 5);
+                const int32_t pm = P > tok_begin ? P : tok_begin;
+                while (r + 1 < R && off_next <= pm) {
+                    r++;
+                    off_r = off_next;
+                    off_next = off_next2;
+                    off_next2 = row_begin(r + 2); // not needed before the next advance
+                    src += stride;
+                }
+                if (P >= off_r && P + 128 <= off_next) {
+                    // the whole piece comes from one row: five dwords, four funnel shifts
+                    const uint32_t p = (uint32_t)(P - off_r);
+                    gptr_cu32 q = src + (p >> 5);
+                    const uint32_t sh = p & 31u;
+                    const uint32_t s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
+                    w[0] = __builtin_amdgcn_alignbit(s1, s0, sh);
+                    w[1] = __builtin_amdgcn_alignbit(s2, s1, sh);
+                    w[2] = __builtin_amdgcn_alignbit(s3, s2, sh);
+                    w[3] = __builtin_amdgcn_alignbit(s4, s3, sh);
+                } else {
+                    // rows meet inside the piece (or it holds the stream's begin / end): OR the contribution of
+                    // every row that overlaps it; dwords outside a row's stream read as zero
+                    uint32_t r2 = r;
+                    int32_t a = off_r, n = off_next;
+                    gptr_cu32 s2p = src;
+                    for (;;) {
+                        const int32_t p = P - a;                       // may be negative: the row starts inside the piece
+                        const int32_t i = p >> 5;                      // floor
                         const uint32_t sh = (uint32_t)p & 31u;
-                        const uint32_t s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
-                        w[0] = __builtin_amdgcn_alignbit(s1, s0, sh);
-                        w[1] = __builtin_amdgcn_alignbit(s2, s1, sh);
-                        w[2] = __builtin_amdgcn_alignbit(s3, s2, sh);
-                        w[3] = __builtin_amdgcn_alignbit(s4, s3, sh);
-                    } else {
-                        // rows meet inside the piece (or it holds the stream's begin / end): dword by dword
-                        uint32_t r2 = r;
-                        int64_t a = off_r, n = off_next;
-                        gptr_cu32 s2p = src;
-#pragma unroll 1
-                        for (int kk = 0; kk < 4; kk++) {
-                            const int64_t B = P + 32 * kk, E = B + 32;
-                            if (E <= tok_begin || B >= tok_end) continue;
-                            uint32_t acc = 0;
-                            for (;;) {
-                                const int64_t lo = B > a ? B : a, hi = E < n ? E : n; // [lo, hi): bits of row r2 inside the dword
-                                if (lo < hi) {
-                                    uint32_t v = local_bits(s2p, (uint64_t)(lo - a), (uint64_t)(n - a));
-                                    if (hi - lo < 32) v &= (1u << (uint32_t)(hi - lo)) - 1u;
-                                    acc |= v << (uint32_t)(lo - B);
-                                }
-                                if (n >= E || r2 + 1 >= R) break;
-                                r2++;
-                                a = n;
-                                n = row_end(r2);
-                                s2p += stride;
-                            }
-                            w[kk] |= acc;
-                        }
+                        const uint32_t ndw = ((uint32_t)(n - a) + 31u) >> 5;
+                        uint32_t s[5];
+#pragma unroll
+                        for (int j = 0; j < 5; j++) s[j] = ((uint32_t)(i + j) < ndw) ? s2p[i + j] : 0u;
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(s[kk + 1], s[kk], sh);
+                        if (n >= P + 128 || r2 + 1 >= R) break;
+                        r2++;
+                        a = n;
+                        n = row_begin(r2 + 1);
+                        s2p += stride;
                     }
                 }
                 u32x4 d;
                 d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
                 *(gptr_u128)(uintptr_t)(base + o) = d;
             }
-            if (o < data_begin || o + 16 > data_end) { // zero the bytes outside [data_begin, data_end) for the CRC
+            if (o < db || o + 16 > de) { // zero the bytes outside [data_begin, data_end) for the CRC
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     uint32_t m = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
-                        const int64_t pos = o + 4 * kk + b;
-                        if (pos >= data_begin && pos < data_end) m |= 0xFFu << (8 * b);
+                        const int32_t pos = o + 4 * kk + b;
+                        if (pos >= db && pos < de) m |= 0xFFu << (8 * b);
                     }
                     w[kk] &= m;
                 }
@@ -1905,10 +1901,11 @@ void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const
 {
     hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, hist, tables);
 }
-void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states,
-                        uint32_t *local)
+void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
+                        JobState *states, uint32_t *local)
 {
-    hipLaunchKernelGGL(encode_rows_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+    if (chan_mask & 1u) hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+    if (chan_mask & 2u) hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
 }
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                      const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials)

@@ -111,9 +111,10 @@ class Encoder:
             pass
 
     # ---- device-resident batch: the hot path ----
-    def submit(self, images, outs, flags=0):
-        """images: list of uint8 CUDA tensors shaped (h, w, c), contiguous.  outs: list of uint8 CUDA
-        tensors with >= max_encoded_size bytes.  Asynchronous; call finish() for the sizes."""
+    @staticmethod
+    def make_batch(images, outs):
+        """Descriptor array (fpng_amd_image[n]) for a list of image / output tensors.  Build it once when the
+        same buffers are encoded repeatedly (a capture pipeline): submit() then costs one C call."""
         n = len(images)
         arr = (Image * n)()
         for i, (im, out) in enumerate(zip(images, outs)):
@@ -123,8 +124,16 @@ class Encoder:
             arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
             arr[i].d_out = out.data_ptr()
             arr[i].out_cap = out.numel()
-        self._keep.append((images, outs, arr))  # buffers of submissions in flight stay alive until finish()
-        check(self.lib.fpng_amd_encode_batch_async(self.h, arr, n, flags))
+        return (images, outs, arr)
+
+    def submit(self, images, outs=None, flags=0):
+        """images: list of uint8 CUDA tensors shaped (h, w, c), contiguous, and outs: list of uint8 CUDA
+        tensors with >= max_encoded_size bytes -- or images = a make_batch() descriptor and outs = None.
+        Asynchronous; call finish() for the sizes."""
+        batch = images if outs is None else self.make_batch(images, outs)
+        self._keep.append(batch)  # buffers of submissions in flight stay alive until finish()
+        n = len(batch[2])
+        check(self.lib.fpng_amd_encode_batch_async(self.h, batch[2], n, flags))
         return n
 
     def phase_names(self):

@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
     for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
     __syncthreads();
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6);
 
     // Everything below is relative to the first byte of the block's range, in 32-bit arithmetic: positions that
     // matter lie within +-2^31 bits of it (a row has < 2^30 token bits), the rest saturates.
@@ -1317,113 +1317,118 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     const int32_t db = sat(data_begin - range_begin), de = sat(data_end - range_begin); // bytes
     gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
 
-    const bool gather = st.mode == 0u;
+    const bool gather = uniform(st.mode) == 0u;
     const int64_t bit0 = range_begin * 8 - job.bit_bias; // zlib bit position of relative bit 0
-    const uint32_t R = job.nrows;
-    const uint32_t stride = job.local_stride;
-    gptr_cu32 src = to_global<gptr_cu32>(local) + job.local_base;
+    const uint32_t R = uniform(job.nrows);
+    const uint32_t stride = uniform(job.local_stride);
+    gptr_cu32 loc = to_global<gptr_cu32>(local) + job.local_base;
     const FPNG_GLOBAL uint64_t *offs = (const FPNG_GLOBAL uint64_t *)(uintptr_t)(row_off + job.row_base);
     int32_t tok_begin = 0, tok_end = 0; // first token; end of the end-of-block symbol (= end of the last row's local stream)
-    // row cursor of this lane: row r spans bits [off_r, off_next), row r+1 ends at off_next2 (fetched ahead)
+    // Row cursor of the WAVE (all of it wave-uniform): per step a wave covers 1 KiB of the file, row r is the
+    // one holding the first token bit of that chunk and spans bits [a, n).
     uint32_t r = 0;
-    int32_t off_r = 0, off_next = 0, off_next2 = 0;
-    auto row_begin = [&](uint32_t rr) { return (rr < R) ? sat((int64_t)offs[rr] - bit0) : tok_end; };
+    int32_t a = 0, n = 0;
+    auto row_begin_lane = [&](uint32_t rr) { return (rr < R) ? sat((int64_t)offs[rr] - bit0) : tok_end; }; // per lane
+    auto row_begin = [&](uint32_t rr) { return (int32_t)uniform((uint32_t)row_begin_lane(rr)); };           // uniform rr
     if (gather) {
-        tok_begin = sat((int64_t)offs[0] - bit0);
-        tok_end = sat((int64_t)st.token_end_bit + (int64_t)(job.table->lit[256] >> 16) - bit0);
-        // the row holding this lane's first position (binary search; later positions advance linearly)
-        const int32_t p0 = ((int32_t)(tid * 128) > tok_begin) ? (int32_t)(tid * 128) : tok_begin;
-        uint32_t lo = 0, hi = R; // invariant: row lo starts at or before p0, row hi (if any) after it
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((int64_t)offs[mid] - bit0 <= (int64_t)p0)
-                lo = mid;
-            else
-                hi = mid;
+        tok_begin = (int32_t)uniform((uint32_t)sat((int64_t)offs[0] - bit0));
+        tok_end = (int32_t)uniform((uint32_t)sat((int64_t)st.token_end_bit + (int64_t)(job.table->lit[256] >> 16) - bit0));
+        // 64-ary search for the row holding the wave's first position
+        const int32_t c0 = (int32_t)(wv * 8192u);
+        const int32_t p0 = c0 > tok_begin ? c0 : tok_begin;
+        uint32_t lo = 0, span = R; // the answer lies in [lo, lo + span); row lo starts at or before p0
+        while (span > 1) {
+            const uint32_t step = (span + 63) >> 6;
+            const bool probe = lane * step < span;
+            const int32_t v = probe ? row_begin_lane(lo + lane * step) : 0;
+            const uint32_t kcnt = (uint32_t)__popcll(__ballot(probe && v <= p0)); // >= 1: lane 0 qualifies
+            lo += (kcnt - 1) * step;
+            span = (span - (kcnt - 1) * step < step) ? span - (kcnt - 1) * step : step;
         }
-        r = lo;
-        off_r = row_begin(r);
-        off_next = row_begin(r + 1);
-        off_next2 = row_begin(r + 2);
-        src += (uint64_t)r * stride;
+        r = uniform(lo);
+        a = row_begin(r);
+        n = row_begin(r + 1);
     }
 
     uint32_t c = 0;
     for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
         const int32_t o = (int32_t)(row * kCrcRowBytes + tid * 16); // byte, relative
+        const int32_t P = o * 8;
+        const int32_t C0 = (int32_t)((row * kCrcRowBytes + wv * 1024u) * 8u), C1 = C0 + 8192; // the wave's chunk (bits)
         uint32_t w[4] = {0, 0, 0, 0};
-        if (o + 16 > db && o < de) {
-            const int32_t P = o * 8;
-            if (!gather || P < tok_begin) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
-                const u32x4 d = *(gptr_cu128)(base + o);
-                w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
+        const bool in_data = o + 16 > db && o < de;
+        if (in_data && (!gather || P < tok_begin)) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
+            const u32x4 d = *(gptr_cu128)(base + o);
+            w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
+        }
+        if (gather && C1 > tok_begin && C0 < tok_end && (C1 >> 3) > db && (C0 >> 3) < de) { // wave-uniform
+            const int32_t cm = C0 > tok_begin ? C0 : tok_begin;
+            // advance the cursor: up to 64 rows per probe
+            while (r + 1 < R && n <= cm) {
+                const int32_t v = row_begin_lane(r + 1 + lane);                     // begin of row r+1+lane (tok_end past the last row)
+                const uint32_t kcnt = (uint32_t)__popcll(__ballot(r + 1 + lane < R && v <= cm)); // >= 1
+                a = __builtin_amdgcn_readlane(v, (int)kcnt - 1);
+                r += kcnt;
+                n = (kcnt < 64) ? __builtin_amdgcn_readlane(v, (int)(kcnt & 63)) : row_begin(r + 1);
             }
-            if (gather && P + 128 > tok_begin) {
-                const int32_t pm = P > tok_begin ? P : tok_begin;
-                while (r + 1 < R && off_next <= pm) {
-                    r++;
-                    off_r = off_next;
-                    off_next = off_next2;
-                    off_next2 = row_begin(r + 2); // not needed before the next advance
+            gptr_cu32 src = loc + (uint64_t)r * stride;
+            if (C0 >= a && C1 <= n) {
+                // the whole chunk comes from one row: five dwords, four funnel shifts per lane
+                const uint32_t p = (uint32_t)(P - a);
+                gptr_cu32 q = src + (p >> 5);
+                const uint32_t sh = p & 31u;
+                const uint32_t s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
+                w[0] = __builtin_amdgcn_alignbit(s1, s0, sh);
+                w[1] = __builtin_amdgcn_alignbit(s2, s1, sh);
+                w[2] = __builtin_amdgcn_alignbit(s3, s2, sh);
+                w[3] = __builtin_amdgcn_alignbit(s4, s3, sh);
+            } else {
+                // rows meet inside the chunk (or it holds the stream's begin / end): every row overlapping the
+                // chunk ORs its bits into the lanes it touches; dwords outside a row's stream read as zero
+                const int32_t v = row_begin_lane(r + 1 + lane); // begins of the next 64 rows, one load
+                int32_t aa = a, nn = n;
+                for (uint32_t j = 0;; j++) {
+                    const int32_t p = P - aa;                     // may be negative: the row starts behind this lane's piece
+                    const int32_t i = p >> 5;                     // floor
+                    const uint32_t sh = (uint32_t)p & 31u;
+                    const uint32_t ndw = ((uint32_t)(nn - aa) + 31u) >> 5;
+                    uint32_t s[5];
+#pragma unroll
+                    for (int t = 0; t < 5; t++) s[t] = ((uint32_t)(i + t) < ndw) ? src[i + t] : 0u;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(s[kk + 1], s[kk], sh);
+                    if (nn >= C1 || r + 1 + j >= R) break;
+                    aa = nn;
+                    nn = (j + 1 < 64) ? __builtin_amdgcn_readlane(v, (int)((j + 1) & 63)) : row_begin(r + 2 + j);
                     src += stride;
                 }
-                if (P >= off_r && P + 128 <= off_next) {
-                    // the whole piece comes from one row: five dwords, four funnel shifts
-                    const uint32_t p = (uint32_t)(P - off_r);
-                    gptr_cu32 q = src + (p >> 5);
-                    const uint32_t sh = p & 31u;
-                    const uint32_t s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
-                    w[0] = __builtin_amdgcn_alignbit(s1, s0, sh);
-                    w[1] = __builtin_amdgcn_alignbit(s2, s1, sh);
-                    w[2] = __builtin_amdgcn_alignbit(s3, s2, sh);
-                    w[3] = __builtin_amdgcn_alignbit(s4, s3, sh);
-                } else {
-                    // rows meet inside the piece (or it holds the stream's begin / end): OR the contribution of
-                    // every row that overlaps it; dwords outside a row's stream read as zero
-                    uint32_t r2 = r;
-                    int32_t a = off_r, n = off_next;
-                    gptr_cu32 s2p = src;
-                    for (;;) {
-                        const int32_t p = P - a;                       // may be negative: the row starts inside the piece
-                        const int32_t i = p >> 5;                      // floor
-                        const uint32_t sh = (uint32_t)p & 31u;
-                        const uint32_t ndw = ((uint32_t)(n - a) + 31u) >> 5;
-                        uint32_t s[5];
-#pragma unroll
-                        for (int j = 0; j < 5; j++) s[j] = ((uint32_t)(i + j) < ndw) ? s2p[i + j] : 0u;
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(s[kk + 1], s[kk], sh);
-                        if (n >= P + 128 || r2 + 1 >= R) break;
-                        r2++;
-                        a = n;
-                        n = row_begin(r2 + 1);
-                        s2p += stride;
-                    }
-                }
+            }
+            if (in_data && P + 128 > tok_begin) {
                 u32x4 d;
                 d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
                 *(gptr_u128)(uintptr_t)(base + o) = d;
             }
-            if (o < db || o + 16 > de) { // zero the bytes outside [data_begin, data_end) for the CRC
+        }
+        if (in_data && (o < db || o + 16 > de)) { // zero the bytes outside [data_begin, data_end) for the CRC
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    uint32_t m = 0;
+            for (int kk = 0; kk < 4; kk++) {
+                uint32_t m = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int32_t pos = o + 4 * kk + b;
-                        if (pos >= db && pos < de) m |= 0xFFu << (8 * b);
-                    }
-                    w[kk] &= m;
+                for (int b = 0; b < 4; b++) {
+                    const int32_t pos = o + 4 * kk + b;
+                    if (pos >= db && pos < de) m |= 0xFFu << (8 * b);
                 }
+                w[kk] &= m;
             }
         }
+        if (!in_data) w[0] = w[1] = w[2] = w[3] = 0;
         w[0] ^= c;
-        uint32_t n = 0;
+        uint32_t nx = 0;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
-            n ^= tab[4 * kk + 0][w[kk] & 0xFF] ^ tab[4 * kk + 1][(w[kk] >> 8) & 0xFF] ^ tab[4 * kk + 2][(w[kk] >> 16) & 0xFF] ^
-                 tab[4 * kk + 3][w[kk] >> 24];
-        c = n;
+            nx ^= tab[4 * kk + 0][w[kk] & 0xFF] ^ tab[4 * kk + 1][(w[kk] >> 8) & 0xFF] ^ tab[4 * kk + 2][(w[kk] >> 16) & 0xFF] ^
+                  tab[4 * kk + 3][w[kk] >> 24];
+        c = nx;
     }
     c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
     if ((tid & 63) == 0) red[tid >> 6] = c;

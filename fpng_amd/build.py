@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfpng_amd.so")
 DROPIN_LIB = os.path.join(LIB_DIR, "libfpng.so")
 SOURCES = ["kernels.hip", "api.cpp", "format.cpp", "synth.cpp"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "fused_kernels.inc"),
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"),
            os.path.join(ROOT, "include", "fpng_amd.h")]
 ARCH = "gfx950"
 

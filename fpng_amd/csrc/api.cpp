@@ -202,13 +202,8 @@ struct fpng_amd_encoder {
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
     uint32_t submit_count = 0;
-    int pipeline = 0; // of the last submission: 0 rows+assemble, 1 count/scan/emit, 2 experimental fused
+    int pipeline = 0; // of the last submission: 0 encode_rows + assemble, 1 count/scan/emit/crc
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
-    // fused single-pass encoder scratch.  d_sync = [ticket | group_acc[G] | group_state[G] | unit_bits[U]] is
-    // cleared with one memset before each launch; unit_start / seams are fully rewritten by the kernel.
-    DeviceBuf<uint64_t> d_sync, d_unit_start;
-    DeviceBuf<uint2> d_seams, d_unit_adler;
-    uint32_t grid_blocks = 0;       // (unused by the current kernels; kept for the experimental path)
     uint32_t last_n = 0;
     // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
     // records coming back) guarded by an event, so fpng_amd_encode_batch_async() never waits for the GPU
@@ -281,11 +276,6 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
     if (rc) return rc;
     fpng_amd_encoder *e = new fpng_amd_encoder();
     e->device = device;
-    {
-        hipDeviceProp_t prop;
-        // encode_kernel is persistent: 6 blocks of 27 KB LDS fit a CU (160 KB), 5 leave headroom
-        e->grid_blocks = (hipGetDeviceProperties(&prop, device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u) * 8u;
-    }
     if (hip_stream) {
         e->stream = (hipStream_t)hip_stream;
     } else {
@@ -331,10 +321,6 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->h_states.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
-    e->d_sync.release();
-    e->d_unit_start.release();
-    e->d_seams.release();
-    e->d_unit_adler.release();
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -369,47 +355,10 @@ namespace {
 
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
-    uint64_t total_rows = 0, total_units = 0, total_tickets = 0, total_groups = 0;
-    uint32_t max_units = 0, max_tickets = 0;
+    uint64_t total_rows = 0;
     uint64_t local_dwords = 0; // scratch for the rows' local streams
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
-    size_t sync_words() const { return 1 + 2 * total_groups + (total_units + 1) / 2 + 1; }
 };
-
-constexpr uint32_t kSegPixelsHost = 1024; // must match kSegPixels in fused_kernels.inc
-
-// unit / ticket geometry of the fused encoder for one job
-int set_units(Job &j, Submission &sub)
-{
-    j.nseg = (j.w + kSegPixelsHost - 1) / kSegPixelsHost;
-    const uint64_t units = (uint64_t)j.nrows * j.nseg;
-    if (sub.total_units + units > 0x7FFFFFF0ull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many row segments in one submission");
-    j.n_units = (uint32_t)units;
-    j.unit_base = (uint32_t)sub.total_units;
-    j.ticket_base = (uint32_t)sub.total_tickets;
-    // 4 vertically adjacent units per ticket keep the Up row in L1/L2; with very wide rows fall back to
-    // stream order so that a ticket never waits for more than `grid` later tickets
-    j.rows_per_ticket = (j.nseg <= 256) ? 4 : 1;
-    const uint64_t tickets = (j.rows_per_ticket == 4) ? (uint64_t)((j.nrows + 3) / 4) * j.nseg : (units + 3) / 4;
-    // placement groups: ~64 stream-consecutive units (whole rows, a multiple of the 4-row ticket height)
-    if (j.rows_per_ticket == 4) {
-        uint32_t k = (16 + j.nseg - 1) / j.nseg;
-        k = std::max(1u, std::min(16u, k));
-        j.group_rows = 4 * k;
-    } else
-        j.group_rows = 1;
-    j.n_groups = (j.nrows + j.group_rows - 1) / j.group_rows;
-    j.group_base = (uint32_t)sub.total_groups;
-    sub.total_groups += j.n_groups;
-    j.ticket_count = (uint32_t)tickets;
-    sub.total_units += units;
-    sub.total_tickets += tickets;
-    sub.max_units = std::max(sub.max_units, j.n_units);
-    sub.max_tickets = std::max(sub.max_tickets, j.ticket_count);
-    return FPNG_AMD_OK;
-}
-
-FusedBuffers fused_buffers(fpng_amd_encoder *e, const Submission &sub);
 
 int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
 {
@@ -471,7 +420,6 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
-        if ((rc = set_units(j, sub))) return rc;
         // a row's local stream: no Deflate code is longer than 15 bits -> < 2 bytes per filtered byte; rows start
         // 16-byte aligned and assemble_kernel may read one dword past the stream
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * 16 + 64 + 31) / 32 + 4 + 3) & ~3ull);
@@ -488,29 +436,11 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if ((rc = sc.d_states.ensure(n))) return rc;
     if ((rc = sc.d_results.ensure(n))) return rc;
     if ((rc = sc.d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
-    if ((rc = e->d_sync.ensure(sub.sync_words()))) return rc;
-    if ((rc = e->d_unit_start.ensure(sub.total_units + 1))) return rc;
-    if ((rc = e->d_seams.ensure(sub.total_units + 1))) return rc;
-    if ((rc = e->d_unit_adler.ensure(sub.total_units + 1))) return rc;
     if (two_pass) {
         if ((rc = sc.d_hist.ensure((size_t)n * 288))) return rc;
         if ((rc = sc.d_dyn.ensure(n))) return rc;
     }
     return FPNG_AMD_OK;
-}
-
-FusedBuffers fused_buffers(fpng_amd_encoder *e, const Submission &sub)
-{
-    FusedBuffers fb;
-    uint64_t *p = e->d_sync.p;
-    fb.ticket = (uint32_t *)p;
-    fb.group_acc = p + 1;
-    fb.group_state = p + 1 + sub.total_groups;
-    fb.unit_bits = (uint32_t *)(p + 1 + 2 * sub.total_groups);
-    fb.unit_start = e->d_unit_start.p;
-    fb.seams = e->d_seams.p;
-    fb.unit_adler = e->d_unit_adler.p;
-    return fb;
 }
 
 } // namespace
@@ -530,21 +460,13 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
     }
-    // Two pipelines produce the same bytes.  Default: two passes over the image (count -> scan -> emit),
-    // the faster one on MI355X today (profiles/).  FPNG_AMD_FUSED=1 selects the experimental single-pass
-    // encoder (encode -> seam/seal -> stored) kept for A/B measurements, see DESIGN.md.
-    static const bool use_fused = [] {
-        const char *v = getenv("FPNG_AMD_FUSED");
-        return v && v[0] == '1';
-    }();
     static const uint32_t n_lanes = [] {
         const char *v = getenv("FPNG_AMD_LANES");
         const int n = v ? atoi(v) : 2;
         return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
     }();
-    // lane = internal stream + scratch set.  Per-kernel profiling and the experimental pipeline (shared
-    // scratch) stay on lane 0, which serialises them.
-    const int lane = (use_fused || e->profiling) ? 0 : (int)(e->submit_count++ % n_lanes);
+    // lane = internal stream + scratch set.  Per-kernel profiling stays on lane 0, which serialises it.
+    const int lane = e->profiling ? 0 : (int)(e->submit_count++ % n_lanes);
     fpng_amd_encoder::Scratch &sc = e->sc[lane];
     hipStream_t s = e->lane_stream[lane];
     Submission sub;
@@ -569,8 +491,8 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
         return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
     }();
-    const bool use_rows = !use_fused && !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
-    e->pipeline = use_fused ? 2 : (use_rows ? 0 : 1);
+    const bool use_rows = !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
+    e->pipeline = use_rows ? 0 : 1;
     if (use_rows) {
         if ((rc = sc.d_local.ensure(sub.local_dwords + 16))) return rc;
         for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
@@ -595,18 +517,7 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
         HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
-    if (use_fused) {
-        const FusedBuffers fb = fused_buffers(e, sub);
-        if (!force_stored) {
-            HIP_TRY(hipMemsetAsync(e->d_sync.p, 0, sub.sync_words() * sizeof(uint64_t), s));
-            launch_encode(s, sc.d_jobs.p, n, sub.max_tickets, fb, sc.d_states.p);
-        }
-        if ((rc = mark(e, s, 1))) return rc;
-        launch_seal(s, sc.d_jobs.p, n, sub.max_units, fb, sc.d_states.p);
-        if ((rc = mark(e, s, 2))) return rc;
-        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
-        if ((rc = mark(e, s, 3))) return rc;
-    } else if (use_rows) {
+    if (use_rows) {
         if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
         if ((rc = mark(e, s, 1))) return rc;
         launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
@@ -640,8 +551,7 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    static const char *names[3] = {"encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize",
-                                   "encode,seal,stored,crc,finalize"};
+    static const char *names[2] = {"encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize"};
     return names[e ? e->pipeline : 0];
 }
 

@@ -29,16 +29,6 @@ struct Job {
     uint64_t local_base;      // dwords
     uint32_t local_stride;    // dwords per row (worst-case token bits of a row + slack)
     uint32_t local_pad;
-    // fused single-pass encoder: a unit = one 1024-pixel segment of one row
-    uint32_t nseg;            // units per row
-    uint32_t n_units;         // nrows * nseg
-    uint32_t unit_base;       // index of the job's first unit in the per-unit scratch arrays
-    uint32_t ticket_base;     // first ticket (a ticket = 4 units) of the job
-    uint32_t ticket_count;
-    uint32_t rows_per_ticket; // 4: vertically adjacent units per ticket; 1: 4 consecutive units of the stream
-    uint32_t group_rows;      // rows per placement group (multiple of 4)
-    uint32_t group_base;      // index of the job's first group in the per-group scratch arrays
-    uint32_t n_groups;
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
 
@@ -56,9 +46,9 @@ struct JobState {
     uint32_t last_unit_bits;
     uint32_t s1, s2;        // Adler raw sums of the job's filtered bytes
     uint32_t adler, crc;
-    uint32_t status;        // fused encoder: nonzero if a bounded wait timed out (host falls back to the two-pass kernels)
+    uint32_t status;        // nonzero = device-side failure, reported in fpng_amd_result.status
     uint32_t pad1;
-    uint64_t adler_s1_acc, adler_s2_acc; // fused encoder: per-unit Adler contributions (already weighted), plain sums
+    uint64_t reserved[2];
 };
 
 struct Result {
@@ -92,17 +82,6 @@ void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_cr
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
                      JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
-struct FusedBuffers {
-    uint32_t *ticket;      // one counter
-    uint32_t *unit_bits;   // per unit (cleared before each launch together with the ticket and the group words)
-    uint64_t *group_acc;   // per group
-    uint64_t *group_state; // per group
-    uint64_t *unit_start;  // per unit
-    void *seams;           // uint2 per unit
-    void *unit_adler;      // uint2 per unit
-};
-void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_tickets, const FusedBuffers &fb, JobState *states);
-void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_units, const FusedBuffers &fb, JobState *states);
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states);
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables);

@@ -1873,7 +1873,15 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
     }
 }
 
-#include "fused_kernels.inc"
+// stored-block fallback as its own launch: the whole-image pipeline decides after encoding (scan_kernel)
+__global__ __launch_bounds__(kRowBlock) void stored_kernel(const Job *jobs, RowInfo *rows_io, const JobState *states)
+{
+    const Job &job = job_of_block(jobs);
+    if (blockIdx.x * kRowWaves >= job.nrows) return;
+    if (states[blockIdx.y].mode != 1u) return;
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + (threadIdx.x >> 6);
+    if (r < job.nrows) stored_row(job, r, lane, rows_io);
+}
 
 } // namespace
 
@@ -1931,20 +1939,6 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
                        results);
 }
 
-static FusedScratch fused_scratch(const FusedBuffers &fb, JobState *states)
-{
-    return FusedScratch{fb.unit_bits, fb.unit_start, fb.group_acc, fb.group_state, (uint2 *)fb.seams, (uint2 *)fb.unit_adler, states};
-}
-void launch_encode(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_tickets, const FusedBuffers &fb, JobState *states)
-{
-    hipLaunchKernelGGL(encode_kernel, dim3(max_tickets, n_jobs), dim3(kBlock), 0, s, jobs, fused_scratch(fb, states));
-}
-void launch_seal(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_units, const FusedBuffers &fb, JobState *states)
-{
-    hipLaunchKernelGGL(seam_kernel, dim3((max_units + 1 + kBlock - 1) / kBlock, n_jobs), dim3(kBlock), 0, s, jobs,
-                       fused_scratch(fb, states));
-    hipLaunchKernelGGL(seal_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, fused_scratch(fb, states));
-}
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
 {
     hipLaunchKernelGGL(stored_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);

@@ -48,6 +48,19 @@ def parse():
     return ap.parse_args()
 
 
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.txt, produced by
+    tools/gpu_profile_round.sh + tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
+    of this command).  PMC counters cannot be collected from inside the timed process."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")), reverse=True):
+        for line in open(path):
+            f = line.split()
+            if len(f) == 5 and f[0] == kernel:
+                return int((float(f[2]) + float(f[4])) * 1e6), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(w, h, c, kind, flags, reps):
     """The reference's CPU path on ONE host core (rank 0, N=1 only).  Checker-side code: this is the
     only place bench.py touches oracle/."""
@@ -150,8 +163,11 @@ def main():
     dom_s = phase_ms[dom] / 1e3
     achieved = alg_bytes / dom_s / 1e9
     kernels_s = sum(phase_ms[k] for k in names) / 1e3
+    traffic, traffic_src = (None, None)
+    if (args.workload, B, args.flags, args.kind) == ("8k", 8, 0, "grad"):  # the command the committed PMC passes ran
+        traffic, traffic_src = committed_traffic(f"{dom}_kernel")
     roofline = {"bound": "hbm", "kernel": f"{dom}_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": phase_ms[dom],
                 "all_kernels_ms": round(kernels_s * 1e3, 4),
                 "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": phase_ms}

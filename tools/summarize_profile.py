@@ -12,7 +12,10 @@ shutil.copy(f"{base}/trace/trace_kernel_stats.csv", f"profiles/{tag}_kernel_stat
 def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[r["Kernel_Name"].replace("fpng_amd::(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].replace("fpng_amd::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if "calib" not in name:
+            name = name.split("<")[0]  # encode_rows_kernel<4> -> encode_rows_kernel
+        agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 

@@ -176,6 +176,27 @@ def test_super_window_tiers(enc, c):
             _assert_same(p, oracle().encode(img, w, h, c_, fl), f"tiers {w}x{h}x{c_} flags={fl}")
 
 
+def test_many_tiny_rows_through_assemble(enc):
+    """Rows of a few bytes: more than 64 rows under one 1 KiB chunk of assemble_kernel (its slow row walk), deep
+    64-ary row searches (h up to 200 000), row seams in nearly every dword."""
+    rng = np.random.default_rng(77)
+    imgs, dims = [], []
+    for (w, h, c) in [(1, 50000, 3), (1, 50000, 4), (2, 70000, 4), (3, 30011, 3), (5, 20000, 4), (1, 200000, 4), (17, 9001, 3)]:
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        elif kind == 1:  # identical rows: Up filter gives zero rows (1-pixel-wide runs of zeros)
+            img = np.repeat(rng.integers(0, 256, (1, w, c), dtype=np.uint8), h, axis=0)
+        else:            # piecewise constant columns with random breaks
+            img = np.repeat(rng.integers(0, 256, ((h + 99) // 100, w, c), dtype=np.uint8), 100, axis=0)[:h]
+        imgs.append(np.ascontiguousarray(img))
+        dims.append((w, h, c))
+    for fl in (0, 1):
+        pngs, _ = _gpu_encode(enc, imgs, fl)
+        for img, (w, h, c), p in zip(imgs, dims, pngs):
+            _assert_same(p, oracle().encode(img, w, h, c, fl), f"tiny rows {w}x{h}x{c} flags={fl}")
+
+
 def test_mixed_batch_shapes_and_channels(enc):
     import fpng_amd
     imgs = [fpng_amd.synth_image(k, w, h, c) for (k, w, h, c) in

@@ -1078,34 +1078,70 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
     gptr_cu8 src = to_global<gptr_cu8>(job.rows) + (size_t)r * bpl;
     gptr_u8 z = to_global<gptr_u8>(job.out) + kPngHeaderBytes;
     const uint64_t n_filtered = (uint64_t)n_row * job.nrows;
-    const uint64_t s0 = (uint64_t)r * n_row;
+    const uint64_t s0 = (uint64_t)r * n_row, s_end = s0 + n_row;
     if (r == 0 && lane == 0) {
         z[0] = 0x78;
         z[1] = 0x01;
     }
-    uint32_t acc_a = 0;
+    // Adler partial sums as in walk_row: byte sum, (bytes to the row end) x (dword byte sum), in-dword offsets
+    uint32_t acc_a = 0, acc_j = 0;
     uint64_t acc_w = 0;
-    for (uint32_t i = lane; i < n_row; i += kWave) {
-        const uint64_t s = s0 + i;
+    // The row's stream bytes [s0, s_end) = filter byte 0 + pixels.  Between stored-block boundaries the file is a
+    // shifted copy of the stream: one piece per stored block the row touches (wave-uniform loop).
+    for (uint64_t s = s0; s < s_end;) {
         const uint64_t blk = s / kStoredBlockMax;
-        const uint64_t pos = 2 + 5 * (blk + 1) + s;
-        const uint32_t v = i ? src[i - 1] : 0u;
-        z[pos] = (uint8_t)v;
-        if (s % kStoredBlockMax == 0) { // first byte of a stored block: write its 5-byte header
+        const uint64_t blk_end = (blk + 1) * kStoredBlockMax;
+        const uint64_t e = blk_end < s_end ? blk_end : s_end;
+        const uint64_t shift = 2 + 5 * (blk + 1); // file position (from the zlib header) = stream position + shift
+        if (s == blk * kStoredBlockMax && lane == 0) { // first byte of a stored block: write its 5-byte header
             const uint64_t remaining = n_filtered - s;
             const uint32_t len = remaining < kStoredBlockMax ? (uint32_t)remaining : kStoredBlockMax;
-            gptr_u8 h = z + pos - 5;
+            gptr_u8 h = z + s + shift - 5;
             h[0] = (remaining <= kStoredBlockMax) ? 1 : 0;
             h[1] = (uint8_t)len;
             h[2] = (uint8_t)(len >> 8);
             h[3] = (uint8_t)~len;
             h[4] = (uint8_t)(~len >> 8);
         }
-        acc_a += v;
-        acc_w += (uint64_t)(n_row - i) * v;
+        uint64_t a = s;
+        if (a == s0) { // the filter-type byte
+            if (lane == 0) z[a + shift] = 0;
+            a++;
+        }
+        if (a < e) {
+            // pixels: stream bytes [a, e) = src[idx0 - 1 ...), idx0 = index in the row's stream
+            const uint32_t len = (uint32_t)(e - a), idx0 = (uint32_t)(a - s0);
+            gptr_u8 dst = z + a + shift;
+            gptr_cu8 sp = src + (idx0 - 1);
+            uint32_t head = (uint32_t)(0u - (uint32_t)(uintptr_t)dst) & 3u; // bytes up to the next destination dword
+            if (head > len) head = len;
+            const uint32_t body = (len - head) >> 2, tail = (len - head) & 3u;
+            if (lane < head + tail) { // the few unaligned bytes at both ends, one per lane
+                const uint32_t o = lane < head ? lane : head + 4 * body + (lane - head);
+                const uint32_t v = sp[o];
+                dst[o] = (uint8_t)v;
+                acc_a += v;
+                acc_w += (uint64_t)(n_row - (idx0 + o)) * v;
+            }
+            // destination-aligned dwords; the source is read as aligned dwords too and re-aligned with v_alignbyte
+            gptr_u32 d32 = (gptr_u32)(uintptr_t)(dst + head);
+            const uint32_t m = (uint32_t)(uintptr_t)(sp + head) & 3u;
+            gptr_cu32 s32 = (gptr_cu32)(uintptr_t)(sp + head - m);
+            for (uint32_t i = lane; i < body; i += kWave) {
+                const uint32_t lo = s32[i];
+                const uint32_t hi = m ? s32[i + 1] : 0u; // both words hold bytes of the piece: never outside the image's pages
+                const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, m);
+                d32[i] = v;
+                const uint32_t bs = __builtin_amdgcn_sad_u8(v, 0u, 0u);
+                acc_a += bs;
+                acc_w += (uint64_t)(n_row - (idx0 + head + 4 * i)) * bs;
+                acc_j = __builtin_amdgcn_udot4(v, 0x03020100u, acc_j, false);
+            }
+        }
+        s = e;
     }
     const uint32_t s1 = wave_sum(acc_a % kAdlerMod) % kAdlerMod;
-    const uint32_t s2 = wave_sum((uint32_t)(acc_w % kAdlerMod)) % kAdlerMod;
+    const uint32_t s2 = wave_sum((uint32_t)((acc_w - acc_j) % kAdlerMod)) % kAdlerMod;
     if (lane == 0) {
         RowInfo ri;
         ri.bits = 0;

@@ -47,7 +47,7 @@ struct JobState {
     uint32_t s1, s2;        // Adler raw sums of the job's filtered bytes
     uint32_t adler, crc;
     uint32_t status;        // nonzero = device-side failure, reported in fpng_amd_result.status
-    uint32_t pad1;
+    uint32_t range_log2;    // log2 of the bytes one assemble/crc block covers (12..16; 0 = 16), chosen by scan_kernel
     uint64_t reserved[2];
 };
 

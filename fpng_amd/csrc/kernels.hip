@@ -1018,6 +1018,15 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
         const uint32_t a1 = (uint32_t)((1 + s_adl[0]) % kAdlerMod);
         const uint32_t a2 = (uint32_t)((n_filtered % kAdlerMod + s_adl[1]) % kAdlerMod);
         st.adler = (a2 << 16) | a1; // Adler-32 of the Up/None-filtered stream (compressed mode)
+        // bytes per assemble/crc block: 64 KiB when the submission has plenty of blocks anyway (every block loads
+        // the 16 KiB CRC table), down to one 4 KiB block row for small files so that the submission still spreads
+        // over ~2048 blocks
+        const uint64_t span = kPngHeaderBytes + zlib_size; // >= aligned data end - 48
+        uint32_t want = 2048u / gridDim.x;                 // blocks this job should get (gridDim.x = jobs)
+        want = want < 4u ? 4u : want;
+        uint32_t rl = 12;
+        while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
+        st.range_log2 = rl;
     }
     // band count (multi-GPU phase 1) stops here; whole images and band emits prepare the output window
     if (!job.whole_png && !(job.flags & 0x100u)) return;
@@ -1258,6 +1267,8 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // row; each lane keeps the CRC of its own 16-byte stripe with slice-by-16 tables that already
 // contain the 4080-byte jump to its next piece.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t crc_range_log2(const JobState &st) { return st.range_log2 ? st.range_log2 : 16u; }
+
 __device__ __forceinline__ uint32_t dev_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t r = 0;
@@ -1279,15 +1290,16 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
     if (!job.whole_png) return;
     const int64_t data_begin = kPngHeaderBytes, data_end = (int64_t)(kPngHeaderBytes + st.zlib_size - 4);
     const int64_t end_aligned = (data_end + 15) & ~15ll;
-    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * kCrcRangeBytes;
+    const uint32_t range_bytes = 1u << crc_range_log2(st);
+    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * range_bytes;
     if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
     for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
     __syncthreads();
     gptr_cu8 base = to_global<gptr_cu8>(job.out);
     const uint32_t tid = threadIdx.x;
     uint32_t c = 0;
-    for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
-        const int64_t o = range_end - kCrcRangeBytes + (int64_t)row * kCrcRowBytes + tid * 16;
+    for (uint32_t row = 0; row < range_bytes / kCrcRowBytes; row++) {
+        const int64_t o = range_end - range_bytes + (int64_t)row * kCrcRowBytes + tid * 16;
         uint32_t w[4] = {0, 0, 0, 0};
         if (o + 16 > data_begin && o < data_end) {
             const u32x4 d = *(gptr_cu128)(base + o);
@@ -1340,7 +1352,8 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     if (!job.whole_png) return;
     const int64_t data_begin = kPngHeaderBytes, data_end = (int64_t)(kPngHeaderBytes + st.zlib_size - 4);
     const int64_t end_aligned = (data_end + 15) & ~15ll;
-    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * kCrcRangeBytes;
+    const uint32_t range_bytes = 1u << uniform(crc_range_log2(st));
+    const int64_t range_end = end_aligned - (int64_t)blockIdx.x * range_bytes;
     if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
     for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
     __syncthreads();
@@ -1348,7 +1361,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
 
     // Everything below is relative to the first byte of the block's range, in 32-bit arithmetic: positions that
     // matter lie within +-2^31 bits of it (a row has < 2^30 token bits), the rest saturates.
-    const int64_t range_begin = range_end - kCrcRangeBytes; // may be negative: bytes in front of the file count as absent
+    const int64_t range_begin = range_end - range_bytes; // may be negative: bytes in front of the file count as absent
     auto sat = [](int64_t v) { return (int32_t)(v > 0x7FFFFFFFll ? 0x7FFFFFFFll : (v < -0x7FFFFFFFll ? -0x7FFFFFFFll : v)); };
     const int32_t db = sat(data_begin - range_begin), de = sat(data_end - range_begin); // bytes
     gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
@@ -1364,6 +1377,8 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     // one holding the first token bit of that chunk and spans bits [a, n).
     uint32_t r = 0;
     int32_t a = 0, n = 0;
+    uint32_t pr = 0; // look-ahead: lane l of pv = begin of row pr+1+l (tok_end past the last row), one coalesced load
+    int32_t pv = 0;
     auto row_begin_lane = [&](uint32_t rr) { return (rr < R) ? sat((int64_t)offs[rr] - bit0) : tok_end; }; // per lane
     auto row_begin = [&](uint32_t rr) { return (int32_t)uniform((uint32_t)row_begin_lane(rr)); };           // uniform rr
     if (gather) {
@@ -1383,11 +1398,18 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
         }
         r = uniform(lo);
         a = row_begin(r);
-        n = row_begin(r + 1);
+        pr = r;
+        pv = row_begin_lane(r + 1 + lane);
+        n = __builtin_amdgcn_readlane(pv, 0);
     }
+    // begin of row x > pr (wave-uniform x): out of the look-ahead vector when it is there
+    auto begin_of = [&](uint32_t x) {
+        const uint32_t l = x - pr - 1;
+        return (l < 64) ? (int32_t)__builtin_amdgcn_readlane(pv, (int)(l & 63)) : row_begin(x);
+    };
 
     uint32_t c = 0;
-    for (uint32_t row = 0; row < kCrcRangeBytes / kCrcRowBytes; row++) {
+    for (uint32_t row = 0; row < range_bytes / kCrcRowBytes; row++) {
         const int32_t o = (int32_t)(row * kCrcRowBytes + tid * 16); // byte, relative
         const int32_t P = o * 8;
         const int32_t C0 = (int32_t)((row * kCrcRowBytes + wv * 1024u) * 8u), C1 = C0 + 8192; // the wave's chunk (bits)
@@ -1399,13 +1421,18 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
         }
         if (gather && C1 > tok_begin && C0 < tok_end && (C1 >> 3) > db && (C0 >> 3) < de) { // wave-uniform
             const int32_t cm = C0 > tok_begin ? C0 : tok_begin;
-            // advance the cursor: up to 64 rows per probe
+            // advance the cursor through the look-ahead vector: no memory access unless it runs out
             while (r + 1 < R && n <= cm) {
-                const int32_t v = row_begin_lane(r + 1 + lane);                     // begin of row r+1+lane (tok_end past the last row)
-                const uint32_t kcnt = (uint32_t)__popcll(__ballot(r + 1 + lane < R && v <= cm)); // >= 1
-                a = __builtin_amdgcn_readlane(v, (int)kcnt - 1);
+                const uint32_t first = r - pr; // lane holding row r+1
+                if (first >= 64) {
+                    pr = r;
+                    pv = row_begin_lane(r + 1 + lane);
+                    continue;
+                }
+                const uint32_t kcnt = (uint32_t)__popcll(__ballot(lane >= first && pr + 1 + lane < R && pv <= cm)); // >= 1
                 r += kcnt;
-                n = (kcnt < 64) ? __builtin_amdgcn_readlane(v, (int)(kcnt & 63)) : row_begin(r + 1);
+                a = __builtin_amdgcn_readlane(pv, (int)(first + kcnt - 1));
+                n = begin_of(r + 1);
             }
             gptr_cu32 src = loc + (uint64_t)r * stride;
             if (C0 >= a && C1 <= n) {
@@ -1421,7 +1448,6 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
             } else {
                 // rows meet inside the chunk (or it holds the stream's begin / end): every row overlapping the
                 // chunk ORs its bits into the lanes it touches; dwords outside a row's stream read as zero
-                const int32_t v = row_begin_lane(r + 1 + lane); // begins of the next 64 rows, one load
                 int32_t aa = a, nn = n;
                 for (uint32_t j = 0;; j++) {
                     const int32_t p = P - aa;                     // may be negative: the row starts behind this lane's piece
@@ -1435,7 +1461,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
                     for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(s[kk + 1], s[kk], sh);
                     if (nn >= C1 || r + 1 + j >= R) break;
                     aa = nn;
-                    nn = (j + 1 < 64) ? __builtin_amdgcn_readlane(v, (int)((j + 1) & 63)) : row_begin(r + 2 + j);
+                    nn = begin_of(r + 2 + j);
                     src += stride;
                 }
             }
@@ -1443,6 +1469,10 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
                 u32x4 d;
                 d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
                 *(gptr_u128)(uintptr_t)(base + o) = d;
+            }
+            if (r - pr >= 32) { // refill the look-ahead early: its latency hides behind this step's CRC
+                pr = r;
+                pv = row_begin_lane(r + 1 + lane);
             }
         }
         if (in_data && (o < db || o + 16 > de)) { // zero the bytes outside [data_begin, data_end) for the CRC
@@ -1535,14 +1565,15 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const
     const uint64_t zlib_size = st.zlib_size;
     const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
     const int64_t end_aligned = (data_end + 15) & ~15ll;
-    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + kCrcRangeBytes - 1) / kCrcRangeBytes);
+    const uint32_t rl = crc_range_log2(st);
+    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
     uint32_t g = 0; // each thread folds G = 2^g consecutive partials
     while (((uint64_t)kBlock << g) < n_ranges) g++;
     const uint32_t G = 1u << g;
     const uint32_t *pj = partials + (size_t)blockIdx.x * max_crc_blocks;
     uint32_t v = 0;
     {
-        const uint32_t X = tabs->pow2[16]; // x^(8*2^16)
+        const uint32_t X = tabs->pow2[rl]; // x^(8*range)
         for (int i = (int)G - 1; i >= 0; i--) {
             const uint32_t j = t * G + (uint32_t)i;
             if (v) v = dev_mulmod(v, X);
@@ -1554,7 +1585,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const
     for (uint32_t l = 0; (1u << l) < kBlock; l++) {
         if ((t & ((2u << l) - 1u)) == 0) {
             const uint32_t other = red[t + (1u << l)];
-            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[16 + g + l]);
+            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[rl + g + l]);
         }
         __syncthreads();
     }

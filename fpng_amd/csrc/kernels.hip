@@ -664,7 +664,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 c4 = __builtin_amdgcn_raw_buffer_load_b128(px.cur, voff4, S << 10, 0);
                 u4 = __builtin_amdgcn_raw_buffer_load_b128(px.up, voff4, S << 10, 0);
             };
-            constexpr int PF4 = 2; // super-windows in flight ahead of the look-ahead one
+            constexpr int PF4 = 1; // super-windows in flight ahead of the look-ahead one
             u32x4 c_first, u_first, rc[PF4], ru[PF4];
             load4(0, c_first, u_first);
 #pragma unroll
@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // One instantiation per channel count (jobs of the other kind leave at once): the 3-channel walk needs far
 // fewer registers than the 4-pixels-per-lane RGBA one and keeps 8 waves per SIMD.
 template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
                                                                                                       JobState *states, uint32_t *local)
 {
     __shared__ PackedTables T;

@@ -1238,11 +1238,22 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 {
     __shared__ PackedTables T;
     __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
-    const Job &job = job_of_block(jobs);
-    if (job.c != C || blockIdx.x * kRowWaves >= job.nrows) return;
+    // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
+    // contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
+    // on the same XCD at about the same time and that row is an L2 hit rather than a second HBM read.
+    uint32_t bx, by;
+    {
+        const uint32_t total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t xcd = lin & 7u, per = total >> 3, rem = total & 7u;
+        const uint32_t logical = xcd * per + (xcd < rem ? xcd : rem) + (lin >> 3);
+        by = logical / gridDim.x;
+        bx = logical - by * gridDim.x;
+    }
+    const Job &job = jobs[by];
+    if (job.c != C || bx * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kRowWaves + wv;
+    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = bx * kRowWaves + wv;
     if (r >= job.nrows) return;
 
     EmitSink sink;
@@ -1273,7 +1284,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
         ri.s2 = res.s2;
         ri.pad = 0;
         rows_out[job.row_base + r] = ri;
-        if (r == job.nrows - 1) states[blockIdx.y].last_unit_bits = res.last_unit_bits;
+        if (r == job.nrows - 1) states[by].last_unit_bits = res.last_unit_bits;
     }
 }
 

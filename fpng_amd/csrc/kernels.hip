@@ -307,6 +307,7 @@ template <int C> struct RowWindows {
             // base pointers aligned down to 4 so that every load is an aligned dword; the row then
             // starts `a` bytes into the resource.  Up row has its own phase.
             const uint32_t a = (uint32_t)((uintptr_t)row & 3);
+            phase = uniform(a);
             cur = make_rsrc(row - a, (a + bpl + 3) & ~3u);
             voff = (3 * lane + a) & ~3u;
             sh = (3 * lane + a) & 3u;
@@ -314,12 +315,14 @@ template <int C> struct RowWindows {
             // in a waterfall loop.  No Up row -> zero-sized resource (reads return 0).
             const uint8_t *ub = up_row ? up_row : row;
             const uint32_t b = (uint32_t)((uintptr_t)ub & 3);
+            up_phase = uniform(b);
             up = make_rsrc(ub - b, up_row ? ((b + bpl + 3) & ~3u) : 0u);
             up_voff = (3 * lane + b) & ~3u;
             up_sh = (3 * lane + b) & 3u;
         }
     }
     uint32_t up_voff = 0, up_sh = 0;
+    uint32_t phase = 0, up_phase = 0; // RGB: byte offset of the row / Up row inside its (dword-aligned) resource
 
     // Raw dwords of this lane's pixel in the 64-pixel window starting at pixel x0 (multiple of 64).
     // Loading and filtering are split so that several windows can be in flight (the walk keeps a
@@ -668,8 +671,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     };
 
     // =====================================================================================
-    // Phase A (RGBA): 256-pixel super-windows with FOUR consecutive pixels per lane (one
-    // buffer_load_dwordx4 per lane for the row and one for the Up row).  The per-window overheads --
+    // Phase A: 256-pixel super-windows with FOUR consecutive pixels per lane (one buffer_load_dwordx4
+    // per lane for the row and one for the Up row; RGB lanes use 12 of the 16 bytes).  The per-window overheads --
     // neighbour compare across lanes, DPP prefix sum, LDS puts, loop -- are paid once per 256 pixels.
     // Only the two cheap tiers are done in this layout (all literal / isolated 1-pixel runs, together
     // ~all of photographic content); any other super-window is replayed through the per-pixel walk
@@ -677,23 +680,54 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // =====================================================================================
     uint32_t k0 = 0;      // first 64-pixel window left for phase B
     uint32_t carry_f = 0; // filtered value of the pixel just before window k0
-    if constexpr (C == 4) {
+    {
+        constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
+        constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
         const uint32_t NS = (w >= 512) ? (w >> 8) - 1 : 0;
         if (NS) {
-            const uint32_t voff4 = lane * 16;
+            const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
-                c4 = __builtin_amdgcn_raw_buffer_load_b128(px.cur, voff4, S << 10, 0);
-                u4 = __builtin_amdgcn_raw_buffer_load_b128(px.up, voff4, S << 10, 0);
+                // RGB: 16 aligned bytes that contain the lane's 12 (the resources start on a dword, the row begins
+                // px.phase / px.up_phase bytes into them)
+                c4 = __builtin_amdgcn_raw_buffer_load_b128(px.cur, voff4, S * kSuperBytes, 0);
+                u4 = __builtin_amdgcn_raw_buffer_load_b128(px.up, voff4, S * kSuperBytes, 0);
+            };
+            // filtered bytes of the lane's four pixels, packed: fd[0..ND)
+            auto filt = [&](const u32x4 &c4, const u32x4 &u4, uint32_t (&fd)[4]) {
+                if constexpr (C == 4) {
+                    sub_bytes_x4(c4, u4, fd);
+                } else {
+                    u32x4 ca, ua;
+                    ca.x = __builtin_amdgcn_alignbyte(c4.y, c4.x, px.phase);
+                    ca.y = __builtin_amdgcn_alignbyte(c4.z, c4.y, px.phase);
+                    ca.z = __builtin_amdgcn_alignbyte(c4.w, c4.z, px.phase);
+                    ua.x = __builtin_amdgcn_alignbyte(u4.y, u4.x, px.up_phase);
+                    ua.y = __builtin_amdgcn_alignbyte(u4.z, u4.y, px.up_phase);
+                    ua.z = __builtin_amdgcn_alignbyte(u4.w, u4.z, px.up_phase);
+                    ca.w = ua.w = 0;
+                    sub_bytes_x4(ca, ua, fd); // (the fourth dword is dead code for the compiler)
+                }
+            };
+            // pixel values (what the per-pixel walk calls f_cur): RGBA = the dwords, RGB = 24-bit fields
+            auto pixels = [&](const uint32_t (&fd)[4], uint32_t (&pv)[4]) {
+                if constexpr (C == 4) {
+                    pv[0] = fd[0], pv[1] = fd[1], pv[2] = fd[2], pv[3] = fd[3];
+                } else {
+                    pv[0] = fd[0] & 0xFFFFFFu;
+                    pv[1] = __builtin_amdgcn_alignbyte(fd[1], fd[0], 3u) & 0xFFFFFFu;
+                    pv[2] = __builtin_amdgcn_alignbyte(fd[2], fd[1], 2u) & 0xFFFFFFu;
+                    pv[3] = fd[2] >> 8;
+                }
             };
             constexpr int PF4 = 1; // super-windows in flight ahead of the look-ahead one
             u32x4 c_first, u_first, rc[PF4], ru[PF4];
             load4(0, c_first, u_first);
 #pragma unroll
             for (int j = 0; j < PF4; j++) load4((uint32_t)j + 1, rc[j], ru[j]);
-            uint32_t f[4];
-            sub_bytes_x4(c_first, u_first, f);
+            uint32_t fd[4];
+            filt(c_first, u_first, fd);
             uint32_t last_f = 0;                                     // pixel just before the super-window
-            uint32_t wgt = bpl - 16u * lane;                         // bytes from this lane's first byte to the row end
+            uint32_t wgt = bpl - kLaneBytes * lane;                  // bytes from this lane's first byte to the row end
             const uint32_t c1_bits = chunk1 & 0xFF;
             // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
             auto gather = [&](uint32_t jw, const uint32_t (&src)[4]) {
@@ -713,15 +747,17 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     if (S >= limit) break;
                     // look-ahead super-window S+1 (always completely inside the row) out of the ring
                     uint32_t fn[4];
-                    sub_bytes_x4(rc[js], ru[js], fn);
+                    filt(rc[js], ru[js], fn);
                     if (S + 1 + PF4 <= NS) load4(S + 1 + PF4, rc[js], ru[js]);
-                    // `same` masks of the four pixel slots
+                    uint32_t f[4]; // the four pixels of this lane
+                    pixels(fd, f);
+                    const uint32_t next_first = (C == 4) ? fn[0] : (fn[0] & 0xFFFFFFu);
                     // per-lane "equals its left neighbour" predicates (their SGPR form is the wave ballot)
                     const bool s0 = (f[0] == lane_prev(f[3], last_f)) && !(S == 0 && lane == 0);
                     const bool s1 = f[1] == f[0], s2 = f[2] == f[1], s3 = f[3] == f[2];
                     const uint64_t M0 = __ballot(s0), M1 = __ballot(s1), M2 = __ballot(s2), M3 = __ballot(s3);
                     const uint32_t last3 = (uint32_t)__builtin_amdgcn_readlane((int)f[3], 63);
-                    const bool next0 = uniform(fn[0]) == last3; // does the next super-window start by repeating this one's last pixel?
+                    const bool next0 = uniform(next_first) == last3; // does the next super-window start by repeating this one's last pixel?
                     const uint64_t any = M0 | M1 | M2 | M3;
                     const bool all_lits = (any == 0);
                     const bool sparse = !all_lits && rle.carry == 0 &&
@@ -738,14 +774,14 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                     hist_add(hist, f[j] & 0xFF, lane);
                                     hist_add(hist, (f[j] >> 8) & 0xFF, lane);
                                     hist_add(hist, (f[j] >> 16) & 0xFF, lane);
-                                    hist_add(hist, f[j] >> 24, lane);
+                                    if (C == 4) hist_add(hist, f[j] >> 24, lane);
                                 }
                             }
                         } else {
                           if (kCount) {
                             uint32_t n[4];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) n[j] = packed_literal_bits<4>(T, f[j]);
+                            for (int j = 0; j < 4; j++) n[j] = packed_literal_bits<C>(T, f[j]);
                             if (sparse) { // repeats are rare: only the pixel slots that have one are touched (uniform tests)
                                 if (M0 && s0 && !(lit_test && c1_bits > n[0])) n[0] = c1_bits;
                                 if (M1 && s1 && !(lit_test && c1_bits > n[1])) n[1] = c1_bits;
@@ -755,17 +791,16 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             row_bits += n[0] + n[1] + n[2] + n[3];
                           }
                           if (kSums) {
-                            // Adler: 16 consecutive bytes per lane
-                            uint32_t a = __builtin_amdgcn_sad_u8(f[0], 0u, 0u);
-                            a = __builtin_amdgcn_sad_u8(f[1], 0u, a);
-                            a = __builtin_amdgcn_sad_u8(f[2], 0u, a);
-                            a = __builtin_amdgcn_sad_u8(f[3], 0u, a);
+                            // Adler: 4*C consecutive bytes per lane
+                            constexpr uint32_t kOffs[4] = {0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu};
+                            uint32_t a = 0;
+#pragma unroll
+                            for (int j = 0; j < ND; j++) {
+                                a = __builtin_amdgcn_sad_u8(fd[j], 0u, a);
+                                acc_j = __builtin_amdgcn_udot4(fd[j], kOffs[j], acc_j, false);
+                            }
                             acc_a += a;
                             acc_w += (uint64_t)wgt * a;
-                            acc_j = __builtin_amdgcn_udot4(f[0], 0x03020100u, acc_j, false);
-                            acc_j = __builtin_amdgcn_udot4(f[1], 0x07060504u, acc_j, false);
-                            acc_j = __builtin_amdgcn_udot4(f[2], 0x0B0A0908u, acc_j, false);
-                            acc_j = __builtin_amdgcn_udot4(f[3], 0x0F0E0D0Cu, acc_j, false);
                           }
                           if (kEmit) {
                             // room for a whole super-window (<= 256 x 48 bits = 384 dwords) in the LDS window
@@ -773,7 +808,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             uint32_t n[4];
                             uint64_t t[4];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) t[j] = packed_literal_token<4>(T, f[j], n[j]);
+                            for (int j = 0; j < 4; j++) t[j] = packed_literal_token<C>(T, f[j], n[j]);
                             if (sparse) {
                                 const uint64_t c1_code = chunk1 >> 8;
                                 if (M0 && s0 && !(lit_test && c1_bits > n[0])) n[0] = c1_bits, t[0] = c1_code;
@@ -812,14 +847,14 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             if (S == 0 && jw == 0) m_cur &= ~1ull;
                             carry_px = (uint32_t)__builtin_amdgcn_readlane((int)f_cur, 63);
                             // look-ahead: next window of this super-window, or (only bit 0 is used) the next super-window
-                            fw = (jw < 3) ? gather(jw + 1, f) : uniform(fn[0]);
+                            fw = (jw < 3) ? gather(jw + 1, f) : uniform(next_first);
                             step(std::false_type{}, 4 * S + jw, fw);
                         }
                     }
                     last_f = last3;
-                    wgt -= 1024;
+                    wgt -= kSuperBytes;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) f[j] = fn[j];
+                    for (int j = 0; j < 4; j++) fd[j] = fn[j];
                     done = S + 1;
                     // run-length-heavy rows gain nothing from this layout: hand the rest of the row to phase B
                     if (gen_streak >= 2) limit = done;

@@ -676,14 +676,16 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // neighbour compare across lanes, DPP prefix sum, LDS puts, loop -- are paid once per 256 pixels.
     // Only the two cheap tiers are done in this layout (all literal / isolated 1-pixel runs, together
     // ~all of photographic content); any other super-window is replayed through the per-pixel walk
-    // below with ds_bpermute gathers.  Super-windows S with 256*(S+2) <= w qualify (full look-ahead).
+    // below with ds_bpermute gathers.  Super-windows S with 256*(S+1) < w qualify.
     // =====================================================================================
     uint32_t k0 = 0;      // first 64-pixel window left for phase B
     uint32_t carry_f = 0; // filtered value of the pixel just before window k0
     {
         constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
         constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
-        const uint32_t NS = (w >= 512) ? (w >> 8) - 1 : 0;
+        // super-windows that are followed by at least one more pixel of the row (the look-ahead pixel exists and
+        // the row's last pixel, which sets the final flush unit, is always left to phase B)
+        const uint32_t NS = (w - 1) >> 8;
         if (NS) {
             const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {

@@ -176,6 +176,32 @@ def test_super_window_tiers(enc, c):
             _assert_same(p, oracle().encode(img, w, h, c_, fl), f"tiers {w}x{h}x{c_} flags={fl}")
 
 
+@pytest.mark.parametrize("c", [3, 4])
+def test_maximum_width_rows(enc, c):
+    """w = 2^24 (the reference's limit, fpng.cpp:1670): 48 / 64 MiB per row, two rows so that the Up filter runs.
+    Mixed content: noisy stretches, long runs (thousands of chunks per row), a few isolated repeats."""
+    w, h = 1 << 24, 2
+    rng = np.random.default_rng(1000 + c)
+    row = rng.integers(0, 256, (w, c), dtype=np.uint8)
+    row[w // 8: w // 2] = row[w // 8]                      # one run of 6.3 M pixels
+    row[5_000_000:5_000_400:2] = row[5_000_001:5_000_401:2]  # isolated pairs
+    img = np.stack([row, np.roll(row, 12345, axis=0)])
+    (png,), (mode,) = _gpu_encode(enc, [np.ascontiguousarray(img)], 0)
+    _assert_same(png, oracle().encode(img, w, h, c, 0), f"max width {w}x{h}x{c}")
+
+
+def test_maximum_height(enc):
+    """h = 2^24 rows of one pixel (the reference's limit): 16.7 M rows through the row scan and the row search."""
+    w, h, c = 1, 1 << 24, 4
+    rng = np.random.default_rng(4321)
+    img = np.repeat(rng.integers(0, 256, (h // 64, w, c), dtype=np.uint8), 64, axis=0)  # 63 zero rows after each change
+    img[1::1000] = rng.integers(0, 256, (len(range(1, h, 1000)), w, c), dtype=np.uint8)
+    img = np.ascontiguousarray(img)
+    for fl in (0, 1):
+        (png,), _ = _gpu_encode(enc, [img], fl)
+        _assert_same(png, oracle().encode(img, w, h, c, fl), f"max height flags={fl}")
+
+
 def test_many_tiny_rows_through_assemble(enc):
     """Rows of a few bytes: more than 64 rows under one 1 KiB chunk of assemble_kernel (its slow row walk), deep
     64-ary row searches (h up to 200 000), row seams in nearly every dword."""

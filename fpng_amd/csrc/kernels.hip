@@ -1,24 +1,28 @@
 // kernels.hip -- CDNA4 (gfx950, wave64) kernels of the fpng encode hot path.
 //
-// Pipeline per submission (all on one stream, no host round trip):
+// Whole images, per submission (one internal stream, no host round trip):
 //
-//   count_kernel     one wavefront per scanline: Up/None filter on the fly, RLE chunking from wave
-//                    ballots, token bit lengths from LDS tables -> bits per row; fused Adler-32
-//                    partial sums of the filtered row.            (reference fpng.cpp:1592-1660 filter,
-//                                                                  :1468-1558 / :1182-1241 token grammar, :407-487 Adler)
-//   scan_kernel      per image: exclusive scan of row bits -> absolute bit offset of every row,
-//                    Adler combine, closed-form "did the coder run out of buffer" decision
-//                    (reference fpng.cpp:567-588), PNG header + Deflate prefix, seam zeroing.
-//   emit_kernel      one wavefront per scanline again: recompute tokens, DPP prefix sum of token
-//                    lengths -> bit offsets, OR tokens into an LDS staging window, stream the
-//                    window out with coalesced stores; rows meet at bit granularity (seam dwords
-//                    are OR-merged).  Stored-block fallback rows are written by the same kernel.
-//   crc_kernel       CRC-32 of the finished IDAT bytes: 16 bytes per lane per step, slice-by-16
-//                    from LDS, lane stripes folded with GF(2) constants (reference fpng.cpp:234-292).
+//   [hist_kernel, build_dynamic_kernel]   2-pass only: symbol histogram, per-image Huffman table + block header
+//   encode_rows_kernel<C>  one wavefront per scanline, ONE walk over the pixels: Up/None filter on the fly, RLE
+//                    chunking from wave ballots, tokens from LDS tables, DPP prefix sum of token lengths -> the
+//                    row's private, dword-aligned LOCAL STREAM (LDS staging window, coalesced stores); bits per
+//                    row and Adler-32 partial sums on the side.  (reference fpng.cpp:1592-1660 filter,
+//                    :1468-1558 / :1182-1241 token grammar, :407-487 Adler)
+//   scan_kernel      per image: exclusive scan of row bits -> absolute bit offset of every row, Adler combine,
+//                    closed-form "did the coder run out of buffer" decision (reference fpng.cpp:567-588),
+//                    PNG header + Deflate prefix.
+//   stored_kernel    only images that fell back: stored blocks (reference fpng.cpp:818-866).
+//   assemble_kernel  shifts the local streams to their bit positions (rows meet inside a dword), stores the
+//                    file 16 bytes per lane and takes the CRC-32 of the same bytes: slice-by-16 from LDS, lane
+//                    stripes folded with GF(2) constants (reference fpng.cpp:234-292).
 //   finalize_kernel  folds the CRC partials, writes Adler / IDAT CRC / IEND and the result record
 //                    (reference fpng.cpp:1764-1800).
 //
-// Integer / byte work throughout, bounded by HBM traffic and LDS table lookups: no MFMA.
+// Row bands (multi-GPU single image) and images whose local streams would not fit the scratch budget use
+// count_kernel -> scan_kernel -> emit_kernel -> crc_kernel: two walks, tokens emitted at their final bit position
+// with the seam dwords OR-merged.
+//
+// Integer / byte work throughout, bounded by VALU issue and HBM traffic: no MFMA.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -127,61 +131,6 @@ __device__ __forceinline__ void sub_bytes_x4(const u32x4 &a, const u32x4 &b, uin
 #undef FPNG_SUB_BYTE0
 #undef FPNG_SUB_BYTE
     r[0] = r0, r[1] = r1, r[2] = r2, r[3] = r3;
-}
-
-// ---------------------------------------------------------------------------------------------
-// pixel access.  Lane i of a 64-pixel window owns pixel x0+i.
-// ---------------------------------------------------------------------------------------------
-template <int C> struct RawPixel;
-template <> struct RawPixel<4> {
-    uint32_t cur, up;
-};
-template <> struct RawPixel<3> {
-    uint32_t cur_lo, cur_hi, up_lo, up_hi, cur_sh, up_sh;
-};
-
-// 3 bytes at an arbitrary address through aligned dword loads only: an aligned dword that contains
-// at least one valid byte never leaves that byte's page, so nothing is touched outside the image.
-__device__ __forceinline__ void load3(gptr_cu8 p, uint32_t &lo, uint32_t &hi, uint32_t &sh)
-{
-    const uintptr_t a = (uintptr_t)p;
-    gptr_cu32 q = (gptr_cu32)(a & ~(uintptr_t)3);
-    sh = (uint32_t)(a & 3);
-    lo = q[0];
-    hi = (sh >= 2) ? q[1] : 0u;
-}
-
-template <int C>
-__device__ __forceinline__ RawPixel<C> load_pixel(gptr_cu8 row, gptr_cu8 up_row, uint32_t x, bool valid)
-{
-    RawPixel<C> r;
-    if constexpr (C == 4) {
-        r.cur = 0;
-        r.up = 0;
-        if (valid) {
-            r.cur = ((gptr_cu32)row)[x];
-            if (up_row) r.up = ((gptr_cu32)up_row)[x];
-        }
-    } else {
-        r.cur_lo = r.cur_hi = r.up_lo = r.up_hi = r.cur_sh = r.up_sh = 0;
-        if (valid) {
-            load3(row + 3u * x, r.cur_lo, r.cur_hi, r.cur_sh);
-            if (up_row) load3(up_row + 3u * x, r.up_lo, r.up_hi, r.up_sh);
-        }
-    }
-    return r;
-}
-
-// filtered pixel value: bytes of (cur - up) mod 256, R in bits 0..7 (reference fpng.cpp:1605-1655)
-template <int C> __device__ __forceinline__ uint32_t filtered(const RawPixel<C> &r)
-{
-    if constexpr (C == 4) {
-        return sub_bytes(r.cur, r.up);
-    } else {
-        const uint32_t c = __builtin_amdgcn_alignbyte(r.cur_hi, r.cur_lo, r.cur_sh);
-        const uint32_t u = __builtin_amdgcn_alignbyte(r.up_hi, r.up_lo, r.up_sh);
-        return sub_bytes(c, u) & 0xFFFFFFu;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -508,8 +508,9 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
             slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
         }
     }
+    // (no memset of the job states: every field is written before it is read -- last_unit_bits by the row walk,
+    // the rest by scan_kernel -- and each extra small launch can get stuck behind the other lane's big grids)
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, n * sizeof(JobState), s));
     if ((rc = mark(e, s, 0))) return rc;
     if (two_pass) {
         HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
@@ -537,11 +538,12 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     else
         launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
     if ((rc = mark(e, s, 4))) return rc;
+    // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
+    // end of the chain; they are read by the host after the `done` event
     launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p,
-                    sc.d_results.p);
+                    slot.results.p);
     if ((rc = mark(e, s, 5))) return rc;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(slot.results.p, sc.d_results.p, n * sizeof(Result), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(slot.done, s));
     slot.in_flight = true;
     slot.n = n;

@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 namespace fpng_amd {
@@ -1961,11 +1962,15 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
 // stored-block fallback as its own launch: the whole-image pipeline decides after encoding (scan_kernel)
 __global__ __launch_bounds__(kRowBlock) void stored_kernel(const Job *jobs, RowInfo *rows_io, const JobState *states)
 {
+    // a small grid that strides over the row blocks: in the common case (nothing fell back) the launch costs a
+    // handful of workgroups instead of one per 8 rows, which matters when another stream keeps the dispatcher busy
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kRowWaves >= job.nrows) return;
     if (states[blockIdx.y].mode != 1u) return;
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + (threadIdx.x >> 6);
-    if (r < job.nrows) stored_row(job, r, lane, rows_io);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t rb = blockIdx.x; rb * kRowWaves < job.nrows; rb += gridDim.x) {
+        const uint32_t r = rb * kRowWaves + wv;
+        if (r < job.nrows) stored_row(job, r, lane, rows_io);
+    }
 }
 
 } // namespace
@@ -2026,7 +2031,9 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
 
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
 {
-    hipLaunchKernelGGL(stored_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
+    const uint32_t row_blocks = (max_rows + kRowWaves - 1) / kRowWaves;
+    const uint32_t per_job = std::max(1u, std::min(row_blocks, 2048u / std::max(1u, n_jobs)));
+    hipLaunchKernelGGL(stored_kernel, dim3(per_job, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
 }
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
 {

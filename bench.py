@@ -37,12 +37,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--kind", default="grad")
+    ap.add_argument("--prewarm", type=int, default=60,
+                    help="untimed steps before the W warmup steps: throughput needs ~40 back-to-back steps (20-50 ms of "
+                         "sustained load) to settle, a cold 20-step run reads 15-25 %% low (DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
     return ap.parse_args()
@@ -126,8 +129,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
+    # warmup: W steps enqueued back to back like the timed ones (the first time two submissions overlap on the GPU
+    # costs several ms once per process; with one finish per warmup step that would land in the timed region)
+    for i in range(args.prewarm + args.warmup):
+        enc.submit(batches[i & 3], None, args.flags)
+    if args.prewarm + args.warmup:
+        res = enc.finish(B)
     barrier()
     t0 = time.perf_counter()
     # K steps are enqueued back to back (the encoder pipelines submissions through a ring of pinned

@@ -387,7 +387,9 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
     int rc;
-    if ((rc = slot.jobs.ensure(n)) || (rc = slot.results.ensure(n))) return rc;
+    // size the pinned records of EVERY slot of the ring now: a later submission must not stop for a hipHostMalloc
+    for (auto &sl : e->slots)
+        if ((rc = sl.jobs.ensure(n)) || (rc = sl.results.ensure(n))) return rc;
     const DeviceTables &dt = g_dev[e->device];
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !(flags & FPNG_AMD_FORCE_UNCOMPRESSED);
     sub = Submission();
@@ -454,8 +456,10 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     // next slot of the ring; wait only if the submission that used it is still running
     e->cur_slot = (e->cur_slot + 1) % fpng_amd_encoder::kSlots;
     fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
-    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-    if (!slot.in) HIP_TRY(hipEventCreateWithFlags(&slot.in, hipEventDisableTiming));
+    for (auto &sl : e->slots) {
+        if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (!sl.in) HIP_TRY(hipEventCreateWithFlags(&sl.in, hipEventDisableTiming));
+    }
     if (slot.in_flight) {
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
@@ -501,7 +505,8 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     if (two_pass) {
         // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
         // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
-        if ((rc = slot.jobs2.ensure(n))) return rc;
+        for (auto &sl : e->slots)
+            if ((rc = sl.jobs2.ensure(n))) return rc;
         for (uint32_t i = 0; i < n; i++) {
             slot.jobs2.p[i] = slot.jobs.p[i];
             slot.jobs2.p[i].table = sc.d_dyn.p + i;

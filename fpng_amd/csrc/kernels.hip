@@ -1467,21 +1467,28 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
             } else {
                 // rows meet inside the chunk (or it holds the stream's begin / end): every row overlapping the
                 // chunk ORs its bits into the lanes it touches; dwords outside a row's stream read as zero
+                // two rows per round, their loads issued together (the second one may be empty)
                 int32_t aa = a, nn = n;
-                for (uint32_t j = 0;; j++) {
-                    const int32_t p = P - aa;                     // may be negative: the row starts behind this lane's piece
-                    const int32_t i = p >> 5;                     // floor
-                    const uint32_t sh = (uint32_t)p & 31u;
-                    const uint32_t ndw = ((uint32_t)(nn - aa) + 31u) >> 5;
-                    uint32_t s[5];
+                for (uint32_t j = 0;; j += 2) {
+                    const bool second = nn < C1 && r + 1 + j < R; // wave-uniform: another row begins inside the chunk
+                    const int32_t nn2 = second ? begin_of(r + 2 + j) : nn;
+                    const int32_t pA = P - aa, pB = P - nn;          // may be negative: the row starts behind this lane's piece
+                    const int32_t iA = pA >> 5, iB = pB >> 5;        // floor
+                    const uint32_t ndwA = ((uint32_t)(nn - aa) + 31u) >> 5, ndwB = second ? ((uint32_t)(nn2 - nn) + 31u) >> 5 : 0u;
+                    gptr_cu32 srcB = src + stride;
+                    uint32_t sA[5], sB[5];
 #pragma unroll
-                    for (int t = 0; t < 5; t++) s[t] = ((uint32_t)(i + t) < ndw) ? src[i + t] : 0u;
+                    for (int t = 0; t < 5; t++) sA[t] = ((uint32_t)(iA + t) < ndwA) ? src[iA + t] : 0u;
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(s[kk + 1], s[kk], sh);
-                    if (nn >= C1 || r + 1 + j >= R) break;
-                    aa = nn;
-                    nn = begin_of(r + 2 + j);
-                    src += stride;
+                    for (int t = 0; t < 5; t++) sB[t] = ((uint32_t)(iB + t) < ndwB) ? srcB[iB + t] : 0u;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++)
+                        w[kk] |= __builtin_amdgcn_alignbit(sA[kk + 1], sA[kk], (uint32_t)pA & 31u) |
+                                 __builtin_amdgcn_alignbit(sB[kk + 1], sB[kk], (uint32_t)pB & 31u);
+                    if (!second || nn2 >= C1 || r + 2 + j >= R) break;
+                    aa = nn2;
+                    nn = begin_of(r + 3 + j);
+                    src += 2 * (uint64_t)stride;
                 }
             }
             if (in_data && P + 128 > tok_begin) {

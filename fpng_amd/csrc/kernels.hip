@@ -103,6 +103,7 @@ typedef const FPNG_GLOBAL uint8_t *gptr_cu8;
 typedef const FPNG_GLOBAL uint32_t *gptr_cu32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const FPNG_GLOBAL u32x4 *gptr_cu128;
+typedef FPNG_GLOBAL u32x4 *gptr_u128;
 typedef FPNG_GLOBAL uint8_t *gptr_u8;
 typedef FPNG_GLOBAL uint32_t *gptr_u32;
 template <typename G, typename T> __device__ __forceinline__ G to_global(T *p) { return (G)(uintptr_t)p; }
@@ -343,6 +344,7 @@ struct EmitSink {
     uint32_t fill;       // bits used in the window
     bool first_flush;
     bool exclusive;      // the destination belongs to this row alone (local stream): no shared dwords
+    bool wide;           // exclusive and flushed 16 bytes per lane (sink_flush_exclusive)
 };
 
 __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t ndw)
@@ -382,8 +384,41 @@ __device__ __forceinline__ void sink_put_wide(EmitSink &s, uint64_t code, uint32
 // The first and the last dword of a row's span may be shared with the neighbouring rows (or with
 // header bytes): those two are OR-merged into memory that scan_kernel zeroed; everything in
 // between belongs to this row alone and is stored plainly, 256 B per wave store.
+// Local streams (exclusive destination): 16 bytes per lane per step -- ds_read_b128, global_store_dwordx4 and the
+// re-zeroing ds_write_b128 move four dwords where the generic path below moves one.  Only multiples of four dwords
+// leave the window, so the destination stays 16-byte aligned; the final flush rounds up into the row's slack.
+__device__ __forceinline__ void sink_flush_exclusive(EmitSink &s, uint32_t lane, bool final)
+{
+    wave_lds_fence();
+    const uint32_t n4 = final ? ((((s.fill + 31) >> 5) + 3u) >> 2) : (s.fill >> 7); // groups of four dwords to write out
+    u32x4 *st4 = (u32x4 *)s.stage;
+    gptr_u128 dst4 = (gptr_u128)(uintptr_t)(s.out32 + s.base_dw);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (uint32_t j = lane; j < n4; j += kWave) {
+        dst4[j] = st4[j];
+        if (!final) st4[j] = zero4;
+    }
+    if (!final && n4) {
+        // up to three complete dwords and the partial one stay: move them to the front of the window
+        wave_lds_fence();
+        const uint32_t rem = (lane < 4) ? s.stage[4 * n4 + lane] : 0u;
+        wave_lds_fence();
+        if (lane < 4) s.stage[4 * n4 + lane] = 0u;
+        wave_lds_fence();
+        if (lane < 4) s.stage[lane] = rem;
+        s.base_dw += 4 * n4;
+        s.fill -= 128u * n4;
+        wave_lds_fence();
+    }
+}
+
 __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool final)
 {
+    if (s.wide) {
+        sink_flush_exclusive(s, lane, final);
+        return;
+    }
     wave_lds_fence();
     const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5);
 #pragma unroll 1
@@ -1173,7 +1208,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                                                      const JobState *states)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kRowWaves >= job.nrows) return;
     const JobState &st = states[blockIdx.y];
@@ -1194,6 +1229,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     sink.fill = (uint32_t)(off & 31);
     sink.first_flush = true;
     sink.exclusive = false;
+    sink.wide = false;
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
@@ -1224,7 +1260,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
                                                                                                       JobState *states, uint32_t *local)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 2]; // + dump slots, see sink_put
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
     // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
     // contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
     // on the same XCD at about the same time and that row is an L2 hit rather than a second HBM read.
@@ -1253,6 +1289,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     sink.fill = zero;
     sink.first_flush = false;
     sink.exclusive = true;
+    sink.wide = (C == 4); // the 3-channel walk has no registers to spare for the 16-byte flush (it would drop to 7 waves/SIMD)
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
@@ -1358,7 +1395,6 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
 // except the head (PNG header + Deflate prefix, written by scan_kernel), and no destination dword is
 // written twice, so the rows need no atomics and no zeroed seams.  Stored-mode jobs only take the CRC.
 // ---------------------------------------------------------------------------------------------
-typedef FPNG_GLOBAL u32x4 *gptr_u128;
 
 __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,

@@ -6,8 +6,20 @@ import numpy as np, torch, fpng_amd
 enc = fpng_amd.Encoder(device=0)
 for (w, h, c) in [(3840, 2160, 4), (7680, 4320, 4), (1920, 1080, 3)]:
     img = fpng_amd.synth_image("grad", w, h, c)
-    enc.encode_host(img, w, h, c, 0)
-    best = 1e9
-    for _ in range(5):
-        t0 = time.perf_counter(); png = enc.encode_host(img, w, h, c, 0); best = min(best, time.perf_counter() - t0)
-    print(f"{w}x{h}x{c}: {best*1e3:.2f} ms per frame  {w*h/best/1e6:.0f} MP/s  (png {len(png)} B, pageable host memory)")
+    mp = w * h / 1e6
+
+    def best_of(fn, n=5):
+        fn()
+        b = 1e9
+        for _ in range(n):
+            t0 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t0)
+        return b, r
+
+    # (a) the Python door as a one-shot call: fresh 'max size' output array + bytes copy on top of the transfers
+    ta, png = best_of(lambda: enc.encode_host(img, w, h, c, 0))
+    # (b) caller-owned, reused output buffer (what the C++ drop-in's std::vector amounts to when it is reused)
+    out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)
+    tb, n = best_of(lambda: enc.encode_host_into(img, w, h, c, out, 0))
+    assert bytes(out[:n]) == png
+    print(f"{w}x{h}x{c}: one-shot {ta*1e3:.2f} ms ({mp/ta/1e3:.1f} GP/s) | reused out buffer {tb*1e3:.2f} ms ({mp/tb/1e3:.1f} GP/s)   png {len(png)} B"
+          "   (page-locking both buffers with hipHostRegister measured the same as the reused pageable ones)")

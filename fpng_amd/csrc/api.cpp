@@ -499,12 +499,14 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
         return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
     }();
-    const bool use_rows = !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
-    e->pipeline = use_rows ? 0 : 1;
-    if (use_rows) {
-        if ((rc = sc.d_local.ensure(sub.local_dwords + 16))) return rc;
-        for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
+    bool use_rows = !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
+    if (use_rows && sc.d_local.ensure(sub.local_dwords + 16) != FPNG_AMD_OK) {
+        (void)hipGetLastError(); // no memory for the local streams right now: the scratch-free pipeline still works
+        use_rows = false;
     }
+    e->pipeline = use_rows ? 0 : 1;
+    if (use_rows)
+        for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
 
     if (two_pass) {
         // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second

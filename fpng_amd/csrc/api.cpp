@@ -49,6 +49,7 @@ struct DeviceTables {
 constexpr int kMaxDevices = 64;
 DeviceTables g_dev[kMaxDevices];
 TokenTable g_host_1pass[5];
+uint32_t g_1pass_bits_per_byte[5]; // longest literal code (and no run token needs more per byte it covers)
 std::mutex g_mu;
 bool g_host_ready = false;
 
@@ -56,6 +57,13 @@ bool host_tables()
 {
     if (g_host_ready) return true;
     if (!build_1pass_tables(&g_host_1pass[3], &g_host_1pass[4])) return false;
+    for (int c = 3; c <= 4; c++) {
+        uint32_t m = 0;
+        for (int i = 0; i < 257; i++) m = std::max(m, g_host_1pass[c].lit[i] >> 16);
+        const uint32_t cap = (c == 3) ? kMaxChunkPixels3 : kMaxChunkPixels4;
+        for (uint32_t q = 1; q <= cap; q++) m = std::max(m, ((g_host_1pass[c].chunk[q] >> 24) + q * c - 1) / (q * c)); // bits per covered byte
+        g_1pass_bits_per_byte[c] = m;
+    }
     g_host_ready = true;
     return true;
 }
@@ -425,9 +433,12 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
-        // a row's local stream: no Deflate code is longer than 15 bits -> < 2 bytes per filtered byte; rows start
-        // 16-byte aligned and assemble_kernel may read one dword past the stream
-        j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * 16 + 64 + 31) / 32 + 4 + 3) & ~3ull);
+        // a row's local stream: at most L bits per filtered byte, L = the longest literal code of the table in use
+        // (12 for the per-image tables of 2-pass, reference fpng.cpp:1111; run tokens need less per byte they
+        // cover), + end-of-block; rows start 16-byte aligned and the 16-byte flush / assemble_kernel may touch up
+        // to four dwords past the stream
+        const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[im.num_chans];
+        j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
         j.local_base = sub.local_dwords;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         sub.local_dwords += (uint64_t)j.local_stride * im.h;

@@ -202,6 +202,36 @@ def test_maximum_height(enc):
         _assert_same(png, oracle().encode(img, w, h, c, fl), f"max height flags={fl}")
 
 
+@pytest.mark.parametrize("c", [3, 4])
+def test_longest_possible_local_streams(enc, c):
+    """Every filtered byte carries the LONGEST literal code of the 1-pass table and no pixel repeats: each row's local
+    stream is as long as the scratch stride allows.  Such an image falls back to stored blocks itself; the images
+    around it in the batch (whose local streams are its neighbours in scratch) must come out untouched."""
+    lens = np.array(oracle().table_1pass(c)[0][:256])
+    worst = np.flatnonzero(lens == lens.max())
+    assert len(worst) >= 2
+    rng = np.random.default_rng(5 + c)
+    w, h = 1300, 37
+    filt = worst[rng.integers(0, len(worst), (h, w, c))].astype(np.uint8)
+    # no two horizontally adjacent filtered pixels equal (that would start a run): patch channel 0 where needed
+    for _ in range(4):
+        same = np.all(filt[:, 1:] == filt[:, :-1], axis=2)
+        ys, xs = np.nonzero(same)
+        filt[ys, xs + 1, 0] = worst[(np.searchsorted(worst, filt[ys, xs + 1, 0]) + 1) % len(worst)]
+    assert not np.all(filt[:, 1:] == filt[:, :-1], axis=2).any()
+    img = np.cumsum(filt.astype(np.uint32), axis=0).astype(np.uint8)   # Up filter of img gives filt back
+    import fpng_amd
+    others = [fpng_amd.synth_image(k, 1300, 29, c, seed=70 + i) for i, k in enumerate(("grad", "blocks", "grad"))]
+    batch = [others[0], np.ascontiguousarray(img), others[1], np.ascontiguousarray(img[:, ::-1]), others[2]]
+    for fl in (0, 1):
+        pngs, modes = _gpu_encode(enc, batch, fl)
+        for im, p in zip(batch, pngs):
+            hh, ww, cc = im.shape
+            _assert_same(p, oracle().encode(im, ww, hh, cc, fl), f"worst-case neighbours {ww}x{hh}x{cc} flags={fl}")
+        if fl == 0:
+            assert modes[1] == 1   # the all-longest-codes image itself is stored
+
+
 def test_many_tiny_rows_through_assemble(enc):
     """Rows of a few bytes: more than 64 rows under one 1 KiB chunk of assemble_kernel (its slow row walk), deep
     64-ary row searches (h up to 200 000), row seams in nearly every dword."""

@@ -64,6 +64,33 @@ def committed_traffic(kernel):
     return None, None
 
 
+def verify_first_output(args, rank, w, h, c, out, size):
+    """sha256 of image 0 (seed 12345 on rank 0) vs the golden vectors produced by the unmodified reference.
+    Returns True/False when a golden vector exists for this input, None otherwise."""
+    import hashlib
+    if rank != 0 or args.kind != "grad" or args.flags not in (0, 1):
+        return None
+    want = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+            for e in json.load(f):
+                if (e["w"], e["h"], e["c"], e["kind"]) == (w, h, c, args.kind):
+                    want = e["flags"][str(args.flags)]["sha256"]
+        if want is None:
+            with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+                for e in json.load(f).values():
+                    if (e["w"], e["h"], e["c"], e["kind"], e["seed0"]) == (w, h, c, args.kind, 12345) and str(args.flags) in e["flags"]:
+                        want = e["flags"][str(args.flags)]["sha256"][0]
+    except OSError:
+        return None
+    if want is None:
+        return None
+    got = hashlib.sha256(out[:size].cpu().numpy().tobytes()).hexdigest()
+    if got != want:
+        raise SystemExit(f"bench.py: PARITY FAILURE, image 0 sha256 {got} != reference {want}")
+    return True
+
+
 def cpu_baseline(w, h, c, kind, flags, reps):
     """The reference's CPU path on ONE host core (rank 0, N=1 only).  Checker-side code: this is the
     only place bench.py touches oracle/."""
@@ -151,6 +178,9 @@ def main():
 
     png_bytes = sum(r[0] for r in res)
     assert all(r[2] == 0 for r in res)
+    # self-check: image 0 of the last timed submission's output set against the reference's bytes
+    # (tests/golden/batches.json / kat.json: sha256 of the unmodified reference encoder's file for this input)
+    parity_checked = verify_first_output(args, rank, w, h, c, out_sets[(args.steps - 1) & 3][0], res[0][0])
     pixels_per_step = B * w * h
     value = world * pixels_per_step * args.steps / elapsed / 1e6
 
@@ -182,6 +212,7 @@ def main():
     line = {
         "metric": "encode megapixels/sec (whole node), 1-pass, device-resident",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "prewarm": args.prewarm, "parity_checked": parity_checked,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{B} x {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' frames per GPU per step, "

@@ -448,40 +448,3 @@ print("fallback ok", enc.phase_names()[0])
         env = dict(os.environ, FPNG_ROOT=ROOT, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "fallback ok count" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
-
-
-def test_full_size_16k_single_image_whole_and_bands(enc):
-    """BASELINE config 4 size: one 16384x16384 RGBA image (1 GiB).  Whole-image encode and the 8-band
-    row-sharded encode must be the same file; zlib inflates it back to the Up-filtered rows."""
-    import torch
-    import fpng_amd
-    from fpng_amd import sharded
-    w = h = 16384
-    img = fpng_amd.synth_image("grad", w, h, 4, seed=777)
-    t = torch.from_numpy(img).cuda()
-    (png,), (mode,) = enc.encode_tensors([t], 0)
-    assert mode == 0
-    cuts = [b[0] for b in sharded.split_rows(h, 8)] + [h]
-    png_bands = sharded.encode_image_bands_local(sharded.GpuBandBackend(enc), t, cuts)
-    assert hashlib.sha256(png_bands).hexdigest() == hashlib.sha256(png).hexdigest()
-    idat = int.from_bytes(png[50:54], "big")
-    assert len(png) == 58 + idat + 16
-    # IHDR stores only the low 16 bits of each dimension (reference fpng.cpp:1773-1774): 16384 fits
-    assert png[16:24] == (16384).to_bytes(4, "big") * 2
-    d = zlib.decompressobj()
-    rows_checked = 0
-    prev = None
-    stride = w * 4 + 1
-    buf = b""
-    src = img.reshape(h, w * 4)
-    for off in range(58, 58 + idat, 1 << 24):
-        buf += d.decompress(png[off:min(off + (1 << 24), 58 + idat)])
-        while len(buf) >= stride:
-            row = np.frombuffer(buf[:stride], dtype=np.uint8)
-            buf = buf[stride:]
-            y = rows_checked
-            exp = src[y] if y == 0 else (src[y] - src[y - 1])
-            assert row[0] == (0 if y == 0 else 2) and (row[1:] == exp).all(), y
-            rows_checked += 1
-    assert rows_checked == h and d.eof
-    assert zlib.crc32(png[54:58 + idat]) == int.from_bytes(png[58 + idat:62 + idat], "big")

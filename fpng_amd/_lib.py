@@ -44,12 +44,17 @@ SIGNATURES = {
     "fpng_amd_adler32_combine": (_u32, [_u32, _u32, _u64]),
     "fpng_amd_max_encoded_size": (_sz, [_u32, _u32, _u32]),
     "fpng_amd_encoder_create": (_int, [C.POINTER(_vp), _int, _vp]),
+    "fpng_amd_encoder_create_on_stream": (_int, [C.POINTER(_vp), _int, _vp]),
+    "fpng_amd_encoder_set_stream": (_int, [_vp, _vp]),
     "fpng_amd_encoder_destroy": (None, [_vp]),
     "fpng_amd_encoder_stream": (_vp, [_vp]),
     "fpng_amd_encoder_join": (_int, [_vp]),
     "fpng_amd_encoder_phase_names": (C.c_char_p, [_vp]),
     "fpng_amd_encode_batch_async": (_int, [_vp, C.POINTER(Image), _u32, _u32]),
     "fpng_amd_encode_finish": (_int, [_vp, C.POINTER(Result), _u32]),
+    "fpng_amd_encode_submit": (_int, [_vp, C.POINTER(Image), _u32, _u32, C.POINTER(_u64)]),
+    "fpng_amd_encode_wait": (_int, [_vp, _u64, C.POINTER(Result), _u32]),
+    "fpng_amd_encode_query": (_int, [_vp, _u64]),
     "fpng_amd_encode_host": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, C.POINTER(_sz)]),
     "fpng_amd_band_count": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(BandStats)]),
     "fpng_amd_band_emit": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _int, _int, _u32, _vp, _sz,
@@ -59,6 +64,7 @@ SIGNATURES = {
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),
+    "fpng_amd_debug_peek": (_int, [_vp, _int, C.POINTER(_u32), _u32]),
     "fpng_amd_calibration_stream": (_int, [_vp, _int, _u32, _vp, _sz]),
 }
 

@@ -80,24 +80,33 @@ def synth_image(kind, w, h, num_chans, seed=12345):
 
 
 class Encoder:
-    """A HIP stream + reusable device scratch (one per thread).  `stream="torch"` enqueues on torch's
-    current stream of `device` so that it orders naturally with torch copies."""
+    """Reusable device scratch + the HIP stream submissions are ordered against (one Encoder per thread).
+    `stream="torch"` (default): every submit() is ordered behind the work already enqueued on torch's CURRENT
+    stream of `device` at that moment (also when that is the default/null stream), so pixels produced by torch
+    kernels need no host synchronisation; join() makes that stream wait for the outputs.  `stream="own"`: a
+    private stream, the caller synchronises.  Anything else: a hipStream_t handle."""
 
     def __init__(self, device=0, stream="torch"):
         self.lib = _lib.load()
         self.device = device
+        self._follow_torch = stream == "torch"
         h = C.c_void_p()
         if stream == "torch":
             with torch.cuda.device(device):
                 sptr = torch.cuda.current_stream().cuda_stream
-            sp = C.c_void_p(sptr) if sptr else None
+            check(self.lib.fpng_amd_encoder_create_on_stream(C.byref(h), device, C.c_void_p(sptr) if sptr else None))
         elif stream is None or stream == "own":
-            sp = None
+            check(self.lib.fpng_amd_encoder_create(C.byref(h), device, None))
         else:
-            sp = C.c_void_p(int(stream))
-        check(self.lib.fpng_amd_encoder_create(C.byref(h), device, sp))
+            check(self.lib.fpng_amd_encoder_create_on_stream(C.byref(h), device, C.c_void_p(int(stream))))
         self.h = h
         self._keep = []
+
+    def _sync_stream(self):
+        if self._follow_torch:
+            with torch.cuda.device(self.device):
+                sptr = torch.cuda.current_stream().cuda_stream
+            check(self.lib.fpng_amd_encoder_set_stream(self.h, C.c_void_p(sptr) if sptr else None))
 
     def close(self):
         if getattr(self, "h", None):
@@ -133,15 +142,32 @@ class Encoder:
         batch = images if outs is None else self.make_batch(images, outs)
         self._keep.append(batch)  # buffers of submissions in flight stay alive until finish()
         n = len(batch[2])
-        check(self.lib.fpng_amd_encode_batch_async(self.h, batch[2], n, flags))
+        self._sync_stream()
+        t = C.c_uint64(0)
+        check(self.lib.fpng_amd_encode_submit(self.h, batch[2], n, flags, C.byref(t)))
+        self.last_ticket = t.value
         return n
+
+    def wait(self, ticket, n):
+        """Waits for the submission `ticket` (see last_ticket) only; returns its (png_size, mode, status) records."""
+        res = (Result * n)()
+        check(self.lib.fpng_amd_encode_wait(self.h, ticket, res, n))
+        return [(r.png_size, r.mode, r.status) for r in res]
+
+    def query(self, ticket):
+        rc = self.lib.fpng_amd_encode_query(self.h, ticket)
+        if rc < 0:
+            check(rc)
+        return bool(rc)
 
     def phase_names(self):
         """Names of the kernels/phases of the last submission's pipeline (see last_phase_ms)."""
         return self.lib.fpng_amd_encoder_phase_names(self.h).decode().split(",")
 
     def join(self):
-        """Device-side join: the encoder's stream waits for every submission made so far (no host wait)."""
+        """Device-side join: the encoder's stream (torch's current one for stream="torch") waits for every
+        submission made so far (no host wait)."""
+        self._sync_stream()
         check(self.lib.fpng_amd_encoder_join(self.h))
 
     def finish(self, n):

@@ -37,11 +37,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(name, defines, verbose=False):
+    """A diagnostic build next to the product (e.g. --variant timing: per-phase cycle counters in encode_image_kernel);
+    select it at run time with FPNG_AMD_LIB=fpng_amd/lib/libfpng_amd_<name>.so."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    out = os.path.join(LIB_DIR, f"libfpng_amd_{name}.so")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall",
+           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + [f"-D{d}" for d in defines]
+    for s in SOURCES:
+        cmd += ["-x", "hip", os.path.join(CSRC, s)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if force or _stale(LIB, srcs + HEADERS):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
                "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB]
         for s in srcs:
             cmd += ["-x", "hip", s]
@@ -60,5 +75,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
-    print(path)
+    if "--variant" in sys.argv:
+        v = sys.argv[sys.argv.index("--variant") + 1]
+        print(build_variant(v, {"timing": ["FPNG_FUSED_TIMING"]}[v], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -51,21 +51,24 @@ DeviceTables g_dev[kMaxDevices];
 TokenTable g_host_1pass[5];
 uint32_t g_1pass_bits_per_byte[5]; // longest literal code (and no run token needs more per byte it covers)
 std::mutex g_mu;
-bool g_host_ready = false;
+std::once_flag g_host_once;
+bool g_host_ok = false;
 
+// thread-safe lazy init: the fpng:: drop-in is re-entrant like the reference
 bool host_tables()
 {
-    if (g_host_ready) return true;
-    if (!build_1pass_tables(&g_host_1pass[3], &g_host_1pass[4])) return false;
-    for (int c = 3; c <= 4; c++) {
-        uint32_t m = 0;
-        for (int i = 0; i < 257; i++) m = std::max(m, g_host_1pass[c].lit[i] >> 16);
-        const uint32_t cap = (c == 3) ? kMaxChunkPixels3 : kMaxChunkPixels4;
-        for (uint32_t q = 1; q <= cap; q++) m = std::max(m, ((g_host_1pass[c].chunk[q] >> 24) + q * c - 1) / (q * c)); // bits per covered byte
-        g_1pass_bits_per_byte[c] = m;
-    }
-    g_host_ready = true;
-    return true;
+    std::call_once(g_host_once, [] {
+        if (!build_1pass_tables(&g_host_1pass[3], &g_host_1pass[4])) return;
+        for (int c = 3; c <= 4; c++) {
+            uint32_t m = 0;
+            for (int i = 0; i < 257; i++) m = std::max(m, g_host_1pass[c].lit[i] >> 16);
+            const uint32_t cap = (c == 3) ? kMaxChunkPixels3 : kMaxChunkPixels4;
+            for (uint32_t q = 1; q <= cap; q++) m = std::max(m, ((g_host_1pass[c].chunk[q] >> 24) + q * c - 1) / (q * c)); // bits per covered byte
+            g_1pass_bits_per_byte[c] = m;
+        }
+        g_host_ok = true;
+    });
+    return g_host_ok;
 }
 
 int ensure_device_tables(int dev)
@@ -100,16 +103,20 @@ int ensure_device_tables(int dev)
 template <typename T> struct DeviceBuf {
     T *p = nullptr;
     size_t cap = 0;
+    bool fresh = false; // set when ensure() (re)allocated: the contents are undefined
+    // (hipFree waits for the device: growing a buffer that a submission in flight still uses is safe, merely a stall;
+    // capacities grow geometrically so that it stops happening after the first few submissions)
     int ensure(size_t n)
     {
         if (n <= cap) return FPNG_AMD_OK;
+        const size_t want = std::max(n, cap + cap / 2);
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = std::max(n, cap * 2);
         hipError_t e = hipMalloc(&p, want * sizeof(T));
         if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipMalloc scratch", e);
         cap = want;
+        fresh = true;
         return FPNG_AMD_OK;
     }
     void release()
@@ -127,6 +134,8 @@ template <typename T> struct PinnedBuf {
         if (n <= cap) return FPNG_AMD_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        cap = 0;
+        n = std::max(n, (size_t)16);
         hipError_t e = hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault);
         if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipHostMalloc", e);
         cap = n;
@@ -187,9 +196,9 @@ struct fpng_amd_encoder {
     PinnedBuf<Result> h_results;
     PinnedBuf<JobState> h_states;
     // Device scratch of one submission.  Batch submissions alternate between kLanes internal streams, each
-    // with its own scratch, so that the latency-bound tail of one submission (row scan, CRC fold, trailer)
-    // and its LDS-bound CRC kernel overlap the VALU-bound row walkers of the next one.  Set 0 also serves
-    // the synchronous entry points (bands, wrap_png), which drain the lanes first.
+    // with its own scratch, so that the tail of one submission (stored fallback, CRC, trailer) overlaps the
+    // VALU-bound encode kernel of the next one.  Set 0 also serves the synchronous entry points (bands, wrap_png),
+    // which drain the lanes first.
     struct Scratch {
         DeviceBuf<Job> d_jobs;
         DeviceBuf<RowInfo> d_rows;
@@ -199,35 +208,43 @@ struct fpng_amd_encoder {
         DeviceBuf<uint32_t> d_partials;
         DeviceBuf<uint32_t> d_hist;
         DeviceBuf<TokenTable> d_dyn;
-        DeviceBuf<uint32_t> d_local; // the rows' local streams (Job::local_base / local_stride)
+        DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
+        // fused pipeline (encode_image_kernel)
+        DeviceBuf<uint64_t> d_unit_state, d_unit_adler;
+        DeviceBuf<uint32_t> d_ctrl;       // [2 x 8 x 32] queue heads of the two channel classes, then job_done[n]
+        DeviceBuf<uint32_t> d_chunk_base; // [2][n + 1]
+        DeviceBuf<uint32_t> d_spill;
+        uint32_t epoch = 0;
         void release()
         {
             d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
             d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
+            d_unit_state.release(), d_unit_adler.release(), d_ctrl.release(), d_chunk_base.release(), d_spill.release();
         }
     };
     static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
-    uint32_t submit_count = 0;
     hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)
-    int pipeline = 0; // of the last submission: 0 encode_rows + assemble, 1 count/scan/emit/crc
+    int pipeline = 0; // of the last submission: 0 fused, 1 rows (encode_rows + assemble), 2 count/scan/emit/crc
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
-    uint32_t last_n = 0;
     // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
-    // records coming back) guarded by an event, so fpng_amd_encode_batch_async() never waits for the GPU
-    // unless all slots are in flight.
-    static constexpr int kSlots = 4;
+    // records coming back) guarded by an event, so fpng_amd_encode_submit() never waits for the GPU unless all
+    // slots are in flight.  A submission's ticket is its sequence number; its records stay readable until its
+    // slot is reused, kSlots submissions later.
+    static constexpr int kSlots = 8;
     struct Slot {
         PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
         PinnedBuf<Result> results;
-        hipEvent_t in = nullptr;   // recorded on the caller's stream: the inputs are ready
+        PinnedBuf<uint32_t> chunk_base;
+        hipEvent_t in = nullptr;     // recorded on the caller's stream: the inputs are ready
         hipEvent_t walked = nullptr; // recorded on the lane after the row walk
-        hipEvent_t done = nullptr; // recorded on the lane: PNGs and result records are complete
+        hipEvent_t done = nullptr;   // recorded on the lane: PNGs and result records are complete
         bool in_flight = false;
         uint32_t n = 0;
+        uint64_t ticket = 0;
     } slots[kSlots];
-    int cur_slot = 0;
+    uint64_t submitted = 0; // tickets handed out so far
 };
 
 extern "C" {
@@ -275,7 +292,7 @@ int fpng_amd_1pass_layout(uint32_t c, uint32_t *first_token_bit, uint32_t *eob_b
     return FPNG_AMD_OK;
 }
 
-int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream)
+static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, bool use_given_stream)
 {
     if (!out) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder pointer");
     *out = nullptr;
@@ -286,8 +303,8 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
     if (rc) return rc;
     fpng_amd_encoder *e = new fpng_amd_encoder();
     e->device = device;
-    if (hip_stream) {
-        e->stream = (hipStream_t)hip_stream;
+    if (use_given_stream) {
+        e->stream = (hipStream_t)hip_stream; // nullptr = the legacy default stream
     } else {
         hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (err != hipSuccess) {
@@ -307,13 +324,35 @@ int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream
     return FPNG_AMD_OK;
 }
 
+int fpng_amd_encoder_create(fpng_amd_encoder **out, int device, void *hip_stream)
+{
+    return encoder_create(out, device, hip_stream, hip_stream != nullptr);
+}
+
+int fpng_amd_encoder_create_on_stream(fpng_amd_encoder **out, int device, void *hip_stream)
+{
+    return encoder_create(out, device, hip_stream, true);
+}
+
+int fpng_amd_encoder_set_stream(fpng_amd_encoder *e, void *hip_stream)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    if (e->own_stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+        e->own_stream = false;
+    }
+    e->stream = (hipStream_t)hip_stream;
+    return FPNG_AMD_OK;
+}
+
 void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &ls : e->lane_stream)
         if (ls) (void)hipStreamSynchronize(ls);
-    (void)hipStreamSynchronize(e->stream);
+    if (e->own_stream) (void)hipStreamSynchronize(e->stream);
     if (e->ev_ready)
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
     e->h_jobs.release();
@@ -321,6 +360,7 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
         sl.jobs.release();
         sl.jobs2.release();
         sl.results.release();
+        sl.chunk_base.release();
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.in) (void)hipEventDestroy(sl.in);
         if (sl.walked) (void)hipEventDestroy(sl.walked);
@@ -367,8 +407,12 @@ namespace {
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
     uint64_t total_rows = 0;
-    uint64_t local_dwords = 0; // scratch for the rows' local streams
+    uint64_t local_dwords = 0; // rows pipeline: scratch for the rows' local streams
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
+    // fused pipeline
+    uint64_t total_units = 0;
+    uint32_t total_chunks[2] = {0, 0}; // per channel class (0: 3 channels, 1: 4 channels)
+    uint32_t chunks_per_job[2] = {0, 0};
 };
 
 int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
@@ -391,20 +435,22 @@ int drain(fpng_amd_encoder *e)
     return FPNG_AMD_OK;
 }
 
-// Fills slot.jobs[0..n) for whole-image jobs and sizes the scratch buffers.
+// Fills slot.jobs[0..n) for whole-image jobs and sizes the scratch buffers.  Only `slot` (which is free) and
+// the lane's device scratch are touched: the records of submissions in flight stay where they are.
 int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_encoder::Scratch &sc, const fpng_amd_image *images,
                  uint32_t n, uint32_t flags, Submission &sub)
 {
     if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
     int rc;
-    // size the pinned records of EVERY slot of the ring now: a later submission must not stop for a hipHostMalloc
-    for (auto &sl : e->slots)
-        if ((rc = sl.jobs.ensure(n)) || (rc = sl.results.ensure(n))) return rc;
+    if ((rc = slot.jobs.ensure(n)) || (rc = slot.results.ensure(n)) || (rc = slot.chunk_base.ensure(2 * ((size_t)n + 1)))) return rc;
     const DeviceTables &dt = g_dev[e->device];
-    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !(flags & FPNG_AMD_FORCE_UNCOMPRESSED);
+    const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     sub = Submission();
     sub.n = n;
+    uint32_t *cb[2] = {slot.chunk_base.p, slot.chunk_base.p + n + 1};
+    bool uniform_chunks[2] = {true, true};
     for (uint32_t i = 0; i < n; i++) {
         const fpng_amd_image &im = images[i];
         if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
@@ -440,12 +486,34 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[im.num_chans];
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
         j.local_base = sub.local_dwords;
+        // fused pipeline: segments of at most kSegMaxPx pixels, as even as 256-pixel granularity allows
+        const uint32_t cls = (im.num_chans == 3) ? 0u : 1u;
+        const uint32_t nseg = (im.w + kSegMaxPx - 1) / kSegMaxPx;
+        j.seg_px = (((im.w + nseg - 1) / nseg) + 255u) & ~255u;
+        j.segs_per_row = (im.w + j.seg_px - 1) / j.seg_px;
+        const uint64_t units = force_stored ? 1ull : ((uint64_t)im.h * j.segs_per_row + kUnitSegs - 1) / kUnitSegs;
+        if (sub.total_units + units > 0xFFFFFFF0ull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many row segments in one batch");
+        j.n_units = (uint32_t)units;
+        j.unit_base = (uint32_t)sub.total_units;
+        j.chunk_base = sub.total_chunks[cls];
+        const uint32_t chunks = (j.n_units + kChunkUnits - 1) / kChunkUnits;
+        cb[0][i] = sub.total_chunks[0];
+        cb[1][i] = sub.total_chunks[1];
+        if (sub.chunks_per_job[cls] == 0) sub.chunks_per_job[cls] = chunks;
+        if (sub.chunks_per_job[cls] != chunks) uniform_chunks[cls] = false;
+        sub.total_chunks[cls] += chunks;
+        sub.total_units += units;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         sub.local_dwords += (uint64_t)j.local_stride * im.h;
         sub.total_rows += im.h;
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
     }
+    cb[0][n] = sub.total_chunks[0];
+    cb[1][n] = sub.total_chunks[1];
+    // "job = chunk / chunks_per_job" holds only when every job is of that class and has the same chunk count
+    for (int c = 0; c < 2; c++)
+        if (!uniform_chunks[c] || sub.chan_mask == 3u) sub.chunks_per_job[c] = 0;
     if ((rc = sc.d_jobs.ensure(n))) return rc;
     if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
     if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
@@ -459,22 +527,70 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     return FPNG_AMD_OK;
 }
 
-} // namespace
+constexpr uint32_t kSpillStride = 1600; // dwords per wave: (1024 px x 4 B + 1) x 12 bits + EOB + slack
+constexpr uint32_t kCtrlQueueWords = 2 * 8 * 32;
 
-extern "C" {
+// encode_image_kernel launches (one per channel class present) for the jobs already uploaded to sc.d_jobs.
+int launch_fused(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_encoder::Scratch &sc, hipStream_t s, const Submission &sub)
+{
+    int rc;
+    const uint32_t n = sub.n;
+    if ((rc = sc.d_unit_state.ensure(2 * sub.total_units)) || (rc = sc.d_unit_adler.ensure(sub.total_units)) ||
+        (rc = sc.d_ctrl.ensure(kCtrlQueueWords + n)) || (rc = sc.d_chunk_base.ensure(2 * ((size_t)n + 1))) ||
+        (rc = sc.d_spill.ensure((size_t)kFusedMaxBlocks * kUnitSegs * kSpillStride)))
+        return rc;
+    // the unit records carry the launch's epoch; fresh (or wrapped-around) arrays are cleared once
+    static const bool always_clear = [] { const char *v = getenv("FPNG_AMD_FUSED_CLEAR"); return v && v[0] == '1'; }();
+    if (always_clear || sc.d_unit_state.fresh || sc.d_unit_adler.fresh || sc.epoch >= 0xFFFFFEu) {
+        HIP_TRY(hipMemsetAsync(sc.d_unit_state.p, 0, (always_clear ? 2 * sub.total_units : sc.d_unit_state.cap) * sizeof(uint64_t), s));
+        HIP_TRY(hipMemsetAsync(sc.d_unit_adler.p, 0, (always_clear ? sub.total_units : sc.d_unit_adler.cap) * sizeof(uint64_t), s));
+        sc.d_unit_state.fresh = sc.d_unit_adler.fresh = false;
+        sc.epoch = 0;
+    }
+    HIP_TRY(hipMemsetAsync(sc.d_ctrl.p, 0, (kCtrlQueueWords + (size_t)n) * sizeof(uint32_t), s));
+    HIP_TRY(hipMemcpyAsync(sc.d_chunk_base.p, slot.chunk_base.p, 2 * ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    for (uint32_t cls = 0; cls < 2; cls++) {
+        if (!sub.total_chunks[cls]) continue;
+        FusedArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.jobs = sc.d_jobs.p;
+        a.chunk_base = sc.d_chunk_base.p + cls * ((size_t)n + 1);
+        a.unit_state = sc.d_unit_state.p;
+        a.unit_adler = sc.d_unit_adler.p;
+        a.tickets = sc.d_ctrl.p + cls * 8 * 32;
+        a.job_done = sc.d_ctrl.p + kCtrlQueueWords;
+        a.spill = sc.d_spill.p;
+        a.states = sc.d_states.p;
+        a.n_jobs = n;
+        a.total_chunks = sub.total_chunks[cls];
+        a.chunks_per_job = sub.chunks_per_job[cls];
+        a.epoch = ++sc.epoch;
+        a.spill_stride = kSpillStride;
+        static const uint32_t dbg = [] { const char *v = getenv("FPNG_AMD_FUSED_DBG"); return v ? (uint32_t)atoi(v) : 0u; }();
+        a.pad = dbg;
+        // persistent grid: every queue (blockIdx & 7) needs a block; more blocks than units only pull empty tickets
+        const uint64_t units = (uint64_t)sub.total_chunks[cls] * kChunkUnits;
+        static const uint32_t max_blocks = [] {
+            const char *v = getenv("FPNG_AMD_FUSED_BLOCKS"); // A/B runs
+            const int b = v ? atoi(v) : (int)kFusedMaxBlocks;
+            return (uint32_t)std::min<int>(std::max(b, 8), (int)kFusedMaxBlocks) & ~7u;
+        }();
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(8, (units + 7) & ~7ull));
+        launch_encode_image(s, cls == 0 ? 3u : 4u, a, blocks);
+    }
+    return FPNG_AMD_OK;
+}
 
-int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags)
+int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags, uint64_t *ticket_out)
 {
     if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
     HIP_TRY(hipSetDevice(e->device));
-    // next slot of the ring; wait only if the submission that used it is still running
-    e->cur_slot = (e->cur_slot + 1) % fpng_amd_encoder::kSlots;
-    fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
-    for (auto &sl : e->slots) {
-        if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        if (!sl.in) HIP_TRY(hipEventCreateWithFlags(&sl.in, hipEventDisableTiming));
-        if (!sl.walked) HIP_TRY(hipEventCreateWithFlags(&sl.walked, hipEventDisableTiming));
-    }
+    // next slot of the ring; wait only if the submission that used it is still running.  Nothing of the encoder's
+    // state changes before the batch has been validated.
+    fpng_amd_encoder::Slot &slot = e->slots[(e->submitted + 1) % fpng_amd_encoder::kSlots];
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (!slot.in) HIP_TRY(hipEventCreateWithFlags(&slot.in, hipEventDisableTiming));
+    if (!slot.walked) HIP_TRY(hipEventCreateWithFlags(&slot.walked, hipEventDisableTiming));
     if (slot.in_flight) {
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
@@ -485,53 +601,53 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
     }();
     // lane = internal stream + scratch set.  Per-kernel profiling stays on lane 0, which serialises it.
-    const int lane = e->profiling ? 0 : (int)(e->submit_count++ % n_lanes);
+    const int lane = e->profiling ? 0 : (int)(e->submitted % n_lanes);
     fpng_amd_encoder::Scratch &sc = e->sc[lane];
     hipStream_t s = e->lane_stream[lane];
     Submission sub;
     int rc = prepare_jobs(e, slot, sc, images, n, flags, sub);
     if (rc) return rc;
-    // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
-    HIP_TRY(hipEventRecord(slot.in, e->stream));
-    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
     const DeviceTables &dt = g_dev[e->device];
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
-    e->phases_recorded = 0;
-    // Default pipeline: ONE walk over the pixels (encode_rows: every row into its local stream), then the
-    // streams are shifted into place while the IDAT CRC is taken (assemble).  Images whose local streams would
-    // not fit the scratch budget, and FPNG_AMD_PIPELINE=count, use the older count -> scan -> emit -> crc
-    // kernels (two walks over the pixels, no scratch), which the row-band entry points need anyway.
-    static const bool prefer_count = [] {
+    // Pipelines.  fused (default): encode_image_kernel, one persistent launch that reads every pixel once and writes
+    // every stream byte once.  rows: encode_rows -> scan -> assemble (rows into scratch streams, shifted into place
+    // by a second kernel).  count: count -> scan -> emit -> crc (two walks, no scratch; what the row bands use).
+    static const int forced = [] {
         const char *v = getenv("FPNG_AMD_PIPELINE");
-        return v && !strcmp(v, "count");
+        if (!v) return -1;
+        return !strcmp(v, "fused") ? 0 : (!strcmp(v, "rows") ? 1 : (!strcmp(v, "count") ? 2 : -1));
     }();
     static const uint64_t local_limit = [] {
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
         return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
     }();
-    bool use_rows = !prefer_count && (sub.local_dwords + 16) * 4 <= local_limit;
-    if (use_rows && sc.d_local.ensure(sub.local_dwords + 16) != FPNG_AMD_OK) {
-        (void)hipGetLastError(); // no memory for the local streams right now: the scratch-free pipeline still works
-        use_rows = false;
+    int pipeline = forced < 0 ? 0 : forced;
+    if (pipeline == 1 && ((sub.local_dwords + 16) * 4 > local_limit || sc.d_local.ensure(sub.local_dwords + 16) != FPNG_AMD_OK)) {
+        (void)hipGetLastError(); // no room for the local streams: the scratch-free pipeline still works
+        pipeline = 2;
     }
-    e->pipeline = use_rows ? 0 : 1;
-    if (use_rows)
+    if (pipeline == 1)
         for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
-
     if (two_pass) {
         // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
         // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
-        for (auto &sl : e->slots)
-            if ((rc = sl.jobs2.ensure(n))) return rc;
+        if ((rc = slot.jobs2.ensure(n))) return rc;
         for (uint32_t i = 0; i < n; i++) {
             slot.jobs2.p[i] = slot.jobs.p[i];
             slot.jobs2.p[i].table = sc.d_dyn.p + i;
             slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
         }
     }
-    // (no memset of the job states: every field is written before it is read -- last_unit_bits by the row walk,
-    // the rest by scan_kernel -- and each extra small launch can get stuck behind the other lane's big grids)
+    // ---- the batch is valid: from here on the submission exists ----
+    e->submitted++;
+    slot.ticket = e->submitted;
+    slot.n = n;
+    e->pipeline = pipeline;
+    e->phases_recorded = 0;
+    // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
+    HIP_TRY(hipEventRecord(slot.in, e->stream));
+    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
     if (two_pass) {
@@ -549,7 +665,16 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
     }();
     const bool stagger = stagger_env < 0 ? two_pass : stagger_env == 1;
     if (stagger && e->prev_walked && !e->profiling) HIP_TRY(hipStreamWaitEvent(s, e->prev_walked, 0));
-    if (use_rows) {
+    if (pipeline == 0) {
+        if ((rc = launch_fused(e, slot, sc, s, sub))) return rc;
+        if ((rc = mark(e, s, 1))) return rc;
+        HIP_TRY(hipEventRecord(slot.walked, s));
+        e->prev_walked = slot.walked;
+        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+        if ((rc = mark(e, s, 2))) return rc;
+        launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
+        if ((rc = mark(e, s, 3))) return rc;
+    } else if (pipeline == 1) {
         if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
         if ((rc = mark(e, s, 1))) return rc;
         HIP_TRY(hipEventRecord(slot.walked, s));
@@ -558,6 +683,8 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         if ((rc = mark(e, s, 2))) return rc;
         launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
         if ((rc = mark(e, s, 3))) return rc;
+        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
+        if ((rc = mark(e, s, 4))) return rc;
     } else {
         if (!force_stored) launch_count(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 1))) return rc;
@@ -565,28 +692,78 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *image
         if ((rc = mark(e, s, 2))) return rc;
         launch_emit(s, sc.d_jobs.p, n, sub.max_rows, sc.d_row_off.p, sc.d_rows.p, sc.d_states.p);
         if ((rc = mark(e, s, 3))) return rc;
-    }
-    if (use_rows)
-        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-    else
         launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
-    if ((rc = mark(e, s, 4))) return rc;
+        if ((rc = mark(e, s, 4))) return rc;
+    }
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
     launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p,
                     slot.results.p);
-    if ((rc = mark(e, s, 5))) return rc;
+    if ((rc = mark(e, s, pipeline == 0 ? 4 : 5))) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, s));
     slot.in_flight = true;
-    slot.n = n;
-    e->last_n = n;
+    if (ticket_out) *ticket_out = slot.ticket;
+    return FPNG_AMD_OK;
+}
+
+fpng_amd_encoder::Slot *slot_of(fpng_amd_encoder *e, uint64_t ticket)
+{
+    if (!ticket || ticket > e->submitted || ticket + fpng_amd_encoder::kSlots <= e->submitted) return nullptr;
+    fpng_amd_encoder::Slot &sl = e->slots[ticket % fpng_amd_encoder::kSlots];
+    return sl.ticket == ticket ? &sl : nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+int fpng_amd_encode_submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags, uint64_t *ticket)
+{
+    return submit(e, images, n, flags, ticket);
+}
+
+int fpng_amd_encode_batch_async(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t flags)
+{
+    return submit(e, images, n, flags, nullptr);
+}
+
+int fpng_amd_encode_query(fpng_amd_encoder *e, uint64_t ticket)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    fpng_amd_encoder::Slot *sl = slot_of(e, ticket);
+    if (!sl) return fail(FPNG_AMD_ERR_INVALID_ARG, "unknown or expired ticket");
+    if (!sl->in_flight) return 1;
+    const hipError_t st = hipEventQuery(sl->done);
+    if (st == hipSuccess) return 1;
+    if (st == hipErrorNotReady) return 0;
+    return fail(FPNG_AMD_ERR_HIP, "hipEventQuery", st);
+}
+
+int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *results, uint32_t n)
+{
+    if (!e) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder");
+    HIP_TRY(hipSetDevice(e->device));
+    fpng_amd_encoder::Slot *sl = slot_of(e, ticket);
+    if (!sl) return fail(FPNG_AMD_ERR_INVALID_ARG, "unknown or expired ticket (records are kept for the last 8 submissions)");
+    if (sl->in_flight) {
+        HIP_TRY(hipEventSynchronize(sl->done));
+        sl->in_flight = false;
+    }
+    if (results) {
+        if (n > sl->n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
+        for (uint32_t i = 0; i < n; i++) {
+            results[i].png_size = sl->results.p[i].png_size;
+            results[i].mode = sl->results.p[i].mode;
+            results[i].status = sl->results.p[i].status;
+        }
+    }
     return FPNG_AMD_OK;
 }
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    static const char *names[2] = {"encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize"};
+    static const char *names[3] = {"encode_image,stored,crc,finalize", "encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize"};
     return names[e ? e->pipeline : 0];
 }
 
@@ -606,13 +783,8 @@ int fpng_amd_encode_finish(fpng_amd_encoder *e, fpng_amd_result *results, uint32
     int rc0 = drain(e); // every outstanding submission is done after this
     if (rc0) return rc0;
     if (results) {
-        const fpng_amd_encoder::Slot &slot = e->slots[e->cur_slot];
-        if (n > slot.n) return fail(FPNG_AMD_ERR_INVALID_ARG, "more results requested than images submitted");
-        for (uint32_t i = 0; i < n; i++) {
-            results[i].png_size = slot.results.p[i].png_size;
-            results[i].mode = slot.results.p[i].mode;
-            results[i].status = slot.results.p[i].status;
-        }
+        if (!e->submitted) return fail(FPNG_AMD_ERR_INVALID_ARG, "nothing was submitted");
+        return fpng_amd_encode_wait(e, e->submitted, results, n);
     }
     return FPNG_AMD_OK;
 }
@@ -671,8 +843,8 @@ static int band_job(fpng_amd_encoder *e, const void *d_rows, const void *d_row_a
 int fpng_amd_band_count(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c,
                         uint32_t y0, uint32_t y1, fpng_amd_band_stats *stats)
 {
-    if (!stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null stats");
-    HIP_TRY(hipSetDevice(e ? e->device : 0));
+    if (!e || !stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
     int rc;
     if ((rc = drain(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -707,9 +879,9 @@ int fpng_amd_band_emit(fpng_amd_encoder *e, const void *d_rows, const void *d_ro
                        uint32_t y0, uint32_t y1, uint64_t start_bit, int is_first, int is_last, uint32_t adler,
                        uint8_t *d_band_out, size_t out_cap, size_t *out_bytes)
 {
-    if (!d_band_out || !out_bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (!e || !d_band_out || !out_bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
     if ((uintptr_t)d_band_out & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_band_out must be 16-byte aligned");
-    HIP_TRY(hipSetDevice(e ? e->device : 0));
+    HIP_TRY(hipSetDevice(e->device));
     int rc;
     if ((rc = drain(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -797,6 +969,21 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     HIP_TRY(hipMemcpyAsync(e->h_results.p, e->sc[0].d_results.p, sizeof(Result), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *png_size = (size_t)e->h_results.p[0].png_size;
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n_words)
+{
+    if (!e || lane < 0 || lane >= fpng_amd_encoder::kLanes || !dst) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (e->sc[lane].d_ctrl.cap < n_words) return fail(FPNG_AMD_ERR_INVALID_ARG, "no control words yet");
+    if (n_words == 16) { // the timing build's counters (head of the spill area), read and cleared
+        HIP_TRY(hipMemcpy(dst, e->sc[lane].d_spill.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(e->sc[lane].d_spill.p, 0, 16 * sizeof(uint32_t)));
+        return FPNG_AMD_OK;
+    }
+    HIP_TRY(hipMemcpy(dst, e->sc[lane].d_ctrl.p, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return FPNG_AMD_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #include <array>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace fpng_amd {
@@ -167,16 +168,16 @@ bool parse_prefix(const uint8_t *prefix, uint32_t nbytes, PendingBits tail, uint
 }
 
 uint32_t g_crc_byte[256];
-bool g_crc_ready = false;
-void ensure_crc()
+std::once_flag g_crc_once;
+void ensure_crc() // callable from any thread (fpng_crc32 is a free function of the re-entrant drop-in)
 {
-    if (g_crc_ready) return;
-    for (uint32_t i = 0; i < 256; i++) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
-        g_crc_byte[i] = c;
-    }
-    g_crc_ready = true;
+    std::call_once(g_crc_once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+            g_crc_byte[i] = c;
+        }
+    });
 }
 
 } // namespace

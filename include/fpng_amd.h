@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPNG_AMD_ABI_VERSION 1
+#define FPNG_AMD_ABI_VERSION 2
 
 /* ---- status codes ---- */
 #define FPNG_AMD_OK 0
@@ -80,6 +80,11 @@ typedef struct fpng_amd_encoder fpng_amd_encoder;
 /* hip_stream: the hipStream_t submissions are ordered against (e.g. torch's current stream: the producer
  * of the pixels), or NULL to let the encoder create its own non-blocking stream. */
 int fpng_amd_encoder_create(fpng_amd_encoder **enc, int device, void *hip_stream);
+/* The same, but hip_stream is taken literally: NULL means the legacy default (null) stream -- e.g. torch's default
+ * stream -- rather than "create one".  Submissions are then ordered behind everything already enqueued there. */
+int fpng_amd_encoder_create_on_stream(fpng_amd_encoder **enc, int device, void *hip_stream);
+/* Re-point the ordering stream (e.g. to torch's current stream before a submission); NULL = the null stream. */
+int fpng_amd_encoder_set_stream(fpng_amd_encoder *enc, void *hip_stream);
 void fpng_amd_encoder_destroy(fpng_amd_encoder *enc);
 void *fpng_amd_encoder_stream(fpng_amd_encoder *enc);
 
@@ -108,6 +113,14 @@ typedef struct fpng_amd_result {
  * fpng_amd_encoder_join().  The pixel and output buffers of submissions in flight must not alias.
  */
 int fpng_amd_encode_batch_async(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t flags);
+
+/* The same call handing back a TICKET for this submission, so that a pipeline with several submissions in flight can
+ * collect each one's result records: fpng_amd_encode_wait() waits for that submission only (later ones keep
+ * running) and copies out its n records; fpng_amd_encode_query() polls (1 done, 0 running).  Records stay
+ * retrievable until 8 further submissions have been made.  A failed submit leaves the encoder unchanged. */
+int fpng_amd_encode_submit(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t flags, uint64_t *ticket);
+int fpng_amd_encode_wait(fpng_amd_encoder *enc, uint64_t ticket, fpng_amd_result *results, uint32_t n);
+int fpng_amd_encode_query(fpng_amd_encoder *enc, uint64_t ticket);
 
 /* Device-side join: the encoder's stream waits (no host wait) for every submission made so far. */
 int fpng_amd_encoder_join(fpng_amd_encoder *enc);
@@ -167,11 +180,14 @@ int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32
 /* ---- instrumentation for bench.py: per-kernel durations of the last submission measured with HIP
  *      events (ms).  With profiling enabled submissions use one lane, i.e. they do not overlap.
  *      fpng_amd_encoder_phase_names(): comma-separated names of the phases of the last submission's
- *      pipeline, e.g. "encode_rows,scan,stored,assemble,finalize". ---- */
+ *      pipeline, e.g. "encode_image,stored,crc,finalize". ---- */
 #define FPNG_AMD_NUM_PHASES 8
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *enc);
+
+/* Instrumentation: the first n_words control words (work-queue heads, diagnostics) of an internal lane's last launch. */
+int fpng_amd_debug_peek(fpng_amd_encoder *enc, int lane, uint32_t *dst, uint32_t n_words);
 
 /* PMC calibration (instrumentation): stream `bytes` of d_buf once with 4- or 16-byte lanes, reading
  * (write=0) or writing (write=1), so rocprofv3 FETCH_SIZE/WRITE_SIZE can be converted to bytes. */

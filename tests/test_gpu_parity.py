@@ -259,7 +259,7 @@ def test_mixed_batch_shapes_and_channels(enc):
             [("grad", 640, 480, 3), ("blocks", 333, 77, 4), ("noise", 50, 50, 4), ("solid", 1, 1, 3), ("grad", 1921, 3, 4),
              ("noise", 7, 300, 3), ("blocks", 1024, 1024, 3), ("grad", 2, 2, 4)]]
     pngs, _ = _gpu_encode(enc, imgs, 0)
-    assert enc.phase_names()[0] == "encode_rows"   # the default whole-image pipeline (one walk + assemble)
+    assert enc.phase_names()[0] == "encode_image"   # the default whole-image pipeline (one persistent launch)
     for img, p in zip(imgs, pngs):
         h, w, c = img.shape
         _assert_same(p, oracle().encode(img, w, h, c, 0), f"{w}x{h}x{c}")
@@ -424,9 +424,9 @@ def test_overlapping_submissions_large_enough_to_run_concurrently(enc):
             _assert_same(bytes(out[:len(exp)].cpu().numpy()), exp, f"overlapped {w}x{h}x{c} flags={fl}")
 
 
-def test_count_pipeline_fallback_same_bytes():
-    """Images whose local streams exceed the scratch budget (here: FPNG_AMD_LOCAL_LIMIT_MB=1, and FPNG_AMD_PIPELINE=count
-    in a second run) take the count -> scan -> emit -> crc kernels; they must produce the same files."""
+def test_alternative_pipelines_same_bytes():
+    """FPNG_AMD_PIPELINE=rows (encode_rows -> scan -> assemble; with FPNG_AMD_LOCAL_LIMIT_MB=1 its scratch does not fit
+    and it falls back to count) and =count (count -> scan -> emit -> crc) must produce the same files as the default."""
     import subprocess
     import sys
     code = r'''
@@ -442,9 +442,10 @@ for fl in (0, 1, 2):
     pngs, _ = enc.encode_tensors([torch.from_numpy(np.ascontiguousarray(c[0])).cuda() for c in cases], fl)
     for (img, w, h, c), p in zip(cases, pngs):
         assert p == oracle().encode(img, w, h, c, fl), (w, h, c, fl)
-print("fallback ok", enc.phase_names()[0])
+print("pipeline ok", enc.phase_names()[0])
 '''
-    for extra in ({"FPNG_AMD_LOCAL_LIMIT_MB": "1"}, {"FPNG_AMD_PIPELINE": "count"}):
+    for extra, first in (({"FPNG_AMD_PIPELINE": "rows"}, "encode_rows"), ({"FPNG_AMD_PIPELINE": "rows", "FPNG_AMD_LOCAL_LIMIT_MB": "1"}, "count"),
+                         ({"FPNG_AMD_PIPELINE": "count"}, "count")):
         env = dict(os.environ, FPNG_ROOT=ROOT, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0 and "fallback ok count" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+        assert out.returncode == 0 and f"pipeline ok {first}" in out.stdout, (extra, out.stdout[-500:], out.stderr[-2000:])

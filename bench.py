@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--prewarm", type=int, default=60,
                     help="untimed steps before the W warmup steps: throughput needs ~40 back-to-back steps (20-50 ms of "
                          "sustained load) to settle, a cold 20-step run reads 15-25 %% low (DESIGN.md section 6)")
+    ap.add_argument("--mode", default="batch", choices=["batch", "rowband"],
+                    help="batch: every rank encodes its own images (BASELINE configs 2/3/5, the headline); rowband: ONE image "
+                         "sharded by rows over the ranks, one IDAT, windows gathered to rank 0 over RCCL (BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
     return ap.parse_args()
@@ -119,6 +122,77 @@ def cpu_baseline(w, h, c, kind, flags, reps):
             "sample": f"1 image {w}x{h}x{c} {kind}, best of {max(1, reps // 2)}, scalar C port", "png_bytes": len(png)}
 
 
+def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
+    """One image, rows sharded over the ranks (SURVEY 8e / BASELINE config 4).  A step = the whole exchange: band encode,
+    all_gather of the band records, placement at the band's bit position, windows to rank 0, wrap.  Steps cannot be
+    pipelined (each one has the host-visible exchange in the middle), so they are timed one after another."""
+    import hashlib
+    import torch.distributed as dist
+    import fpng_amd
+    from fpng_amd import sharded
+    if not distributed:  # a one-rank group so that the same code path (incl. the nccl collectives) runs
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    img = fpng_amd.synth_image(args.kind, w, h, c, seed=777 if args.workload == "16k" else 12345)
+    y0, y1 = sharded.split_rows(h, world)[rank]
+    rows = torch.from_numpy(img[y0:y1]).to(dev)
+    above = torch.from_numpy(img[y0 - 1]).to(dev) if y0 else None
+    del img
+    enc = fpng_amd.Encoder(device=local_rank)
+    be = sharded.GpuBandBackend(enc)
+
+    def step():
+        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1, args.flags)
+        torch.cuda.synchronize()
+        return png
+
+    for _ in range(max(1, args.warmup)):
+        png = step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        png = step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        parity = None
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+                g = json.load(f)["c4"]
+            if (w, h, c, args.kind, args.flags) == (g["w"], g["h"], g["c"], g["kind"], 0):
+                got = hashlib.sha256(png.cpu().numpy().tobytes()).hexdigest()
+                if got != g["flags"]["0"]["sha256"][0]:
+                    raise SystemExit(f"bench.py: PARITY FAILURE, row-band file sha256 {got}")
+                parity = True
+        except OSError:
+            pass
+        png_bytes = int(png.numel())
+        alg = w * h * c + png_bytes
+        print(json.dumps({
+            "metric": "encode megapixels/sec (whole node), 1-pass, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
+            "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "prewarm": 0, "parity_checked": parity,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"ONE {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' image as {world} row band(s), one IDAT, "
+                                   f"flags={args.flags}, windows gathered to rank 0, bit-exact fpng PNG output", "width": w, "height": h,
+                       "channels": c, "png_bytes": png_bytes, "parallelism": f"rows sharded over {world} GPU(s); exchange: "
+                       "all_gather of one 72-byte record per rank (+ all_reduce of 288 counters for 2-pass), windows sent to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": "whole step (band encode + exchange + place + gather + wrap)",
+                         "achieved": round(alg / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": round(alg / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg},
+        }))
+    enc.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +209,8 @@ def main():
 
     import fpng_amd
     w, h, c = WORKLOADS[args.workload]
+    if args.mode == "rowband":
+        return rowband(args, rank, local_rank, world, distributed, dev, w, h, c)
     B = args.batch
     # B distinct frames per rank (seed varies per image and per rank)
     imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]

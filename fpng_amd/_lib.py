@@ -25,9 +25,20 @@ class Result(C.Structure):
     _fields_ = [("png_size", C.c_uint64), ("mode", C.c_uint32), ("status", C.c_uint32)]
 
 
+class HostImage(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("num_chans", C.c_uint32), ("reserved", C.c_uint32),
+                ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_size", C.POINTER(C.c_size_t)), ("path", C.c_char_p)]
+
+
+class Band(C.Structure):
+    _fields_ = [("d_rows", C.c_void_p), ("d_row_above", C.c_void_p), ("w", C.c_uint32), ("num_chans", C.c_uint32),
+                ("y0", C.c_uint32), ("y1", C.c_uint32), ("h_total", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class BandStats(C.Structure):
     _fields_ = [("token_bits", C.c_uint64), ("adler_s1", C.c_uint32), ("adler_s2", C.c_uint32),
-                ("adler_len", C.c_uint64), ("last_unit_bits", C.c_uint32), ("reserved", C.c_uint32)]
+                ("adler_len", C.c_uint64), ("last_unit_bits", C.c_uint32), ("first_token_bit", C.c_uint32),
+                ("eob_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/fpng_amd.h declares: (restype, argtypes)
@@ -56,11 +67,12 @@ SIGNATURES = {
     "fpng_amd_encode_wait": (_int, [_vp, _u64, C.POINTER(Result), _u32]),
     "fpng_amd_encode_query": (_int, [_vp, _u64]),
     "fpng_amd_encode_host": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, C.POINTER(_sz)]),
-    "fpng_amd_band_count": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(BandStats)]),
-    "fpng_amd_band_emit": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _int, _int, _u32, _vp, _sz,
-                                  C.POINTER(_sz)]),
+    "fpng_amd_encode_host_batch": (_int, [_vp, C.POINTER(HostImage), _u32, _u32, _int]),
+    "fpng_amd_band_hist": (_int, [_vp, C.POINTER(Band), _vp]),
+    "fpng_amd_band_encode": (_int, [_vp, C.POINTER(Band), _u32, _vp, C.POINTER(BandStats)]),
+    "fpng_amd_band_place": (_int, [_vp, C.POINTER(Band), _u64, _u64, _vp, _sz, C.POINTER(_u64), C.POINTER(_sz)]),
     "fpng_amd_1pass_layout": (_int, [_u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
-    "fpng_amd_wrap_png": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, C.POINTER(_sz)]),
+    "fpng_amd_wrap_png": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, C.POINTER(_sz)]),
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BandStats, FpngAmdError, Image, Result, check
+from ._lib import Band, BandStats, FpngAmdError, HostImage, Image, Result, check
 
 FPNG_ENCODE_SLOWER = 1        # reference src/fpng.h:38
 FPNG_FORCE_UNCOMPRESSED = 2   # reference src/fpng.h:41
@@ -215,23 +215,59 @@ class Encoder:
                                             C.byref(n)))
         return n.value
 
-    # ---- row bands (multi-GPU, one image) ----
-    def band_count(self, rows, row_above, w, num_chans, y0, y1):
+    def encode_host_batch(self, images, flags=0, outs=None, paths=None, writer_threads=0):
+        """Many host frames (uint8 arrays shaped (h, w, c)): uploads, encodes, downloads and file writes of consecutive
+        frames overlap (fpng_amd_encode_host_batch).  outs: caller-owned uint8 arrays (>= max_encoded_size) or None when
+        every frame goes to a file; paths: file names or None.  Returns the PNG sizes."""
+        n = len(images)
+        arr = (HostImage * n)()
+        sizes = (C.c_size_t * n)()
+        keep = []
+        for i, im in enumerate(images):
+            im = np.ascontiguousarray(im, dtype=np.uint8)
+            keep.append(im)
+            h, w, c = im.shape
+            arr[i].pixels = im.ctypes.data
+            arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
+            if outs is not None:
+                arr[i].out = outs[i].ctypes.data
+                arr[i].out_cap = outs[i].size
+            arr[i].out_size = C.cast(C.byref(sizes, i * C.sizeof(C.c_size_t)), C.POINTER(C.c_size_t))
+            if paths is not None:
+                p = paths[i].encode() if isinstance(paths[i], str) else paths[i]
+                keep.append(p)
+                arr[i].path = p
+        check(self.lib.fpng_amd_encode_host_batch(self.h, arr, n, flags, writer_threads))
+        return [int(s) for s in sizes]
+
+    # ---- row bands (multi-GPU, one image): see include/fpng_amd.h ----
+    @staticmethod
+    def _band(rows, row_above, w, num_chans, y0, y1, h_total):
+        b = Band()
+        b.d_rows = rows.data_ptr()
+        b.d_row_above = row_above.data_ptr() if row_above is not None else None
+        b.w, b.num_chans, b.y0, b.y1, b.h_total = w, num_chans, y0, y1, h_total
+        return b
+
+    def band_hist(self, band, d_hist):
+        self._sync_stream()
+        check(self.lib.fpng_amd_band_hist(self.h, C.byref(band), d_hist.data_ptr()))
+
+    def band_encode(self, band, flags=0, d_hist=None):
+        self._sync_stream()
         st = BandStats()
-        ra = row_above.data_ptr() if row_above is not None else None
-        check(self.lib.fpng_amd_band_count(self.h, rows.data_ptr(), ra, w, num_chans, y0, y1, C.byref(st)))
+        check(self.lib.fpng_amd_band_encode(self.h, C.byref(band), flags, d_hist.data_ptr() if d_hist is not None else None, C.byref(st)))
         return st
 
-    def band_emit(self, rows, row_above, w, num_chans, y0, y1, start_bit, is_first, is_last, adler, out):
-        n = C.c_size_t(0)
-        ra = row_above.data_ptr() if row_above is not None else None
-        check(self.lib.fpng_amd_band_emit(self.h, rows.data_ptr(), ra, w, num_chans, y0, y1, start_bit, int(is_first),
-                                          int(is_last), adler, out.data_ptr(), out.numel(), C.byref(n)))
-        return n.value
+    def band_place(self, band, start_bit, zlib_size, window):
+        off, n = C.c_uint64(0), C.c_size_t(0)
+        check(self.lib.fpng_amd_band_place(self.h, C.byref(band), start_bit, zlib_size, window.data_ptr(), window.numel(),
+                                           C.byref(off), C.byref(n)))
+        return off.value, n.value
 
-    def wrap_png(self, png_buf, zlib_size, w, h, num_chans):
+    def wrap_png(self, png_buf, zlib_size, adler, w, h, num_chans):
         n = C.c_size_t(0)
-        check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, w, h, num_chans, C.byref(n)))
+        check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, adler, w, h, num_chans, C.byref(n)))
         return n.value
 
     # ---- instrumentation ----

@@ -12,8 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace fpng_amd;
@@ -245,6 +248,10 @@ struct fpng_amd_encoder {
         uint64_t ticket = 0;
     } slots[kSlots];
     uint64_t submitted = 0; // tickets handed out so far
+    uint64_t band_token_bits = 0; // row bands: what fpng_amd_band_encode() left for fpng_amd_band_place()
+    uint32_t band_eob_bits = 0;
+    bool band_two_pass = false;
+    hipEvent_t band_copied[4] = {}; // the pinned job record h_jobs[k] of an asynchronous band call has been uploaded
 };
 
 extern "C" {
@@ -367,6 +374,8 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     }
     for (auto &ls : e->lane_stream)
         if (ls) (void)hipStreamDestroy(ls);
+    for (auto &ev : e->band_copied)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &s : e->sc) s.release();
     e->h_results.release();
     e->h_states.release();
@@ -622,10 +631,10 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
         return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
     }();
-    int pipeline = forced < 0 ? 0 : forced;
+    int pipeline = forced < 0 ? 1 : forced;
     if (pipeline == 1 && ((sub.local_dwords + 16) * 4 > local_limit || sc.d_local.ensure(sub.local_dwords + 16) != FPNG_AMD_OK)) {
-        (void)hipGetLastError(); // no room for the local streams: the scratch-free pipeline still works
-        pipeline = 2;
+        (void)hipGetLastError(); // no room for the local streams: the pipeline that places rows straight from LDS still works
+        pipeline = 0;
     }
     if (pipeline == 1)
         for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
@@ -816,117 +825,343 @@ int fpng_amd_encode_host(fpng_amd_encoder *e, const void *pixels, uint32_t w, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// row bands
+// Host-buffer front door for MANY frames: a ring of device staging buffers and three actors -- an uploader
+// thread (H2D of frame k+1), the calling thread (encode submissions, one per frame, each ordered behind its upload) and a
+// downloader thread (D2H of frame k, then the optional file write on a pool of writer threads) -- so that the two PCIe
+// directions and the encoder overlap instead of taking turns as in fpng_amd_encode_host().
 // ------------------------------------------------------------------------------------------------
-static int band_job(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c, uint32_t y0,
-                    uint32_t y1, Job &j)
+namespace {
+struct HostRing {
+    static constexpr int kDepth = 3;
+    DeviceBuf<uint8_t> d_in[kDepth], d_out[kDepth];
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t uploaded[kDepth] = {};
+};
+} // namespace
+
+int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *imgs, uint32_t n, uint32_t flags, int n_writer_threads)
 {
-    if (!e || !d_rows) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
-    if (y1 <= y0) return fail(FPNG_AMD_ERR_INVALID_ARG, "empty band");
-    int rc = check_dims(w, y1, c);
-    if (rc) return rc;
-    if (y0 > 0 && !d_row_above) return fail(FPNG_AMD_ERR_INVALID_ARG, "band needs the row above its first row");
-    if (c == 4 && (((uintptr_t)d_rows & 3) || ((uintptr_t)d_row_above & 3)))
-        return fail(FPNG_AMD_ERR_INVALID_ARG, "RGBA rows must be 4-byte aligned");
-    std::memset(&j, 0, sizeof j);
-    j.rows = (const uint8_t *)d_rows;
-    j.row_above = (const uint8_t *)d_row_above;
-    j.w = w, j.c = c, j.bpl = w * c;
-    j.nrows = y1 - y0;
-    j.y0 = y0;
-    j.h_total = y1;
-    j.one_pass = 1;
-    j.table = g_dev[e->device].one_pass[c];
+    if (!e || !imgs || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
+    int rc;
+    for (uint32_t i = 0; i < n; i++) {
+        if ((rc = check_dims(imgs[i].w, imgs[i].h, imgs[i].num_chans))) return rc;
+        if (!imgs[i].pixels || (!imgs[i].out && !imgs[i].path)) return fail(FPNG_AMD_ERR_INVALID_ARG, "image without pixels or destination");
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = drain(e))) return rc;
+    static thread_local HostRing tl_ring; // (staging buffers are kept between calls; an encoder is used by one thread)
+    HostRing &ring = tl_ring;             // (the worker threads below must see THIS thread's ring, not their own)
+    if (!ring.up) {
+        HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
+        for (auto &ev : ring.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    size_t max_in = 0, max_out = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        max_in = std::max(max_in, (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans);
+        max_out = std::max(max_out, fpng_amd_max_encoded_size(imgs[i].w, imgs[i].h, imgs[i].num_chans));
+    }
+    for (int k = 0; k < HostRing::kDepth; k++)
+        if ((rc = ring.d_in[k].ensure(max_in + 16)) || (rc = ring.d_out[k].ensure(max_out + 64))) return rc;
+
+    // slot k is handed round: uploader (state 0 -> 1), caller submits (1 -> 2), downloader frees it (2 -> 0)
+    std::mutex mu;
+    std::condition_variable cv;
+    int state[HostRing::kDepth] = {0, 0, 0};
+    uint64_t tickets[HostRing::kDepth] = {0, 0, 0};
+    std::atomic<int> failed{0};
+    const int device = e->device;
+    std::vector<size_t> sizes(n, 0);
+    std::vector<std::vector<uint8_t>> file_bufs; // frames that go to files without a caller buffer
+    // writer pool: finished files are handed to n_writer_threads threads (reference fpng.cpp:1806-1828 writes inline)
+    struct WriteJob { const char *path; const uint8_t *data; size_t size; };
+    std::vector<WriteJob> wq;
+    size_t wq_head = 0;
+    bool wq_closed = false;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::vector<std::thread> writers;
+    const int nw = std::max(0, std::min(n_writer_threads, 16));
+    for (int t = 0; t < nw; t++)
+        writers.emplace_back([&] {
+            for (;;) {
+                WriteJob job;
+                {
+                    std::unique_lock<std::mutex> lk(wmu);
+                    wcv.wait(lk, [&] { return wq_head < wq.size() || wq_closed; });
+                    if (wq_head >= wq.size()) return;
+                    job = wq[wq_head++];
+                }
+                FILE *f = fopen(job.path, "wb");
+                if (!f || fwrite(job.data, 1, job.size, f) != job.size) failed = FPNG_AMD_ERR_INVALID_ARG;
+                if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+            }
+        });
+    file_bufs.resize(n);
+
+    std::thread uploader([&] {
+        (void)hipSetDevice(device);
+        for (uint32_t i = 0; i < n && !failed; i++) {
+            const int k = (int)(i % HostRing::kDepth);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return state[k] == 0 || failed; });
+            }
+            if (failed) break;
+            const size_t bytes = (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans;
+            if (hipMemcpyAsync(ring.d_in[k].p, imgs[i].pixels, bytes, hipMemcpyHostToDevice, ring.up) != hipSuccess ||
+                hipEventRecord(ring.uploaded[k], ring.up) != hipSuccess || hipStreamSynchronize(ring.up) != hipSuccess)
+                failed = FPNG_AMD_ERR_HIP;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                state[k] = 1;
+            }
+            cv.notify_all();
+        }
+    });
+    std::thread downloader([&] {
+        (void)hipSetDevice(device);
+        for (uint32_t i = 0; i < n && !failed; i++) {
+            const int k = (int)(i % HostRing::kDepth);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return state[k] == 2 || failed; });
+            }
+            if (failed) break;
+            fpng_amd_result res;
+            if (fpng_amd_encode_wait(e, tickets[k], &res, 1) != FPNG_AMD_OK || res.status) {
+                failed = FPNG_AMD_ERR_HIP;
+            } else {
+                uint8_t *dst = imgs[i].out;
+                if (!dst) {
+                    file_bufs[i].resize(res.png_size);
+                    dst = file_bufs[i].data();
+                } else if (imgs[i].out_cap < res.png_size) {
+                    failed = FPNG_AMD_ERR_BUFFER_TOO_SMALL;
+                }
+                if (!failed && (hipMemcpyAsync(dst, ring.d_out[k].p, res.png_size, hipMemcpyDeviceToHost, ring.down) != hipSuccess ||
+                                hipStreamSynchronize(ring.down) != hipSuccess))
+                    failed = FPNG_AMD_ERR_HIP;
+                sizes[i] = (size_t)res.png_size;
+                if (!failed && imgs[i].path) {
+                    if (nw) {
+                        {
+                            std::lock_guard<std::mutex> lk(wmu);
+                            wq.push_back({imgs[i].path, dst, (size_t)res.png_size});
+                        }
+                        wcv.notify_one();
+                    } else {
+                        FILE *f = fopen(imgs[i].path, "wb");
+                        if (!f || fwrite(dst, 1, res.png_size, f) != res.png_size) failed = FPNG_AMD_ERR_INVALID_ARG;
+                        if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                state[k] = 0;
+            }
+            cv.notify_all();
+        }
+    });
+    // the calling thread: one encode submission per frame, ordered behind that frame's upload
+    for (uint32_t i = 0; i < n && !failed; i++) {
+        const int k = (int)(i % HostRing::kDepth);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return state[k] == 1 || failed; });
+        }
+        if (failed) break;
+        fpng_amd_image im;
+        im.d_pixels = ring.d_in[k].p;
+        im.w = imgs[i].w, im.h = imgs[i].h, im.num_chans = imgs[i].num_chans;
+        im.d_out = ring.d_out[k].p;
+        im.out_cap = ring.d_out[k].cap;
+        // (the upload was waited for on the host: nothing more to order the submission against)
+        uint64_t t = 0;
+        if ((rc = submit(e, &im, 1, flags, &t))) failed = rc;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            tickets[k] = t;
+            state[k] = 2;
+        }
+        cv.notify_all();
+    }
+    if (failed) cv.notify_all();
+    uploader.join();
+    downloader.join();
+    {
+        std::lock_guard<std::mutex> lk(wmu);
+        wq_closed = true;
+    }
+    wcv.notify_all();
+    for (auto &t : writers) t.join();
+    for (uint32_t i = 0; i < n; i++)
+        if (imgs[i].out_size) *imgs[i].out_size = sizes[i];
+    if (failed) return fail(failed, "host batch failed (copy, encode or file write)");
     return FPNG_AMD_OK;
 }
 
-int fpng_amd_band_count(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c,
-                        uint32_t y0, uint32_t y1, fpng_amd_band_stats *stats)
+// ------------------------------------------------------------------------------------------------
+// row bands: one image sharded by rows over several GPUs.  Per band: [histogram ->] encode (rows into
+// the encoder's local streams, counts to the host: the one exchange step) -> place (the streams shifted to the band's
+// bit position inside a window that shares the file's 16-byte geometry).  Same kernels as whole images.
+// ------------------------------------------------------------------------------------------------
+static int band_check(fpng_amd_encoder *e, const fpng_amd_band *b)
 {
-    if (!e || !stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (!e || !b || !b->d_rows) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (b->y1 <= b->y0 || b->y1 > b->h_total) return fail(FPNG_AMD_ERR_INVALID_ARG, "empty or out-of-range band");
+    int rc = check_dims(b->w, b->h_total, b->num_chans);
+    if (rc) return rc;
+    if (b->y0 > 0 && !b->d_row_above) return fail(FPNG_AMD_ERR_INVALID_ARG, "band needs the row above its first row");
+    if (b->num_chans == 4 && (((uintptr_t)b->d_rows & 3) || ((uintptr_t)b->d_row_above & 3)))
+        return fail(FPNG_AMD_ERR_INVALID_ARG, "RGBA rows must be 4-byte aligned");
+    return FPNG_AMD_OK;
+}
+
+// The asynchronous band calls upload their job record from pinned memory: before record k is rewritten, the previous
+// upload from it must have happened.
+static int band_record_free(fpng_amd_encoder *e, int k)
+{
+    if (!e->band_copied[k])
+        HIP_TRY(hipEventCreateWithFlags(&e->band_copied[k], hipEventDisableTiming));
+    else
+        HIP_TRY(hipEventSynchronize(e->band_copied[k]));
+    return FPNG_AMD_OK;
+}
+
+static void band_job(fpng_amd_encoder *e, const fpng_amd_band *b, bool two_pass, Job &j)
+{
+    std::memset(&j, 0, sizeof j);
+    j.rows = (const uint8_t *)b->d_rows;
+    j.row_above = (const uint8_t *)b->d_row_above;
+    j.w = b->w, j.c = b->num_chans, j.bpl = b->w * b->num_chans;
+    j.nrows = b->y1 - b->y0;
+    j.y0 = b->y0;
+    j.h_total = b->h_total;
+    j.one_pass = two_pass ? 0 : 1;
+    j.is_first = b->y0 == 0;
+    j.is_last = b->y1 == b->h_total;
+    j.bit_bias = (int64_t)kPngHeaderBytes * 8;
+    const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[b->num_chans];
+    j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
+    j.table = two_pass ? e->sc[0].d_dyn.p : g_dev[e->device].one_pass[b->num_chans];
+}
+
+int fpng_amd_band_hist(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t *d_hist288)
+{
+    int rc = band_check(e, b);
+    if (rc) return rc;
+    if (!d_hist288) return fail(FPNG_AMD_ERR_INVALID_ARG, "null histogram");
     HIP_TRY(hipSetDevice(e->device));
-    int rc;
-    if ((rc = drain(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if ((rc = e->h_jobs.ensure(1))) return rc;
+    if ((rc = drain(e)) || (rc = e->h_jobs.ensure(4)) || (rc = e->sc[0].d_jobs.ensure(4)) || (rc = band_record_free(e, 2))) return rc;
+    Job &j = e->h_jobs.p[2];
+    band_job(e, b, true, j);
+    j.table = g_dev[e->device].symbols[b->num_chans];
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p + 2, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(e->band_copied[2], s));
+    HIP_TRY(hipMemsetAsync(d_hist288, 0, 288 * sizeof(uint32_t), s));
+    launch_hist(s, e->sc[0].d_jobs.p + 2, 1, j.nrows, d_hist288);
+    HIP_TRY(hipGetLastError());
+    return FPNG_AMD_OK;
+}
+
+int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t flags, const uint32_t *d_hist288,
+                         fpng_amd_band_stats *stats)
+{
+    int rc = band_check(e, b);
+    if (rc) return rc;
+    if (!stats) return fail(FPNG_AMD_ERR_INVALID_ARG, "null stats");
+    if (flags & FPNG_AMD_FORCE_UNCOMPRESSED) return fail(FPNG_AMD_ERR_INVALID_ARG, "stored images have no band path: encode them whole");
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) != 0;
+    if (two_pass && !d_hist288) return fail(FPNG_AMD_ERR_INVALID_ARG, "2-pass bands need the image's histogram");
+    HIP_TRY(hipSetDevice(e->device));
+    fpng_amd_encoder::Scratch &sc = e->sc[0];
+    if ((rc = drain(e)) || (rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = e->h_states.ensure(2))) return rc;
+    if (two_pass && (rc = sc.d_dyn.ensure(1))) return rc;
+    if ((rc = band_record_free(e, 0))) return rc;
     Job &j = e->h_jobs.p[0];
-    if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
-    j.is_first = 0; // offsets relative to start_bit = 0: only the total is used
-    j.is_last = 0;
-    j.start_bit = 0;
-    if ((rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_rows.ensure(j.nrows)) || (rc = e->sc[0].d_row_off.ensure(j.nrows)) ||
-        (rc = e->sc[0].d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
+    band_job(e, b, two_pass, j);
+    if ((rc = sc.d_rows.ensure(j.nrows)) || (rc = sc.d_row_off.ensure(j.nrows)) || (rc = sc.d_states.ensure(1)) ||
+        (rc = sc.d_local.ensure((uint64_t)j.local_stride * j.nrows + 16)))
         return rc;
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->sc[0].d_states.p, 0, sizeof(JobState), s));
-    launch_count(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_rows.p, e->sc[0].d_states.p);
-    launch_scan(s, e->sc[0].d_jobs.p, 1, e->sc[0].d_rows.p, e->sc[0].d_row_off.p, e->sc[0].d_states.p);
+    if (two_pass) { // the table every rank builds from the same (all-reduced) histogram
+        Job &jb = e->h_jobs.p[1];
+        jb = j;
+        jb.table = g_dev[e->device].symbols[b->num_chans];
+        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p + 1, &jb, sizeof(Job), hipMemcpyHostToDevice, s));
+        launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p);
+    }
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    launch_scan(s, sc.d_jobs.p, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // band count: sums only
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->sc[0].d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(e->h_states.p, sc.d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
+    uint32_t *ftb = (uint32_t *)(e->h_states.p + 1); // [0] first_token_bit, [1] end-of-block entry of the table in use
+    if (two_pass) {
+        HIP_TRY(hipMemcpyAsync(ftb, &sc.d_dyn.p->first_token_bit, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ftb + 1, &sc.d_dyn.p->lit[256], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    } else {
+        ftb[0] = g_host_1pass[b->num_chans].first_token_bit;
+        ftb[1] = g_host_1pass[b->num_chans].lit[256];
+    }
     HIP_TRY(hipStreamSynchronize(s));
     const JobState &st = e->h_states.p[0];
-    stats->token_bits = st.token_end_bit;
+    stats->token_bits = st.token_end_bit - (j.is_first ? ftb[0] : 0); // (scan starts the first band at the table's first token bit)
     stats->adler_s1 = st.s1;
     stats->adler_s2 = st.s2;
     stats->adler_len = (uint64_t)(j.bpl + 1) * j.nrows;
     stats->last_unit_bits = st.last_unit_bits;
+    stats->first_token_bit = ftb[0];
+    stats->eob_bits = ftb[1] >> 16;
     stats->reserved = 0;
+    e->band_token_bits = stats->token_bits;
+    e->band_eob_bits = stats->eob_bits;
+    e->band_two_pass = two_pass;
     return FPNG_AMD_OK;
 }
 
-int fpng_amd_band_emit(fpng_amd_encoder *e, const void *d_rows, const void *d_row_above, uint32_t w, uint32_t c,
-                       uint32_t y0, uint32_t y1, uint64_t start_bit, int is_first, int is_last, uint32_t adler,
-                       uint8_t *d_band_out, size_t out_cap, size_t *out_bytes)
+int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t start_bit, uint64_t zlib_size, uint8_t *d_window,
+                        size_t window_cap, uint64_t *window_file_offset, size_t *window_bytes)
 {
-    if (!e || !d_band_out || !out_bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
-    if ((uintptr_t)d_band_out & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_band_out must be 16-byte aligned");
+    int rc = band_check(e, b);
+    if (rc) return rc;
+    if (!d_window || !window_file_offset || !window_bytes || zlib_size < 6) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
+    if ((uintptr_t)d_window & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_window must be 16-byte aligned");
     HIP_TRY(hipSetDevice(e->device));
-    int rc;
-    if ((rc = drain(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if ((rc = e->h_jobs.ensure(1))) return rc;
-    Job &j = e->h_jobs.p[0];
-    if ((rc = band_job(e, d_rows, d_row_above, w, c, y0, y1, j))) return rc;
-    const TokenTable &tab = g_host_1pass[c];
-    if (is_first) start_bit = tab.first_token_bit;
-    j.is_first = is_first ? 1 : 0;
-    j.is_last = is_last ? 1 : 0;
+    fpng_amd_encoder::Scratch &sc = e->sc[0];
+    if ((rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = band_record_free(e, 3))) return rc;
+    Job &j = e->h_jobs.p[3];
+    band_job(e, b, e->band_two_pass, j);
+    // the window: whole 16-byte pieces of the FILE from the piece holding the band's first bit to the one holding its last
+    const uint64_t file_bit0 = (uint64_t)kPngHeaderBytes * 8 + start_bit;
+    const uint32_t eob_bits = j.is_last ? e->band_eob_bits : 0u;
+    const uint64_t file_bit1 = file_bit0 + e->band_token_bits + eob_bits;
+    const uint64_t wb0 = j.is_first ? 0 : ((file_bit0 >> 3) & ~15ull);
+    const uint64_t wb1 = (((file_bit1 + 7) >> 3) + 15) & ~15ull;
+    *window_file_offset = wb0;
+    *window_bytes = (size_t)(wb1 - wb0);
+    if (window_cap < wb1 - wb0) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "band window too small");
     j.start_bit = start_bit;
-    j.out = d_band_out;
-    j.out_cap = out_cap;
-    const uint64_t first_byte = is_first ? 0 : (start_bit >> 3);
-    j.bit_bias = -(int64_t)(first_byte * 8);
-    j.flags = 0x100; // band emit: scan_kernel prepares seams/prefix in the band window
-    if ((rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_rows.ensure(j.nrows)) || (rc = e->sc[0].d_row_off.ensure(j.nrows)) ||
-        (rc = e->sc[0].d_states.ensure(1)) || (rc = e->h_states.ensure(1)))
-        return rc;
+    j.flags = 0x100u | 0x200u; // band placement through scan_kernel + assemble_kernel
+    j.band_zlib_size = zlib_size;
+    j.out = d_window - wb0;    // file byte 0 as the window sees it (only bytes >= wb0 are ever touched)
+    j.out_cap = window_cap + wb0;
+    j.crc_blocks = (uint32_t)((kPngHeaderBytes + zlib_size + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
+    if ((rc = sc.d_partials.ensure(((size_t)j.crc_blocks) << 4))) return rc; // (ranges may be as small as 4 KiB)
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(e->sc[0].d_states.p, 0, sizeof(JobState), s));
-    launch_count(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_rows.p, e->sc[0].d_states.p);
-    launch_scan(s, e->sc[0].d_jobs.p, 1, e->sc[0].d_rows.p, e->sc[0].d_row_off.p, e->sc[0].d_states.p);
-    launch_emit(s, e->sc[0].d_jobs.p, 1, j.nrows, e->sc[0].d_row_off.p, e->sc[0].d_rows.p, e->sc[0].d_states.p);
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p + 3, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(e->band_copied[3], s));
+    launch_scan(s, sc.d_jobs.p + 3, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // absolute row offsets, stream head
+    launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks << 4, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
+                    sc.d_partials.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_states.p, e->sc[0].d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint64_t end_bit = e->h_states.p[0].token_end_bit;
-    uint64_t bytes;
-    if (is_last) {
-        const uint32_t eob_len = tab.lit[256] >> 16;
-        bytes = ((end_bit + eob_len + 7) >> 3) - first_byte;
-        if (bytes + 4 > out_cap) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "band buffer too small");
-        const uint8_t be[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
-        HIP_TRY(hipMemcpy(d_band_out + bytes, be, 4, hipMemcpyHostToDevice));
-        bytes += 4;
-    } else {
-        bytes = ((end_bit + 7) >> 3) - first_byte;
-    }
-    *out_bytes = (size_t)bytes;
     return FPNG_AMD_OK;
 }
 
-int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t w, uint32_t h, uint32_t c,
+int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h, uint32_t c,
                       size_t *png_size)
 {
     if (!e || !d_png || !png_size || zlib_size < 6) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
@@ -934,12 +1169,11 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     int rc = check_dims(w, h, c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    if ((rc = drain(e))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if ((rc = e->h_jobs.ensure(1)) || (rc = e->sc[0].d_jobs.ensure(1)) || (rc = e->sc[0].d_states.ensure(1)) ||
-        (rc = e->h_states.ensure(1)) || (rc = e->sc[0].d_results.ensure(1)) || (rc = e->h_results.ensure(1)) ||
-        (rc = e->sc[0].d_rows.ensure(1)))
+    fpng_amd_encoder::Scratch &sc = e->sc[0];
+    if ((rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = sc.d_states.ensure(1)) || (rc = e->h_states.ensure(2)) ||
+        (rc = sc.d_results.ensure(1)) || (rc = sc.d_rows.ensure(1)))
         return rc;
+    if ((rc = band_record_free(e, 0))) return rc;
     Job &j = e->h_jobs.p[0];
     std::memset(&j, 0, sizeof j);
     j.out = d_png;
@@ -949,26 +1183,21 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     make_png_header(j.png_header, w, h, c);
     j.png_header[50] = (uint8_t)(zlib_size >> 24), j.png_header[51] = (uint8_t)(zlib_size >> 16);
     j.png_header[52] = (uint8_t)(zlib_size >> 8), j.png_header[53] = (uint8_t)zlib_size;
-    // the stream's own Adler bytes are re-written by finalize_kernel: read them back first
-    uint8_t be[4];
-    HIP_TRY(hipMemcpy(be, d_png + kPngHeaderBytes + zlib_size - 4, 4, hipMemcpyDeviceToHost));
     JobState &st = e->h_states.p[0];
     std::memset(&st, 0, sizeof st);
     st.zlib_size = zlib_size;
     st.mode = 0;
-    st.adler = ((uint32_t)be[0] << 24) | ((uint32_t)be[1] << 16) | ((uint32_t)be[2] << 8) | be[3];
-    if ((rc = e->sc[0].d_partials.ensure(j.crc_blocks))) return rc;
+    st.adler = adler; // finalize_kernel writes it behind the stream (reference fpng.cpp:1569-1577)
+    if ((rc = sc.d_partials.ensure(j.crc_blocks))) return rc;
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->sc[0].d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->sc[0].d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sc.d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_png, j.png_header, kPngHeaderBytes, hipMemcpyHostToDevice, s));
-    launch_crc(s, e->sc[0].d_jobs.p, 1, j.crc_blocks, e->sc[0].d_states.p, g_dev[e->device].crc, e->sc[0].d_partials.p);
-    launch_finalize(s, e->sc[0].d_jobs.p, 1, j.crc_blocks, e->sc[0].d_rows.p, e->sc[0].d_states.p, g_dev[e->device].crc, e->sc[0].d_partials.p,
-                    e->sc[0].d_results.p);
+    HIP_TRY(hipEventRecord(e->band_copied[0], s));
+    launch_crc(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p);
+    launch_finalize(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_rows.p, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p, sc.d_results.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_results.p, e->sc[0].d_results.p, sizeof(Result), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    *png_size = (size_t)e->h_results.p[0].png_size;
+    *png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes; // asynchronous: complete when the encoder's stream gets there
     return FPNG_AMD_OK;
 }
 

@@ -24,6 +24,7 @@ struct Job {
     uint32_t row_base;        // index of the job's first row in the per-row scratch arrays
     uint32_t one_pass, whole_png, is_first, is_last;
     uint32_t crc_blocks;      // upper bound of CRC ranges for this job
+    uint64_t band_zlib_size;  // row bands, placement phase: size of the WHOLE image's zlib stream (bands share the file's geometry)
     // whole images: every row is first encoded into its own dword-aligned stream in scratch ("local stream"),
     // assemble_kernel then shifts the streams into place.  Row r lives at local + local_base + r*local_stride.
     uint64_t local_base;      // dwords

@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
     if (t == 0) {
         st.token_end_bit = s_last;
         st.mode = stored ? 1u : 0u;
-        st.zlib_size = zlib_size;
+        st.zlib_size = (!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_size;
         st.s1 = (uint32_t)s_adl[0];
         st.s2 = (uint32_t)s_adl[1];
         const uint32_t a1 = (uint32_t)((1 + s_adl[0]) % kAdlerMod);
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
         // bytes per assemble/crc block: 64 KiB when the submission has plenty of blocks anyway (every block loads
         // the 16 KiB CRC table), down to one 4 KiB block row for small files so that the submission still spreads
         // over ~2048 blocks
-        const uint64_t span = kPngHeaderBytes + zlib_size; // >= aligned data end - 48
+        const uint64_t span = kPngHeaderBytes + ((!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_size); // >= aligned data end - 48
         uint32_t want = 2048u / gridDim.x;                 // blocks this job should get (gridDim.x = jobs)
         want = want < 4u ? 4u : want;
         uint32_t rl = 12;
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
                 zl[tab->header_bits >> 3] |= tab->header[tab->header_bits >> 3];
         }
     }
-    if (assemble && !stored) {
+    if (assemble && !stored && job.is_first) {
         const uint32_t head_end = kPngHeaderBytes + ((tab->header_bits + 7) >> 3);
         for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
     }
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     wave_lds_fence();
 
     const RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, 0u, job.w, lane, &sink);
-    if (r == job.nrows - 1) {
+    if (r == job.nrows - 1 && job.is_last) {
         // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of ri.bits
         const uint32_t eob = T.lit[256];
         sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
@@ -1950,12 +1950,21 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     __shared__ uint32_t red[kWavesPerBlock];
     const Job &job = job_of_block(jobs);
     const JobState &st = states[blockIdx.y];
-    if (!job.whole_png) return;
+    // row bands (flag 0x100): the rows of a band land in a private window that shares the whole file's geometry
+    // (job.out = window - first file byte of the window, st.zlib_size = the whole image's): bits outside the band stay 0
+    const bool band = !job.whole_png;
+    if (band && !(job.flags & 0x100u)) return;
     const int64_t data_begin = kPngHeaderBytes, data_end = (int64_t)(kPngHeaderBytes + st.zlib_size - 4);
     const int64_t end_aligned = (data_end + 15) & ~15ll;
     const uint32_t range_bytes = 1u << uniform(crc_range_log2(st));
     const int64_t range_end = end_aligned - (int64_t)blockIdx.x * range_bytes;
     if (range_end <= (data_begin & ~15ll)) return; // nothing of the data in this range
+    const uint32_t eob_bits = job.is_last ? (job.table->lit[256] >> 16) : 0u; // only the image's last band carries the end-of-block symbol
+    if (band) { // most ranges of the file belong to other bands
+        const int64_t fb0 = job.is_first ? 0 : (int64_t)row_off[job.row_base] + job.bit_bias;
+        const int64_t fb1 = (int64_t)st.token_end_bit + eob_bits + job.bit_bias;
+        if (fb1 <= (range_end - (int64_t)range_bytes) * 8 || fb0 >= range_end * 8) return;
+    }
     for (int i = threadIdx.x; i < 16 * 256; i += kBlock) (&tab[0][0])[i] = (&tabs->striped[0][0])[i];
     __syncthreads();
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6);
@@ -1984,7 +1993,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     auto row_begin = [&](uint32_t rr) { return (int32_t)uniform((uint32_t)row_begin_lane(rr)); };           // uniform rr
     if (gather) {
         tok_begin = (int32_t)uniform((uint32_t)sat((int64_t)offs[0] - bit0));
-        tok_end = (int32_t)uniform((uint32_t)sat((int64_t)st.token_end_bit + (int64_t)(job.table->lit[256] >> 16) - bit0));
+        tok_end = (int32_t)uniform((uint32_t)sat((int64_t)st.token_end_bit + (int64_t)eob_bits - bit0));
         // 64-ary search for the row holding the wave's first position
         const int32_t c0 = (int32_t)(wv * 8192u);
         const int32_t p0 = c0 > tok_begin ? c0 : tok_begin;
@@ -2016,7 +2025,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
         const int32_t C0 = (int32_t)((row * kCrcRowBytes + wv * 1024u) * 8u), C1 = C0 + 8192; // the wave's chunk (bits)
         uint32_t w[4] = {0, 0, 0, 0};
         const bool in_data = o + 16 > db && o < de;
-        if (in_data && (!gather || P < tok_begin)) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
+        if (in_data && (!gather || (P < tok_begin && job.is_first))) { // stored image, or the piece (also) holds head bytes: scan_kernel wrote them
             const u32x4 d = *(gptr_cu128)(base + o);
             w[0] = d.x, w[1] = d.y, w[2] = d.z, w[3] = d.w;
         }
@@ -2073,7 +2082,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
                     src += 2 * (uint64_t)stride;
                 }
             }
-            if (in_data && P + 128 > tok_begin) {
+            if (in_data && P + 128 > tok_begin && P < tok_end) { // (a band's window ends with the piece that holds its last bit)
                 u32x4 d;
                 d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
                 *(gptr_u128)(uintptr_t)(base + o) = d;

@@ -10,13 +10,18 @@ Two regimes:
 * one huge image -- rows are sharded into contiguous bands, but the output stays ONE IDAT / ONE
   zlib stream / ONE Deflate block like the reference (reference fpng.cpp:1764-1800; the fpng decoder
   rejects a second IDAT, fpng.cpp:3032-3033).  Bands therefore meet at BIT granularity:
-    1. every rank counts its band:            token bits, Adler partial sums, last flush unit
-    2. all_gather of one 5-word record per rank (the only collective on the critical path)
+    0. (2-pass only) every rank histograms its band; one all_reduce of 288 counters; every rank builds
+       the same Huffman table from the sum
+    1. every rank encodes its band into scratch streams and learns its token bits, Adler partial sums,
+       last flush unit
+    2. all_gather of one small record per rank (the only exchange on the critical path)
     3. everyone derives every band's start bit (exclusive prefix sum), the global Adler-32 and the
        reference's "ran out of buffer -> stored blocks" decision (closed form)
-    4. every rank emits its band at its bit phase into a private byte window whose foreign bits are 0
-    5. windows are sent to the root and OR-merged (neighbouring bands share one byte)
-    6. the root wraps the stream: PNG header, IDAT CRC-32, IEND.
+    4. every rank shifts its band to its bit position inside a WINDOW of whole 16-byte pieces of the
+       file (foreign bits 0)
+    5. windows go to the root; neighbouring windows share one 16-byte piece, which is OR-merged, the
+       rest is copied
+    6. the root wraps the stream: PNG header, Adler-32, IDAT CRC-32, IEND.
 
 The arithmetic of steps 2-5 is plain Python here; the per-band work is done by a "band backend":
 the HIP encoder on GPUs (`GpuBandBackend`), or a CPU stand-in injected by the gloo tests.
@@ -27,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 ADLER_MOD = 65521
+ENCODE_SLOWER = 1
 
 
 @dataclass
@@ -36,6 +42,8 @@ class BandStats:
     s2: int          # raw position-weighted sum, mod 65521
     nbytes: int      # filtered bytes in the band
     last_unit_bits: int
+    first_token_bit: int = 0   # same on every rank (1-pass: constant; 2-pass: length of the dynamic header)
+    eob_bits: int = 12
 
 
 @dataclass
@@ -56,7 +64,7 @@ def split_rows(h, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def plan_bands(stats, w, h, c, first_token_bit, eob_bits, prefix_bytes):
+def plan_bands(stats, w, h, c, first_token_bit, eob_bits, one_pass=True):
     """Steps 2-3: from the gathered per-band records to the global layout."""
     start_bits, pos = [], first_token_bit
     for s in stats:
@@ -77,34 +85,37 @@ def plan_bands(stats, w, h, c, first_token_bit, eob_bits, prefix_bytes):
     for s in stats:
         if s.nbytes:
             last_unit = s.last_unit_bits
-    stored = (D < prefix_bytes) or (((end_bit - last_unit) >> 3) + 8 > D) or (((end_bit + eob_bits + 7) >> 3) + 4 > D)
+    stored = (one_pass and D < first_token_bit // 8) or (((end_bit - last_unit) >> 3) + 8 > D) or (((end_bit + eob_bits + 7) >> 3) + 4 > D)
     zlib_size = ((end_bit + eob_bits + 7) >> 3) + 4
     return BandPlan(start_bits, end_bit, adler, stored, zlib_size)
 
 
 class GpuBandBackend:
-    """Per-band work on this rank's GPU through the C ABI (fpng_amd_band_count / _band_emit / _wrap_png)."""
+    """Per-band work on this rank's GPU through the C ABI (fpng_amd_band_hist / _encode / _place / _wrap_png)."""
 
     def __init__(self, encoder):
-        from . import api
         self.enc = encoder
-        self.api = api
 
-    def layout(self, c):
-        return self.api.layout_1pass(c)
+    def hist(self, rows, row_above, w, c, y0, y1, h):
+        hist = torch.empty(288, dtype=torch.int32, device=rows.device)
+        self.enc.band_hist(self.enc._band(rows, row_above, w, c, y0, y1, h), hist)
+        return hist
 
-    def count(self, rows, row_above, w, c, y0, y1):
-        st = self.enc.band_count(rows, row_above, w, c, y0, y1)
-        return BandStats(st.token_bits, st.adler_s1, st.adler_s2, st.adler_len, st.last_unit_bits)
+    def encode(self, rows, row_above, w, c, y0, y1, h, flags, hist):
+        self._band = self.enc._band(rows, row_above, w, c, y0, y1, h)
+        self._keep = (rows, row_above, hist)
+        st = self.enc.band_encode(self._band, flags, hist)
+        return BandStats(st.token_bits, st.adler_s1, st.adler_s2, st.adler_len, st.last_unit_bits, st.first_token_bit, st.eob_bits)
 
-    def emit(self, rows, row_above, w, c, y0, y1, start_bit, is_first, is_last, adler):
-        cap = ((w * c + 1) * (y1 - y0) * 12 + 7) // 8 + 256
-        out = torch.empty(cap, dtype=torch.uint8, device=rows.device)
-        n = self.enc.band_emit(rows, row_above, w, c, y0, y1, start_bit, is_first, is_last, adler, out)
-        return out[:n]
+    def place(self, start_bit, zlib_size, token_bits, device):
+        """-> (file offset of the window, window tensor): 16-byte pieces of the file, foreign bits zero."""
+        cap = ((token_bits + 7) >> 3) + 64 + 512
+        win = torch.empty((cap + 15) & ~15, dtype=torch.uint8, device=device)
+        off, n = self.enc.band_place(self._band, start_bit, zlib_size, win)
+        return off, win[:n]
 
-    def wrap(self, png_buf, zlib_size, w, h, c):
-        n = self.enc.wrap_png(png_buf, zlib_size, w, h, c)
+    def wrap(self, png_buf, zlib_size, adler, w, h, c):
+        n = self.enc.wrap_png(png_buf, zlib_size, adler, w, h, c)
         return png_buf[:n]
 
     def encode_whole(self, image, w, h, c, flags):
@@ -112,24 +123,43 @@ class GpuBandBackend:
         return pngs[0]
 
 
-def encode_image_bands_local(backend, image, cuts):
+def merge_window(png_buf, file_off, win, first, start_bit):
+    """Step 5: a band's window into the file.  Everything is copied except the window's first 16-byte piece when the
+    band shares it with its predecessor (each wrote zeros where the other's bits are): that one is OR-ed.  A band that
+    starts exactly on a piece boundary shares nothing."""
+    n = win.numel()
+    if first:
+        png_buf[58:n] = win[58:]   # (the PNG header's bytes of the first window are undefined: wrap() writes them)
+        return
+    head = min(16, n) if (58 * 8 + start_bit) % 128 else 0
+    view = png_buf[file_off:file_off + head]
+    torch.bitwise_or(view, win[:head], out=view)
+    if n > head:
+        png_buf[file_off + head:file_off + n] = win[head:]
+
+
+def encode_image_bands_local(backend, image, cuts, flags=0):
     """Single-process version of the band pipeline (bands processed one after another on one GPU):
-    the same count -> plan -> emit -> OR-merge -> wrap steps, used by the GPU parity tests and handy
+    the same hist -> encode -> plan -> place -> merge -> wrap steps, used by the GPU parity tests and handy
     for images too tall for one submission.  image: uint8 tensor (h, w, c); cuts: row boundaries."""
     h, w, c = image.shape
-    first_token_bit, eob_bits, prefix_bytes = backend.layout(c)
     bands = [(y0, y1) for y0, y1 in zip(cuts[:-1], cuts[1:]) if y1 > y0]
     above = lambda y0: image[y0 - 1] if y0 else None  # noqa: E731
-    stats = [backend.count(image[y0:y1], above(y0), w, c, y0, y1) for y0, y1 in bands]
-    plan = plan_bands(stats, w, h, c, first_token_bit, eob_bits, prefix_bytes)
+    hist = None
+    if flags & ENCODE_SLOWER:
+        hist = sum(backend.hist(image[y0:y1], above(y0), w, c, y0, y1, h).to(torch.int64) for y0, y1 in bands).to(torch.int32)
+    # one encoder holds one band's streams at a time: encode and place band after band (two walks over the rows
+    # in this single-GPU form; on N GPUs every rank keeps its band's streams between the two phases)
+    stats = [backend.encode(image[y0:y1], above(y0), w, c, y0, y1, h, flags, hist) for y0, y1 in bands]
+    plan = plan_bands(stats, w, h, c, stats[0].first_token_bit, stats[0].eob_bits, not (flags & ENCODE_SLOWER))
     if plan.stored:
         return backend.encode_whole(image, w, h, c, 2)
-    png_buf = torch.zeros(58 + plan.zlib_size + 16 + 64, dtype=torch.uint8, device=image.device)
+    png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=image.device)
     for i, (y0, y1) in enumerate(bands):
-        piece = backend.emit(image[y0:y1], above(y0), w, c, y0, y1, plan.start_bits[i], i == 0, i == len(bands) - 1,
-                             plan.adler)
-        _or_into(png_buf, 58 + (0 if i == 0 else plan.start_bits[i] >> 3), piece)
-    return bytes(backend.wrap(png_buf, plan.zlib_size, w, h, c).cpu().numpy())
+        backend.encode(image[y0:y1], above(y0), w, c, y0, y1, h, flags, hist)
+        off, win = backend.place(plan.start_bits[i], plan.zlib_size, stats[i].token_bits, image.device)
+        merge_window(png_buf, off, win, i == 0, plan.start_bits[i])
+    return bytes(backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c).cpu().numpy())
 
 
 def _all_gather_records(rec, group, device):
@@ -140,75 +170,73 @@ def _all_gather_records(rec, group, device):
     return [o.tolist() for o in out]
 
 
-def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, group=None, root=0):
+def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0, group=None, root=0):
     """Encode ONE w x h image whose rows [y0,y1) live on this rank (`rows`: uint8 tensor (y1-y0, w, c);
-    `row_above`: the image row y0-1 (tensor (w, c)) or None when y0 == 0).  1-pass.  Returns the PNG
-    as a uint8 tensor on the root, None elsewhere.  Output is byte-identical to the single-GPU /
-    reference encoding of the whole image."""
+    `row_above`: the image row y0-1 (tensor (w, c)) or None when y0 == 0).  flags: 0 or FPNG_ENCODE_SLOWER.
+    Returns the PNG as a uint8 tensor on the root, None elsewhere.  Output is byte-identical to the
+    single-GPU / reference encoding of the whole image."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     device = rows.device
-    first_token_bit, eob_bits, prefix_bytes = backend.layout(c)
     nrows = y1 - y0
-    if nrows > 0:
-        st = backend.count(rows, row_above, w, c, y0, y1)
-    else:
-        st = BandStats(0, 0, 0, 0, 0)
-    recs = _all_gather_records([st.token_bits, st.s1, st.s2, st.nbytes, st.last_unit_bits, y0, y1], group, device)
-    order = sorted(range(world), key=lambda r: (recs[r][5], recs[r][6]))  # bands in row order
-    stats = [BandStats(*recs[r][:5]) for r in order]
-    plan = plan_bands(stats, w, h, c, first_token_bit, eob_bits, prefix_bytes)
-    non_empty = [r for r in order if recs[r][6] > recs[r][5]]
+    hist = None
+    if flags & ENCODE_SLOWER:
+        # step 0: the image's histogram = sum of the bands' (288 counters through one all_reduce)
+        hist = backend.hist(rows, row_above, w, c, y0, y1, h) if nrows > 0 else torch.zeros(288, dtype=torch.int32, device=device)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    st = backend.encode(rows, row_above, w, c, y0, y1, h, flags, hist) if nrows > 0 else BandStats(0, 0, 0, 0, 0, 0, 0)
+    recs = _all_gather_records([st.token_bits, st.s1, st.s2, st.nbytes, st.last_unit_bits, st.first_token_bit, st.eob_bits, y0, y1],
+                               group, device)
+    order = sorted(range(world), key=lambda r: (recs[r][7], recs[r][8]))  # bands in row order
+    stats = [BandStats(*recs[r][:7]) for r in order]
+    non_empty = [r for r in order if recs[r][8] > recs[r][7]]
+    ftb, eob = recs[non_empty[0]][5], recs[non_empty[0]][6]
+    plan = plan_bands(stats, w, h, c, ftb, eob, not (flags & ENCODE_SLOWER))
     my_pos = order.index(rank)
 
     if plan.stored:
-        # Rare path (incompressible image): the stored-block layout has no bit seams; gather the raw
-        # rows on the root and let it write the stored stream.
-        parts = [None] * world if rank == root else None
-        dist.gather_object(rows.cpu().numpy().tobytes() if nrows else b"", parts, dst=root, group=group)
+        # Rare path (incompressible image): the stored-block layout has no bit seams; the root collects the raw
+        # rows (padded all_gather of equal-size tensors) and writes the stored stream.
+        max_rows = max(recs[r][8] - recs[r][7] for r in range(world))
+        pad = torch.zeros((max_rows, w, c), dtype=torch.uint8, device=device)
+        if nrows:
+            pad[:nrows] = rows
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
         if rank != root:
             return None
-        import numpy as np
-        whole = b"".join(parts[r] for r in order)
-        img = torch.from_numpy(np.frombuffer(whole, dtype=np.uint8).reshape(h, w, c).copy()).to(device)
+        img = torch.cat([parts[r][:recs[r][8] - recs[r][7]] for r in order]).contiguous()
         png = backend.encode_whole(img, w, h, c, 2)
+        import numpy as np
         return torch.from_numpy(np.frombuffer(png, dtype=np.uint8).copy())
 
-    band = None
+    win, off = None, 0
     if nrows > 0:
-        is_first = rank == non_empty[0]
-        is_last = rank == non_empty[-1]
-        band = backend.emit(rows, row_above, w, c, y0, y1, plan.start_bits[my_pos], is_first, is_last, plan.adler)
+        off, win = backend.place(plan.start_bits[my_pos], plan.zlib_size, st.token_bits, device)
 
-    # ---- step 5: windows to the root, OR-merge at the shared seam bytes ----
-    sizes = _all_gather_records([0 if band is None else int(band.numel())], group, device)
+    # ---- step 5: windows to the root; the offsets follow from the plan, the sizes are exchanged ----
+    geo = _all_gather_records([off, 0 if win is None else int(win.numel())], group, device)
     if rank == root:
-        png_buf = torch.zeros(58 + plan.zlib_size + 16 + 64, dtype=torch.uint8, device=device)
+        png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=device)
         pending = []
         for r in non_empty:
-            n = sizes[r][0]
             if r == root:
-                tmp = band
-            else:
-                tmp = torch.empty(n, dtype=torch.uint8, device=device)
-                pending.append((dist.irecv(tmp, src=_global_rank(group, r), group=group), r, tmp))
                 continue
-            _or_into(png_buf, 58 + (0 if r == non_empty[0] else plan.start_bits[order.index(r)] >> 3), tmp)
+            tmp = torch.empty(geo[r][1], dtype=torch.uint8, device=device)
+            pending.append((dist.irecv(tmp, src=_global_rank(group, r), group=group), r, tmp))
+        wins = {root: win} if win is not None else {}
         for req, r, tmp in pending:
             req.wait()
-            _or_into(png_buf, 58 + (0 if r == non_empty[0] else plan.start_bits[order.index(r)] >> 3), tmp)
-        return backend.wrap(png_buf, plan.zlib_size, w, h, c)
-    if band is not None:
-        dist.send(band.contiguous(), dst=_global_rank(group, root), group=group)
+            wins[r] = tmp
+        for r in non_empty:  # in row order: a window's first piece is OR-ed onto its predecessor's last one
+            merge_window(png_buf, geo[r][0], wins[r], r == non_empty[0], plan.start_bits[order.index(r)])
+        return backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c)
+    if win is not None:
+        dist.send(win.contiguous(), dst=_global_rank(group, root), group=group)
     return None
 
 
 def _global_rank(group, r):
     return r if group is None else dist.get_global_rank(group, r)
-
-
-def _or_into(buf, offset, piece):
-    view = buf[offset:offset + piece.numel()]
-    torch.bitwise_or(view, piece, out=view)
 
 
 def shard_batch(n_images, rank, world):

@@ -134,41 +134,74 @@ int fpng_amd_encode_finish(fpng_amd_encoder *enc, fpng_amd_result *results, uint
 int fpng_amd_encode_host(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
                          uint32_t flags, uint8_t *out, size_t out_cap, size_t *out_size);
 
+/* fpng_encode_image_to_memory() / fpng_encode_image_to_file() (reference src/fpng.h:48-52, src/fpng.cpp:1806-1828) for MANY
+ * frames in host memory: uploads, encodes, downloads and file writes of consecutive frames overlap (a ring of device
+ * staging buffers, an uploader and a downloader thread, n_writer_threads file writers; 0 = the downloader writes).
+ * Per frame: `out` (caller buffer of out_cap bytes, may be NULL when `path` is set), `path` (may be NULL), *out_size. */
+typedef struct fpng_amd_host_image {
+    const void *pixels;
+    uint32_t w, h, num_chans, reserved;
+    uint8_t *out;
+    size_t out_cap;
+    size_t *out_size;
+    const char *path;
+} fpng_amd_host_image;
+int fpng_amd_encode_host_batch(fpng_amd_encoder *enc, const fpng_amd_host_image *images, uint32_t n, uint32_t flags,
+                               int n_writer_threads);
+
 /* ---- row-band interface: one image sharded by rows over several GPUs.
  *      The stream stays ONE IDAT / ONE Deflate block; bands are stitched at bit granularity. ---- */
+
+typedef struct fpng_amd_band {
+    const void *d_rows;      /* DEVICE pointer to row y0 of the image (pitch w*num_chans) */
+    const void *d_row_above; /* row y0-1 (ignored when y0 == 0): the Up filter's only dependency across bands */
+    uint32_t w, num_chans;
+    uint32_t y0, y1;         /* rows [y0, y1) of the image */
+    uint32_t h_total;        /* height of the whole image */
+    uint32_t reserved;
+} fpng_amd_band;
 
 typedef struct fpng_amd_band_stats {
     uint64_t token_bits;  /* bits of all tokens of the band's rows */
     uint32_t adler_s1;    /* raw byte sum of the band's filtered bytes mod 65521 */
     uint32_t adler_s2;    /* raw position-weighted sum mod 65521 */
     uint64_t adler_len;   /* filtered bytes in the band = (w*c+1)*rows */
-    uint32_t last_unit_bits; /* size of the band's final flush unit (failure rule) */
+    uint32_t last_unit_bits;  /* size of the band's final flush unit (failure rule) */
+    uint32_t first_token_bit; /* where row tokens start in the zlib stream: 490 / 503 for 1-pass (reference src/fpng.cpp:535,
+                                 :551), the dynamic header's length for 2-pass -- the same on every rank */
+    uint32_t eob_bits;        /* length of the end-of-block code of the table in use */
     uint32_t reserved;
 } fpng_amd_band_stats;
 
-/* Phase 1: count.  d_rows points at row y0 of the image, d_row_above at row y0-1 (ignored when
- * y0 == 0).  Synchronous (returns the band's stats to the host). */
-int fpng_amd_band_count(fpng_amd_encoder *enc, const void *d_rows, const void *d_row_above, uint32_t w,
-                        uint32_t num_chans, uint32_t y0, uint32_t y1, fpng_amd_band_stats *stats);
+/* 2-pass only (FPNG_AMD_ENCODE_SLOWER), asynchronous on the encoder's stream: d_hist288[0..288) (device, uint32) = symbol
+ * histogram of the band (reference src/fpng.cpp:1021-1084 / :1299-1363).  The caller sums the bands' histograms over the
+ * ranks (one all-reduce of 1152 bytes) and hands the result to fpng_amd_band_encode(): every rank builds the same table. */
+int fpng_amd_band_hist(fpng_amd_encoder *enc, const fpng_amd_band *band, uint32_t *d_hist288);
 
-/* Phase 2: emit the band's tokens at absolute stream bit `start_bit` into d_band_out, which
- * represents stream bytes [start_bit/8, ...).  Bits outside the band are written as zero so
- * neighbouring bands can be OR-merged.  If is_first, the 1-pass prefix is written too (start_bit
- * must then equal the table's first token bit and d_band_out starts at stream byte 0).  If is_last,
- * EOB + padding + the big-endian `adler` are appended.  *out_bytes = bytes of d_band_out used.
- * Must follow fpng_amd_band_count() on the same encoder with the same rows. */
-int fpng_amd_band_emit(fpng_amd_encoder *enc, const void *d_rows, const void *d_row_above, uint32_t w,
-                       uint32_t num_chans, uint32_t y0, uint32_t y1, uint64_t start_bit, int is_first, int is_last,
-                       uint32_t adler, uint8_t *d_band_out, size_t out_cap, size_t *out_bytes);
+/* Phase 1: the band's rows are encoded into the encoder's scratch streams (the same encode_rows kernel as whole images);
+ * the band's counts come back to the host -- the only synchronisation of the band path: `stats` is what the ranks
+ * exchange (one all_gather of a few words).  flags: 0 or FPNG_AMD_ENCODE_SLOWER (then d_hist288 = the image's histogram). */
+int fpng_amd_band_encode(fpng_amd_encoder *enc, const fpng_amd_band *band, uint32_t flags, const uint32_t *d_hist288,
+                         fpng_amd_band_stats *stats);
+
+/* Phase 2, asynchronous on the encoder's stream: the streams of the last fpng_amd_band_encode() are shifted to stream
+ * bit `start_bit` (first band: stats.first_token_bit) of an image whose zlib stream has `zlib_size` bytes, into a
+ * WINDOW of whole 16-byte pieces of the file: d_window[0] is file byte *window_file_offset (a multiple of 16; 0 for the
+ * first band, whose window also receives the stream's head), *window_bytes bytes are defined; bits that belong to other
+ * bands are 0, so neighbouring windows are merged by OR-ing their one shared 16-byte piece.  The image's last band
+ * (y1 == h_total) appends the end-of-block code.  PNG header, Adler-32, CRC and IEND are fpng_amd_wrap_png()'s. */
+int fpng_amd_band_place(fpng_amd_encoder *enc, const fpng_amd_band *band, uint64_t start_bit, uint64_t zlib_size,
+                        uint8_t *d_window, size_t window_cap, uint64_t *window_file_offset, size_t *window_bytes);
+
+/* Wrap an assembled zlib stream (device memory, at d_png + 58, its last 4 bytes = room for the Adler-32) into the PNG
+ * container: 58-byte header, big-endian `adler`, IDAT CRC-32, IEND (reference src/fpng.cpp:1764-1800).  Asynchronous on
+ * the encoder's stream; *png_size = 58 + zlib_size + 16 is returned at once. */
+int fpng_amd_wrap_png(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h,
+                      uint32_t num_chans, size_t *png_size);
 
 /* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
- * and the EOB length (12) -- what the host needs to lay out bands and evaluate the failure rule. */
+ * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
-
-/* Wrap an assembled zlib stream (device memory, at d_png + 58) into the PNG container: 58-byte
- * header, IDAT CRC-32, IEND (reference src/fpng.cpp:1764-1800).  Synchronous. */
-int fpng_amd_wrap_png(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t w, uint32_t h,
-                      uint32_t num_chans, size_t *png_size);
 
 /* ---- synthetic inputs for tests/bench, host memory ---- */
 #define FPNG_AMD_SYNTH_NOISE 0

@@ -789,3 +789,56 @@ uint64_t fpo_encode_band_1pass(const void *image, uint32_t w, uint32_t h, uint32
     if (last_unit_bits) *last_unit_bits = k.last_unit_bits;
     return bw.overflow ? 0 : bw.pos;
 }
+
+/* Row bands with either table: the symbol histogram of rows [y0,y1) (2-pass, pass 1; the histograms of an image's
+ * bands add up to the whole image's, src/fpng.cpp:1021-1084 / :1299-1363), and the band's token bits under the 1-pass
+ * table (lit_freq == NULL) or under the table built from the WHOLE image's histogram.  *first_token_bit = where row
+ * tokens start in the zlib stream, hdr (>= 400 bytes) receives the stream's head (zlib header + block header). */
+void fpo_band_hist(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t y0, uint32_t y1, uint32_t hist[288])
+{
+    ensure_init();
+    walker k;
+    memset(&k, 0, sizeof k);
+    memset(hist, 0, 288 * sizeof(uint32_t));
+    k.img = (const uint8_t *)image;
+    k.w = w, k.h = h, k.c = num_chans;
+    k.hist = hist;
+    walk_rows(&k, y0, y1);
+}
+
+uint64_t fpo_encode_band(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t y0, uint32_t y1,
+                         const uint32_t *lit_freq, uint8_t *out, size_t out_cap, uint32_t *adler_s1, uint32_t *adler_s2,
+                         uint64_t *adler_len, uint32_t *last_unit_bits, uint32_t *first_token_bit, uint32_t *eob_bits,
+                         uint32_t *eob_code, uint8_t *hdr)
+{
+    ensure_init();
+    bitw bw = {out, out_cap, 0, 0};
+    walker k;
+    huff_table dyn;
+    memset(&k, 0, sizeof k);
+    k.img = (const uint8_t *)image;
+    k.w = w, k.h = h, k.c = num_chans;
+    if (lit_freq) {
+        *first_token_bit = fpo_build_dynamic_table(lit_freq, num_chans, dyn.len, dyn.code, hdr);
+        k.t = &dyn;
+    } else {
+        const uint8_t *pre = (num_chans == 3) ? k_prefix3 : k_prefix4;
+        const uint32_t pre_len = (num_chans == 3) ? 62 : 61;
+        memset(hdr, 0, 400);
+        memcpy(hdr, pre, pre_len);
+        hdr[pre_len] = (num_chans == 3) ? PREFIX3_TAIL_VAL : PREFIX4_TAIL_VAL;
+        *first_token_bit = pre_len * 8 + ((num_chans == 3) ? PREFIX3_TAIL_BITS : PREFIX4_TAIL_BITS);
+        k.t = (num_chans == 3) ? &g_tab3 : &g_tab4;
+        k.lit_test = (num_chans == 4);
+        k.one_pass_3ch_units = (num_chans == 3);
+    }
+    *eob_bits = k.t->len[256];
+    *eob_code = k.t->code[256];
+    k.bw = &bw;
+    walk_rows(&k, y0, y1);
+    if (adler_s1) *adler_s1 = (uint32_t)k.s1;
+    if (adler_s2) *adler_s2 = (uint32_t)k.s2;
+    if (adler_len) *adler_len = k.nbytes;
+    if (last_unit_bits) *last_unit_bits = k.last_unit_bits;
+    return bw.overflow ? 0 : bw.pos;
+}

@@ -52,6 +52,13 @@ uint64_t fpo_encode_band_1pass(const void *image, uint32_t w, uint32_t h, uint32
                                uint32_t *adler_s1, uint32_t *adler_s2, uint64_t *adler_len,
                                uint32_t *last_unit_bits);
 
+/* Row bands under either table (tests of the multi-GPU orchestration): see fpng_oracle.c */
+void fpo_band_hist(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t y0, uint32_t y1, uint32_t hist[288]);
+uint64_t fpo_encode_band(const void *image, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t y0, uint32_t y1,
+                         const uint32_t *lit_freq, uint8_t *out, size_t out_cap, uint32_t *adler_s1, uint32_t *adler_s2,
+                         uint64_t *adler_len, uint32_t *last_unit_bits, uint32_t *first_token_bit, uint32_t *eob_bits,
+                         uint32_t *eob_code, uint8_t *hdr);
+
 /* Exposed for unit tests of the derived format tables. */
 void fpo_get_1pass_table(uint32_t num_chans, uint8_t len_out[288], uint16_t code_out[288],
                          const uint8_t **prefix, uint32_t *prefix_len, uint32_t *start_bit);

@@ -1,6 +1,7 @@
 """CPU stand-in for the per-band GPU work, built on the oracle (TEST INFRASTRUCTURE).  It lets the
-world_size-2 gloo tests exercise the real orchestration of fpng_amd/sharded.py (record all_gather,
-start-bit prefix sums, Adler combine, failure rule, seam OR-merge, wrap) without a GPU."""
+world_size-2 gloo tests exercise the real orchestration of fpng_amd/sharded.py (histogram all_reduce,
+record all_gather, start-bit prefix sums, Adler combine, failure rule, window merge, wrap) without a GPU."""
+import ctypes as C
 import zlib
 
 import numpy as np
@@ -14,39 +15,54 @@ class OracleBandBackend:
     def __init__(self, image):
         self.image = np.ascontiguousarray(image)  # the whole image (the oracle filters from it directly)
         self.h, self.w, self.c = self.image.shape
+        L = oracle().L
+        L.fpo_band_hist.restype = None
+        L.fpo_band_hist.argtypes = [C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p]
+        L.fpo_encode_band.restype = C.c_uint64
+        L.fpo_encode_band.argtypes = [C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        self.L = L
 
-    def layout(self, c):
-        lens, codes, prefix, sbit = oracle().table_1pass(c)
-        return sbit, int(lens[256]), len(prefix)
+    def hist(self, rows, row_above, w, c, y0, y1, h):
+        hist = np.zeros(288, dtype=np.uint32)
+        self.L.fpo_band_hist(self.image.ctypes.data, w, h, c, y0, y1, hist.ctypes.data)
+        return torch.from_numpy(hist.astype(np.int32))
 
-    def count(self, rows, row_above, w, c, y0, y1):
-        bits, buf, s1, s2, ln = oracle().band_1pass(self.image, w, self.h, c, y0, y1)
-        return BandStats(bits, s1, s2, ln, oracle().last_unit_bits)
+    def encode(self, rows, row_above, w, c, y0, y1, h, flags, hist):
+        cap = ((w * c + 1) * (y1 - y0) * 12 + 7) // 8 + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        s1, s2, lu, ftb, eobb, eobc = (C.c_uint32(0) for _ in range(6))
+        ln = C.c_uint64(0)
+        hdr = np.zeros(400, dtype=np.uint8)
+        hp = None
+        if flags & 1:
+            self._hist = np.ascontiguousarray(hist.numpy().astype(np.uint32))
+            hp = self._hist.ctypes.data
+        bits = self.L.fpo_encode_band(self.image.ctypes.data, w, h, c, y0, y1, hp, out.ctypes.data, cap, C.byref(s1), C.byref(s2),
+                                      C.byref(ln), C.byref(lu), C.byref(ftb), C.byref(eobb), C.byref(eobc), hdr.ctypes.data)
+        self._band = dict(bits=int(bits), val=int.from_bytes(out[: (bits + 7) // 8].tobytes(), "little"), first=y0 == 0, last=y1 == h,
+                          ftb=ftb.value, eob_bits=eobb.value, eob_code=eobc.value, hdr=hdr)
+        return BandStats(int(bits), s1.value, s2.value, ln.value, lu.value, ftb.value, eobb.value)
 
-    def emit(self, rows, row_above, w, c, y0, y1, start_bit, is_first, is_last, adler):
-        lens, codes, prefix, sbit = oracle().table_1pass(c)
-        bits, buf, *_ = oracle().band_1pass(self.image, w, self.h, c, y0, y1)
-        val = int.from_bytes(buf.tobytes(), "little")
-        first_byte = 0 if is_first else start_bit >> 3
-        acc = val << (start_bit - 8 * first_byte)
-        end = start_bit + bits
-        if is_first:
-            tail_bits = sbit - 8 * len(prefix)
-            tail_val = {3: 30, 4: 1}[c]
-            assert start_bit == sbit
-            acc |= int.from_bytes(prefix, "little") | (tail_val << (8 * len(prefix)))
-            assert tail_bits == {3: 7, 4: 2}[c]
-        if is_last:
-            acc |= int(codes[256]) << (end - 8 * first_byte)
-            end += int(lens[256])
-            end = (end + 7) & ~7
-            acc |= int.from_bytes(adler.to_bytes(4, "big"), "little") << (end - 8 * first_byte)
-            end += 32
-        nbytes = ((end + 7) >> 3) - first_byte
-        return torch.from_numpy(np.frombuffer(acc.to_bytes(nbytes, "little"), dtype=np.uint8).copy())
+    def place(self, start_bit, zlib_size, token_bits, device):
+        b = self._band
+        fb0 = 58 * 8 + start_bit
+        wb0 = 0 if b["first"] else (fb0 >> 3) & ~15
+        acc = b["val"] << (fb0 - 8 * wb0)
+        end = fb0 + b["bits"]
+        if b["first"]:
+            assert start_bit == b["ftb"]
+            acc |= int.from_bytes(b["hdr"][: (b["ftb"] + 7) // 8].tobytes(), "little") << (58 * 8)
+        if b["last"]:
+            acc |= b["eob_code"] << (end - 8 * wb0)
+            end += b["eob_bits"]
+        wb1 = (((end + 7) >> 3) + 15) & ~15
+        win = np.frombuffer(acc.to_bytes(wb1 - wb0, "little"), dtype=np.uint8).copy()
+        if b["first"]:
+            win[:58] = 0xEE  # undefined bytes: the merge must not use them
+        return wb0, torch.from_numpy(win)
 
-    def wrap(self, png_buf, zlib_size, w, h, c):
-        z = bytes(png_buf[58:58 + zlib_size].numpy())
+    def wrap(self, png_buf, zlib_size, adler, w, h, c):
+        z = bytes(png_buf[58:58 + zlib_size - 4].numpy()) + adler.to_bytes(4, "big")
         whole = oracle().encode(self.image, w, h, c, 0)  # container bytes (header) from the oracle
         hdr = bytearray(whole[:58])
         hdr[50:54] = zlib_size.to_bytes(4, "big")

@@ -259,7 +259,7 @@ def test_mixed_batch_shapes_and_channels(enc):
             [("grad", 640, 480, 3), ("blocks", 333, 77, 4), ("noise", 50, 50, 4), ("solid", 1, 1, 3), ("grad", 1921, 3, 4),
              ("noise", 7, 300, 3), ("blocks", 1024, 1024, 3), ("grad", 2, 2, 4)]]
     pngs, _ = _gpu_encode(enc, imgs, 0)
-    assert enc.phase_names()[0] == "encode_image"   # the default whole-image pipeline (one persistent launch)
+    assert enc.phase_names()[0] == "encode_rows"   # the default whole-image pipeline (one walk into scratch streams + assemble)
     for img, p in zip(imgs, pngs):
         h, w, c = img.shape
         _assert_same(p, oracle().encode(img, w, h, c, 0), f"{w}x{h}x{c}")
@@ -301,6 +301,64 @@ def test_host_buffer_entry_point(enc):
     assert not ok                                           # reference fpng.cpp:1676-1680
 
 
+def test_host_batch_overlapped_copies_and_file_writers(enc, tmp_path):
+    """fpng_amd_encode_host_batch: more frames than ring slots, mixed sizes, to memory and to files (writer pool)."""
+    import fpng_amd
+    specs = [("grad", 640, 480, 3), ("blocks", 333, 77, 4), ("noise", 50, 50, 4), ("grad", 1921, 131, 4), ("solid", 1, 1, 3),
+             ("grad", 800, 600, 4), ("blocks", 1024, 257, 3), ("grad", 64, 2000, 4), ("noise", 300, 200, 3)]
+    imgs = [fpng_amd.synth_image(k, w, h, c, seed=50 + i) for i, (k, w, h, c) in enumerate(specs)]
+    for fl in (0, 1):
+        exp = [oracle().encode(im, im.shape[1], im.shape[0], im.shape[2], fl) for im in imgs]
+        outs = [np.empty(fpng_amd.max_encoded_size(im.shape[1], im.shape[0], im.shape[2]), dtype=np.uint8) for im in imgs]
+        sizes = enc.encode_host_batch(imgs, fl, outs=outs)
+        for o, n, e in zip(outs, sizes, exp):
+            _assert_same(o[:n].tobytes(), e, f"host batch flags={fl}")
+        paths = [str(tmp_path / f"f{fl}_{i}.png") for i in range(len(imgs))]
+        sizes = enc.encode_host_batch(imgs, fl, paths=paths, writer_threads=3)
+        for p, n, e in zip(paths, sizes, exp):
+            with open(p, "rb") as f:
+                assert f.read() == e and n == len(e)
+
+
+def test_tickets_return_each_submissions_records(enc):
+    """fpng_amd_encode_submit / _wait: several submissions in flight, every one's result records are retrievable."""
+    import torch
+    import fpng_amd
+    subs = []
+    for b in range(5):
+        imgs = [fpng_amd.synth_image(k, 200 + 40 * b, 100 + i, 4, seed=10 * b + i) for i, k in enumerate(("grad", "blocks", "noise"))]
+        ts = [torch.from_numpy(i).cuda() for i in imgs]
+        outs = [torch.empty(fpng_amd.max_encoded_size(t.shape[1], t.shape[0], 4) + 64, dtype=torch.uint8, device="cuda") for t in ts]
+        enc.submit(ts, outs, 0)
+        subs.append((imgs, outs, enc.last_ticket))
+    for imgs, outs, ticket in reversed(subs):   # any order
+        res = enc.wait(ticket, 3)
+        for img, out, (size, mode, status) in zip(imgs, outs, res):
+            exp = oracle().encode(img, img.shape[1], img.shape[0], 4, 0)
+            assert status == 0 and size == len(exp) and mode == ((exp[60] >> 1) & 3 == 0)
+            _assert_same(bytes(out[:size].cpu().numpy()), exp, "ticketed submission")
+    enc.finish(3)
+    with pytest.raises(Exception):
+        enc.wait(10 ** 9, 1)      # unknown ticket
+
+
+def test_submit_is_ordered_behind_torch_work_without_host_sync(enc):
+    """The default Encoder follows torch's current stream: pixels produced by torch kernels immediately before submit()
+    (no synchronisation in between) are the pixels that get encoded."""
+    import torch
+    import fpng_amd
+    base = torch.from_numpy(fpng_amd.synth_image("grad", 2048, 1536, 4)).cuda()
+    for rep in range(4):
+        big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        big.random_()                                   # keep the stream busy in front of the producer
+        img = (base.to(torch.int16) + (rep + 1)).to(torch.uint8)          # the producer of the pixels: torch kernels
+        out = torch.empty(fpng_amd.max_encoded_size(2048, 1536, 4) + 64, dtype=torch.uint8, device="cuda")
+        enc.submit([img], [out], 0)
+        (size, mode, status), = enc.finish(1)
+        ref_img = img.cpu().numpy()
+        _assert_same(bytes(out[:size].cpu().numpy()), oracle().encode(ref_img, 2048, 1536, 4, 0), f"torch-produced pixels, rep {rep}")
+
+
 def test_repeated_submissions_reuse_scratch(enc):
     import fpng_amd
     img = fpng_amd.synth_image("grad", 800, 600, 4)
@@ -340,8 +398,9 @@ def test_row_bands_stitched_at_bit_granularity(enc):
         h, w, c = img.shape
         for nb in (2, 3, 8):
             cuts = [0] + sorted(int(v) for v in rng.integers(0, h + 1, nb - 1)) + [h]
-            png = sharded.encode_image_bands_local(be, torch.from_numpy(np.ascontiguousarray(img)).cuda(), cuts)
-            _assert_same(png, oracle().encode(img, w, h, c, 0), f"bands {w}x{h}x{c} cuts={cuts}")
+            for fl in (0, 1):   # 2-pass: the bands' histograms are summed, every band is coded with the image's table
+                png = sharded.encode_image_bands_local(be, torch.from_numpy(np.ascontiguousarray(img)).cuda(), cuts, fl)
+                _assert_same(png, oracle().encode(img, w, h, c, fl), f"bands {w}x{h}x{c} cuts={cuts} flags={fl}")
 
 
 def test_row_bands_4k_eight_bands(enc):
@@ -352,6 +411,35 @@ def test_row_bands_4k_eight_bands(enc):
     cuts = [b[0] for b in sharded.split_rows(2160, 8)] + [2160]
     png = sharded.encode_image_bands_local(sharded.GpuBandBackend(enc), torch.from_numpy(img).cuda(), cuts)
     assert hashlib.sha256(png).hexdigest() == "d0f30341ef67c6ea2f67fdb6d6892d493e77999a70b1b0415e16eb81ea653d33"
+    png = sharded.encode_image_bands_local(sharded.GpuBandBackend(enc), torch.from_numpy(img).cuda(), cuts, 1)
+    assert hashlib.sha256(png).hexdigest() == "69c0ad6dba32822b642e2b4ca5e247c554dd19e08cb848262dce309674a453cd"
+
+
+def test_row_sharded_through_nccl_one_rank(enc):
+    """The real collective path (torch.distributed backend nccl = RCCL) with a one-rank group: all_reduce of the histogram,
+    all_gather of the band records, window merge, wrap."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, hashlib
+sys.path.insert(0, os.path.join(os.environ["FPNG_ROOT"], "tests")); sys.path.insert(0, os.environ["FPNG_ROOT"])
+import torch, torch.distributed as dist, fpng_amd
+from fpng_amd import sharded
+from cpu_ref import oracle
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+enc = fpng_amd.Encoder(device=0)
+be = sharded.GpuBandBackend(enc)
+for (k, w, h, c) in [("grad", 1921, 257, 4), ("blocks", 640, 480, 3), ("noise", 100, 60, 4)]:
+    img = fpng_amd.synth_image(k, w, h, c)
+    for fl in (0, 1):
+        png = sharded.encode_image_row_sharded(be, torch.from_numpy(img).cuda(), None, w, h, c, 0, h, fl)
+        assert bytes(png.cpu().numpy()) == oracle().encode(img, w, h, c, fl), (k, w, h, c, fl)
+print("nccl one-rank ok")
+dist.destroy_process_group()
+'''
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPNG_ROOT=ROOT), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nccl one-rank ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
 def test_cpp_dropin_namespace_fpng(enc, tmp_path):
@@ -425,8 +513,9 @@ def test_overlapping_submissions_large_enough_to_run_concurrently(enc):
 
 
 def test_alternative_pipelines_same_bytes():
-    """FPNG_AMD_PIPELINE=rows (encode_rows -> scan -> assemble; with FPNG_AMD_LOCAL_LIMIT_MB=1 its scratch does not fit
-    and it falls back to count) and =count (count -> scan -> emit -> crc) must produce the same files as the default."""
+    """FPNG_AMD_PIPELINE=fused (encode_image_kernel: one persistent launch, rows placed straight from LDS; also what the
+    default pipeline falls back to when its scratch streams do not fit, here forced with FPNG_AMD_LOCAL_LIMIT_MB=1) and
+    =count (count -> scan -> emit -> crc, two walks) must produce the same files as the default."""
     import subprocess
     import sys
     code = r'''
@@ -444,7 +533,7 @@ for fl in (0, 1, 2):
         assert p == oracle().encode(img, w, h, c, fl), (w, h, c, fl)
 print("pipeline ok", enc.phase_names()[0])
 '''
-    for extra, first in (({"FPNG_AMD_PIPELINE": "rows"}, "encode_rows"), ({"FPNG_AMD_PIPELINE": "rows", "FPNG_AMD_LOCAL_LIMIT_MB": "1"}, "count"),
+    for extra, first in (({"FPNG_AMD_PIPELINE": "fused"}, "encode_image"), ({"FPNG_AMD_LOCAL_LIMIT_MB": "1"}, "encode_image"),
                          ({"FPNG_AMD_PIPELINE": "count"}, "count")):
         env = dict(os.environ, FPNG_ROOT=ROOT, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

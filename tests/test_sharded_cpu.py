@@ -41,9 +41,10 @@ def _worker(rank, world, port, seed, n_cases, q):
         be = OracleBandBackend(img)
         rows = torch.from_numpy(img[y0:y1].copy())
         above = torch.from_numpy(img[y0 - 1].copy()) if y0 > 0 else None
-        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1)
+        fl = i % 2  # 1-pass and 2-pass (histogram all_reduce, dynamic table) alternate
+        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1, fl)
         if rank == 0:
-            exp = oracle().encode(img, w, h, c, 0)
+            exp = oracle().encode(img, w, h, c, fl)
             got = bytes(png.numpy())
             stored += (exp[60] >> 1) & 3 == 0
             if got != exp:
@@ -85,8 +86,8 @@ def test_plan_bands_matches_whole_image_layout():
         img, w, h, c = fuzz_image(rng)
         be = OracleBandBackend(img)
         cuts = sorted(set([0, h] + [int(v) for v in rng.integers(0, h + 1, 3)]))
-        stats = [be.count(None, None, w, c, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
-        plan = sharded.plan_bands(stats, w, h, c, *be.layout(c))
+        stats = [be.encode(None, None, w, c, a, b, h, 0, None) for a, b in zip(cuts[:-1], cuts[1:])]
+        plan = sharded.plan_bands(stats, w, h, c, stats[0].first_token_bit, stats[0].eob_bits)
         exp = oracle().encode(img, w, h, c, 0)
         assert plan.stored == ((exp[60] >> 1) & 3 == 0)
         if not plan.stored:

@@ -464,6 +464,35 @@ def test_cpp_dropin_namespace_fpng(enc, tmp_path):
         assert f.read() == oracle().encode(img, 100, 50, 4, 0)
 
 
+def test_command_line_harness(tmp_path):
+    """fpng_amd_test (tools/fpng_amd_test.cpp, the fpng_test workflow over the drop-in): timing run, CSV, and both fuzz modes
+    with the CPU encoders as byte-for-byte judges."""
+    import subprocess
+    exe = os.path.join(ROOT, "fpng_amd", "lib", "fpng_amd_test")
+    judges = [os.path.join(ROOT, "oracle", "libfpng_oracle.so")]
+    if have_ref():
+        judges.append(os.path.join(ROOT, "oracle", "_ref", "libfpng_ref.so"))
+    out = str(tmp_path / "fpng.png")
+
+    def run(*args):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
+        assert r.returncode == 0, (args, r.stdout[-800:], r.stderr[-800:])
+        return r.stdout
+
+    for j in judges:
+        txt = run("--judge", j, "-o", out, "-b", "4", "-p", "2", "synth:grad:1280x720x4")
+        assert "bytes identical" in txt and "device-resident" in txt and "threads, one image each" in txt
+        with open(out, "rb") as f:
+            import fpng_amd
+            assert f.read() == oracle().encode(fpng_amd.synth_image("grad", 1280, 720, 4), 1280, 720, 4, 0)
+        csv = run("--judge", j, "-c", "-s", "-o", out, "synth:blocks:640x480x3")
+        assert csv.count(",") == 13 and csv.startswith("synth:blocks:640x480x3, 640, 480, 3,")
+        assert "trials ok (byte-identical" in run("--judge", j, "-e", "-n", "40", "synth:grad:200x150x4")
+        assert "trials ok (byte-identical" in run("--judge", j, "-e", "-s", "-n", "20", "synth:blocks:333x77x3")
+        assert "trials ok (byte-identical" in run("--judge", j, "-E", "-n", "6", "-m", "700")
+    assert "decode verified" in run("-u", "-o", out, out)      # a file written by fpng as input, no judge: round trip only
+
+
 def test_pipelined_submissions_without_intermediate_finish(enc):
     """fpng_amd_encode_batch_async() may be called repeatedly before fpng_amd_encode_finish(): submissions
     go through a ring of pinned slots and alternate between the encoder's two lanes."""

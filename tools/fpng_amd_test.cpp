@@ -1,0 +1,345 @@
+// fpng_amd_test -- the fpng_test workflow (reference src/fpng_test.cpp:975-1639) pointed at the MI355X path.
+//
+//   fpng_amd_test [options] <input>
+//     <input>   synth:<noise|solid|grad|blocks>:<W>x<H>x<C>[:seed]   (SURVEY.md B.1 generators)
+//               or a .png written by fpng (decoded with fpng::fpng_decode_file; no other PNG loader here)
+//     -s        2-pass compression (FPNG_ENCODE_SLOWER)            reference fpng_test.cpp:1027
+//     -u        stored Deflate blocks (FPNG_FORCE_UNCOMPRESSED)    reference fpng_test.cpp:1031
+//     -c        one line of comma separated values                 reference fpng_test.cpp:1608-1633
+//     -e        fuzz the encoder by mutating the input's pixels    reference fpng_test.cpp:381-615
+//     -E        fuzz with random-noise images of random size       reference fpng_test.cpp:617-682
+//     -n N      fuzz trials (default 1000, as the reference)       -m D  largest dimension for -E (default 8193)
+//     -b N      also time N frames per call through fpng_amd_encode_host_batch (overlapped copies) and N
+//               device-resident frames per submission (kernel-only rate)
+//     -o file   write the encoded file (default fpng.png, as the reference)
+//     --judge lib.so   a CPU encoder to compare every output byte for byte against: a library exporting
+//               ref_encode() (the reference build) or fpo_encode() (the C restatement).  With -p N the same library
+//               gives the CPU baseline: N threads, one image each (whole-node figure).
+//
+// Every encode goes through the drop-in `namespace fpng` (include/fpng.h -> libfpng.so -> C ABI -> HIP kernels);
+// decode and verification as the reference does them: best of 3 encodes, best of 5 decodes, MP/s = 2^20 pixels per
+// second like the reference prints (fpng_test.cpp:1212) with the 10^6 figure next to it.
+#include "fpng.h"
+#include "fpng_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <dlfcn.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+typedef int (*judge_fn)(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *, size_t, size_t *);
+
+struct Options {
+    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false;
+    uint32_t trials = 1000, max_dim = 8193, batch = 0, cpu_threads = 0;
+    const char *input = nullptr, *out = "fpng.png", *judge_path = nullptr;
+};
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Rng { // xorshift32, as the synthetic generators
+    uint32_t s;
+    explicit Rng(uint32_t seed) : s(seed ? seed : 1u) {}
+    uint32_t next()
+    {
+        s ^= s << 13, s ^= s >> 17, s ^= s << 5;
+        return s;
+    }
+    uint32_t range(uint32_t lo, uint32_t hi) { return lo + next() % (hi - lo); } // [lo, hi)
+    double unit() { return next() / 4294967296.0; }
+};
+
+bool load_input(const char *spec, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, uint32_t &c)
+{
+    if (!strncmp(spec, "synth:", 6)) {
+        char kind[16] = {0};
+        unsigned seed = 12345;
+        if (sscanf(spec + 6, "%15[a-z]:%ux%ux%u:%u", kind, &w, &h, &c, &seed) < 4) return false;
+        const int k = !strcmp(kind, "noise") ? 0 : !strcmp(kind, "solid") ? 1 : !strcmp(kind, "grad") ? 2 : !strcmp(kind, "blocks") ? 3 : -1;
+        if (k < 0 || (c != 3 && c != 4)) return false;
+        px.resize((size_t)w * h * c);
+        return fpng_amd_synth_image(k, seed, w, h, c, px.data()) == 0;
+    }
+    uint32_t cf = 0;
+    if (fpng::fpng_decode_file(spec, px, w, h, cf, 4) != fpng::FPNG_DECODE_SUCCESS) return false;
+    if (cf == 3) { // keep the file's channel count, like the reference's 24 bpp path
+        std::vector<uint8_t> p3((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++) memcpy(&p3[i * 3], &px[i * 4], 3);
+        px.swap(p3);
+    }
+    c = cf;
+    return true;
+}
+
+bool encode_checked(const uint8_t *px, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, judge_fn judge, std::vector<uint8_t> &png,
+                    const char *what)
+{
+    if (!fpng::fpng_encode_image_to_memory(px, w, h, c, png, flags)) {
+        fprintf(stderr, "%s: fpng_encode_image_to_memory() failed!\n", what);
+        return false;
+    }
+    std::vector<uint8_t> dec;
+    uint32_t dw, dh, dc;
+    if (fpng::fpng_decode_memory(png.data(), (uint32_t)png.size(), dec, dw, dh, dc, c) != fpng::FPNG_DECODE_SUCCESS || dw != w || dh != h ||
+        dc != c || memcmp(dec.data(), px, (size_t)w * h * c) != 0) {
+        fprintf(stderr, "%s: decoded image failed verification\n", what);
+        return false;
+    }
+    if (judge) {
+        std::vector<uint8_t> ref(fpng_amd_max_encoded_size(w, h, c) + 64);
+        size_t n = 0;
+        if (!judge(px, w, h, c, flags, ref.data(), ref.size(), &n) || n != png.size() || memcmp(ref.data(), png.data(), n) != 0) {
+            fprintf(stderr, "%s: output differs from the CPU encoder's (%zu vs %zu bytes)\n", what, png.size(), n);
+            return false;
+        }
+    }
+    return true;
+}
+
+// reference fuzz_test_encoder (fpng_test.cpp:381-615): mutate the source image, encode, decode, compare
+int fuzz_encoder(const std::vector<uint8_t> &src, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, const Options &o, judge_fn judge)
+{
+    std::vector<uint8_t> tmp, png;
+    for (uint32_t trial = 0; trial < o.trials; trial++) {
+        Rng r(trial + 1);
+        tmp = src;
+        const double u = r.unit();
+        const char *kind;
+        if (u < 0.05) { // colour fill runs over the whole image
+            kind = "colour fill runs";
+            for (size_t ofs = 0; ofs < tmp.size();) {
+                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, (left < 32 ? left : 32) + 1);
+                uint8_t lit[4] = {(uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next()};
+                for (uint32_t i = 0; i < run; i++, ofs += c) memcpy(&tmp[ofs], lit, c);
+            }
+        } else if (u < 0.10) { // runs that are xor-ed, filled or skipped
+            kind = "mixed runs";
+            for (size_t ofs = 0; ofs < tmp.size();) {
+                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, (left < 32 ? left : 32) + 1);
+                uint8_t lit[4] = {(uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next()};
+                const double v = r.unit();
+                for (uint32_t i = 0; i < run; i++, ofs += c)
+                    for (uint32_t j = 0; j < c; j++) {
+                        if (v > 0.8)
+                            tmp[ofs + j] ^= lit[j];
+                        else if (v > 0.4)
+                            tmp[ofs + j] = lit[j];
+                    }
+            }
+        } else { // sparse random byte damage
+            kind = "random bytes";
+            const double fract = 0.000001 + r.unit() * 0.1;
+            for (auto &b : tmp)
+                if (r.unit() < fract) b = (uint8_t)r.next();
+        }
+        char what[96];
+        snprintf(what, sizeof what, "fuzz trial %u (%s)", trial, kind);
+        if (!encode_checked(tmp.data(), w, h, c, flags, judge, png, what)) return EXIT_FAILURE;
+        if (trial % 50 == 0) printf("%u: %s, %zu bytes ok\n", trial, kind, png.size());
+    }
+    printf("fuzz_test_encoder: %u trials ok%s\n", o.trials, judge ? " (byte-identical to the CPU encoder)" : "");
+    return EXIT_SUCCESS;
+}
+
+// reference fuzz_test_encoder2 (fpng_test.cpp:617-682): random-noise images of random dimensions
+int fuzz_encoder2(uint32_t flags, const Options &o, judge_fn judge)
+{
+    Rng r(1);
+    std::vector<uint8_t> px, png;
+    for (uint32_t trial = 0; trial < o.trials; trial++) {
+        const uint32_t w = r.range(1, o.max_dim + 1), h = r.range(1, o.max_dim + 1), c = (r.next() & 1) ? 4 : 3;
+        px.resize((size_t)w * h * c);
+        uint8_t *p = px.data();
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            const uint32_t v = r.next();
+            *p++ = (uint8_t)v, *p++ = (uint8_t)(v >> 8), *p++ = (uint8_t)(v >> 16);
+            if (c == 4) *p++ = (uint8_t)(v >> 24);
+        }
+        char what[64];
+        snprintf(what, sizeof what, "Testing %ux%u %u", w, h, c);
+        if (!encode_checked(px.data(), w, h, c, flags, judge, png, what)) return EXIT_FAILURE;
+        printf("%s: fpng size %zu\n", what, png.size());
+    }
+    printf("fuzz_test_encoder2: %u trials ok%s\n", o.trials, judge ? " (byte-identical to the CPU encoder)" : "");
+    return EXIT_SUCCESS;
+}
+
+// N frames per call: host batch (PCIe inclusive, overlapped) and device-resident submissions (kernel-only)
+void batch_rates(const std::vector<uint8_t> &px, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, uint32_t n, double &host_s, double &dev_s)
+{
+    host_s = dev_s = -1;
+    fpng_amd_encoder *enc = nullptr;
+    if (fpng_amd_encoder_create(&enc, -1, nullptr)) return;
+    const size_t cap = fpng_amd_max_encoded_size(w, h, c) + 64;
+    std::vector<std::vector<uint8_t>> outs(n, std::vector<uint8_t>(cap));
+    std::vector<size_t> sizes(n);
+    std::vector<fpng_amd_host_image> hi(n);
+    for (uint32_t i = 0; i < n; i++) {
+        memset(&hi[i], 0, sizeof hi[i]);
+        hi[i].pixels = px.data(), hi[i].w = w, hi[i].h = h, hi[i].num_chans = c;
+        hi[i].out = outs[i].data(), hi[i].out_cap = cap, hi[i].out_size = &sizes[i];
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        const double t0 = now();
+        if (fpng_amd_encode_host_batch(enc, hi.data(), n, flags, 0)) break;
+        const double t = (now() - t0) / n;
+        host_s = (host_s < 0 || t < host_s) ? t : host_s;
+    }
+    // device-resident: n copies of the frame, one submission per timing
+    std::vector<void *> d_in(n), d_out(n);
+    std::vector<fpng_amd_image> im(n);
+    bool ok = true;
+    for (uint32_t i = 0; i < n && ok; i++) {
+        ok = hipMalloc(&d_in[i], px.size()) == hipSuccess && hipMalloc(&d_out[i], cap) == hipSuccess &&
+             hipMemcpy(d_in[i], px.data(), px.size(), hipMemcpyHostToDevice) == hipSuccess;
+        im[i].d_pixels = d_in[i], im[i].w = w, im[i].h = h, im[i].num_chans = c, im[i].d_out = (uint8_t *)d_out[i], im[i].out_cap = cap;
+    }
+    for (int rep = 0; rep < 12 && ok; rep++) {
+        const double t0 = now();
+        if (fpng_amd_encode_batch_async(enc, im.data(), n, flags) || fpng_amd_encode_finish(enc, nullptr, 0)) break;
+        const double t = (now() - t0) / n;
+        if (rep >= 2) dev_s = (dev_s < 0 || t < dev_s) ? t : dev_s;
+    }
+    for (uint32_t i = 0; i < n; i++) (void)hipFree(d_in[i]), (void)hipFree(d_out[i]);
+    fpng_amd_encoder_destroy(enc);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strcmp(a, "--judge") && i + 1 < argc)
+            o.judge_path = argv[++i];
+        else if (a[0] == '-' && a[1] && !a[2]) {
+            switch (a[1]) {
+            case 's': o.slower = true; break;
+            case 'u': o.uncompressed = true; break;
+            case 'c': o.csv = true; break;
+            case 'e': o.fuzz = true; break;
+            case 'E': o.fuzz2 = true; break;
+            case 'n': o.trials = (uint32_t)atoi(argv[++i]); break;
+            case 'm': o.max_dim = (uint32_t)atoi(argv[++i]); break;
+            case 'b': o.batch = (uint32_t)atoi(argv[++i]); break;
+            case 'p': o.cpu_threads = (uint32_t)atoi(argv[++i]); break;
+            case 'o': o.out = argv[++i]; break;
+            default: fprintf(stderr, "Unrecognized option: %s\n", a); return EXIT_FAILURE;
+            }
+        } else
+            o.input = a;
+    }
+    if (!o.input && !o.fuzz2) {
+        printf("Usage: fpng_amd_test [-s] [-u] [-c] [-e] [-E] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
+               "[--judge cpu_encoder.so] <synth:kind:WxHxC[:seed] | file written by fpng>\n");
+        return EXIT_FAILURE;
+    }
+    fpng::fpng_init();
+    if (!fpng::fpng_cpu_supports_sse41()) { // (the drop-in answers "is the MI355X path usable")
+        fprintf(stderr, "no usable GPU: fpng_amd has no CPU path\n");
+        return EXIT_FAILURE;
+    }
+    judge_fn judge = nullptr;
+    if (o.judge_path) {
+        void *lib = dlopen(o.judge_path, RTLD_NOW);
+        if (lib) {
+            if (void (*init)() = (void (*)())dlsym(lib, "ref_init")) init();
+            judge = (judge_fn)dlsym(lib, "ref_encode");
+            if (!judge) judge = (judge_fn)dlsym(lib, "fpo_encode");
+        }
+        if (!judge) {
+            fprintf(stderr, "cannot use %s as judge: %s\n", o.judge_path, dlerror());
+            return EXIT_FAILURE;
+        }
+    }
+    const uint32_t flags = (o.slower ? fpng::FPNG_ENCODE_SLOWER : 0) | (o.uncompressed ? fpng::FPNG_FORCE_UNCOMPRESSED : 0);
+    if (o.fuzz2) return fuzz_encoder2(flags, o, judge);
+
+    std::vector<uint8_t> px;
+    uint32_t w = 0, h = 0, c = 0;
+    if (!load_input(o.input, px, w, h, c)) {
+        fprintf(stderr, "Failed loading %s\n", o.input);
+        return EXIT_FAILURE;
+    }
+    if (!o.csv) printf("Dimensions: %ux%u, %u channels, total pixels: %llu\n", w, h, c, (unsigned long long)w * h);
+    if (o.fuzz) return fuzz_encoder(px, w, h, c, flags, o, judge);
+
+    // ---- encode: best of 3, one reused vector (reference fpng_test.cpp:1181-1209) ----
+    std::vector<uint8_t> png;
+    double enc_s = 1e9;
+    for (int i = 0; i < 3; i++) {
+        const double t0 = now();
+        if (!fpng::fpng_encode_image_to_memory(px.data(), w, h, c, png, flags)) {
+            fprintf(stderr, "fpng_encode_image_to_memory() failed!\n");
+            return EXIT_FAILURE;
+        }
+        enc_s = std::min(enc_s, now() - t0);
+    }
+    if (!encode_checked(px.data(), w, h, c, flags, judge, png, "verification")) return EXIT_FAILURE;
+    if (FILE *f = fopen(o.out, "wb")) {
+        fwrite(png.data(), 1, png.size(), f);
+        fclose(f);
+    }
+    // ---- decode: best of 5 (reference fpng_test.cpp:1182, :1236-1262) ----
+    std::vector<uint8_t> dec;
+    double dec_s = 1e9;
+    for (int i = 0; i < 5; i++) {
+        uint32_t dw, dh, dc;
+        const double t0 = now();
+        if (fpng::fpng_decode_memory(png.data(), (uint32_t)png.size(), dec, dw, dh, dc, c) != fpng::FPNG_DECODE_SUCCESS) return EXIT_FAILURE;
+        dec_s = std::min(dec_s, now() - t0);
+    }
+    double host_batch_s = -1, dev_s = -1;
+    if (o.batch) batch_rates(px, w, h, c, flags, o.batch, host_batch_s, dev_s);
+    // ---- CPU baseline through the judge library: N threads, one image each ----
+    double cpu1_s = -1, cpuN_s = -1;
+    if (judge && o.cpu_threads) {
+        auto run = [&](uint32_t threads) {
+            std::vector<std::thread> ts;
+            std::vector<double> best(threads, 1e9);
+            for (uint32_t t = 0; t < threads; t++)
+                ts.emplace_back([&, t] {
+                    std::vector<uint8_t> out(fpng_amd_max_encoded_size(w, h, c) + 64);
+                    size_t n = 0;
+                    for (int rep = 0; rep < 3; rep++) {
+                        const double t0 = now();
+                        judge(px.data(), w, h, c, flags, out.data(), out.size(), &n);
+                        best[t] = std::min(best[t], now() - t0);
+                    }
+                });
+            for (auto &t : ts) t.join();
+            double worst = 0;
+            for (double b : best) worst = std::max(worst, b);
+            return worst;
+        };
+        cpu1_s = run(1);
+        cpuN_s = run(o.cpu_threads) / o.cpu_threads; // seconds per image with all threads busy
+    }
+    const double mip = (double)w * h / (1024.0 * 1024.0), mp = (double)w * h / 1e6;
+    if (o.csv) {
+        // file, w, h, chans, fpng: encode s, size MiB, decode s, encode MiP/s, decode MiP/s (the reference's fpng columns), then
+        // encode MP/s (10^6), host-batch s/frame, device-resident s/frame, CPU 1-thread s, CPU N-thread s/image
+        printf("%s, %u, %u, %u,    %f, %f, %f, %4.3f, %4.3f,    %4.3f, %f, %f, %f, %f\n", o.input, w, h, c, enc_s, png.size() / (1024.0 * 1024.0),
+               dec_s, mip / enc_s, mip / dec_s, mp / enc_s, host_batch_s, dev_s, cpu1_s, cpuN_s);
+        return EXIT_SUCCESS;
+    }
+    printf("** Encoding:\nFPNG (MI355X, drop-in, PCIe inclusive): %4.6f secs, %zu bytes, %4.3f MB, %4.3f MiP/sec (%4.3f MP/sec)\n", enc_s, png.size(),
+           png.size() / (1024.0 * 1024.0), mip / enc_s, mp / enc_s);
+    if (host_batch_s > 0) printf("  %u frames per call, copies overlapped:   %4.6f secs/frame, %4.3f MP/sec\n", o.batch, host_batch_s, mp / host_batch_s);
+    if (dev_s > 0) printf("  %u device-resident frames per submission: %4.6f secs/frame, %4.3f MP/sec\n", o.batch, dev_s, mp / dev_s);
+    if (cpu1_s > 0)
+        printf("CPU encoder (%s): 1 thread %4.6f secs (%4.3f MP/sec); %u threads, one image each: %4.3f MP/sec in total\n", o.judge_path, cpu1_s,
+               mp / cpu1_s, o.cpu_threads, mp / cpuN_s);
+    printf("** Decoding:\nFPNG (CPU): %3.6f secs, %4.3f MiP/sec\n", dec_s, mip / dec_s);
+    printf("Wrote %s; decode verified%s\n", o.out, judge ? "; bytes identical to the CPU encoder's" : "");
+    return EXIT_SUCCESS;
+}

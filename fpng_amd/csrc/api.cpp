@@ -619,13 +619,13 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     const DeviceTables &dt = g_dev[e->device];
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
-    // Pipelines.  fused (default): encode_image_kernel, one persistent launch that reads every pixel once and writes
-    // every stream byte once.  rows: encode_rows -> scan -> assemble (rows into scratch streams, shifted into place
-    // by a second kernel).  count: count -> scan -> emit -> crc (two walks, no scratch; what the row bands use).
+    // Pipelines.  rows (default): encode_rows -> scan -> assemble: every row into its own scratch stream, shifted into
+    // place by a second kernel that also takes the CRC.  fused (FPNG_AMD_PIPELINE=fused, and the fallback when the scratch
+    // streams do not fit): encode_image_kernel, one persistent launch that places the rows straight from LDS.
     static const int forced = [] {
         const char *v = getenv("FPNG_AMD_PIPELINE");
         if (!v) return -1;
-        return !strcmp(v, "fused") ? 0 : (!strcmp(v, "rows") ? 1 : (!strcmp(v, "count") ? 2 : -1));
+        return !strcmp(v, "fused") ? 0 : (!strcmp(v, "rows") ? 1 : -1);
     }();
     static const uint64_t local_limit = [] {
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
@@ -693,15 +693,6 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
         if ((rc = mark(e, s, 3))) return rc;
         launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-        if ((rc = mark(e, s, 4))) return rc;
-    } else {
-        if (!force_stored) launch_count(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p);
-        if ((rc = mark(e, s, 1))) return rc;
-        launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
-        if ((rc = mark(e, s, 2))) return rc;
-        launch_emit(s, sc.d_jobs.p, n, sub.max_rows, sc.d_row_off.p, sc.d_rows.p, sc.d_states.p);
-        if ((rc = mark(e, s, 3))) return rc;
-        launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
         if ((rc = mark(e, s, 4))) return rc;
     }
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
@@ -772,7 +763,7 @@ int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    static const char *names[3] = {"encode_image,stored,crc,finalize", "encode_rows,scan,stored,assemble,finalize", "count,scan,emit,crc,finalize"};
+    static const char *names[2] = {"encode_image,stored,crc,finalize", "encode_rows,scan,stored,assemble,finalize"};
     return names[e ? e->pipeline : 0];
 }
 

@@ -97,11 +97,8 @@ struct CrcDeviceTables {
 };
 void build_crc_device_tables(CrcDeviceTables *t);
 
-void launch_count(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states);
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
-void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
-                 const JobState *states);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);

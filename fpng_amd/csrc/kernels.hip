@@ -225,14 +225,6 @@ template <int C> __device__ __forceinline__ uint64_t packed_literal_token(const 
     return (uint64_t)lo | ((uint64_t)hi << s01);
 }
 
-template <int C> __device__ __forceinline__ uint32_t packed_literal_bits(const PackedTables &T, uint32_t f)
-{
-    // the four codes (16 bits each) cannot carry into bit 24: the top byte of the sum is the sum of the lengths
-    uint32_t s = T.lit[f & 0xFF] + T.lit[(f >> 8) & 0xFF] + T.lit[(f >> 16) & 0xFF];
-    if (C == 4) s += T.lit[f >> 24];
-    return s >> 24;
-}
-
 // ---- pixel windows through buffer resources: out-of-range lanes read 0, no exec masking ----
 // The descriptor must live in SGPRs; whenever the compiler cannot prove base/size wave-uniform it wraps
 // EVERY load through it in a waterfall loop (cdna_hip_programming.md T20), so force them uniform here.
@@ -332,19 +324,16 @@ __device__ __forceinline__ uint64_t valid_mask(uint32_t x0, uint32_t limit)
 //   * table entries are packed so that code lengths add up in the low byte and an entry can be used
 //     directly as a shift amount.
 // ---------------------------------------------------------------------------------------------
-// Count: token lengths + Adler sums of a row.  Hist: symbol histogram (2-pass).  Emit: tokens at their final
-// bit position (row bands).  Encode: tokens into the row's private scratch stream AND the sums of Count, so
-// that a whole image needs one walk over its pixels.
-enum class Pass { Count, Hist, Emit, Encode };
+// Hist: symbol histogram (2-pass, pass 1).  Encode: tokens into the wave's private stream (a row's scratch stream or a
+// segment's LDS window) together with the row's bit count and Adler sums, so that an image needs one walk over its pixels.
+enum class Pass { Hist, Encode };
 
 struct EmitSink {
     uint32_t *stage;     // this wave's LDS window
     gptr_u32 out32;      // dword view of the destination (bit 0 of dword 0 = destination bit 0)
     uint64_t base_dw;    // destination dword index of stage[0]
     uint32_t fill;       // bits used in the window
-    bool first_flush;
-    bool exclusive;      // the destination belongs to this row alone (local stream): no shared dwords
-    bool wide;           // exclusive and flushed 16 bytes per lane (sink_flush_exclusive)
+    bool wide;           // flushed 16 bytes per lane (sink_flush_exclusive)
 };
 
 __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t ndw)
@@ -380,11 +369,9 @@ __device__ __forceinline__ void sink_put_wide(EmitSink &s, uint64_t code, uint32
     atomicOr(&s.stage[d + 2], (uint32_t)((code >> 1) >> (63 - sh)));
 }
 
-// Write out the complete dwords of the window (all of them when `final`), keep the partial one.
-// The first and the last dword of a row's span may be shared with the neighbouring rows (or with
-// header bytes): those two are OR-merged into memory that scan_kernel zeroed; everything in
-// between belongs to this row alone and is stored plainly, 256 B per wave store.
-// Local streams (exclusive destination): 16 bytes per lane per step -- ds_read_b128, global_store_dwordx4 and the
+// Write out the complete dwords of the window (all of them when `final`), keep the partial one.  The destination is
+// the wave's own stream (a row's local stream, a segment's spill area): plain coalesced stores.
+// 4-channel local streams: 16 bytes per lane per step -- ds_read_b128, global_store_dwordx4 and the
 // re-zeroing ds_write_b128 move four dwords where the generic path below moves one.  Only multiples of four dwords
 // leave the window, so the destination stays 16-byte aligned; the final flush rounds up into the row's slack.
 __device__ __forceinline__ void sink_flush_exclusive(EmitSink &s, uint32_t lane, bool final)
@@ -422,17 +409,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
     wave_lds_fence();
     const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5);
 #pragma unroll 1
-    for (uint32_t j = lane; j < ndw; j += kWave) {
-        const uint32_t v = s.stage[j];
-        gptr_u32 dst = s.out32 + s.base_dw + j;
-        // the last dword is shared only when the row ends inside it (then it holds the next row's
-        // first bit, or the job's end, both of which scan_kernel zeroed)
-        const bool shared = !s.exclusive && ((j == 0 && s.first_flush) || (final && j == ndw - 1 && (s.fill & 31u)));
-        if (shared) {
-            if (v) __hip_atomic_fetch_or(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else
-            *dst = v;
-    }
+    for (uint32_t j = lane; j < ndw; j += kWave) s.out32[s.base_dw + j] = s.stage[j];
     if (!final) {
         const uint32_t rem = s.stage[ndw]; // partial dword, uniform address
         wave_lds_fence();
@@ -441,7 +418,6 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
         if (lane == 0) s.stage[0] = rem;
         s.base_dw += ndw;
         s.fill &= 31;
-        s.first_flush = s.first_flush && (ndw == 0);
         wave_lds_fence();
     }
 }
@@ -466,15 +442,15 @@ struct RowResult {
 // xe = w or a multiple of 256 below w).  Segments of a row are independent units of work: the only state that crosses
 // a segment boundary is the pixel before it and the length (mod CAP) of the run that ends there, and both are
 // recovered from the pixels in front of the segment.
-template <int C, Pass PASS>
+// WHOLE: the caller walks complete rows (xb = 0, xe = w known at compile time: the segment logic folds away).
+template <int C, Pass PASS, bool WHOLE = true>
 __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t xb,
                                               uint32_t xe, uint32_t lane, EmitSink *sink)
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
-    constexpr bool kEmit = PASS == Pass::Emit || PASS == Pass::Encode;  // builds and stages the token bits
-    constexpr bool kCount = PASS == Pass::Count;                        // token lengths only
-    constexpr bool kSums = PASS == Pass::Count || PASS == Pass::Encode; // Adler sums, final flush unit
+    constexpr bool kEmit = PASS == Pass::Encode; // builds and stages the token bits
+    constexpr bool kSums = PASS == Pass::Encode; // Adler sums, final flush unit
     const uint32_t w = uniform(job.w), bpl = uniform(job.bpl);
     const uint8_t *row = job.rows + (size_t)r * bpl;
     const bool filter_up = (uniform(job.y0) + r) != 0;
@@ -485,7 +461,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     const uint64_t lane_le_mask = (2ull << lane) - 1ull;
     const uint32_t nwin = (w + 63) >> 6;
     const uint32_t n_interior = (w >= 128) ? (w >> 6) - 1 : 0; // windows k with (k+2)*64 <= w
-    const bool first_seg = xb == 0, last_seg = xe == w;
+    if (WHOLE) xb = 0;
+    const bool first_seg = WHOLE || xb == 0, last_seg = WHOLE || xe == w;
     const uint32_t nwin_end = last_seg ? nwin : (xe >> 6);     // windows [xb/64, nwin_end) belong to this segment
 
     RowWindows<C> px;
@@ -558,8 +535,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             // no pixel of this window repeats its left neighbour: every lane is a literal pixel
             if (kEmit)
                 code = packed_literal_token<C>(T, f_cur, nbits);
-            else if (kCount)
-                nbits = packed_literal_bits<C>(T, f_cur);
             else if (valid) {
                 hist_add(hist, f_cur & 0xFF, lane);
                 hist_add(hist, (f_cur >> 8) & 0xFF, lane);
@@ -585,10 +560,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     if (C == 4) hist_add(hist, f_cur >> 24, lane);
                 }
             } else {
-                if (kEmit)
-                    code = packed_literal_token<C>(T, f_cur, nbits);
-                else
-                    nbits = packed_literal_bits<C>(T, f_cur);
+                code = packed_literal_token<C>(T, f_cur, nbits);
                 const uint32_t c1_bits = chunk1 & 0xFF;
                 if (same && !(lit_test && c1_bits > nbits)) {
                     nbits = c1_bits;
@@ -612,8 +584,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     code = ce >> 8;
                     if (lit_test && q == 1) { // a 1-pixel chunk can only be the run's last pixel here
                         uint32_t lbits = 0;
-                        const uint64_t lcode = kEmit ? packed_literal_token<C>(T, f_cur, lbits) : 0ull;
-                        if (kCount) lbits = packed_literal_bits<C>(T, f_cur);
+                        const uint64_t lcode = packed_literal_token<C>(T, f_cur, lbits);
                         if (nbits > lbits) {
                             nbits = lbits;
                             code = lcode;
@@ -637,12 +608,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             } else {
                 uint32_t lbits = 0;
                 uint64_t lcode = 0;
-                if (!same || (lit_test && ends && q == 1)) {
-                    if (kEmit)
-                        lcode = packed_literal_token<C>(T, f_cur, lbits);
-                    else
-                        lbits = packed_literal_bits<C>(T, f_cur);
-                }
+                if (!same || (lit_test && ends && q == 1)) lcode = packed_literal_token<C>(T, f_cur, lbits);
                 bool as_lits = !same;
                 if (ends) {
                     const uint32_t ce = T.chunk[q];
@@ -665,7 +631,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             // size of the final flush unit of the row = token of its last pixel (scan_kernel's failure rule)
             if (PASS != Pass::Hist && x0 + 64 >= w) last_unit = (uint32_t)__builtin_amdgcn_readlane((int)nbits, (w - 1) & 63);
         }
-        if (kCount) row_bits += nbits; // per lane, reduced after the loop
         if (kSums) {
             // Adler-32 partial sums (reference fpng.cpp:407-487 computes the same quantity serially).  Lanes
             // past the row end read 0 (RGBA) or are masked (RGB shares an aligned dword with real bytes).
@@ -802,18 +767,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                 }
                             }
                         } else {
-                          if (kCount) {
-                            uint32_t n[4];
-#pragma unroll
-                            for (int j = 0; j < 4; j++) n[j] = packed_literal_bits<C>(T, f[j]);
-                            if (sparse) { // repeats are rare: only the pixel slots that have one are touched (uniform tests)
-                                if (M0 && s0 && !(lit_test && c1_bits > n[0])) n[0] = c1_bits;
-                                if (M1 && s1 && !(lit_test && c1_bits > n[1])) n[1] = c1_bits;
-                                if (M2 && s2 && !(lit_test && c1_bits > n[2])) n[2] = c1_bits;
-                                if (M3 && s3 && !(lit_test && c1_bits > n[3])) n[3] = c1_bits;
-                            }
-                            row_bits += n[0] + n[1] + n[2] + n[3];
-                          }
                           if (kSums) {
                             // Adler: 4*C consecutive bytes per lane
                             constexpr uint32_t kOffs[4] = {0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu};
@@ -925,7 +878,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.s1 = res.s2 = 0;
     if (kSums) {
         const uint32_t fl_bits = first_seg ? plit_len(fl) : 0u;
-        res.bits = (kCount ? wave_sum(row_bits) : row_bits) + fl_bits;
+        res.bits = row_bits + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
         res.last_unit_bits = last_unit + ((C == 3 && one_pass && w == 1) ? fl_bits : 0u);
@@ -936,38 +889,11 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         const uint32_t fb = first_seg ? filter_byte : 0u;
         res.s1 = (wave_sum(la) + fb) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * fb) % kAdlerMod;
-    } else if (kEmit) {
-        res.bits = row_bits;
     }
     return res;
 }
 
 __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return jobs[blockIdx.y]; }
-
-// ---------------------------------------------------------------------------------------------
-// count_kernel: grid (ceil(max_rows/4), n_jobs), block 256 = 4 rows
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void count_kernel(const Job *jobs, RowInfo *rows_out, JobState *states)
-{
-    __shared__ PackedTables T;
-    const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kRowWaves >= job.nrows) return;
-    stage_packed_tables(T, job.table);
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + uniform(threadIdx.x >> 6);
-    if (r >= job.nrows) return;
-    RowResult res = (job.c == 4) ? walk_row<4, Pass::Count>(job, T, nullptr, r, 0u, job.w, lane, nullptr)
-                                 : walk_row<3, Pass::Count>(job, T, nullptr, r, 0u, job.w, lane, nullptr);
-    if (lane == 0) {
-        RowInfo ri;
-        ri.bits = res.bits;
-        ri.s1 = res.s1;
-        ri.s2 = res.s2;
-        ri.pad = 0;
-        rows_out[job.row_base + r] = ri;
-        if (r == job.nrows - 1) states[blockIdx.y].last_unit_bits = res.last_unit_bits;
-    }
-}
 
 // hist_kernel (2-pass, pass 1): literal / length-symbol histogram of the whole image
 // (reference fpng.cpp:1021-1084 / :1299-1363).  job.table here is the "symbol" table whose
@@ -1114,56 +1040,27 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
         while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
         st.range_log2 = rl;
     }
-    // band count (multi-GPU phase 1) stops here; whole images and band emits prepare the output window
+    // a band's counting phase stops here; whole images and band placements prepare the head of the output
     if (!job.whole_png && !(job.flags & 0x100u)) return;
 
-    // --- zero the seam dwords, then write PNG header + Deflate prefix ---
-    // (flag 0x200: the rows sit in local streams and assemble_kernel places them; it wants the head followed
-    // by zeros up to the next 16-byte boundary and needs no zeroed seams)
-    const bool assemble = (job.flags & 0x200u) != 0;
-    gptr_u32 out32 = to_global<gptr_u32>(job.out);
-    const int64_t bias = job.bit_bias;
-    if (!stored && !assemble) {
-        for (uint32_t r = t; r < job.nrows; r += kBlock) {
-            const uint64_t o = row_off[job.row_base + r] + bias;
-            out32[o >> 5] = 0; // dword holding the first bit of row r (and the last bits of row r-1)
-        }
-        if (t == 0) {
-            // last bit written by this job: after EOB + byte padding for the final band
-            const uint64_t end_bit = (job.is_last ? ((s_last + eob_len + 7) & ~7ull) : s_last) + bias;
-            out32[(end_bit - 1) >> 5] = 0;
-            if (job.is_last) out32[(s_last + bias) >> 5] = 0;
-        }
-    }
-    __threadfence_block();
+    // --- PNG header + Deflate block header; assemble_kernel, which places the rows, wants the head followed by zeros
+    //     up to the next 16-byte boundary ---
     __syncthreads();
     gptr_u8 out = to_global<gptr_u8>(job.out);
     if (job.whole_png)
         for (uint32_t i = t; i < kPngHeaderBytes; i += kBlock) out[i] = job.png_header[i];
-    gptr_u8 zl = out + (bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
+    gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
     if (!stored && job.is_first) {
-        // whole prefix bytes; the pending tail bits are OR-ed into the (zeroed) seam byte below
-        const uint32_t whole = tab->header_bits >> 3;
-        for (uint32_t i = t; i < whole; i += kBlock) zl[i] = tab->header[i];
-    }
-    __syncthreads();
-    if (t == 0) {
-        if (job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
-        if (!stored && job.is_first && (tab->header_bits & 7)) {
-            if (assemble)
-                zl[tab->header_bits >> 3] = tab->header[tab->header_bits >> 3];
-            else
-                zl[tab->header_bits >> 3] |= tab->header[tab->header_bits >> 3];
-        }
-    }
-    if (assemble && !stored && job.is_first) {
-        const uint32_t head_end = kPngHeaderBytes + ((tab->header_bits + 7) >> 3);
+        const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
+        for (uint32_t i = t; i < head_bytes; i += kBlock) zl[i] = tab->header[i];
+        const uint32_t head_end = kPngHeaderBytes + head_bytes;
         for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
     }
+    if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
 // ---------------------------------------------------------------------------------------------
-// emit_kernel: grid (ceil(max_rows/4), n_jobs)
+// Stored-block fallback
 // ---------------------------------------------------------------------------------------------
 // Stored-block fallback, one row per wave (reference fpng.cpp:818-866 over the filter-0 stream,
 // :1728-1758).  Stream byte s of the filter-0 image sits at zlib offset 2 + 5*(s/65535+1) + s.
@@ -1247,50 +1144,6 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
     }
 }
 
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80))) void emit_kernel(const Job *jobs, const uint64_t *row_off, RowInfo *rows_io,
-                                                     const JobState *states)
-{
-    __shared__ PackedTables T;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
-    const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kRowWaves >= job.nrows) return;
-    const JobState &st = states[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = blockIdx.x * kRowWaves + wv;
-    if (st.mode == 1u) {
-        if (r < job.nrows) stored_row(job, r, lane, rows_io);
-        return;
-    }
-    stage_packed_tables(T, job.table);
-    __syncthreads();
-    if (r >= job.nrows) return;
-
-    EmitSink sink;
-    sink.stage = stage[wv];
-    sink.out32 = to_global<gptr_u32>(job.out);
-    const uint64_t off = row_off[job.row_base + r] + job.bit_bias;
-    sink.base_dw = off >> 5;
-    sink.fill = (uint32_t)(off & 31);
-    sink.first_flush = true;
-    sink.exclusive = false;
-    sink.wide = false;
-    sink_zero(sink, lane, kStageDwords);
-    wave_lds_fence();
-
-    if (job.c == 4)
-        walk_row<4, Pass::Emit>(job, T, nullptr, r, 0u, job.w, lane, &sink);
-    else
-        walk_row<3, Pass::Emit>(job, T, nullptr, r, 0u, job.w, lane, &sink);
-
-    if (r == job.nrows - 1 && job.is_last) {
-        // end of block symbol; zero bits up to the byte boundary follow implicitly
-        // (reference fpng.cpp:1564-1567)
-        const uint32_t eob = T.lit[256];
-        sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
-        sink.fill += plit_len(eob);
-    }
-    sink_flush(sink, lane, true);
-}
-
 // ---------------------------------------------------------------------------------------------
 // encode_rows_kernel: grid (ceil(max_rows/8), n_jobs).  ONE walk over the pixels of a whole image: each wave
 // encodes its row into the row's private, dword-aligned local stream (plain coalesced stores, nothing is
@@ -1330,8 +1183,6 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     const uint32_t zero = uniform(job.local_pad);
     sink.base_dw = zero;
     sink.fill = zero;
-    sink.first_flush = false;
-    sink.exclusive = true;
     sink.wide = (C == 4); // the 3-channel walk has no registers to spare for the 16-byte flush (it would drop to 7 waves/SIMD)
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
@@ -1491,7 +1342,7 @@ __device__ __forceinline__ RowResult encode_segment(const Job &job, const Packed
     const uint32_t S = uniform(job.segs_per_row), seg_px = uniform(job.seg_px), w = uniform(job.w);
     const uint32_t r = g / S, si = g - r * S;
     const uint32_t xb = si * seg_px, xe = (xb + seg_px < w) ? xb + seg_px : w;
-    RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, xb, xe, lane, &sink);
+    RowResult res = walk_row<C, Pass::Encode, false>(job, T, nullptr, r, xb, xe, lane, &sink);
     image_end = (r == uniform(job.nrows) - 1) && xe == w;
     // image-level Adler weights: every byte of row r is followed by the later rows (see scan_kernel)
     const uint32_t n_row_mod = (uniform(job.bpl) + 1u) % kAdlerMod;
@@ -1611,8 +1462,6 @@ __global__ __launch_bounds__(kFusedBlock) __attribute__((amdgpu_num_sgpr(80), am
                 const uint32_t zero = uniform(job.local_pad); // (a zero the compiler cannot see, see encode_rows_kernel)
                 sink.base_dw = zero;
                 sink.fill = zero;
-                sink.first_flush = false;
-                sink.exclusive = true;
                 sink.wide = false;
                 sink_zero(sink, lane, kStageDwords);
                 wave_lds_fence();
@@ -2581,10 +2430,6 @@ static dim3 row_grid(uint32_t max_rows, uint32_t n_jobs)
     return dim3((max_rows + kRowWaves - 1) / kRowWaves, n_jobs, 1);
 }
 
-void launch_count(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, JobState *states)
-{
-    hipLaunchKernelGGL(count_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
-}
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist)
 {
     hipLaunchKernelGGL(hist_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, hist);
@@ -2592,11 +2437,6 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
     hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, row_off, states);
-}
-void launch_emit(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, const uint64_t *row_off, RowInfo *rows,
-                 const JobState *states)
-{
-    hipLaunchKernelGGL(emit_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, row_off, rows, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {

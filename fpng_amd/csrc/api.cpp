@@ -212,6 +212,7 @@ struct fpng_amd_encoder {
         DeviceBuf<uint32_t> d_hist;
         DeviceBuf<TokenTable> d_dyn;
         DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
+        DeviceBuf<uint32_t> d_arrivals; // rows pipeline: two self-resetting arrival counters per job
         // fused pipeline (encode_image_kernel)
         DeviceBuf<uint64_t> d_unit_state, d_unit_adler;
         DeviceBuf<uint32_t> d_ctrl;       // [2 x 8 x 32] queue heads of the two channel classes, then job_done[n]
@@ -221,7 +222,7 @@ struct fpng_amd_encoder {
         void release()
         {
             d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
-            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
+            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release(), d_arrivals.release();
             d_unit_state.release(), d_unit_adler.release(), d_ctrl.release(), d_chunk_base.release(), d_spill.release();
         }
     };
@@ -557,6 +558,7 @@ int launch_fused(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         sc.epoch = 0;
     }
     HIP_TRY(hipMemsetAsync(sc.d_ctrl.p, 0, (kCtrlQueueWords + (size_t)n) * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, (size_t)n * sizeof(JobState), s)); // (status: set only when a look-back gives up)
     HIP_TRY(hipMemcpyAsync(sc.d_chunk_base.p, slot.chunk_base.p, 2 * ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     for (uint32_t cls = 0; cls < 2; cls++) {
         if (!sub.total_chunks[cls]) continue;
@@ -684,22 +686,32 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
         if ((rc = mark(e, s, 3))) return rc;
     } else if (pipeline == 1) {
-        if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+        // three launches: rows (+ the row scan by whoever finishes an image), stored fallback, assemble (+ CRC fold, trailer
+        // and result record by whoever finishes an image)
+        if ((rc = sc.d_arrivals.ensure(2 * (size_t)n))) return rc;
+        if (sc.d_arrivals.fresh) {
+            HIP_TRY(hipMemsetAsync(sc.d_arrivals.p, 0, sc.d_arrivals.cap * sizeof(uint32_t), s));
+            sc.d_arrivals.fresh = false;
+        }
+        if (force_stored)
+            launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // (no rows are encoded: sizes and header only)
+        else
+            launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_row_off.p, sc.d_arrivals.p);
         if ((rc = mark(e, s, 1))) return rc;
         HIP_TRY(hipEventRecord(slot.walked, s));
         e->prev_walked = slot.walked;
-        launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
-        if ((rc = mark(e, s, 2))) return rc;
         launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+        if ((rc = mark(e, s, 2))) return rc;
+        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, sc.d_rows.p,
+                        slot.results.p, sc.d_arrivals.p);
         if ((rc = mark(e, s, 3))) return rc;
-        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-        if ((rc = mark(e, s, 4))) return rc;
     }
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
-    launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p,
-                    slot.results.p);
-    if ((rc = mark(e, s, pipeline == 0 ? 4 : 5))) return rc;
+    if (pipeline == 0) {
+        launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
+        if ((rc = mark(e, s, 4))) return rc;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, s));
     slot.in_flight = true;
@@ -763,7 +775,7 @@ int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    static const char *names[2] = {"encode_image,stored,crc,finalize", "encode_rows,scan,stored,assemble,finalize"};
+    static const char *names[2] = {"encode_image,stored,crc,finalize", "encode_rows,stored,assemble"};
     return names[e ? e->pipeline : 0];
 }
 
@@ -1086,7 +1098,7 @@ int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t f
         launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p);
     }
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_row_off.p, nullptr);
     launch_scan(s, sc.d_jobs.p, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // band count: sums only
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_states.p, sc.d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
@@ -1147,7 +1159,7 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
     HIP_TRY(hipEventRecord(e->band_copied[3], s));
     launch_scan(s, sc.d_jobs.p + 3, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // absolute row offsets, stream head
     launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks << 4, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
-                    sc.d_partials.p);
+                    sc.d_partials.p, sc.d_rows.p, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     return FPNG_AMD_OK;
 }

@@ -100,12 +100,16 @@ void build_crc_device_tables(CrcDeviceTables *t);
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
+// whole images (Job::whole_png): the wave that finishes an image's last row block also does its row scan (scan_kernel's
+// work).  arrivals: two zeroed counters per job, [2j] row blocks, [2j+1] assemble ranges; both reset themselves.
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
-                        JobState *states, uint32_t *local);
+                        JobState *states, uint32_t *local, uint64_t *row_off, uint32_t *arrivals);
 // one launch per channel count present in the batch (args.chunk_base / tickets of that kind)
 void launch_encode_image(hipStream_t s, uint32_t num_chans, const FusedArgs &args, uint32_t n_blocks);
-void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials);
+// whole images: the block that completes an image's last range also does finalize_kernel's work (results[j])
+void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
+                     const RowInfo *rows, Result *results, uint32_t *arrivals);
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,

@@ -924,24 +924,34 @@ __global__ __launch_bounds__(kRowBlock) void hist_kernel(const Job *jobs, uint32
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// scan_kernel: one block per job
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *scratch, uint64_t &total)
+// Words that one workgroup writes and another one reads INSIDE a launch: 8-byte granules, agent-scope relaxed atomics
+// (write-through stores, L1-bypassing loads; cdna_hip_programming.md Guideline 16, R2).
+typedef FPNG_GLOBAL uint64_t *gptr_u64;
+#define FPNG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
 {
-    // scratch: kBlock entries; simple Hillis-Steele in LDS (called O(rows/256) times per image)
-    const uint32_t t = threadIdx.x;
-    scratch[t] = v;
-    __syncthreads();
-    for (uint32_t o = 1; o < kBlock; o <<= 1) {
-        uint64_t add = (t >= o) ? scratch[t - o] : 0;
-        __syncthreads();
-        scratch[t] += add;
-        __syncthreads();
+    return __hip_atomic_load((gptr_u64)(uintptr_t)p, FPNG_RLX_AGENT);
+}
+__device__ __forceinline__ void granule_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store((gptr_u64)(uintptr_t)p, v, FPNG_RLX_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row scan of one job, done by ONE wave: exclusive scan of the rows' token bits -> absolute bit offset of every row,
+// Adler combine, the reference's compressed-or-stored decision, sizes, head of the output.  Called by the wave that
+// finishes a whole image's last row block inside encode_rows_kernel (the rows' records were written by other
+// workgroups of the same launch: granule loads), and by scan_kernel for the row bands.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_exclusive_sum_u64(uint64_t v, uint32_t lane, uint64_t &total)
+{
+    uint64_t incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, kWave) << 32) | (uint32_t)__shfl_up((int)(uint32_t)incl, o, kWave);
+        if ((int)lane >= o) incl += up;
     }
-    const uint64_t incl = scratch[t];
-    total = scratch[kBlock - 1];
-    __syncthreads();
+    total = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
     return incl - v;
 }
 
@@ -953,88 +963,78 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
     p[3] = (uint8_t)v;
 }
 
-__global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off,
-                                                     JobState *states)
+__device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
+                                              uint32_t lane)
 {
-    __shared__ uint64_t scratch[kBlock];
-    __shared__ uint64_t s_adl[2];
-    const Job &job = jobs[blockIdx.x];
-    JobState &st = states[blockIdx.x];
-    const uint32_t t = threadIdx.x;
     const TokenTable *tab = job.table;
     const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
     const bool force_stored = (job.flags & 2u) != 0;
+    // The rows' records were stored write-through by other workgroups (of this launch, or of an earlier one): ONE
+    // agent-scope acquire drops whatever this CU's L1 holds, after which plain 16-byte loads see them and pipeline.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const FPNG_GLOBAL u32x4 *rg = (const FPNG_GLOBAL u32x4 *)(uintptr_t)(rows + job.row_base); // {bits, s1, s2, -} per row
 
     // --- exclusive scan of row bits (absolute zlib bit positions), Adler combine ---
     const uint64_t first_bit = job.is_first ? tab->first_token_bit : job.start_bit;
-    uint64_t carry = first_bit;
+    uint64_t s_last = first_bit; // zlib bit position after the last token
     uint64_t a_s1 = 0, a_s2 = 0;
     const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
     if (!force_stored) {
-        // every thread owns a contiguous chunk of rows: local sums, ONE block scan of the 256 chunk
-        // totals, then the chunk is walked again to hand out the row offsets
-        const uint32_t per = (job.nrows + kBlock - 1) / kBlock;
-        const uint32_t r0 = t * per, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
+        // every lane owns a contiguous chunk of rows: local sums, one wave scan of the 64 chunk totals, then the chunk is
+        // walked again to hand out the row offsets
+        const uint32_t per = (job.nrows + kWave - 1) / kWave;
+        const uint32_t r0 = lane * per < job.nrows ? lane * per : job.nrows, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
         uint64_t local = 0;
         for (uint32_t r = r0; r < r1; r++) {
-            const RowInfo ri = rows[job.row_base + r];
-            local += ri.bits;
+            const u32x4 ri = rg[r];
+            const uint32_t s1 = ri.y, s2 = ri.z;
+            local += ri.x;
             // S2 of the concatenation: every byte of this row is followed by the later rows
             const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
-            a_s1 += ri.s1;
-            a_s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
+            a_s1 += s1;
+            a_s2 += (s2 + after * s1) % kAdlerMod;
         }
         uint64_t total;
-        uint64_t pos = first_bit + block_exclusive_scan_u64(local, scratch, total);
+        uint64_t pos = first_bit + wave_exclusive_sum_u64(local, lane, total);
         for (uint32_t r = r0; r < r1; r++) {
             row_off[job.row_base + r] = pos;
-            pos += rows[job.row_base + r].bits;
+            pos += rg[r].x;
         }
-        carry += total;
+        s_last += total;
     }
-    const uint64_t s_last = carry; // zlib bit position after the last token
-    // block-reduce the Adler sums
-    a_s1 %= kAdlerMod;
-    a_s2 %= kAdlerMod;
-    {
-        uint64_t tot;
-        block_exclusive_scan_u64(a_s1, scratch, tot);
-        if (t == 0) s_adl[0] = tot % kAdlerMod;
-        block_exclusive_scan_u64(a_s2, scratch, tot);
-        if (t == 0) s_adl[1] = tot % kAdlerMod;
-        __syncthreads();
-    }
+    const uint64_t S1 = wave_sum((uint32_t)(a_s1 % kAdlerMod)) % kAdlerMod, S2 = wave_sum((uint32_t)(a_s2 % kAdlerMod)) % kAdlerMod;
 
     // --- compressed or stored?  (closed form of reference fpng.cpp:567-588) ---
-    const uint32_t eob = tab->lit[256];
-    const uint32_t eob_len = eob >> 16;
+    const uint32_t eob_len = tab->lit[256] >> 16;
     // byte budget the reference hands to the coder (fpng.cpp:1705): whole image only
     const uint64_t n_total = (uint64_t)(job.bpl + 1) * job.h_total;
     const uint64_t D = ((58 + n_total + 7) & ~7ull) - 58;
+    const uint32_t last_unit_bits = __hip_atomic_load((gptr_u32)(uintptr_t)&st.last_unit_bits, FPNG_RLX_AGENT);
     bool stored = force_stored;
     if (job.whole_png && !force_stored) {
         if (job.one_pass && D < tab->header_bits / 8) stored = true;                 // fpng.cpp:1169, :1455
-        if (((s_last - st.last_unit_bits) >> 3) + 8 > D) stored = true;              // last PUT_BITS_FLUSH
+        if (((s_last - last_unit_bits) >> 3) + 8 > D) stored = true;                  // last PUT_BITS_FLUSH
         if (((s_last + eob_len + 7) >> 3) + 4 > D) stored = true;                    // EOB + Adler
     }
     const uint64_t zlib_bytes_no_adler = stored ? (2 + n_filtered + 5 * ((n_filtered + kStoredBlockMax - 1) / kStoredBlockMax))
                                                 : ((s_last + eob_len + 7) >> 3);
-    const uint64_t zlib_size = zlib_bytes_no_adler + 4;
+    const uint64_t zlib_size = (!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_bytes_no_adler + 4;
 
-    if (t == 0) {
+    if (lane == 0) {
         st.token_end_bit = s_last;
         st.mode = stored ? 1u : 0u;
-        st.zlib_size = (!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_size;
-        st.s1 = (uint32_t)s_adl[0];
-        st.s2 = (uint32_t)s_adl[1];
-        const uint32_t a1 = (uint32_t)((1 + s_adl[0]) % kAdlerMod);
-        const uint32_t a2 = (uint32_t)((n_filtered % kAdlerMod + s_adl[1]) % kAdlerMod);
+        st.status = 0;
+        st.zlib_size = zlib_size;
+        st.s1 = (uint32_t)S1;
+        st.s2 = (uint32_t)S2;
+        const uint32_t a1 = (uint32_t)((1 + S1) % kAdlerMod);
+        const uint32_t a2 = (uint32_t)((n_filtered % kAdlerMod + S2) % kAdlerMod);
         st.adler = (a2 << 16) | a1; // Adler-32 of the Up/None-filtered stream (compressed mode)
         // bytes per assemble/crc block: 64 KiB when the submission has plenty of blocks anyway (every block loads
         // the 16 KiB CRC table), down to one 4 KiB block row for small files so that the submission still spreads
         // over ~2048 blocks
-        const uint64_t span = kPngHeaderBytes + ((!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_size); // >= aligned data end - 48
-        uint32_t want = 2048u / gridDim.x;                 // blocks this job should get (gridDim.x = jobs)
+        const uint64_t span = kPngHeaderBytes + zlib_size; // >= aligned data end - 48
+        uint32_t want = 2048u / n_jobs;                    // blocks this job should get
         want = want < 4u ? 4u : want;
         uint32_t rl = 12;
         while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
@@ -1045,18 +1045,24 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const Row
 
     // --- PNG header + Deflate block header; assemble_kernel, which places the rows, wants the head followed by zeros
     //     up to the next 16-byte boundary ---
-    __syncthreads();
     gptr_u8 out = to_global<gptr_u8>(job.out);
     if (job.whole_png)
-        for (uint32_t i = t; i < kPngHeaderBytes; i += kBlock) out[i] = job.png_header[i];
+        for (uint32_t i = lane; i < kPngHeaderBytes; i += kWave)
+            if (i < 50 || i >= 54) out[i] = job.png_header[i];
     gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
     if (!stored && job.is_first) {
         const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
-        for (uint32_t i = t; i < head_bytes; i += kBlock) zl[i] = tab->header[i];
+        for (uint32_t i = lane; i < head_bytes; i += kWave) zl[i] = tab->header[i];
         const uint32_t head_end = kPngHeaderBytes + head_bytes;
-        for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
+        for (uint32_t i = head_end + lane; i < ((head_end + 15u) & ~15u); i += kWave) out[i] = 0;
     }
-    if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
+    if (lane == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
+}
+
+// scan_kernel: one wave per job (row bands: counting phase and placement phase)
+__global__ __launch_bounds__(kWave) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+{
+    scan_job_wave(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1153,9 +1159,11 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
 // fewer registers than the 4-pixels-per-lane RGBA one and keeps 8 waves per SIMD.
 template <int C>
 __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
-                                                                                                      JobState *states, uint32_t *local)
+                                                                                                      JobState *states, uint32_t *local,
+                                                                                                      uint64_t *row_off, uint32_t *arrivals)
 {
     __shared__ PackedTables T;
+    __shared__ uint32_t arrived; // waves of this block that have published their row
     __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
     // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
     // contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
@@ -1171,6 +1179,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     const Job &job = jobs[by];
     if (job.c != C || bx * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
+    if (threadIdx.x == 0) arrived = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = bx * kRowWaves + wv;
     if (r >= job.nrows) return;
@@ -1195,14 +1204,27 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
         sink.fill += plit_len(eob);
     }
     sink_flush(sink, lane, true);
+    // The row's record, as granules: the wave that completes the image reads all of them within this launch.  Whole
+    // images only (row bands run scan_kernel between their phases anyway).
+    uint32_t block_complete = 0;
     if (lane == 0) {
-        RowInfo ri;
-        ri.bits = res.bits;
-        ri.s1 = res.s1;
-        ri.s2 = res.s2;
-        ri.pad = 0;
-        rows_out[job.row_base + r] = ri;
-        if (r == job.nrows - 1) states[by].last_unit_bits = res.last_unit_bits;
+        uint64_t *rg = (uint64_t *)(rows_out + job.row_base + r);
+        granule_store(rg, (uint64_t)res.bits | ((uint64_t)res.s1 << 32));
+        granule_store(rg + 1, (uint64_t)res.s2);
+        if (r == job.nrows - 1) __hip_atomic_store((gptr_u32)(uintptr_t)&states[by].last_unit_bits, res.last_unit_bits, FPNG_RLX_AGENT);
+        if (job.whole_png) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is out before the row counts as done
+            const uint32_t rows_here = (job.nrows - bx * kRowWaves < kRowWaves) ? job.nrows - bx * kRowWaves : kRowWaves;
+            block_complete = atomicAdd(&arrived, 1u) + 1u == rows_here;
+        }
+    }
+    if (uniform(block_complete)) {
+        uint32_t before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(arrivals + 2 * by, 1u, FPNG_RLX_AGENT);
+        if (uniform(before) + 1u == (job.nrows + kRowWaves - 1) / kRowWaves) { // the image's last row block: this wave does the row scan
+            scan_job_wave(job, states[by], rows_out, row_off, gridDim.y, lane);
+            if (lane == 0) __hip_atomic_store((gptr_u32)(uintptr_t)(arrivals + 2 * by), 0u, FPNG_RLX_AGENT); // ready for the next launch
+        }
     }
 }
 
@@ -1233,8 +1255,6 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // The image's last-finishing unit computes what scan_kernel computes for the other pipelines: Adler-32, the
 // reference's compressed-or-stored decision (reference fpng.cpp:567-588), the IDAT length.
 // ---------------------------------------------------------------------------------------------
-typedef FPNG_GLOBAL uint64_t *gptr_u64;
-#define FPNG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr uint32_t kFusedBlock = kWave * kUnitSegs;
 constexpr uint32_t kSpinLimit = 1u << 20; // ~ a second; a healthy look-back needs a handful of polls
@@ -1251,15 +1271,6 @@ struct FusedShared {
     uint32_t failed;
     uint32_t red[2 * kUnitSegs];
 };
-
-__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
-{
-    return __hip_atomic_load((gptr_u64)(uintptr_t)p, FPNG_RLX_AGENT);
-}
-__device__ __forceinline__ void granule_store(uint64_t *p, uint64_t v)
-{
-    __hip_atomic_store((gptr_u64)(uintptr_t)p, v, FPNG_RLX_AGENT);
-}
 
 // Wave-level decoupled look-back: zlib bit position of unit u's first bit = first_bit + sum of the aggregates of
 // units 0..u-1 of the job.  `st` points at the job's first granule pair.  Returns false on timeout.
@@ -1784,6 +1795,141 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
 }
 
 // ---------------------------------------------------------------------------------------------
+// finalize_kernel: one block per job
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dev_crc_byte(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    return c;
+}
+
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *red64)
+{
+    const uint32_t t = threadIdx.x;
+    red64[t] = v;
+    __syncthreads();
+    for (uint32_t o = kBlock / 2; o > 0; o >>= 1) {
+        if (t < o) red64[t] += red64[t + o];
+        __syncthreads();
+    }
+    const uint64_t r = red64[0];
+    __syncthreads();
+    return r;
+}
+
+// One block (kBlock threads) finishes one image: CRC fold, Adler, IDAT CRC, IEND, result record.  `partials` of a
+// launch that calls this from its own last block were written by other workgroups: granule-style loads.
+__device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows, JobState &st, const CrcDeviceTables *tabs,
+                                             const uint32_t *pj, Result &result, uint32_t *red, uint64_t *red64)
+{
+    const uint32_t t = threadIdx.x;
+    if (!job.whole_png) {
+        if (t == 0) {
+            result.png_size = 0;
+            result.mode = st.mode;
+            result.status = 0;
+        }
+        return;
+    }
+    uint32_t adler = st.adler;
+    if (st.mode == 1u) {
+        // stored mode: Adler of the filter-0 stream from the per-row partials written by stored_row
+        const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
+        uint64_t s1 = 0, s2 = 0;
+        for (uint32_t r = t; r < job.nrows; r += kBlock) {
+            const RowInfo ri = rows[job.row_base + r];
+            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+            s1 += ri.s1;
+            s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
+        }
+        const uint64_t S1 = block_sum_u64(s1 % kAdlerMod, red64) % kAdlerMod;
+        const uint64_t S2 = block_sum_u64(s2 % kAdlerMod, red64) % kAdlerMod;
+        const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
+        adler = (uint32_t)(((n_filtered % kAdlerMod + S2) % kAdlerMod) << 16) | (uint32_t)((1 + S1) % kAdlerMod);
+    }
+
+    // ---- fold the CRC partials.  Partial j sits (j ranges + one block row) before the common end
+    //      point, so  T = XOR_j p_j * X^j  with X = x^(8*64Ki); all needed constants are x^(8*2^i). ----
+    const uint64_t zlib_size = st.zlib_size;
+    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    const uint32_t rl = crc_range_log2(st);
+    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
+    uint32_t g = 0; // each thread folds G = 2^g consecutive partials
+    while (((uint64_t)kBlock << g) < n_ranges) g++;
+    const uint32_t G = 1u << g;
+    uint32_t v = 0;
+    {
+        const uint32_t X = tabs->pow2[rl]; // x^(8*range)
+        for (int i = (int)G - 1; i >= 0; i--) {
+            const uint32_t j = t * G + (uint32_t)i;
+            if (v) v = dev_mulmod(v, X);
+            if (j < n_ranges) v ^= __hip_atomic_load((gptr_cu32)(uintptr_t)(pj + j), FPNG_RLX_AGENT);
+        }
+    }
+    red[t] = v;
+    __syncthreads();
+    for (uint32_t l = 0; (1u << l) < kBlock; l++) {
+        if ((t & ((2u << l) - 1u)) == 0) {
+            const uint32_t other = red[t + (1u << l)];
+            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[rl + g + l]);
+        }
+        __syncthreads();
+    }
+    const uint32_t folded = red[0];
+    __syncthreads();
+    // x^(8*(zlib_size-4)) as a product over the set bits of the exponent, multiplied as a tree
+    {
+        const uint64_t e = zlib_size - 4;
+        uint32_t f = 0x80000000u; // 1
+        if (t < 48 && ((e >> t) & 1)) f = tabs->pow2[t];
+        red[t] = f;
+        __syncthreads();
+        for (uint32_t o = 32; o > 0; o >>= 1) {
+            if (t < o) red[t] = dev_mulmod(red[t], red[t + o]);
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        gptr_u8 out = to_global<gptr_u8>(job.out);
+        const uint32_t pad = (uint32_t)(end_aligned - data_end);
+        const uint32_t raw_data = dev_mulmod(dev_mulmod(folded, tabs->inv_row), tabs->inv_pad[pad]);
+        // running CRC state (init ~0) after "IDAT", advanced over the data, then the 4 Adler bytes
+        uint32_t s = 0xFFFFFFFFu;
+        s = dev_crc_byte(s, 'I');
+        s = dev_crc_byte(s, 'D');
+        s = dev_crc_byte(s, 'A');
+        s = dev_crc_byte(s, 'T');
+        s = dev_mulmod(s, red[0]) ^ raw_data;
+        gptr_u8 tail = out + kPngHeaderBytes + zlib_size - 4;
+        store_be32(tail, adler); // reference fpng.cpp:1569-1577 / :851-863
+        s = dev_crc_byte(s, adler >> 24);
+        s = dev_crc_byte(s, (adler >> 16) & 0xFF);
+        s = dev_crc_byte(s, (adler >> 8) & 0xFF);
+        s = dev_crc_byte(s, adler & 0xFF);
+        const uint32_t crc = ~s;
+        store_be32(tail + 4, crc); // reference fpng.cpp:1797-1800
+        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+        for (int i = 0; i < 12; i++) tail[8 + i] = iend[i];
+        st.adler = adler;
+        st.crc = crc;
+        result.png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes;
+        result.mode = st.mode;
+        result.status = st.status;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const RowInfo *rows, JobState *states,
+                                                         const CrcDeviceTables *tabs, const uint32_t *partials,
+                                                         uint32_t max_crc_blocks, Result *results)
+{
+    __shared__ uint32_t red[kBlock];
+    __shared__ uint64_t red64[kBlock];
+    finalize_job(jobs[blockIdx.x], rows, states[blockIdx.x], tabs, partials + (size_t)blockIdx.x * max_crc_blocks, results[blockIdx.x], red, red64);
+}
+
+// ---------------------------------------------------------------------------------------------
 // assemble_kernel: same geometry and CRC arithmetic as crc_kernel, but the 16 bytes a lane feeds to its CRC
 // stripe are ASSEMBLED here from the rows' local streams and stored to the file: row r's stream is shifted
 // to file bit row_off[r] + bias, neighbouring rows meet inside a dword.  Nothing is read back from the file
@@ -1791,14 +1937,15 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
 // written twice, so the rows need no atomics and no zeroed seams.  Stored-mode jobs only take the CRC.
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const JobState *states, const uint64_t *row_off,
+__global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
-                                                         uint32_t max_crc_blocks)
+                                                         uint32_t max_crc_blocks, const RowInfo *rows, Result *results, uint32_t *arrivals)
 {
     __shared__ uint32_t tab[16][256];
     __shared__ uint32_t red[kWavesPerBlock];
+    __shared__ uint32_t completes_image;
     const Job &job = job_of_block(jobs);
-    const JobState &st = states[blockIdx.y];
+    JobState &st = states[blockIdx.y];
     // row bands (flag 0x100): the rows of a band land in a private window that shares the whole file's geometry
     // (job.out = window - first file byte of the window, st.zlib_size = the whole image's): bits outside the band stay 0
     const bool band = !job.whole_png;
@@ -1932,9 +2079,18 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
                 }
             }
             if (in_data && P + 128 > tok_begin && P < tok_end) { // (a band's window ends with the piece that holds its last bit)
-                u32x4 d;
-                d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
-                *(gptr_u128)(uintptr_t)(base + o) = d;
+                if (band || o + 16 <= de) {
+                    u32x4 d;
+                    d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
+                    *(gptr_u128)(uintptr_t)(base + o) = d;
+                } else {
+                    // the file's last data piece: the bytes behind the data (Adler-32 ...) are written by the block that
+                    // finishes the image, possibly before this store reaches memory -- every byte has ONE writer per launch
+                    for (int32_t bb = 0; o + bb < de; bb++) {
+                        const uint32_t dw = (bb >> 2) == 0 ? w[0] : ((bb >> 2) == 1 ? w[1] : ((bb >> 2) == 2 ? w[2] : w[3]));
+                        to_global<gptr_u8>(job.out)[range_begin + o + bb] = (uint8_t)(dw >> (8 * (bb & 3)));
+                    }
+                }
             }
             if (r - pr >= 32) { // refill the look-ahead early: its latency hides behind this step's CRC
                 pr = r;
@@ -1965,136 +2121,22 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, const
     c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
     if ((tid & 63) == 0) red[tid >> 6] = c;
     __syncthreads();
-    if (tid == 0) partials[(size_t)blockIdx.y * max_crc_blocks + blockIdx.x] = red[0] ^ red[1] ^ red[2] ^ red[3];
-}
-
-// ---------------------------------------------------------------------------------------------
-// finalize_kernel: one block per job
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dev_crc_byte(uint32_t c, uint32_t byte)
-{
-    c ^= byte;
-    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-    return c;
-}
-
-__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *red64)
-{
-    const uint32_t t = threadIdx.x;
-    red64[t] = v;
+    if (tid == 0) {
+        __hip_atomic_store((gptr_u32)(uintptr_t)(partials + (size_t)blockIdx.y * max_crc_blocks + blockIdx.x), red[0] ^ red[1] ^ red[2] ^ red[3], FPNG_RLX_AGENT);
+        completes_image = 0;
+        if (!band) { // whole images: the block that completes the file's last range also finishes the image
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t rl = crc_range_log2(st);
+            const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
+            completes_image = __hip_atomic_fetch_add(arrivals + 2 * blockIdx.y + 1, 1u, FPNG_RLX_AGENT) + 1u == n_ranges;
+        }
+    }
     __syncthreads();
-    for (uint32_t o = kBlock / 2; o > 0; o >>= 1) {
-        if (t < o) red64[t] += red64[t + o];
-        __syncthreads();
-    }
-    const uint64_t r = red64[0];
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const RowInfo *rows, JobState *states,
-                                                         const CrcDeviceTables *tabs, const uint32_t *partials,
-                                                         uint32_t max_crc_blocks, Result *results)
-{
-    __shared__ uint32_t red[kBlock];
-    __shared__ uint64_t red64[kBlock];
-    const Job &job = jobs[blockIdx.x];
-    JobState &st = states[blockIdx.x];
-    const uint32_t t = threadIdx.x;
-    if (!job.whole_png) {
-        if (t == 0) {
-            results[blockIdx.x].png_size = 0;
-            results[blockIdx.x].mode = st.mode;
-            results[blockIdx.x].status = 0;
-        }
-        return;
-    }
-    uint32_t adler = st.adler;
-    if (st.mode == 1u) {
-        // stored mode: Adler of the filter-0 stream from the per-row partials written by stored_row
-        const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
-        uint64_t s1 = 0, s2 = 0;
-        for (uint32_t r = t; r < job.nrows; r += kBlock) {
-            const RowInfo ri = rows[job.row_base + r];
-            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
-            s1 += ri.s1;
-            s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
-        }
-        const uint64_t S1 = block_sum_u64(s1 % kAdlerMod, red64) % kAdlerMod;
-        const uint64_t S2 = block_sum_u64(s2 % kAdlerMod, red64) % kAdlerMod;
-        const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
-        adler = (uint32_t)(((n_filtered % kAdlerMod + S2) % kAdlerMod) << 16) | (uint32_t)((1 + S1) % kAdlerMod);
-    }
-
-    // ---- fold the CRC partials.  Partial j sits (j ranges + one block row) before the common end
-    //      point, so  T = XOR_j p_j * X^j  with X = x^(8*64Ki); all needed constants are x^(8*2^i). ----
-    const uint64_t zlib_size = st.zlib_size;
-    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
-    const int64_t end_aligned = (data_end + 15) & ~15ll;
-    const uint32_t rl = crc_range_log2(st);
-    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
-    uint32_t g = 0; // each thread folds G = 2^g consecutive partials
-    while (((uint64_t)kBlock << g) < n_ranges) g++;
-    const uint32_t G = 1u << g;
-    const uint32_t *pj = partials + (size_t)blockIdx.x * max_crc_blocks;
-    uint32_t v = 0;
-    {
-        const uint32_t X = tabs->pow2[rl]; // x^(8*range)
-        for (int i = (int)G - 1; i >= 0; i--) {
-            const uint32_t j = t * G + (uint32_t)i;
-            if (v) v = dev_mulmod(v, X);
-            if (j < n_ranges) v ^= pj[j];
-        }
-    }
-    red[t] = v;
-    __syncthreads();
-    for (uint32_t l = 0; (1u << l) < kBlock; l++) {
-        if ((t & ((2u << l) - 1u)) == 0) {
-            const uint32_t other = red[t + (1u << l)];
-            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[rl + g + l]);
-        }
-        __syncthreads();
-    }
-    const uint32_t folded = red[0];
-    __syncthreads();
-    // x^(8*(zlib_size-4)) as a product over the set bits of the exponent, multiplied as a tree
-    {
-        const uint64_t e = zlib_size - 4;
-        uint32_t f = 0x80000000u; // 1
-        if (t < 48 && ((e >> t) & 1)) f = tabs->pow2[t];
-        red[t] = f;
-        __syncthreads();
-        for (uint32_t o = 32; o > 0; o >>= 1) {
-            if (t < o) red[t] = dev_mulmod(red[t], red[t + o]);
-            __syncthreads();
-        }
-    }
-    if (t == 0) {
-        gptr_u8 out = to_global<gptr_u8>(job.out);
-        const uint32_t pad = (uint32_t)(end_aligned - data_end);
-        const uint32_t raw_data = dev_mulmod(dev_mulmod(folded, tabs->inv_row), tabs->inv_pad[pad]);
-        // running CRC state (init ~0) after "IDAT", advanced over the data, then the 4 Adler bytes
-        uint32_t s = 0xFFFFFFFFu;
-        s = dev_crc_byte(s, 'I');
-        s = dev_crc_byte(s, 'D');
-        s = dev_crc_byte(s, 'A');
-        s = dev_crc_byte(s, 'T');
-        s = dev_mulmod(s, red[0]) ^ raw_data;
-        gptr_u8 tail = out + kPngHeaderBytes + zlib_size - 4;
-        store_be32(tail, adler); // reference fpng.cpp:1569-1577 / :851-863
-        s = dev_crc_byte(s, adler >> 24);
-        s = dev_crc_byte(s, (adler >> 16) & 0xFF);
-        s = dev_crc_byte(s, (adler >> 8) & 0xFF);
-        s = dev_crc_byte(s, adler & 0xFF);
-        const uint32_t crc = ~s;
-        store_be32(tail + 4, crc); // reference fpng.cpp:1797-1800
-        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
-        for (int i = 0; i < 12; i++) tail[8 + i] = iend[i];
-        st.adler = adler;
-        st.crc = crc;
-        results[blockIdx.x].png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes;
-        results[blockIdx.x].mode = st.mode;
-        results[blockIdx.x].status = 0;
+    if (completes_image) {
+        uint32_t *fred = &tab[0][0];                      // (the CRC tables are no longer needed)
+        uint64_t *fred64 = (uint64_t *)(&tab[0][0] + kBlock);
+        finalize_job(job, rows, st, tabs, partials + (size_t)blockIdx.y * max_crc_blocks, results[blockIdx.y], fred, fred64);
+        if (tid == 0) __hip_atomic_store((gptr_u32)(uintptr_t)(arrivals + 2 * blockIdx.y + 1), 0u, FPNG_RLX_AGENT); // ready for the next launch
     }
 }
 
@@ -2436,17 +2478,19 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 }
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, row_off, states);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, rows, row_off, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {
     hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, hist, tables);
 }
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
-                        JobState *states, uint32_t *local)
+                        JobState *states, uint32_t *local, uint64_t *row_off, uint32_t *arrivals)
 {
-    if (chan_mask & 1u) hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
-    if (chan_mask & 2u) hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+    if (chan_mask & 1u)
+        hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local, row_off, arrivals);
+    if (chan_mask & 2u)
+        hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local, row_off, arrivals);
 }
 void launch_encode_image(hipStream_t s, uint32_t num_chans, const FusedArgs &args, uint32_t n_blocks)
 {
@@ -2455,11 +2499,12 @@ void launch_encode_image(hipStream_t s, uint32_t num_chans, const FusedArgs &arg
     else
         hipLaunchKernelGGL(encode_image_kernel<4>, dim3(n_blocks), dim3(kFusedBlock), 0, s, args);
 }
-void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials)
+void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
+                     const RowInfo *rows, Result *results, uint32_t *arrivals)
 {
     hipLaunchKernelGGL(assemble_kernel, dim3(max_crc_blocks, n_jobs), dim3(kBlock), 0, s, jobs, states, row_off, local, tabs,
-                       partials, max_crc_blocks);
+                       partials, max_crc_blocks, rows, results, arrivals);
 }
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials)

@@ -1209,12 +1209,18 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
     if (!e || lane < 0 || lane >= fpng_amd_encoder::kLanes || !dst) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (e->sc[lane].d_ctrl.cap < n_words) return fail(FPNG_AMD_ERR_INVALID_ARG, "no control words yet");
+    if (n_words == 8) { // the timing build's cycle counts of build_dynamic_kernel (head of the histogram scratch)
+        if (!e->sc[lane].d_hist.p) return fail(FPNG_AMD_ERR_INVALID_ARG, "no 2-pass submission yet");
+        const uint32_t page = (dst[7] == 0xFEEDu) ? 8u : 0u; // (second page: the table builder's inner phases)
+        HIP_TRY(hipMemcpy(dst, e->sc[lane].d_hist.p + page, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return FPNG_AMD_OK;
+    }
     if (n_words == 16) { // the timing build's counters (head of the spill area), read and cleared
         HIP_TRY(hipMemcpy(dst, e->sc[lane].d_spill.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(e->sc[lane].d_spill.p, 0, 16 * sizeof(uint32_t)));
         return FPNG_AMD_OK;
     }
+    if (e->sc[lane].d_ctrl.cap < n_words) return fail(FPNG_AMD_ERR_INVALID_ARG, "no control words yet");
     HIP_TRY(hipMemcpy(dst, e->sc[lane].d_ctrl.p, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return FPNG_AMD_OK;
 }

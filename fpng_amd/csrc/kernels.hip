@@ -2151,7 +2151,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
 // parent walking (parallel), Kraft repair, shortest codes to the heaviest symbols, canonical
 // bit-reversed codes, run-length packing of the code lengths with symbols 16/17/18.
 // ---------------------------------------------------------------------------------------------
-struct BuilderLds {
+struct __attribute__((aligned(16))) BuilderLds {
     uint32_t count[288];            // 16-bit symbol counts
     uint32_t skey[288], ssym[288];  // used symbols sorted by (count, symbol)
     uint32_t iw[288];               // internal node weights (mod 2^16)
@@ -2171,50 +2171,89 @@ __device__ __forceinline__ uint32_t dev_bitrev(uint32_t v, uint32_t n)
 }
 
 // Code lengths (<= max_len) and canonical codes for n symbols with counts L.count[0..n).
-__device__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uint32_t lane)
+__device__ __forceinline__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uint32_t lane, uint64_t *tb = nullptr) // (inlined: L must be known to live in LDS)
 {
-    // ---- stable sort of the used symbols by count: every element computes its own rank ----
-    if (lane == 0) L.used = 0;
-    wave_lds_fence();
-    for (uint32_t i = lane; i < n; i += kWave) {
-        const uint32_t k = L.count[i];
-        if (k) {
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; j++) {
-                const uint32_t kj = L.count[j];
-                rank += (kj != 0) && (kj < k || (kj == k && j < i));
-            }
-            L.skey[rank] = k;
-            L.ssym[rank] = i;
-            atomicAdd(&L.used, 1u);
-        }
+#ifdef FPNG_FUSED_TIMING
+#define FPNG_TB(i) if (tb) tb[i] = __builtin_readcyclecounter()
+#else
+#define FPNG_TB(i)
+#endif
+    FPNG_TB(0);
+    // ---- stable sort of the used symbols by count: every element computes its own rank.  Composite keys
+    //      count << 9 | symbol are distinct, so the rank is a plain "how many keys are smaller" (branch-free, four keys
+    //      per LDS load); unused symbols get the largest key and do not take part. ----
+    for (uint32_t i = lane; i < 288; i += kWave) {
+        const uint32_t k = (i < n) ? L.count[i] : 0u;
+        L.code[i] = k ? ((k << 9) | i) : 0xFFFFFFFFu; // (L.code doubles as key scratch: it is rebuilt at the end)
     }
+    wave_lds_fence();
+    {
+        uint32_t own[5], rank[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 5; q++) own[q] = (lane + 64u * q < 288u) ? L.code[lane + 64u * q] : 0xFFFFFFFFu;
+        const u32x4 *k4 = (const u32x4 *)L.code;
+        const uint32_t n4 = (n + 3) >> 2;
+#pragma unroll 2
+        for (uint32_t j = 0; j < n4; j++) {
+            const u32x4 v = k4[j];
+#pragma unroll
+            for (int q = 0; q < 5; q++) rank[q] += (uint32_t)(v.x < own[q]) + (uint32_t)(v.y < own[q]) + (uint32_t)(v.z < own[q]) + (uint32_t)(v.w < own[q]);
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++)
+            if (own[q] != 0xFFFFFFFFu) {
+                L.skey[rank[q]] = own[q] >> 9;
+                L.ssym[rank[q]] = own[q] & 511u;
+                mine++;
+            }
+        const uint32_t used_all = wave_sum(mine);
+        if (lane == 0) L.used = used_all;
+    }
+    wave_lds_fence();
     for (uint32_t i = lane; i < 40; i += kWave) L.num_codes[i] = 0;
     for (uint32_t i = lane; i < n; i += kWave) L.len[i] = 0, L.code[i] = 0;
     wave_lds_fence();
+    FPNG_TB(1); // rank sort
     const uint32_t used = L.used;
     if (used == 1) {
         if (lane == 0) L.num_codes[1] = 1;
     } else if (used >= 2) {
         if (lane == 0) {
             // two-queue merge: leaves ascending, internal nodes in creation order; an internal node is
-            // taken only when strictly lighter than the next leaf (reference fpng.cpp:645-651)
+            // taken only when strictly lighter than the next leaf (reference fpng.cpp:645-651).
+            // The heads of both queues and their successors are kept in registers: an LDS load issued when a queue
+            // advances is needed only after its NEXT advance, so the loop does not wait for LDS; weights of internal
+            // nodes made just now are forwarded instead of read back.  (Measured alternatives, both slower: the same
+            // loop on scalar registers with readfirstlane after every load, and both queues held in vector registers
+            // with v_readlane / v_writelane: a lone wave issues an instruction every ~8 cycles whatever it is.)
             uint32_t leaf = 0, root = 0, made = 0;
+            uint32_t key_head = L.skey[0], key_next = (used > 1) ? L.skey[1] : 0u;
+            uint32_t iw_head = 0, iw_next = 0; // iw[root], iw[root + 1] (meaningful when the index is below `made`)
             while (made < used - 1) {
                 uint32_t wsum = 0;
                 for (int k = 0; k < 2; k++) {
-                    if (leaf >= used || (root < made && L.iw[root] < L.skey[leaf])) {
-                        wsum += L.iw[root];
+                    if (leaf >= used || (root < made && iw_head < key_head)) {
+                        wsum += iw_head;
                         L.iparent[root++] = (int)made;
+                        iw_head = iw_next;
+                        if (root + 1 < made) iw_next = L.iw[root + 1];
                     } else {
-                        wsum += L.skey[leaf];
+                        wsum += key_head;
                         L.lparent[leaf++] = (int)made;
+                        key_head = key_next;
+                        if (leaf + 1 < used) key_next = L.skey[leaf + 1];
                     }
                 }
-                L.iw[made++] = wsum & 0xFFFFu;
+                wsum &= 0xFFFFu;
+                L.iw[made] = wsum;
+                if (made == root) iw_head = wsum;          // the queue was empty: the new node is its head
+                else if (made == root + 1) iw_next = wsum; // ... or the head's successor
+                made++;
             }
         }
         wave_lds_fence();
+        FPNG_TB(2); // merge
         // leaf depth = number of parent hops to the root (the last internal node)
         for (uint32_t i = lane; i < used; i += kWave) {
             int node = L.lparent[i], d = 1;
@@ -2225,27 +2264,31 @@ __device__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uin
             atomicAdd(&L.num_codes[d > 39 ? 39 : d], 1);
         }
         wave_lds_fence();
-        if (lane == 0) {
-            // Kraft repair (reference fpng.cpp:663-674)
-            for (uint32_t l = max_len + 1; l < 40; l++) {
-                L.num_codes[max_len] += L.num_codes[l];
-                L.num_codes[l] = 0;
-            }
-            uint32_t total = 0;
-            for (uint32_t l = max_len; l > 0; l--) total += (uint32_t)L.num_codes[l] << (max_len - l);
+        FPNG_TB(3); // depths
+        {
+            // Kraft repair (reference fpng.cpp:663-674), by the whole wave with lane l holding num_codes[l]: the
+            // reference's inner search "largest l < max_len with codes" is one ballot instead of a walk through LDS
+            // (skewed histograms need hundreds of repair steps).
+            int nc = (lane < 40) ? L.num_codes[lane] : 0;
+            const uint32_t over = wave_sum((lane > max_len && lane < 40) ? (uint32_t)nc : 0u);
+            if (lane == max_len) nc += (int)over;
+            if (lane > max_len) nc = 0;
+            uint32_t total = wave_sum((lane >= 1 && lane <= max_len) ? ((uint32_t)nc << (max_len - lane)) : 0u);
             while (total != (1u << max_len)) {
-                L.num_codes[max_len]--;
-                for (uint32_t l = max_len - 1; l > 0; l--)
-                    if (L.num_codes[l]) {
-                        L.num_codes[l]--;
-                        L.num_codes[l + 1] += 2;
-                        break;
-                    }
+                const uint64_t have = __ballot(nc != 0 && lane >= 1 && lane < max_len);
+                if (lane == max_len) nc--;
+                if (have) {
+                    const uint32_t l = 63u - (uint32_t)__builtin_clzll(have);
+                    if (lane == l) nc--;
+                    if (lane == l + 1) nc += 2;
+                }
                 total--;
             }
+            if (lane < 40) L.num_codes[lane] = nc;
         }
     }
     wave_lds_fence();
+    FPNG_TB(4); // Kraft
     // shortest codes to the END of the sorted order (reference fpng.cpp:697-698)
     for (uint32_t i = lane; i < used; i += kWave) {
         const uint32_t from_end = used - 1 - i;
@@ -2257,17 +2300,27 @@ __device__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uin
         L.len[L.ssym[i]] = l;
     }
     wave_lds_fence();
-    // canonical codes in symbol order, bit-reversed (reference fpng.cpp:699-708)
-    for (uint32_t i = lane; i < n; i += kWave) {
-        const uint32_t l = L.len[i];
-        if (!l) continue;
+    // canonical codes in symbol order, bit-reversed (reference fpng.cpp:699-708): a symbol's code = first code of its
+    // length + number of earlier symbols of the same length (ballot prefix counts, one length at a time)
+    {
+        uint32_t len5[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) len5[q] = (lane + 64u * q < n) ? L.len[lane + 64u * q] : 0u;
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
         uint32_t first = 0;
-        for (uint32_t k = 1; k < l; k++) first = (first + (uint32_t)L.num_codes[k]) << 1;
-        uint32_t before = 0;
-        for (uint32_t j = 0; j < i; j++) before += (L.len[j] == l);
-        L.code[i] = dev_bitrev(first + before, l);
+        for (uint32_t l = 1; l <= max_len; l++) {
+            uint32_t seen = 0; // symbols of length l in the rounds before
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const uint64_t m = __ballot(len5[q] == l);
+                if (len5[q] == l) L.code[lane + 64u * q] = dev_bitrev(first + seen + (uint32_t)__popcll(m & lt_mask), l);
+                seen += (uint32_t)__popcll(m);
+            }
+            first = (first + uniform((uint32_t)L.num_codes[l])) << 1;
+        }
     }
     wave_lds_fence();
+    FPNG_TB(5); // lengths + codes
 }
 
 __device__ __forceinline__ void hdr_put(BuilderLds &L, uint32_t &pos, uint32_t v, uint32_t nbits)
@@ -2278,7 +2331,7 @@ __device__ __forceinline__ void hdr_put(BuilderLds &L, uint32_t &pos, uint32_t v
     pos += nbits;
 }
 
-__global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, const uint32_t *hist_all, TokenTable *tables)
+__global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, uint32_t *hist_all, TokenTable *tables)
 {
     __shared__ BuilderLds L;
     const Job &job = jobs[blockIdx.x];
@@ -2304,7 +2357,20 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
     }
     for (uint32_t i = lane; i < 100; i += kWave) L.hdr[i] = 0;
     wave_lds_fence();
+#ifdef FPNG_FUSED_TIMING
+    uint64_t bt[8];
+    bt[0] = __builtin_readcyclecounter();
+#define FPNG_BT(i) bt[i] = __builtin_readcyclecounter()
+#else
+#define FPNG_BT(i)
+#endif
+#ifdef FPNG_FUSED_TIMING
+    uint64_t tb[6] = {0, 0, 0, 0, 0, 0};
+    dev_build_table(L, 288, 12, lane, tb);
+#else
     dev_build_table(L, 288, 12, lane);
+#endif
+    FPNG_BT(1);
     for (uint32_t i = lane; i < 288; i += kWave) L.lit_len[i] = L.len[i], L.lit_code[i] = L.code[i];
     wave_lds_fence();
 
@@ -2318,6 +2384,7 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
     for (uint32_t i = lane; i < 19; i += kWave) L.c2[i] = 0;
     wave_lds_fence();
 
+    FPNG_BT(2);
     // ---- run-length packing of the code lengths (reference fpng.cpp:711-726, :770-794) ----
     if (lane == 0) {
         uint32_t np = 0, zrun = 0, rep = 0, prev = 0xFF;
@@ -2374,7 +2441,9 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
     wave_lds_fence();
     for (uint32_t i = lane; i < 288; i += kWave) L.count[i] = (i < 19) ? (L.c2[i] & 0xFFFFu) : 0u;
     wave_lds_fence();
+    FPNG_BT(3);
     dev_build_table(L, 19, 7, lane);
+    FPNG_BT(4);
     for (uint32_t i = lane; i < 19; i += kWave) L.cl_len[i] = L.len[i], L.cl_code[i] = L.code[i];
     wave_lds_fence();
 
@@ -2403,6 +2472,7 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
     }
     wave_lds_fence();
 
+    FPNG_BT(5);
     // ---- publish the table in the layout the row kernels consume ----
     const uint32_t hbits = L.tmp;
     for (uint32_t i = lane; i < 288; i += kWave) out->lit[i] = L.lit_code[i] | (L.lit_len[i] << 16);
@@ -2420,6 +2490,14 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, c
         out->first_token_bit = hbits;
         out->header_bits = hbits;
     }
+#ifdef FPNG_FUSED_TIMING
+    FPNG_BT(6);
+    if (lane == 0 && blockIdx.x == 0) // cycles: table(288), sequence, run-length packing, table(19), header, publish
+    {
+        for (int i = 0; i < 6; i++) ((uint32_t *)hist_all)[i] = (uint32_t)(bt[i + 1] - bt[i]);
+        for (int i = 0; i < 5; i++) ((uint32_t *)hist_all)[8 + i] = (uint32_t)(tb[i + 1] - tb[i]); // inside table(288): sort, merge, depths, Kraft, codes
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2482,7 +2560,7 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {
-    hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, hist, tables);
+    hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, (uint32_t *)hist, tables);
 }
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local, uint64_t *row_off, uint32_t *arrivals)

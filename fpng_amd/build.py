@@ -88,6 +88,6 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     if "--variant" in sys.argv:
         v = sys.argv[sys.argv.index("--variant") + 1]
-        print(build_variant(v, {"timing": ["FPNG_FUSED_TIMING"]}[v], verbose=True))
+        print(build_variant(v, {"timing": ["FPNG_BUILD_TIMING"]}[v], verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

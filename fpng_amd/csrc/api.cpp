@@ -212,25 +212,17 @@ struct fpng_amd_encoder {
         DeviceBuf<uint32_t> d_hist;
         DeviceBuf<TokenTable> d_dyn;
         DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
-        DeviceBuf<uint32_t> d_arrivals; // rows pipeline: two self-resetting arrival counters per job
-        // fused pipeline (encode_image_kernel)
-        DeviceBuf<uint64_t> d_unit_state, d_unit_adler;
-        DeviceBuf<uint32_t> d_ctrl;       // [2 x 8 x 32] queue heads of the two channel classes, then job_done[n]
-        DeviceBuf<uint32_t> d_chunk_base; // [2][n + 1]
-        DeviceBuf<uint32_t> d_spill;
-        uint32_t epoch = 0;
+        hipEvent_t last_done = nullptr; // `done` event (owned by a slot) of the last submission that used this set
         void release()
         {
             d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
-            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release(), d_arrivals.release();
-            d_unit_state.release(), d_unit_adler.release(), d_ctrl.release(), d_chunk_base.release(), d_spill.release();
+            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
         }
     };
     static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)
-    int pipeline = 0; // of the last submission: 0 fused, 1 rows (encode_rows + assemble), 2 count/scan/emit/crc
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
     // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
     // records coming back) guarded by an event, so fpng_amd_encode_submit() never waits for the GPU unless all
@@ -240,9 +232,9 @@ struct fpng_amd_encoder {
     struct Slot {
         PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
         PinnedBuf<Result> results;
-        PinnedBuf<uint32_t> chunk_base;
         hipEvent_t in = nullptr;     // recorded on the caller's stream: the inputs are ready
-        hipEvent_t walked = nullptr; // recorded on the lane after the row walk
+        hipEvent_t prepped = nullptr; // job records (2-pass: and the per-image tables) are on the device
+        hipEvent_t walked = nullptr; // recorded after the row walk
         hipEvent_t done = nullptr;   // recorded on the lane: PNGs and result records are complete
         bool in_flight = false;
         uint32_t n = 0;
@@ -321,8 +313,13 @@ static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, 
         }
         e->own_stream = true;
     }
-    for (auto &ls : e->lane_stream) {
-        hipError_t err = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
+    // FPNG_AMD_STREAM_PRIO=high|low: priority of the internal streams (A/B runs; default: the normal priority 0)
+    int prio_low = 0, prio_high = 0, prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (const char *v = getenv("FPNG_AMD_STREAM_PRIO")) prio = !strcmp(v, "high") ? prio_high : (!strcmp(v, "low") ? prio_low : 0);
+    for (int i = 0; i < fpng_amd_encoder::kLanes; i++) {
+        hipStream_t &ls = e->lane_stream[i];
+        hipError_t err = hipStreamCreateWithPriority(&ls, hipStreamNonBlocking, prio);
         if (err != hipSuccess) {
             fpng_amd_encoder_destroy(e);
             return fail(FPNG_AMD_ERR_HIP, "hipStreamCreate (lane)", err);
@@ -368,10 +365,10 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
         sl.jobs.release();
         sl.jobs2.release();
         sl.results.release();
-        sl.chunk_base.release();
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.in) (void)hipEventDestroy(sl.in);
         if (sl.walked) (void)hipEventDestroy(sl.walked);
+        if (sl.prepped) (void)hipEventDestroy(sl.prepped);
     }
     for (auto &ls : e->lane_stream)
         if (ls) (void)hipStreamDestroy(ls);
@@ -419,10 +416,6 @@ struct Submission {
     uint64_t total_rows = 0;
     uint64_t local_dwords = 0; // rows pipeline: scratch for the rows' local streams
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
-    // fused pipeline
-    uint64_t total_units = 0;
-    uint32_t total_chunks[2] = {0, 0}; // per channel class (0: 3 channels, 1: 4 channels)
-    uint32_t chunks_per_job[2] = {0, 0};
 };
 
 int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
@@ -453,14 +446,12 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if (!e || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "batch larger than 65535 images");
     int rc;
-    if ((rc = slot.jobs.ensure(n)) || (rc = slot.results.ensure(n)) || (rc = slot.chunk_base.ensure(2 * ((size_t)n + 1)))) return rc;
+    if ((rc = slot.jobs.ensure(n)) || (rc = slot.results.ensure(n))) return rc;
     const DeviceTables &dt = g_dev[e->device];
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     sub = Submission();
     sub.n = n;
-    uint32_t *cb[2] = {slot.chunk_base.p, slot.chunk_base.p + n + 1};
-    bool uniform_chunks[2] = {true, true};
     for (uint32_t i = 0; i < n; i++) {
         const fpng_amd_image &im = images[i];
         if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
@@ -496,34 +487,12 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[im.num_chans];
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
         j.local_base = sub.local_dwords;
-        // fused pipeline: segments of at most kSegMaxPx pixels, as even as 256-pixel granularity allows
-        const uint32_t cls = (im.num_chans == 3) ? 0u : 1u;
-        const uint32_t nseg = (im.w + kSegMaxPx - 1) / kSegMaxPx;
-        j.seg_px = (((im.w + nseg - 1) / nseg) + 255u) & ~255u;
-        j.segs_per_row = (im.w + j.seg_px - 1) / j.seg_px;
-        const uint64_t units = force_stored ? 1ull : ((uint64_t)im.h * j.segs_per_row + kUnitSegs - 1) / kUnitSegs;
-        if (sub.total_units + units > 0xFFFFFFF0ull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many row segments in one batch");
-        j.n_units = (uint32_t)units;
-        j.unit_base = (uint32_t)sub.total_units;
-        j.chunk_base = sub.total_chunks[cls];
-        const uint32_t chunks = (j.n_units + kChunkUnits - 1) / kChunkUnits;
-        cb[0][i] = sub.total_chunks[0];
-        cb[1][i] = sub.total_chunks[1];
-        if (sub.chunks_per_job[cls] == 0) sub.chunks_per_job[cls] = chunks;
-        if (sub.chunks_per_job[cls] != chunks) uniform_chunks[cls] = false;
-        sub.total_chunks[cls] += chunks;
-        sub.total_units += units;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         sub.local_dwords += (uint64_t)j.local_stride * im.h;
         sub.total_rows += im.h;
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
     }
-    cb[0][n] = sub.total_chunks[0];
-    cb[1][n] = sub.total_chunks[1];
-    // "job = chunk / chunks_per_job" holds only when every job is of that class and has the same chunk count
-    for (int c = 0; c < 2; c++)
-        if (!uniform_chunks[c] || sub.chan_mask == 3u) sub.chunks_per_job[c] = 0;
     if ((rc = sc.d_jobs.ensure(n))) return rc;
     if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
     if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
@@ -533,61 +502,6 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if (two_pass) {
         if ((rc = sc.d_hist.ensure((size_t)n * 288))) return rc;
         if ((rc = sc.d_dyn.ensure(n))) return rc;
-    }
-    return FPNG_AMD_OK;
-}
-
-constexpr uint32_t kSpillStride = 1600; // dwords per wave: (1024 px x 4 B + 1) x 12 bits + EOB + slack
-constexpr uint32_t kCtrlQueueWords = 2 * 8 * 32;
-
-// encode_image_kernel launches (one per channel class present) for the jobs already uploaded to sc.d_jobs.
-int launch_fused(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_encoder::Scratch &sc, hipStream_t s, const Submission &sub)
-{
-    int rc;
-    const uint32_t n = sub.n;
-    if ((rc = sc.d_unit_state.ensure(2 * sub.total_units)) || (rc = sc.d_unit_adler.ensure(sub.total_units)) ||
-        (rc = sc.d_ctrl.ensure(kCtrlQueueWords + n)) || (rc = sc.d_chunk_base.ensure(2 * ((size_t)n + 1))) ||
-        (rc = sc.d_spill.ensure((size_t)kFusedMaxBlocks * kUnitSegs * kSpillStride)))
-        return rc;
-    // the unit records carry the launch's epoch; fresh (or wrapped-around) arrays are cleared once
-    static const bool always_clear = [] { const char *v = getenv("FPNG_AMD_FUSED_CLEAR"); return v && v[0] == '1'; }();
-    if (always_clear || sc.d_unit_state.fresh || sc.d_unit_adler.fresh || sc.epoch >= 0xFFFFFEu) {
-        HIP_TRY(hipMemsetAsync(sc.d_unit_state.p, 0, (always_clear ? 2 * sub.total_units : sc.d_unit_state.cap) * sizeof(uint64_t), s));
-        HIP_TRY(hipMemsetAsync(sc.d_unit_adler.p, 0, (always_clear ? sub.total_units : sc.d_unit_adler.cap) * sizeof(uint64_t), s));
-        sc.d_unit_state.fresh = sc.d_unit_adler.fresh = false;
-        sc.epoch = 0;
-    }
-    HIP_TRY(hipMemsetAsync(sc.d_ctrl.p, 0, (kCtrlQueueWords + (size_t)n) * sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, (size_t)n * sizeof(JobState), s)); // (status: set only when a look-back gives up)
-    HIP_TRY(hipMemcpyAsync(sc.d_chunk_base.p, slot.chunk_base.p, 2 * ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    for (uint32_t cls = 0; cls < 2; cls++) {
-        if (!sub.total_chunks[cls]) continue;
-        FusedArgs a;
-        std::memset(&a, 0, sizeof a);
-        a.jobs = sc.d_jobs.p;
-        a.chunk_base = sc.d_chunk_base.p + cls * ((size_t)n + 1);
-        a.unit_state = sc.d_unit_state.p;
-        a.unit_adler = sc.d_unit_adler.p;
-        a.tickets = sc.d_ctrl.p + cls * 8 * 32;
-        a.job_done = sc.d_ctrl.p + kCtrlQueueWords;
-        a.spill = sc.d_spill.p;
-        a.states = sc.d_states.p;
-        a.n_jobs = n;
-        a.total_chunks = sub.total_chunks[cls];
-        a.chunks_per_job = sub.chunks_per_job[cls];
-        a.epoch = ++sc.epoch;
-        a.spill_stride = kSpillStride;
-        static const uint32_t dbg = [] { const char *v = getenv("FPNG_AMD_FUSED_DBG"); return v ? (uint32_t)atoi(v) : 0u; }();
-        a.pad = dbg;
-        // persistent grid: every queue (blockIdx & 7) needs a block; more blocks than units only pull empty tickets
-        const uint64_t units = (uint64_t)sub.total_chunks[cls] * kChunkUnits;
-        static const uint32_t max_blocks = [] {
-            const char *v = getenv("FPNG_AMD_FUSED_BLOCKS"); // A/B runs
-            const int b = v ? atoi(v) : (int)kFusedMaxBlocks;
-            return (uint32_t)std::min<int>(std::max(b, 8), (int)kFusedMaxBlocks) & ~7u;
-        }();
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(8, (units + 7) & ~7ull));
-        launch_encode_image(s, cls == 0 ? 3u : 4u, a, blocks);
     }
     return FPNG_AMD_OK;
 }
@@ -602,6 +516,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     if (!slot.in) HIP_TRY(hipEventCreateWithFlags(&slot.in, hipEventDisableTiming));
     if (!slot.walked) HIP_TRY(hipEventCreateWithFlags(&slot.walked, hipEventDisableTiming));
+    if (!slot.prepped) HIP_TRY(hipEventCreateWithFlags(&slot.prepped, hipEventDisableTiming));
     if (slot.in_flight) {
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
@@ -611,35 +526,54 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const int n = v ? atoi(v) : 2;
         return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
     }();
-    // lane = internal stream + scratch set.  Per-kernel profiling stays on lane 0, which serialises it.
-    const int lane = e->profiling ? 0 : (int)(e->submitted % n_lanes);
+    // Schedules.
+    // lanes (default): whole chains alternate between FPNG_AMD_LANES (default 2) streams, each with its own scratch set.
+    // stages (FPNG_AMD_SCHED=stages; measured 8 % slower for 1-pass, 2 % faster for 2-pass): the three stages of a submission run on three streams -- prep (job records; 2-pass: histogram
+    //   walk and table build), walk (encode_rows) and place (stored fallback, assemble) -- linked by events, with a ring
+    //   of three scratch sets.  Walks of consecutive submissions then follow each other without a gap on the walk stream
+    //   (they are bound by instruction issue), while the memory-bound placement of submission k and the preparation of
+    //   k+2 run next to the walk of k+1.  An encoder with nothing in flight puts the whole chain on one stream: no
+    //   event hops in the latency of a single submission.
+    // Per-kernel profiling stays on one stream, which serialises it.
+    static const int sched_stages = [] {
+        const char *v = getenv("FPNG_AMD_SCHED");
+        return (v && !strcmp(v, "stages")) ? 1 : 0;
+    }();
+    int lane;
+    hipStream_t sp, s, sy;
+    if (e->profiling) {
+        lane = 0;
+        sp = s = sy = e->lane_stream[0];
+    } else if (sched_stages) {
+        lane = (int)(e->submitted % 3);
+        fpng_amd_encoder::Slot &prev = e->slots[e->submitted % fpng_amd_encoder::kSlots];
+        if (prev.in_flight && hipEventQuery(prev.done) == hipSuccess) prev.in_flight = false;
+        (void)hipGetLastError();
+        const bool idle = !prev.in_flight;
+        sp = idle ? e->lane_stream[1] : e->lane_stream[0];
+        s = e->lane_stream[1];
+        sy = idle ? e->lane_stream[1] : e->lane_stream[2];
+    } else {
+        lane = (int)(e->submitted % n_lanes);
+        sp = s = sy = e->lane_stream[lane];
+    }
     fpng_amd_encoder::Scratch &sc = e->sc[lane];
-    hipStream_t s = e->lane_stream[lane];
     Submission sub;
     int rc = prepare_jobs(e, slot, sc, images, n, flags, sub);
     if (rc) return rc;
     const DeviceTables &dt = g_dev[e->device];
     const bool force_stored = (flags & FPNG_AMD_FORCE_UNCOMPRESSED) != 0;
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
-    // Pipelines.  rows (default): encode_rows -> scan -> assemble: every row into its own scratch stream, shifted into
-    // place by a second kernel that also takes the CRC.  fused (FPNG_AMD_PIPELINE=fused, and the fallback when the scratch
-    // streams do not fit): encode_image_kernel, one persistent launch that places the rows straight from LDS.
-    static const int forced = [] {
-        const char *v = getenv("FPNG_AMD_PIPELINE");
-        if (!v) return -1;
-        return !strcmp(v, "fused") ? 0 : (!strcmp(v, "rows") ? 1 : -1);
-    }();
+    // Every row is encoded into its own scratch stream ("local stream"), a second kernel shifts the streams into place and
+    // takes the CRC.  The scratch is sized for the worst case of the table in use (FPNG_AMD_LOCAL_LIMIT_MB caps it).
     static const uint64_t local_limit = [] {
         const char *v = getenv("FPNG_AMD_LOCAL_LIMIT_MB");
-        return (v ? (uint64_t)atoll(v) : 49152ull) << 20;
+        return (v ? (uint64_t)atoll(v) : 98304ull) << 20;
     }();
-    int pipeline = forced < 0 ? 1 : forced;
-    if (pipeline == 1 && ((sub.local_dwords + 16) * 4 > local_limit || sc.d_local.ensure(sub.local_dwords + 16) != FPNG_AMD_OK)) {
-        (void)hipGetLastError(); // no room for the local streams: the pipeline that places rows straight from LDS still works
-        pipeline = 0;
-    }
-    if (pipeline == 1)
-        for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
+    if ((sub.local_dwords + 16) * 4 > local_limit)
+        return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "scratch for the rows' local streams exceeds FPNG_AMD_LOCAL_LIMIT_MB: submit fewer images per call");
+    if ((rc = sc.d_local.ensure(sub.local_dwords + 16))) return rc;
+    for (uint32_t i = 0; i < n; i++) slot.jobs.p[i].flags |= 0x200u;
     if (two_pass) {
         // pass 1 works on the symbol table; the per-job dynamic table is built on device.  The second
         // job array (same jobs, pointing at their dynamic tables) is prepared now so nothing waits later.
@@ -654,18 +588,22 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     e->submitted++;
     slot.ticket = e->submitted;
     slot.n = n;
-    e->pipeline = pipeline;
     e->phases_recorded = 0;
     // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
     HIP_TRY(hipEventRecord(slot.in, e->stream));
-    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
-    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
-    if ((rc = mark(e, s, 0))) return rc;
+    HIP_TRY(hipStreamWaitEvent(sp, slot.in, 0));
+    if (sc.last_done) HIP_TRY(hipStreamWaitEvent(sp, sc.last_done, 0)); // the scratch set's previous user
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, sp));
+    if ((rc = mark(e, sp, 0))) return rc;
     if (two_pass) {
-        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
-        launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
-        launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
-        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), sp));
+        launch_hist(sp, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
+        launch_build_dynamic(sp, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
+        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, sp));
+    }
+    if (sp != s) {
+        HIP_TRY(hipEventRecord(slot.prepped, sp));
+        HIP_TRY(hipStreamWaitEvent(s, slot.prepped, 0));
     }
     // 2-pass only: the row walk of this submission waits for the walk of the previous one (other lane), so that
     // its own histogram pass and table build run under that walk instead of next to the other lane's (+9 %, measured;
@@ -674,46 +612,30 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const char *v = getenv("FPNG_AMD_STAGGER");
         return v ? (v[0] == '1' ? 1 : 0) : -1;
     }();
-    const bool stagger = stagger_env < 0 ? two_pass : stagger_env == 1;
+    const bool stagger = !sched_stages && (stagger_env < 0 ? two_pass : stagger_env == 1);
     if (stagger && e->prev_walked && !e->profiling) HIP_TRY(hipStreamWaitEvent(s, e->prev_walked, 0));
-    if (pipeline == 0) {
-        if ((rc = launch_fused(e, slot, sc, s, sub))) return rc;
-        if ((rc = mark(e, s, 1))) return rc;
-        HIP_TRY(hipEventRecord(slot.walked, s));
-        e->prev_walked = slot.walked;
-        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
-        if ((rc = mark(e, s, 2))) return rc;
-        launch_crc(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, dt.crc, sc.d_partials.p);
-        if ((rc = mark(e, s, 3))) return rc;
-    } else if (pipeline == 1) {
-        // three launches: rows (+ the row scan by whoever finishes an image), stored fallback, assemble (+ CRC fold, trailer
-        // and result record by whoever finishes an image)
-        if ((rc = sc.d_arrivals.ensure(2 * (size_t)n))) return rc;
-        if (sc.d_arrivals.fresh) {
-            HIP_TRY(hipMemsetAsync(sc.d_arrivals.p, 0, sc.d_arrivals.cap * sizeof(uint32_t), s));
-            sc.d_arrivals.fresh = false;
-        }
-        if (force_stored)
-            launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // (no rows are encoded: sizes and header only)
-        else
-            launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_row_off.p, sc.d_arrivals.p);
-        if ((rc = mark(e, s, 1))) return rc;
-        HIP_TRY(hipEventRecord(slot.walked, s));
-        e->prev_walked = slot.walked;
-        launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
-        if ((rc = mark(e, s, 2))) return rc;
-        launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, sc.d_rows.p,
-                        slot.results.p, sc.d_arrivals.p);
-        if ((rc = mark(e, s, 3))) return rc;
-    }
+    // five launches: rows, row scan (sizes, offsets, stored-or-compressed decision, stream head), stored fallback,
+    // assemble (+ CRC partials), finalize (CRC fold, trailer, result record).  Folding the scan into the last row block and
+    // the finalize step into the last assemble block (three launches) was measured on the same box: 11 % less throughput
+    // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
+    if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    if ((rc = mark(e, s, 1))) return rc;
+    HIP_TRY(hipEventRecord(slot.walked, s));
+    e->prev_walked = slot.walked;
+    if (sy != s) HIP_TRY(hipStreamWaitEvent(sy, slot.walked, 0));
+    launch_scan(sy, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+    if ((rc = mark(e, sy, 2))) return rc;
+    launch_stored(sy, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+    if ((rc = mark(e, sy, 3))) return rc;
+    launch_assemble(sy, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
+    if ((rc = mark(e, sy, 4))) return rc;
+    launch_finalize(sy, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
+    if ((rc = mark(e, sy, 5))) return rc;
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
-    if (pipeline == 0) {
-        launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
-        if ((rc = mark(e, s, 4))) return rc;
-    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(slot.done, s));
+    HIP_TRY(hipEventRecord(slot.done, sy));
+    sc.last_done = slot.done;
     slot.in_flight = true;
     if (ticket_out) *ticket_out = slot.ticket;
     return FPNG_AMD_OK;
@@ -775,8 +697,8 @@ int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    static const char *names[2] = {"encode_image,stored,crc,finalize", "encode_rows,stored,assemble"};
-    return names[e ? e->pipeline : 0];
+    (void)e;
+    return "encode_rows,scan,stored,assemble,finalize";
 }
 
 int fpng_amd_encoder_join(fpng_amd_encoder *e)
@@ -1098,7 +1020,7 @@ int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t f
         launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p);
     }
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_row_off.p, nullptr);
+    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     launch_scan(s, sc.d_jobs.p, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // band count: sums only
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_states.p, sc.d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));
@@ -1159,7 +1081,7 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
     HIP_TRY(hipEventRecord(e->band_copied[3], s));
     launch_scan(s, sc.d_jobs.p + 3, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // absolute row offsets, stream head
     launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks << 4, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
-                    sc.d_partials.p, sc.d_rows.p, nullptr, nullptr);
+                    sc.d_partials.p);
     HIP_TRY(hipGetLastError());
     return FPNG_AMD_OK;
 }
@@ -1215,14 +1137,7 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
         HIP_TRY(hipMemcpy(dst, e->sc[lane].d_hist.p + page, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return FPNG_AMD_OK;
     }
-    if (n_words == 16) { // the timing build's counters (head of the spill area), read and cleared
-        HIP_TRY(hipMemcpy(dst, e->sc[lane].d_spill.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(e->sc[lane].d_spill.p, 0, 16 * sizeof(uint32_t)));
-        return FPNG_AMD_OK;
-    }
-    if (e->sc[lane].d_ctrl.cap < n_words) return fail(FPNG_AMD_ERR_INVALID_ARG, "no control words yet");
-    HIP_TRY(hipMemcpy(dst, e->sc[lane].d_ctrl.p, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return FPNG_AMD_OK;
+    return fail(FPNG_AMD_ERR_INVALID_ARG, "unknown debug page");
 }
 
 int fpng_amd_calibration_stream(fpng_amd_encoder *e, int write, uint32_t lane_bytes, void *d_buf, size_t bytes)

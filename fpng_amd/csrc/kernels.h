@@ -30,13 +30,6 @@ struct Job {
     uint64_t local_base;      // dwords
     uint32_t local_stride;    // dwords per row (worst-case token bits of a row + slack)
     uint32_t local_pad;
-    // fused pipeline (encode_image_kernel): rows are cut into segments of seg_px pixels (a multiple of 256), eight
-    // consecutive segments (row-major) form a unit = the work of one 512-thread block, eight consecutive units a chunk
-    uint32_t seg_px, segs_per_row;
-    uint32_t n_units;         // ceil(nrows * segs_per_row / 8); 1 for FORCE_UNCOMPRESSED jobs
-    uint32_t unit_base;       // index of the job's first unit in the per-unit arrays
-    uint32_t chunk_base;      // index of the job's first chunk in the submission's chunk order
-    uint32_t fused_pad;
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
 
@@ -59,27 +52,6 @@ struct JobState {
     uint64_t reserved[2];
 };
 
-// Arguments of encode_image_kernel (one submission).
-struct FusedArgs {
-    const Job *jobs;
-    const uint32_t *chunk_base; // [n_jobs + 1]: prefix sums of the jobs' chunk counts
-    uint64_t *unit_state;       // two 8-byte granules per unit: aggregate, inclusive prefix (see kernels.hip)
-    uint64_t *unit_adler;       // per unit: Adler raw sums of its filtered bytes with image-level weights, s1 | s2 << 32
-    uint32_t *tickets;          // 8 work-queue heads (one per XCD), 32 dwords apart; zero at launch
-    uint32_t *job_done;         // per job: units finished; zero at launch
-    uint32_t *spill;            // per (block, wave): spill_stride dwords for segments that outgrow their LDS window
-    JobState *states;
-    uint32_t n_jobs, total_chunks;
-    uint32_t chunks_per_job;    // != 0: every job has this many chunks (no search)
-    uint32_t epoch;             // 1 .. 2^24-1, different from every value the state arrays may still hold
-    uint32_t spill_stride;      // dwords
-    uint32_t pad;
-};
-constexpr uint32_t kSegMaxPx = 1024;      // pixels per segment at most
-constexpr uint32_t kUnitSegs = 8;         // segments per unit = waves per block
-constexpr uint32_t kChunkUnits = 8;       // units per chunk (the XCD-affinity granule of the work queue)
-constexpr uint32_t kFusedMaxBlocks = 1024; // persistent grid: 4 blocks of 8 waves per CU
-
 struct Result {
     uint64_t png_size;
     uint32_t mode;
@@ -100,16 +72,10 @@ void build_crc_device_tables(CrcDeviceTables *t);
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
-// whole images (Job::whole_png): the wave that finishes an image's last row block also does its row scan (scan_kernel's
-// work).  arrivals: two zeroed counters per job, [2j] row blocks, [2j+1] assemble ranges; both reset themselves.
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
-                        JobState *states, uint32_t *local, uint64_t *row_off, uint32_t *arrivals);
-// one launch per channel count present in the batch (args.chunk_base / tickets of that kind)
-void launch_encode_image(hipStream_t s, uint32_t num_chans, const FusedArgs &args, uint32_t n_blocks);
-// whole images: the block that completes an image's last range also does finalize_kernel's work (results[j])
+                        JobState *states, uint32_t *local);
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
-                     const RowInfo *rows, Result *results, uint32_t *arrivals);
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,

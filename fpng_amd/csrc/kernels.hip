@@ -438,14 +438,9 @@ struct RowResult {
     uint32_t s1, s2;         // Adler raw sums of the filtered row, mod 65521
 };
 
-// Walks the pixels [xb, xe) of row r: the whole row (xb = 0, xe = w), or one SEGMENT of it (xb a multiple of 256,
-// xe = w or a multiple of 256 below w).  Segments of a row are independent units of work: the only state that crosses
-// a segment boundary is the pixel before it and the length (mod CAP) of the run that ends there, and both are
-// recovered from the pixels in front of the segment.
-// WHOLE: the caller walks complete rows (xb = 0, xe = w known at compile time: the segment logic folds away).
-template <int C, Pass PASS, bool WHOLE = true>
-__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t xb,
-                                              uint32_t xe, uint32_t lane, EmitSink *sink)
+// Walks row r of the job.
+template <int C, Pass PASS>
+__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink)
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
@@ -461,9 +456,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     const uint64_t lane_le_mask = (2ull << lane) - 1ull;
     const uint32_t nwin = (w + 63) >> 6;
     const uint32_t n_interior = (w >= 128) ? (w >> 6) - 1 : 0; // windows k with (k+2)*64 <= w
-    if (WHOLE) xb = 0;
-    const bool first_seg = WHOLE || xb == 0, last_seg = WHOLE || xe == w;
-    const uint32_t nwin_end = last_seg ? nwin : (xe >> 6);     // windows [xb/64, nwin_end) belong to this segment
 
     RowWindows<C> px;
     px.init(row, up_row, bpl, lane);
@@ -476,7 +468,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     uint64_t acc_w = 0;
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
     const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
-    if (kEmit && first_seg) {
+    if (kEmit) {
         if (lane == 0) {
             const uint64_t v = (uint64_t)plit_code(fl) << (sink->fill & 31);
             atomicOr(&sink->stage[sink->fill >> 5], (uint32_t)v);
@@ -487,35 +479,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
 
     uint32_t f_cur = 0; // state of the per-pixel walk (phase B): filtered pixels and `same` mask of window k
     uint64_t m_cur = 0;
-
-    // State in front of a segment that does not start the row: the filtered pixel xb-1 and t(xb-1) mod CAP, the
-    // length of the run of "equals its left neighbour" pixels ending there.  One window load in the common case
-    // (pixel xb-1 differs from xb-2); a run is followed back window by window to its start.
-    uint32_t seg_prev_f = 0;
-    if (!first_seg) {
-        uint32_t k = (xb >> 6) - 1, t = 0;
-        uint32_t fk = px.filtered_at(k << 6);
-        seg_prev_f = (uint32_t)__builtin_amdgcn_readlane((int)fk, 63);
-        for (;;) {
-            // bit l: pixel 64k+l equals its left neighbour; bit 0 needs the window before (looked at only when it matters)
-            uint64_t m = __ballot(fk == lane_prev(fk, ~fk)) & ~1ull;
-            uint32_t ones = (uint32_t)__builtin_clzll(~m); // consecutive set bits from bit 63 down (0..63)
-            if (ones < 63 || k == 0) {
-                t += ones;
-                break;
-            }
-            const uint32_t fp = px.filtered_at((k - 1) << 6);
-            const bool b0 = (uint32_t)__builtin_amdgcn_readlane((int)fk, 0) == (uint32_t)__builtin_amdgcn_readlane((int)fp, 63);
-            if (!b0) {
-                t += 63;
-                break;
-            }
-            t += 64;
-            k--;
-            fk = fp;
-        }
-        rle.carry = t % Rle<C>::CAP;
-    }
 
     auto step = [&](auto tail_tag, uint32_t k, uint32_t f_next) {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -663,17 +626,15 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // ~all of photographic content); any other super-window is replayed through the per-pixel walk
     // below with ds_bpermute gathers.  Super-windows S with 256*(S+1) < w qualify.
     // =====================================================================================
-    uint32_t k0 = xb >> 6;         // first 64-pixel window left for phase B
-    uint32_t carry_f = seg_prev_f; // filtered value of the pixel just before window k0
+    uint32_t k0 = 0;      // first 64-pixel window left for phase B
+    uint32_t carry_f = 0; // filtered value of the pixel just before window k0
     {
         constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
         constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
         // super-windows that are followed by at least one more pixel of the row (the look-ahead pixel exists and
         // the row's last pixel, which sets the final flush unit, is always left to phase B)
-        const uint32_t NS = (w - 1) >> 8;                // row level: bounds the loads ahead
-        const uint32_t S0 = xb >> 8;                     // this segment's super-windows: [S0, NSE)
-        const uint32_t NSE = last_seg ? NS : (xe >> 8);  // (a segment that does not end the row ends on a super-window boundary)
-        if (NSE > S0) {
+        const uint32_t NS = (w - 1) >> 8;
+        if (NS > 0) {
             const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
                 // RGB: 16 aligned bytes that contain the lane's 12 (the resources start on a dword, the row begins
@@ -710,13 +671,13 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             };
             constexpr int PF4 = 1; // super-windows in flight ahead of the look-ahead one
             u32x4 c_first, u_first, rc[PF4], ru[PF4];
-            load4(S0, c_first, u_first);
+            load4(0, c_first, u_first);
 #pragma unroll
-            for (int j = 0; j < PF4; j++) load4(S0 + (uint32_t)j + 1, rc[j], ru[j]);
+            for (int j = 0; j < PF4; j++) load4((uint32_t)j + 1, rc[j], ru[j]);
             uint32_t fd[4];
             filt(c_first, u_first, fd);
-            uint32_t last_f = seg_prev_f;                            // pixel just before the super-window
-            uint32_t wgt = bpl - kLaneBytes * lane - S0 * kSuperBytes; // bytes from this lane's first byte to the row end
+            uint32_t last_f = 0;                            // pixel just before the super-window
+            uint32_t wgt = bpl - kLaneBytes * lane; // bytes from this lane's first byte to the row end
             const uint32_t c1_bits = chunk1 & 0xFF;
             // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
             auto gather = [&](uint32_t jw, const uint32_t (&src)[4]) {
@@ -728,8 +689,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 const uint32_t comp = lane & 3;
                 return comp == 0 ? t0 : (comp == 1 ? t1 : (comp == 2 ? t2 : t3));
             };
-            uint32_t gen_streak = 1, done = S0, limit = NSE; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
-            for (uint32_t Sb = S0; Sb < limit; Sb += PF4) {
+            uint32_t gen_streak = 1, done = 0, limit = NS; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
+            for (uint32_t Sb = 0; Sb < limit; Sb += PF4) {
 #pragma unroll
                 for (int js = 0; js < PF4; js++) {
                     const uint32_t S = Sb + (uint32_t)js;
@@ -780,6 +741,10 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             acc_w += (uint64_t)wgt * a;
                           }
                           if (kEmit) {
+                            // room for a whole super-window (<= 256 x 48 bits = 384 dwords) in the LDS window.  Checked before
+                            // the tokens exist: a flush between building them and putting them keeps them all alive across
+                            // its loop (spills in the hot path)
+                            if (sink->fill > (uint32_t)(kStageDwords - 420) * 32u) sink_flush(*sink, lane, false);
                             uint32_t n[4];
                             uint64_t t[4];
 #pragma unroll
@@ -793,10 +758,6 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                             }
                             const uint32_t nA = n[0] + n[1], nB = n[2] + n[3], nL = nA + nB;
                             const uint32_t incl = wave_inclusive_sum(nL);
-                            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                            // the window is written out only when this super-window's tokens (<= 256 x 48 bits = 384
-                            // dwords) really do not fit any more
-                            if (sink->fill + total > (uint32_t)(kStageDwords - 4) * 32u) sink_flush(*sink, lane, false);
                             const uint32_t pos = sink->fill + incl - nL;
                             if (__ballot(nA > 64 || nB > 64)) {
                                 // noisy pixels: a pair does not fit 64 bits, put the four tokens one by one
@@ -808,6 +769,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                 sink_put_wide(*sink, t[0] | (t[1] << n[0]), pos);
                                 sink_put_wide(*sink, t[2] | (t[3] << n[2]), pos + nA);
                             }
+                            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                             sink->fill += total;
                             row_bits += total;
                           }
@@ -857,7 +819,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         m_cur = __ballot(f_cur == lane_prev(f_cur, carry_f)) & valid_mask(k0 << 6, w);
         if (k0 == 0) m_cur &= ~1ull;
         // interior windows: ring-fed, unmasked
-        const uint32_t lim_int = n_interior < nwin_end ? n_interior : nwin_end;
+        const uint32_t lim_int = n_interior;
         for (uint32_t kb = k0; kb < lim_int; kb += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
@@ -869,7 +831,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             }
         }
         // the last one or two windows of the row: masked body, look-ahead loaded directly
-        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < nwin_end; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
+        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
     }
 
     RowResult res;
@@ -877,7 +839,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
     if (kSums) {
-        const uint32_t fl_bits = first_seg ? plit_len(fl) : 0u;
+        const uint32_t fl_bits = plit_len(fl);
         res.bits = row_bits + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
@@ -885,8 +847,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         const uint32_t la = acc_a % kAdlerMod;
         const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod); // every byte weight is positive
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
-        // weights count the bytes up to the ROW end, so the sums of a row's segments simply add up
-        const uint32_t fb = first_seg ? filter_byte : 0u;
+        const uint32_t fb = filter_byte;
         res.s1 = (wave_sum(la) + fb) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * fb) % kAdlerMod;
     }
@@ -910,9 +871,9 @@ __global__ __launch_bounds__(kRowBlock) void hist_kernel(const Job *jobs, uint32
     const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + uniform(threadIdx.x >> 6);
     if (r < job.nrows) {
         if (job.c == 4)
-            walk_row<4, Pass::Hist>(job, T, hist, r, 0u, job.w, lane, nullptr);
+            walk_row<4, Pass::Hist>(job, T, hist, r, lane, nullptr);
         else
-            walk_row<3, Pass::Hist>(job, T, hist, r, 0u, job.w, lane, nullptr);
+            walk_row<3, Pass::Hist>(job, T, hist, r, lane, nullptr);
         if (lane == 0) hist_add(hist, (job.y0 + r) ? 2 : 0, r); // the row's filter-type literal
     }
     __syncthreads();
@@ -938,10 +899,8 @@ __device__ __forceinline__ void granule_store(uint64_t *p, uint64_t v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row scan of one job, done by ONE wave: exclusive scan of the rows' token bits -> absolute bit offset of every row,
-// Adler combine, the reference's compressed-or-stored decision, sizes, head of the output.  Called by the wave that
-// finishes a whole image's last row block inside encode_rows_kernel (the rows' records were written by other
-// workgroups of the same launch: granule loads), and by scan_kernel for the row bands.
+// Row scan of one job by one 256-thread block: exclusive scan of the rows' token bits -> absolute bit offset of every
+// row, Adler combine, the reference's compressed-or-stored decision, sizes, head of the output.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t wave_exclusive_sum_u64(uint64_t v, uint32_t lane, uint64_t &total)
 {
@@ -963,15 +922,13 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
     p[3] = (uint8_t)v;
 }
 
-__device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
-                                              uint32_t lane)
+__device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
+                                         uint64_t (*wsum)[kWavesPerBlock] /* LDS [3][kWavesPerBlock] */)
 {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = uniform(t >> 6);
     const TokenTable *tab = job.table;
     const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
     const bool force_stored = (job.flags & 2u) != 0;
-    // The rows' records were stored write-through by other workgroups (of this launch, or of an earlier one): ONE
-    // agent-scope acquire drops whatever this CU's L1 holds, after which plain 16-byte loads see them and pipeline.
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const FPNG_GLOBAL u32x4 *rg = (const FPNG_GLOBAL u32x4 *)(uintptr_t)(rows + job.row_base); // {bits, s1, s2, -} per row
 
     // --- exclusive scan of row bits (absolute zlib bit positions), Adler combine ---
@@ -980,10 +937,10 @@ __device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, cons
     uint64_t a_s1 = 0, a_s2 = 0;
     const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
     if (!force_stored) {
-        // every lane owns a contiguous chunk of rows: local sums, one wave scan of the 64 chunk totals, then the chunk is
-        // walked again to hand out the row offsets
-        const uint32_t per = (job.nrows + kWave - 1) / kWave;
-        const uint32_t r0 = lane * per < job.nrows ? lane * per : job.nrows, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
+        // every thread owns a contiguous chunk of rows: local sums, one scan of the 256 chunk totals (per wave, then across
+        // the four waves through LDS), then the chunk is walked again to hand out the row offsets
+        const uint32_t per = (job.nrows + kBlock - 1) / kBlock;
+        const uint32_t r0 = t * per < job.nrows ? t * per : job.nrows, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
         uint64_t local = 0;
         for (uint32_t r = r0; r < r1; r++) {
             const u32x4 ri = rg[r];
@@ -994,22 +951,40 @@ __device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, cons
             a_s1 += s1;
             a_s2 += (s2 + after * s1) % kAdlerMod;
         }
-        uint64_t total;
-        uint64_t pos = first_bit + wave_exclusive_sum_u64(local, lane, total);
+        uint64_t wave_total;
+        const uint64_t excl = wave_exclusive_sum_u64(local, lane, wave_total);
+        if (lane == 0) wsum[0][wv] = wave_total;
+        __syncthreads();
+        uint64_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kWavesPerBlock; k++) {
+            const uint64_t v = wsum[0][k];
+            if (k < wv) before += v;
+            total += v;
+        }
+        uint64_t pos = first_bit + before + excl;
         for (uint32_t r = r0; r < r1; r++) {
             row_off[job.row_base + r] = pos;
             pos += rg[r].x;
         }
         s_last += total;
     }
-    const uint64_t S1 = wave_sum((uint32_t)(a_s1 % kAdlerMod)) % kAdlerMod, S2 = wave_sum((uint32_t)(a_s2 % kAdlerMod)) % kAdlerMod;
+    {
+        const uint32_t w1 = wave_sum((uint32_t)(a_s1 % kAdlerMod)), w2 = wave_sum((uint32_t)(a_s2 % kAdlerMod));
+        if (lane == 0) wsum[1][wv] = w1, wsum[2][wv] = w2;
+    }
+    __syncthreads();
+    uint64_t S1 = 0, S2 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kWavesPerBlock; k++) S1 += wsum[1][k], S2 += wsum[2][k];
+    S1 %= kAdlerMod, S2 %= kAdlerMod;
 
     // --- compressed or stored?  (closed form of reference fpng.cpp:567-588) ---
     const uint32_t eob_len = tab->lit[256] >> 16;
     // byte budget the reference hands to the coder (fpng.cpp:1705): whole image only
     const uint64_t n_total = (uint64_t)(job.bpl + 1) * job.h_total;
     const uint64_t D = ((58 + n_total + 7) & ~7ull) - 58;
-    const uint32_t last_unit_bits = __hip_atomic_load((gptr_u32)(uintptr_t)&st.last_unit_bits, FPNG_RLX_AGENT);
+    const uint32_t last_unit_bits = st.last_unit_bits;
     bool stored = force_stored;
     if (job.whole_png && !force_stored) {
         if (job.one_pass && D < tab->header_bits / 8) stored = true;                 // fpng.cpp:1169, :1455
@@ -1020,7 +995,7 @@ __device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, cons
                                                 : ((s_last + eob_len + 7) >> 3);
     const uint64_t zlib_size = (!job.whole_png && job.band_zlib_size) ? job.band_zlib_size : zlib_bytes_no_adler + 4;
 
-    if (lane == 0) {
+    if (t == 0) {
         st.token_end_bit = s_last;
         st.mode = stored ? 1u : 0u;
         st.status = 0;
@@ -1047,22 +1022,23 @@ __device__ __forceinline__ void scan_job_wave(const Job &job, JobState &st, cons
     //     up to the next 16-byte boundary ---
     gptr_u8 out = to_global<gptr_u8>(job.out);
     if (job.whole_png)
-        for (uint32_t i = lane; i < kPngHeaderBytes; i += kWave)
+        for (uint32_t i = t; i < kPngHeaderBytes; i += kBlock)
             if (i < 50 || i >= 54) out[i] = job.png_header[i];
     gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
     if (!stored && job.is_first) {
         const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
-        for (uint32_t i = lane; i < head_bytes; i += kWave) zl[i] = tab->header[i];
+        for (uint32_t i = t; i < head_bytes; i += kBlock) zl[i] = tab->header[i];
         const uint32_t head_end = kPngHeaderBytes + head_bytes;
-        for (uint32_t i = head_end + lane; i < ((head_end + 15u) & ~15u); i += kWave) out[i] = 0;
+        for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
     }
-    if (lane == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
+    if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
-// scan_kernel: one wave per job (row bands: counting phase and placement phase)
-__global__ __launch_bounds__(kWave) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+// scan_kernel: one block per job (whole images; row bands: counting phase and placement phase)
+__global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    scan_job_wave(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, threadIdx.x);
+    __shared__ uint64_t wsum[3][kWavesPerBlock];
+    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1159,11 +1135,9 @@ __device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *r
 // fewer registers than the 4-pixels-per-lane RGBA one and keeps 8 waves per SIMD.
 template <int C>
 __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
-                                                                                                      JobState *states, uint32_t *local,
-                                                                                                      uint64_t *row_off, uint32_t *arrivals)
+                                                                                                      JobState *states, uint32_t *local)
 {
     __shared__ PackedTables T;
-    __shared__ uint32_t arrived; // waves of this block that have published their row
     __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
     // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
     // contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
@@ -1179,7 +1153,6 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     const Job &job = jobs[by];
     if (job.c != C || bx * kRowWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
-    if (threadIdx.x == 0) arrived = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = bx * kRowWaves + wv;
     if (r >= job.nrows) return;
@@ -1196,7 +1169,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
-    const RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, 0u, job.w, lane, &sink);
+    const RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, lane, &sink);
     if (r == job.nrows - 1 && job.is_last) {
         // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of ri.bits
         const uint32_t eob = T.lit[256];
@@ -1204,518 +1177,15 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
         sink.fill += plit_len(eob);
     }
     sink_flush(sink, lane, true);
-    // The row's record, as granules: the wave that completes the image reads all of them within this launch.  Whole
-    // images only (row bands run scan_kernel between their phases anyway).
-    uint32_t block_complete = 0;
     if (lane == 0) {
-        uint64_t *rg = (uint64_t *)(rows_out + job.row_base + r);
-        granule_store(rg, (uint64_t)res.bits | ((uint64_t)res.s1 << 32));
-        granule_store(rg + 1, (uint64_t)res.s2);
-        if (r == job.nrows - 1) __hip_atomic_store((gptr_u32)(uintptr_t)&states[by].last_unit_bits, res.last_unit_bits, FPNG_RLX_AGENT);
-        if (job.whole_png) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is out before the row counts as done
-            const uint32_t rows_here = (job.nrows - bx * kRowWaves < kRowWaves) ? job.nrows - bx * kRowWaves : kRowWaves;
-            block_complete = atomicAdd(&arrived, 1u) + 1u == rows_here;
-        }
+        RowInfo ri;
+        ri.bits = res.bits;
+        ri.s1 = res.s1;
+        ri.s2 = res.s2;
+        ri.pad = 0;
+        rows_out[job.row_base + r] = ri;
+        if (r == job.nrows - 1) states[by].last_unit_bits = res.last_unit_bits;
     }
-    if (uniform(block_complete)) {
-        uint32_t before = 0;
-        if (lane == 0) before = __hip_atomic_fetch_add(arrivals + 2 * by, 1u, FPNG_RLX_AGENT);
-        if (uniform(before) + 1u == (job.nrows + kRowWaves - 1) / kRowWaves) { // the image's last row block: this wave does the row scan
-            scan_job_wave(job, states[by], rows_out, row_off, gridDim.y, lane);
-            if (lane == 0) __hip_atomic_store((gptr_u32)(uintptr_t)(arrivals + 2 * by), 0u, FPNG_RLX_AGENT); // ready for the next launch
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// encode_image_kernel: the whole-image path in ONE persistent launch -- every pixel is read once and every byte of
-// the compressed stream is written once, at its final position.
-//
-// Work decomposition.  A row is cut into SEGMENTS of at most 1024 pixels (a multiple of 256; the row walker treats a
-// segment like a short row, see walk_row).  Eight consecutive segments in row-major order form a UNIT: one 512-thread
-// block, one wave per segment, each wave encodes its segment into its 4 KiB LDS window (a segment whose tokens
-// outgrow the window spills them to a private scratch stream in global memory: incompressible content only).
-// The unit's position in the Deflate stream is the sum of the token bits of all units before it, which the block
-// obtains with a decoupled look-back over per-unit records (aggregate = the unit's own bits, inclusive prefix = bits
-// up to its end) while its tokens wait in LDS; then the block shifts its eight segment streams into place with
-// 16-byte stores.  Neighbouring units meet inside a byte: the later unit owns it and receives the earlier unit's
-// last bits with the aggregate record.
-//
-// Work distribution.  Blocks pull units from eight queues (one per XCD, blockIdx & 7 = the XCD a block runs on as
-// far as observed; only L2 locality depends on that): queue k holds the chunks (8 units) k, k+8, k+16, ... of the
-// submission, so that the eight XCDs advance through the images in lock step, the rows above a unit's rows were
-// read by the same XCD a moment ago, and the unit a block waits for in the look-back is always owned by a block that
-// already runs (tickets are handed out in order): no assumption about dispatch order or residency.
-//
-// Inter-block visibility: all shared words are 8-byte granules written and read with agent-scope atomics
-// (write-through stores, L1-bypassing loads; cdna_hip_programming.md Guideline 16, R2) carrying the submission's
-// epoch, so the arrays need no clearing between launches.  Spins are bounded and end in JobState::status.
-//
-// The image's last-finishing unit computes what scan_kernel computes for the other pipelines: Adler-32, the
-// reference's compressed-or-stored decision (reference fpng.cpp:567-588), the IDAT length.
-// ---------------------------------------------------------------------------------------------
-
-constexpr uint32_t kFusedBlock = kWave * kUnitSegs;
-constexpr uint32_t kSpinLimit = 1u << 20; // ~ a second; a healthy look-back needs a handful of polls
-
-struct FusedShared {
-    uint32_t ticket_chunk, ticket_unit, job;          // this round's work (written by wave 0)
-    uint32_t seg_bits[kUnitSegs];                     // token bits per segment
-    uint32_t seg_off[kUnitSegs + 1];                  // exclusive prefix of seg_bits
-    uint32_t seg_spilled[kUnitSegs];                  // 1: the segment's stream sits in its spill area, not in LDS
-    uint32_t seg_s1[kUnitSegs], seg_s2[kUnitSegs];    // Adler sums, image-level weights
-    uint32_t prefix_lo, prefix_hi;                    // zlib bit position of the unit's first bit
-    uint32_t tail;                                    // the bits in front of it that share its first byte
-    uint32_t finalize;                                // this block finished the image's last outstanding unit
-    uint32_t failed;
-    uint32_t red[2 * kUnitSegs];
-};
-
-// Wave-level decoupled look-back: zlib bit position of unit u's first bit = first_bit + sum of the aggregates of
-// units 0..u-1 of the job.  `st` points at the job's first granule pair.  Returns false on timeout.
-__device__ __forceinline__ bool unit_look_back(const uint64_t *st, uint32_t u, uint32_t epoch, uint32_t lane, uint32_t *abort_word,
-                                               uint32_t dbg, uint32_t *dbg_out, uint64_t &prefix, uint32_t &tail7)
-{
-    uint64_t d_ma = 0, d_mp = 0, d_mi = 0;
-    uint32_t d_f = 0, d_back = 0;
-    uint64_t sum = 0;
-    uint32_t back = 1; // lane l looks at unit u - back - l
-    bool have_tail = false;
-    uint32_t t7 = 0;
-    for (uint32_t spins = 0; spins < kSpinLimit; spins++) {
-        const uint32_t d = back + lane;
-        const bool inr = d <= u;
-        uint64_t ga = 0, gp = 0;
-        if (inr) {
-            if (dbg & 2u) {
-                ga = __hip_atomic_load((gptr_u64)(uintptr_t)(st + 2 * (size_t)(u - d)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                gp = __hip_atomic_load((gptr_u64)(uintptr_t)(st + 2 * (size_t)(u - d) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                ga = granule_load(st + 2 * (size_t)(u - d));
-                gp = granule_load(st + 2 * (size_t)(u - d) + 1);
-            }
-        }
-        const bool va = inr && (uint32_t)(ga >> 40) == epoch;
-        const bool vp = inr && (uint32_t)(gp >> 40) == epoch;
-        const uint64_t ma = __ballot(va), mp = __ballot(vp), mi = __ballot(inr);
-        if (!have_tail && (ma & 1ull)) { // unit u-1: its last seven bits
-            t7 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga) >> 20) & 0x7Fu;
-            have_tail = true;
-        }
-        const uint32_t f = mp ? (uint32_t)__builtin_ctzll(mp) : 64u; // nearest unit with an inclusive prefix
-        d_ma = ma, d_mp = mp, d_mi = mi, d_f = f, d_back = back;
-        const uint64_t below = (f < 64u) ? ((1ull << f) - 1ull) : ~0ull;
-        // without a prefix in the window, move on only if unit 0 (whose prefix is what ends the search) lies beyond it
-        const bool ready = have_tail && ((ma & below & mi) == (below & mi)) && (f < 64u || back + 63u < u);
-        if (!ready) {
-            // (a window that reaches unit 0 without a prefix: unit 0's is about to appear; unit 0 never looks back)
-            __builtin_amdgcn_s_sleep(4);
-            if (dbg & 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            // somebody else gave up: do not sit out the own limit as well
-            if ((spins & 255u) == 255u && __hip_atomic_load((gptr_u32)(uintptr_t)abort_word, FPNG_RLX_AGENT)) break;
-            continue;
-        }
-        const uint32_t agg = ((uint32_t)ga & 0xFFFFFu);
-        const uint32_t part = wave_sum((lane < f && inr) ? agg : 0u);
-        sum += part;
-        if (f < 64u) {
-            const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gp, (int)f);
-            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gp >> 32), (int)f) & 0xFFu;
-            prefix = (((uint64_t)phi << 32) | plo) + sum;
-            tail7 = t7;
-            return true;
-        }
-        back += 64;
-    }
-    if (lane == 0) {
-        const uint32_t was = __hip_atomic_exchange((gptr_u32)(uintptr_t)abort_word, 1u, FPNG_RLX_AGENT);
-        if (!was) { // the first one to give up leaves a note (tools/fused_debug.py)
-            dbg_out[0] = 0xDEB06u, dbg_out[1] = u, dbg_out[2] = d_back, dbg_out[3] = d_f, dbg_out[4] = have_tail;
-            dbg_out[5] = (uint32_t)d_ma, dbg_out[6] = (uint32_t)(d_ma >> 32), dbg_out[7] = (uint32_t)d_mp, dbg_out[8] = (uint32_t)(d_mp >> 32);
-            dbg_out[9] = (uint32_t)d_mi, dbg_out[10] = (uint32_t)(d_mi >> 32), dbg_out[11] = epoch, dbg_out[12] = blockIdx.x;
-        }
-    }
-    return false;
-}
-
-// dword `idx` of a segment's token stream (LDS window or spill area); out-of-range reads give 0
-__device__ __forceinline__ uint32_t seg_dword(const uint32_t *lds, gptr_cu32 glb, bool spilled, int32_t idx, uint32_t ndw)
-{
-    if ((uint32_t)idx >= ndw) return 0u;
-    return spilled ? glb[idx] : lds[idx];
-}
-
-template <int C>
-__device__ __forceinline__ RowResult encode_segment(const Job &job, const PackedTables &T, uint32_t g, uint32_t lane, EmitSink &sink,
-                                                    bool &image_end)
-{
-    const uint32_t S = uniform(job.segs_per_row), seg_px = uniform(job.seg_px), w = uniform(job.w);
-    const uint32_t r = g / S, si = g - r * S;
-    const uint32_t xb = si * seg_px, xe = (xb + seg_px < w) ? xb + seg_px : w;
-    RowResult res = walk_row<C, Pass::Encode, false>(job, T, nullptr, r, xb, xe, lane, &sink);
-    image_end = (r == uniform(job.nrows) - 1) && xe == w;
-    // image-level Adler weights: every byte of row r is followed by the later rows (see scan_kernel)
-    const uint32_t n_row_mod = (uniform(job.bpl) + 1u) % kAdlerMod;
-    const uint32_t after = (uint32_t)(((uint64_t)((uniform(job.nrows) - 1 - r) % kAdlerMod) * n_row_mod) % kAdlerMod);
-    res.s2 = (uint32_t)((res.s2 + (uint64_t)after * res.s1) % kAdlerMod);
-    return res;
-}
-
-// One instantiation per channel count (its own queues: FusedArgs::chunk_base counts only the jobs of that kind).
-//
-// Register budget: the row walker alone fills the 64 VGPRs / 80 SGPRs that 8 waves per SIMD allow, so nothing of the
-// surrounding per-unit state may stay live across it.  The body is therefore written in phases that re-read the
-// unit's identity from LDS (volatile loads: the compiler cannot carry the values through) and re-derive the rest.
-struct UnitCtx {
-    uint32_t j, u, n_units;
-    const Job *job;
-};
-// (the asm statement makes the compiler forget what it knows about memory, LDS included)
-#define FPNG_UNIT_CTX(c)                                                                               \
-    UnitCtx c;                                                                                         \
-    {                                                                                                  \
-        asm volatile("" ::: "memory");                                                                 \
-        c.j = uniform(sh.job);                                                                         \
-        c.job = a.jobs + c.j;                                                                          \
-        c.u = (uniform(sh.ticket_chunk) - uniform(c.job->chunk_base)) * kChunkUnits + uniform(sh.ticket_unit); \
-        c.n_units = uniform(c.job->n_units);                                                           \
-    }
-
-template <int C>
-__global__ __launch_bounds__(kFusedBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_image_kernel(const FusedArgs a)
-{
-    __shared__ PackedTables T;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kUnitSegs][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
-    __shared__ FusedShared sh;
-    __shared__ const TokenTable *staged_table;
-    if (threadIdx.x == 0) staged_table = nullptr;
-#ifdef FPNG_FUSED_TIMING
-    // diagnostic build (python -m fpng_amd.build --variant timing): cycles per phase, summed over this block's units
-    __shared__ uint64_t tm_acc[8];
-    __shared__ uint64_t tm_last;
-    if (threadIdx.x < 8) tm_acc[threadIdx.x] = 0;
-#define FPNG_TM(i)                                              \
-    if (threadIdx.x == 0) {                                     \
-        const uint64_t now_ = __builtin_readcyclecounter();     \
-        tm_acc[i] += now_ - tm_last;                            \
-        tm_last = now_;                                         \
-    }
-#define FPNG_TM_START() if (threadIdx.x == 0) tm_last = __builtin_readcyclecounter();
-#else
-#define FPNG_TM(i)
-#define FPNG_TM_START()
-#endif
-
-    for (;;) {
-        __syncthreads(); // the previous round's readers of sh / the LDS windows are done
-        FPNG_TM_START();
-        // ---------------- next unit: ticket from this XCD's queue, job lookup (wave 0) ----------------
-        if (threadIdx.x < kWave) {
-            const uint32_t lane = threadIdx.x, xcd = blockIdx.x & 7u;
-            uint32_t t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + xcd * 32u, 1u, FPNG_RLX_AGENT);
-            t = uniform(t);
-            const uint32_t chunk = (t / kChunkUnits) * 8u + xcd; // queue k holds chunks k, k+8, ...
-            uint32_t j = 0;
-            if (chunk < a.total_chunks) {
-                if (a.chunks_per_job) {
-                    j = chunk / a.chunks_per_job;
-                } else { // 64-ary search for the job whose chunk range holds `chunk`
-                    uint32_t lo = 0, span = a.n_jobs;
-                    while (span > 1) {
-                        const uint32_t step = (span + 63) >> 6;
-                        const bool probe = lane * step < span;
-                        const uint32_t v = probe ? a.chunk_base[lo + lane * step] : 0xFFFFFFFFu;
-                        const uint32_t kcnt = (uint32_t)__popcll(__ballot(probe && v <= chunk)); // >= 1: lane 0 qualifies
-                        lo += (kcnt - 1) * step;
-                        span = (span - (kcnt - 1) * step < step) ? span - (kcnt - 1) * step : step;
-                    }
-                    j = uniform(lo);
-                }
-            }
-            if (lane == 0) {
-                sh.ticket_chunk = chunk;
-                sh.ticket_unit = t % kChunkUnits;
-                sh.job = j;
-                sh.finalize = 0;
-                sh.failed = 0;
-            }
-        }
-        __syncthreads();
-        FPNG_TM(0); // ticket
-        if (uniform(sh.ticket_chunk) >= a.total_chunks) break; // this queue is empty
-        {
-            FPNG_UNIT_CTX(c);
-            if (c.u >= c.n_units) continue; // the job's last chunk is not full
-        }
-
-        // ---------------- encode: wave = segment ----------------
-        {
-            FPNG_UNIT_CTX(c);
-            const Job &job = *c.job;
-            const bool force_stored = (uniform(job.flags) & 2u) != 0;
-            if (!force_stored && job.table != staged_table) { // (block-uniform)
-                __syncthreads();
-                stage_packed_tables(T, job.table);
-                if (threadIdx.x == 0) staged_table = job.table;
-                __syncthreads();
-            }
-            const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6);
-            const uint32_t nseg_total = force_stored ? 0u : uniform(job.nrows) * uniform(job.segs_per_row);
-            const uint32_t g = c.u * kUnitSegs + wv;
-            uint32_t my_bits = 0, my_s1 = 0, my_s2 = 0;
-            bool my_spilled = false;
-            if (g < nseg_total) {
-                EmitSink sink;
-                sink.stage = stage[wv];
-                sink.out32 = to_global<gptr_u32>(a.spill + ((size_t)blockIdx.x * kUnitSegs + wv) * a.spill_stride);
-                const uint32_t zero = uniform(job.local_pad); // (a zero the compiler cannot see, see encode_rows_kernel)
-                sink.base_dw = zero;
-                sink.fill = zero;
-                sink.wide = false;
-                sink_zero(sink, lane, kStageDwords);
-                wave_lds_fence();
-                bool image_end = false;
-                const RowResult res = encode_segment<C>(job, T, g, lane, sink, image_end);
-                my_bits = res.bits;
-                my_s1 = res.s1, my_s2 = res.s2;
-                if (image_end) {
-                    // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567)
-                    const uint32_t eob = T.lit[256];
-                    sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
-                    sink.fill += plit_len(eob);
-                    my_bits += plit_len(eob);
-                    if (lane == 0)
-                        __hip_atomic_store((gptr_u32)(uintptr_t)&a.states[uniform(sh.job)].last_unit_bits, res.last_unit_bits, FPNG_RLX_AGENT);
-                }
-                my_spilled = sink.base_dw != 0;
-                if (my_spilled) sink_flush(sink, lane, true); // the rest of the stream joins what was spilled
-                wave_lds_fence();
-            }
-            FPNG_TM(1); // wave 0's walk
-            if ((threadIdx.x & 63) == 0) {
-                const uint32_t wv2 = threadIdx.x >> 6;
-                sh.seg_bits[wv2] = my_bits;
-                sh.seg_spilled[wv2] = my_spilled ? 1u : 0u;
-                sh.seg_s1[wv2] = my_s1;
-                sh.seg_s2[wv2] = my_s2;
-            }
-        }
-        __syncthreads();
-        FPNG_TM(2); // waiting for the slowest wave
-
-        // ---------------- place: aggregate, look-back, prefix (wave 0) ----------------
-        if (threadIdx.x < kWave) {
-            const uint32_t lane = threadIdx.x;
-            FPNG_UNIT_CTX(c);
-            const Job &job = *c.job;
-            const uint32_t u = c.u, n_units = c.n_units;
-            const bool force_stored = (uniform(job.flags) & 2u) != 0;
-            const TokenTable *tab = job.table;
-            uint64_t *ust = a.unit_state + 2 * (size_t)uniform(job.unit_base);
-            uint32_t b = (lane < kUnitSegs) ? sh.seg_bits[lane] : 0u;
-            const uint32_t incl = wave_inclusive_sum(b);
-            const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)incl, kUnitSegs - 1);
-            if (lane <= kUnitSegs) sh.seg_off[lane] = (lane < kUnitSegs) ? incl - b : A;
-            // the unit's last seven bits (units that have a successor hold at least eight)
-            uint32_t t7 = 0;
-            if (A >= 7 && u + 1 < n_units) {
-                // segments from the back until seven bits are collected (a segment has at least one bit)
-                uint32_t got = 0;
-                for (int s = kUnitSegs - 1; s >= 0 && got < 7; s--) {
-                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)b, s);
-                    if (!sb) continue;
-                    const uint32_t take = (sb < 7 - got) ? sb : 7 - got;
-                    const bool sp = sh.seg_spilled[s] != 0;
-                    gptr_cu32 gsp = to_global<gptr_cu32>(a.spill + ((size_t)blockIdx.x * kUnitSegs + s) * a.spill_stride);
-                    const uint32_t ndw = (sb + 31) >> 5, p0 = sb - take;
-                    const uint32_t d0 = seg_dword(stage[s], gsp, sp, (int32_t)(p0 >> 5), ndw);
-                    const uint32_t d1 = seg_dword(stage[s], gsp, sp, (int32_t)(p0 >> 5) + 1, ndw);
-                    const uint32_t bits = (uint32_t)((((uint64_t)d1 << 32) | d0) >> (p0 & 31)) & ((1u << take) - 1u);
-                    t7 |= bits << (7 - got - take); // bit 6 = the unit's last bit, earlier bits below
-                    got += take;
-                }
-            }
-            uint64_t prefix = 0;
-            uint32_t tail = 0;
-            bool ok = true;
-            uint64_t *mine = ust + 2 * (size_t)u;
-            if (!force_stored) {
-                if (lane == 0) granule_store(mine, ((uint64_t)((a.epoch << 8) | 1u) << 32) | (A | (t7 << 20)));
-                if (u == 0) {
-                    const uint32_t hb = tab->header_bits;
-                    prefix = tab->first_token_bit;
-                    tail = (hb & 7u) ? (tab->header[hb >> 3] & ((1u << (hb & 7u)) - 1u)) : 0u;
-                } else {
-                    uint32_t prev7 = 0;
-                    ok = unit_look_back(ust, u, a.epoch, lane, a.tickets + 8 * 32 - 1, a.pad, a.job_done - 31, prefix, prev7);
-                    const uint32_t k = (uint32_t)prefix & 7u; // kPngHeaderBytes * 8 is a multiple of 8
-                    tail = k ? (prev7 >> (7u - k)) : 0u;
-                }
-                const uint64_t incl_prefix = prefix + A;
-                if (lane == 0) granule_store(mine + 1, ((uint64_t)((a.epoch << 8) | (uint32_t)((incl_prefix >> 32) & 0xFFu)) << 32) | (uint32_t)incl_prefix);
-            }
-            FPNG_TM(3); // look-back
-            // Adler partial of the unit, then count the unit as finished (ordered behind the stores above)
-            const uint32_t s1 = wave_sum(lane < kUnitSegs ? sh.seg_s1[lane] : 0u) % kAdlerMod;
-            const uint32_t s2 = wave_sum(lane < kUnitSegs ? sh.seg_s2[lane] : 0u) % kAdlerMod;
-            if (lane == 0) {
-                granule_store(a.unit_adler + uniform(job.unit_base) + u, ((uint64_t)s2 << 32) | s1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint32_t before = __hip_atomic_fetch_add(a.job_done + c.j, 1u, FPNG_RLX_AGENT);
-                sh.prefix_lo = (uint32_t)prefix;
-                sh.prefix_hi = (uint32_t)(prefix >> 32);
-                sh.tail = tail;
-                sh.finalize = (before + 1 == n_units) ? 1u : 0u;
-                sh.failed = ok ? 0u : 1u;
-            }
-        }
-        __syncthreads();
-        FPNG_TM(4); // done counter + barrier
-
-        // ---------------- copy: the eight streams to file bit F0 ----------------
-        {
-            const uint32_t tid = threadIdx.x, wv = uniform(threadIdx.x >> 6);
-            FPNG_UNIT_CTX(c);
-            const Job &job = *c.job;
-            const uint32_t u = c.u, n_units = c.n_units;
-            const bool force_stored = (uniform(job.flags) & 2u) != 0;
-            const TokenTable *tab = job.table;
-            gptr_u8 out = to_global<gptr_u8>(job.out);
-            const bool failed = uniform(sh.failed) != 0;
-            const uint32_t A = uniform(sh.seg_off[kUnitSegs]);
-            const uint64_t P = ((uint64_t)uniform(sh.prefix_hi) << 32) | uniform(sh.prefix_lo);
-            const uint64_t F0 = (uint64_t)kPngHeaderBytes * 8 + P, F1 = F0 + A;
-            const uint64_t lo = F0 >> 3, hi = (u + 1 == n_units) ? ((F1 + 7) >> 3) : (F1 >> 3); // bytes this unit owns
-            // A stream that outgrows the output buffer (>= the stored size) is one the reference gives up on
-            // (its coder runs out of room, fpng.cpp:567-588): the image will be redone as stored blocks, and the
-            // bytes beyond the buffer are not written at all.
-            const bool beyond = hi + 20 > uniform64(job.out_cap);
-            if (!force_stored && !failed && !beyond) {
-                if (u == 0) {
-                    // PNG header (IDAT length: by the finalizing block) and the Deflate block header's whole bytes
-                    for (uint32_t i = tid; i < kPngHeaderBytes; i += kFusedBlock)
-                        if (i < 50 || i >= 54) out[i] = job.png_header[i];
-                    for (uint32_t i = tid; i < (tab->header_bits >> 3); i += kFusedBlock) out[kPngHeaderBytes + i] = tab->header[i];
-                }
-                const uint64_t p_first = lo >> 4;
-                const uint32_t npieces = (uint32_t)(((hi - 1) >> 4) - p_first) + 1u;
-                const int32_t rel0 = (int32_t)((int64_t)(p_first * 128) - (int64_t)F0); // first piece's bit 0 relative to the unit's bit 0: (-128, 0]
-                const uint32_t tail = uniform(sh.tail), k = (uint32_t)F0 & 7u;
-                for (uint32_t i0 = 0; i0 < npieces; i0 += kFusedBlock) {
-                    const uint32_t i = i0 + tid;
-                    const int32_t rel = rel0 + (int32_t)(i * 128u);
-                    const int32_t cw0 = rel0 + (int32_t)((i0 + wv * 64u) * 128u), cw1 = cw0 + 8192; // the wave's 1 KiB chunk
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    if (cw0 < (int32_t)A && i0 + wv * 64u < npieces) {
-#pragma unroll 1
-                        for (uint32_t s = 0; s < kUnitSegs; s++) {
-                            const int32_t sa = (int32_t)uniform(sh.seg_off[s]), sn = (int32_t)uniform(sh.seg_off[s + 1]);
-                            if (sn == sa || sn <= cw0 || sa >= cw1) continue;
-                            const bool sp = uniform(sh.seg_spilled[s]) != 0;
-                            gptr_cu32 gsp = to_global<gptr_cu32>(a.spill + ((size_t)blockIdx.x * kUnitSegs + s) * a.spill_stride);
-                            const int32_t pr = rel - sa;
-                            const int32_t ii = pr >> 5; // floor
-                            const uint32_t shf = (uint32_t)pr & 31u, ndw = ((uint32_t)(sn - sa) + 31u) >> 5;
-                            uint32_t d[5];
-#pragma unroll
-                            for (int t = 0; t < 5; t++) d[t] = seg_dword(stage[s], gsp, sp, ii + t, ndw);
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) w[kk] |= __builtin_amdgcn_alignbit(d[kk + 1], d[kk], shf);
-                        }
-                    }
-                    if (i == 0 && k) { // the bits in front of the unit inside its first byte
-                        const uint32_t q = ((uint32_t)F0 & 127u) - k;
-                        const uint32_t v = tail << (q & 31u);
-                        if ((q >> 5) == 0) w[0] |= v; else if ((q >> 5) == 1) w[1] |= v; else if ((q >> 5) == 2) w[2] |= v; else w[3] |= v;
-                    }
-                    if (i < npieces) {
-                        const uint64_t byte0 = (p_first + i) * 16;
-                        if (byte0 >= lo && byte0 + 16 <= hi) {
-                            u32x4 v;
-                            v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
-                            *(gptr_u128)(uintptr_t)(out + byte0) = v;
-                        } else { // first / last piece: only the owned bytes
-                            for (uint32_t bb = 0; bb < 16; bb++) {
-                                const uint64_t pos = byte0 + bb;
-                                if (pos >= lo && pos < hi) {
-                                    const uint32_t dw = (bb >> 2) == 0 ? w[0] : ((bb >> 2) == 1 ? w[1] : ((bb >> 2) == 2 ? w[2] : w[3]));
-                                    out[pos] = (uint8_t)(dw >> (8 * (bb & 3)));
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            if ((force_stored || (beyond && u == 0)) && tid < kPngHeaderBytes && (tid < 50 || tid >= 54)) out[tid] = job.png_header[tid];
-            if (failed && tid == 0) __hip_atomic_store((gptr_u32)(uintptr_t)&a.states[c.j].status, 1u, FPNG_RLX_AGENT);
-        }
-
-        FPNG_TM(5); // wave 0's copy
-        // ---------------- the image's last unit to finish: Adler-32, compressed or stored, sizes ----------------
-        if (uniform(sh.finalize)) {
-            const uint32_t tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6);
-            FPNG_UNIT_CTX(c);
-            const Job &job = *c.job;
-            const uint32_t n_units = c.n_units;
-            JobState &st = a.states[c.j];
-            const bool force_stored = (uniform(job.flags) & 2u) != 0;
-            const TokenTable *tab = job.table;
-            const uint64_t n_filtered = (uint64_t)(uniform(job.bpl) + 1) * uniform(job.nrows);
-            uint64_t s1 = 0, s2 = 0;
-            uint64_t total = 0; // zlib bit position behind the end-of-block symbol
-            if (!force_stored) {
-                const uint64_t *adl = a.unit_adler + uniform(job.unit_base);
-                for (uint32_t q = tid; q < n_units; q += kFusedBlock) {
-                    const uint64_t v = granule_load(adl + q);
-                    s1 += (uint32_t)v;
-                    s2 += (uint32_t)(v >> 32);
-                }
-                const uint64_t gl = granule_load(a.unit_state + 2 * ((size_t)uniform(job.unit_base) + n_units - 1) + 1);
-                total = (gl & 0xFFFFFFFFull) | (((gl >> 32) & 0xFFull) << 32);
-            }
-            const uint32_t r1 = wave_sum((uint32_t)(s1 % kAdlerMod)), r2 = wave_sum((uint32_t)(s2 % kAdlerMod));
-            if (lane == 0) sh.red[wv] = r1, sh.red[kUnitSegs + wv] = r2;
-            __syncthreads();
-            if (tid == 0) {
-                uint64_t S1 = 0, S2 = 0;
-                for (uint32_t q = 0; q < kUnitSegs; q++) S1 += sh.red[q], S2 += sh.red[kUnitSegs + q];
-                S1 %= kAdlerMod, S2 %= kAdlerMod;
-                const uint32_t eob_len = force_stored ? 0u : (tab->lit[256] >> 16);
-                const uint64_t s_last = total - eob_len; // bit position after the last token
-                // byte budget the reference hands to the coder (fpng.cpp:1705), closed form of its failure rule
-                const uint64_t D = ((58 + n_filtered + 7) & ~7ull) - 58;
-                bool stored = force_stored;
-                if (!force_stored) {
-                    const uint32_t lub = __hip_atomic_load((gptr_u32)(uintptr_t)&st.last_unit_bits, FPNG_RLX_AGENT);
-                    if (uniform(job.one_pass) && D < tab->header_bits / 8) stored = true; // fpng.cpp:1169, :1455
-                    if (((s_last - lub) >> 3) + 8 > D) stored = true;                      // last PUT_BITS_FLUSH
-                    if (((s_last + eob_len + 7) >> 3) + 4 > D) stored = true;              // EOB + Adler
-                }
-                const uint64_t zlib_no_adler = stored ? (2 + n_filtered + 5 * ((n_filtered + kStoredBlockMax - 1) / kStoredBlockMax))
-                                                      : ((s_last + eob_len + 7) >> 3);
-                const uint64_t zlib_size = zlib_no_adler + 4;
-                st.token_end_bit = s_last;
-                st.mode = stored ? 1u : 0u;
-                st.zlib_size = zlib_size;
-                st.s1 = (uint32_t)S1;
-                st.s2 = (uint32_t)S2;
-                st.adler = ((uint32_t)((n_filtered % kAdlerMod + S2) % kAdlerMod) << 16) | (uint32_t)((1 + S1) % kAdlerMod);
-                const uint64_t span = kPngHeaderBytes + zlib_size;
-                uint32_t want = 2048u / a.n_jobs;
-                want = want < 4u ? 4u : want;
-                uint32_t rl = 12;
-                while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
-                st.range_log2 = rl;
-                store_be32(to_global<gptr_u8>(job.out) + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
-            }
-        }
-    }
-#ifdef FPNG_FUSED_TIMING
-    __syncthreads();
-    if (threadIdx.x < 6) atomicAdd((unsigned long long *)(a.spill) + threadIdx.x, (unsigned long long)tm_acc[threadIdx.x]);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1865,7 +1335,7 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
         for (int i = (int)G - 1; i >= 0; i--) {
             const uint32_t j = t * G + (uint32_t)i;
             if (v) v = dev_mulmod(v, X);
-            if (j < n_ranges) v ^= __hip_atomic_load((gptr_cu32)(uintptr_t)(pj + j), FPNG_RLX_AGENT);
+            if (j < n_ranges) v ^= pj[j];
         }
     }
     red[t] = v;
@@ -1939,11 +1409,10 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const
 
 __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
-                                                         uint32_t max_crc_blocks, const RowInfo *rows, Result *results, uint32_t *arrivals)
+                                                         uint32_t max_crc_blocks)
 {
     __shared__ uint32_t tab[16][256];
     __shared__ uint32_t red[kWavesPerBlock];
-    __shared__ uint32_t completes_image;
     const Job &job = job_of_block(jobs);
     JobState &st = states[blockIdx.y];
     // row bands (flag 0x100): the rows of a band land in a private window that shares the whole file's geometry
@@ -2079,18 +1548,9 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
                 }
             }
             if (in_data && P + 128 > tok_begin && P < tok_end) { // (a band's window ends with the piece that holds its last bit)
-                if (band || o + 16 <= de) {
-                    u32x4 d;
-                    d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
-                    *(gptr_u128)(uintptr_t)(base + o) = d;
-                } else {
-                    // the file's last data piece: the bytes behind the data (Adler-32 ...) are written by the block that
-                    // finishes the image, possibly before this store reaches memory -- every byte has ONE writer per launch
-                    for (int32_t bb = 0; o + bb < de; bb++) {
-                        const uint32_t dw = (bb >> 2) == 0 ? w[0] : ((bb >> 2) == 1 ? w[1] : ((bb >> 2) == 2 ? w[2] : w[3]));
-                        to_global<gptr_u8>(job.out)[range_begin + o + bb] = (uint8_t)(dw >> (8 * (bb & 3)));
-                    }
-                }
+                u32x4 d; // (the last data piece also covers the bytes behind the data: finalize_kernel writes those afterwards)
+                d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
+                *(gptr_u128)(uintptr_t)(base + o) = d;
             }
             if (r - pr >= 32) { // refill the look-ahead early: its latency hides behind this step's CRC
                 pr = r;
@@ -2121,23 +1581,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
     c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
     if ((tid & 63) == 0) red[tid >> 6] = c;
     __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store((gptr_u32)(uintptr_t)(partials + (size_t)blockIdx.y * max_crc_blocks + blockIdx.x), red[0] ^ red[1] ^ red[2] ^ red[3], FPNG_RLX_AGENT);
-        completes_image = 0;
-        if (!band) { // whole images: the block that completes the file's last range also finishes the image
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t rl = crc_range_log2(st);
-            const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
-            completes_image = __hip_atomic_fetch_add(arrivals + 2 * blockIdx.y + 1, 1u, FPNG_RLX_AGENT) + 1u == n_ranges;
-        }
-    }
-    __syncthreads();
-    if (completes_image) {
-        uint32_t *fred = &tab[0][0];                      // (the CRC tables are no longer needed)
-        uint64_t *fred64 = (uint64_t *)(&tab[0][0] + kBlock);
-        finalize_job(job, rows, st, tabs, partials + (size_t)blockIdx.y * max_crc_blocks, results[blockIdx.y], fred, fred64);
-        if (tid == 0) __hip_atomic_store((gptr_u32)(uintptr_t)(arrivals + 2 * blockIdx.y + 1), 0u, FPNG_RLX_AGENT); // ready for the next launch
-    }
+    if (tid == 0) partials[(size_t)blockIdx.y * max_crc_blocks + blockIdx.x] = red[0] ^ red[1] ^ red[2] ^ red[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2173,7 +1617,7 @@ __device__ __forceinline__ uint32_t dev_bitrev(uint32_t v, uint32_t n)
 // Code lengths (<= max_len) and canonical codes for n symbols with counts L.count[0..n).
 __device__ __forceinline__ void dev_build_table(BuilderLds &L, uint32_t n, uint32_t max_len, uint32_t lane, uint64_t *tb = nullptr) // (inlined: L must be known to live in LDS)
 {
-#ifdef FPNG_FUSED_TIMING
+#ifdef FPNG_BUILD_TIMING
 #define FPNG_TB(i) if (tb) tb[i] = __builtin_readcyclecounter()
 #else
 #define FPNG_TB(i)
@@ -2357,14 +1801,14 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, u
     }
     for (uint32_t i = lane; i < 100; i += kWave) L.hdr[i] = 0;
     wave_lds_fence();
-#ifdef FPNG_FUSED_TIMING
+#ifdef FPNG_BUILD_TIMING
     uint64_t bt[8];
     bt[0] = __builtin_readcyclecounter();
 #define FPNG_BT(i) bt[i] = __builtin_readcyclecounter()
 #else
 #define FPNG_BT(i)
 #endif
-#ifdef FPNG_FUSED_TIMING
+#ifdef FPNG_BUILD_TIMING
     uint64_t tb[6] = {0, 0, 0, 0, 0, 0};
     dev_build_table(L, 288, 12, lane, tb);
 #else
@@ -2490,7 +1934,7 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, u
         out->first_token_bit = hbits;
         out->header_bits = hbits;
     }
-#ifdef FPNG_FUSED_TIMING
+#ifdef FPNG_BUILD_TIMING
     FPNG_BT(6);
     if (lane == 0 && blockIdx.x == 0) // cycles: table(288), sequence, run-length packing, table(19), header, publish
     {
@@ -2556,33 +2000,25 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 }
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, rows, row_off, states);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, row_off, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {
     hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, (uint32_t *)hist, tables);
 }
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
-                        JobState *states, uint32_t *local, uint64_t *row_off, uint32_t *arrivals)
+                        JobState *states, uint32_t *local)
 {
     if (chan_mask & 1u)
-        hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local, row_off, arrivals);
+        hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
     if (chan_mask & 2u)
-        hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local, row_off, arrivals);
-}
-void launch_encode_image(hipStream_t s, uint32_t num_chans, const FusedArgs &args, uint32_t n_blocks)
-{
-    if (num_chans == 3)
-        hipLaunchKernelGGL(encode_image_kernel<3>, dim3(n_blocks), dim3(kFusedBlock), 0, s, args);
-    else
-        hipLaunchKernelGGL(encode_image_kernel<4>, dim3(n_blocks), dim3(kFusedBlock), 0, s, args);
+        hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
 }
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
-                     const RowInfo *rows, Result *results, uint32_t *arrivals)
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials)
 {
     hipLaunchKernelGGL(assemble_kernel, dim3(max_crc_blocks, n_jobs), dim3(kBlock), 0, s, jobs, states, row_off, local, tabs,
-                       partials, max_crc_blocks, rows, results, arrivals);
+                       partials, max_crc_blocks);
 }
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials)

@@ -23,10 +23,8 @@ b 8k_noise --kind noise --steps 10 --warmup 3
 b 4k_blocks --workload 4k --batch 16 --kind blocks --steps 20 --warmup 5
 b 16k --workload 16k --batch 1 --steps 20 --warmup 5
 b 16k_rowband --mode rowband --workload 16k --steps 5 --warmup 2
-FPNG_AMD_PIPELINE=fused b 8k_fused --steps 20 --warmup 5
-for p in rows fused; do FPNG_AMD_PIPELINE=$p timeout 200 python tools/latency.py 2>/dev/null; done > $O/latency_$TAG.txt; cat $O/latency_$TAG.txt
+timeout 200 python tools/latency.py 2>/dev/null > $O/latency_$TAG.txt; cat $O/latency_$TAG.txt
 python tools/host_path_timing.py > $O/host_path_$TAG.txt 2>/dev/null; tail -5 $O/host_path_$TAG.txt
 bash tools/gpu_profile_round.sh $TAG > /dev/null 2>&1
-FPNG_AMD_PIPELINE=fused bash tools/gpu_profile_round.sh ${TAG}_fused > /dev/null 2>&1
 bash tools/gpu_sq_counters.sh $TAG > /dev/null 2>&1
 ls $O/prof_$TAG $O/sq_$TAG | head -20

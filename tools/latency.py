@@ -22,4 +22,4 @@ for (w, h, c) in [(512, 512, 3), (1920, 1080, 3), (3840, 2160, 4), (7680, 4320, 
             enc.finish(1)
             ts.append(time.perf_counter() - t0)
         ts.sort()
-        print(f"{os.environ.get('FPNG_AMD_PIPELINE', 'rows'):5s} {w}x{h}x{c} flags={flags}: median {ts[100] * 1e6:7.1f} us, best {ts[0] * 1e6:7.1f} us")
+        print(f"{w}x{h}x{c} flags={flags}: median {ts[100] * 1e6:7.1f} us, best {ts[0] * 1e6:7.1f} us")

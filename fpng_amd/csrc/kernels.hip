@@ -37,7 +37,16 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kRowWaves = 8;               // rows (waves) per block of the row kernels: 7 of 8 Up rows are L1/L2-hot
+// Rows (waves) per block of encode_rows_kernel.  Every block re-reads the row above its first row (another block's row,
+// rarely still in L2), so bigger blocks mean less traffic -- but coarser scheduling costs more: measured on one box,
+// 8 x 8K RGBA / 256 x 1080p RGB / 1024 x 512^2: 16 rows 480 / 465 / - GP/s, 8 rows 517 / 482 / 314, 4 rows 537 / 522 / 323,
+// 3 rows 524 / 503 / 301, 2 rows 513 / 501 / 304.
+#ifndef FPNG_ROW_WAVES
+#define FPNG_ROW_WAVES 4
+#endif
+constexpr int kRowWaves = FPNG_ROW_WAVES;
+constexpr int kHistWaves = 8;              // hist_kernel: one LDS histogram (36 KiB) and one round of global atomics per block
+constexpr int kHistBlock = kWave * kHistWaves;
 constexpr int kRowBlock = kWave * kRowWaves;
 constexpr int kStageDwords = 1024;         // per-wave LDS staging window of the output bit stream
 constexpr int kStageFlushAt = kStageDwords - 136; // a 64-pixel window adds at most 64*60 bits = 120 dwords
@@ -778,7 +787,9 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     } else {
                         // general case: replay the super-window as four 64-pixel windows of the per-pixel walk
                         gen_streak++;
+#ifndef FPNG_X1
                         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
+#endif
                         uint32_t fw = gather(0, f);
                         uint32_t carry_px = last_f;
 #pragma unroll 1
@@ -810,7 +821,9 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // Phase B: per-pixel walk (lane = pixel) of windows k0 .. nwin-1: everything for RGB, the row tail for RGBA
     // =====================================================================================
     {
+#ifndef FPNG_X2
         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
+#endif
         Raw ring[PF];
         const Raw raw0 = px.load_raw(k0 << 6);
 #pragma unroll
@@ -859,16 +872,16 @@ __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return job
 // hist_kernel (2-pass, pass 1): literal / length-symbol histogram of the whole image
 // (reference fpng.cpp:1021-1084 / :1299-1363).  job.table here is the "symbol" table whose
 // chunk[q] holds (length symbol - 256).
-__global__ __launch_bounds__(kRowBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+__global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
 {
     __shared__ PackedTables T;
     __shared__ uint32_t hist[288 * kHistReplicas];
     const Job &job = job_of_block(jobs);
-    if (blockIdx.x * kRowWaves >= job.nrows) return;
+    if (blockIdx.x * kHistWaves >= job.nrows) return;
     stage_packed_tables(T, job.table);
-    for (int i = threadIdx.x; i < 288 * kHistReplicas; i += kRowBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < 288 * kHistReplicas; i += kHistBlock) hist[i] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kRowWaves + uniform(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kHistWaves + uniform(threadIdx.x >> 6);
     if (r < job.nrows) {
         if (job.c == 4)
             walk_row<4, Pass::Hist>(job, T, hist, r, lane, nullptr);
@@ -878,7 +891,7 @@ __global__ __launch_bounds__(kRowBlock) void hist_kernel(const Job *jobs, uint32
     }
     __syncthreads();
     uint32_t *dst = hist_out + (size_t)blockIdx.y * 288;
-    for (int i = threadIdx.x; i < 288; i += kRowBlock) {
+    for (int i = threadIdx.x; i < 288; i += kHistBlock) {
         uint32_t s = 0;
         for (int rep = 0; rep < kHistReplicas; rep++) s += hist[i * kHistReplicas + ((rep + i) & (kHistReplicas - 1))];
         if (s) atomicAdd(&dst[i], s);
@@ -1996,7 +2009,7 @@ static dim3 row_grid(uint32_t max_rows, uint32_t n_jobs)
 
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist)
 {
-    hipLaunchKernelGGL(hist_kernel, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, hist);
+    hipLaunchKernelGGL(hist_kernel, dim3((max_rows + kHistWaves - 1) / kHistWaves, n_jobs, 1), dim3(kHistBlock), 0, s, jobs, hist);
 }
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {

@@ -215,23 +215,41 @@ __device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const Tok
 __device__ __forceinline__ uint32_t plit_code(uint32_t e) { return e & 0xFFFFu; }
 __device__ __forceinline__ uint32_t plit_len(uint32_t e) { return e >> 24; }
 
+// Two packed entries a (first in the stream), b: (code(b) << len(a)) | code(a), and len(a) + len(b).  Written with
+// SDWA operand selects by hand: the compiler picks them for the shift and the length sum, but masks the codes with
+// separate v_and instructions and builds the upper half with VOP3 forms that cannot select sub-dwords (11 instructions
+// per RGBA pixel instead of 9; this is the innermost arithmetic of the walk).
+__device__ __forceinline__ uint32_t join_codes(uint32_t a, uint32_t b)
+{
+    uint32_t t, r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:WORD_0" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(t), "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_lens(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // all literals of one pixel as one token; entries are packed (see PackedTables)
 template <int C> __device__ __forceinline__ uint64_t packed_literal_token(const PackedTables &T, uint32_t f, uint32_t &nbits)
 {
     const uint32_t e0 = T.lit[f & 0xFF], e1 = T.lit[(f >> 8) & 0xFF], e2 = T.lit[(f >> 16) & 0xFF];
-    const uint32_t lo = (plit_code(e1) << plit_len(e0)) | plit_code(e0);
-    const uint32_t s01 = plit_len(e0) + plit_len(e1);
-    uint32_t hi, sum;
+    const uint32_t lo = join_codes(e0, e1);
+    const uint32_t s01 = add_lens(e0, e1);
+    uint32_t hi;
     if (C == 4) {
         const uint32_t e3 = T.lit[f >> 24];
-        hi = (plit_code(e3) << plit_len(e2)) | plit_code(e2);
-        sum = s01 + plit_len(e2) + plit_len(e3);
+        hi = join_codes(e2, e3);
+        nbits = s01 + add_lens(e2, e3);
     } else {
         hi = plit_code(e2);
-        sum = s01 + plit_len(e2);
+        nbits = s01 + plit_len(e2);
     }
-    nbits = sum;
-    return (uint64_t)lo | ((uint64_t)hi << s01);
+    uint64_t tok = (uint64_t)hi << s01; // (its low s01 <= 24 bits are zero, lo fits below them)
+    return tok | lo;
 }
 
 // ---- pixel windows through buffer resources: out-of-range lanes read 0, no exec masking ----
@@ -685,7 +703,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             for (int j = 0; j < PF4; j++) load4((uint32_t)j + 1, rc[j], ru[j]);
             uint32_t fd[4];
             filt(c_first, u_first, fd);
-            uint32_t last_f = 0;                            // pixel just before the super-window
+            // pixel just before the super-window; in front of pixel 0: a value pixel 0 cannot equal (it has no left neighbour)
+            uint32_t last_f = ~uniform(fd[0]);
             uint32_t wgt = bpl - kLaneBytes * lane; // bytes from this lane's first byte to the row end
             const uint32_t c1_bits = chunk1 & 0xFF;
             // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
@@ -712,7 +731,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     pixels(fd, f);
                     const uint32_t next_first = (C == 4) ? fn[0] : (fn[0] & 0xFFFFFFu);
                     // per-lane "equals its left neighbour" predicates (their SGPR form is the wave ballot)
-                    const bool s0 = (f[0] == lane_prev(f[3], last_f)) && !(S == 0 && lane == 0);
+                    const bool s0 = f[0] == lane_prev(f[3], last_f); // (pixel 0 of the row: last_f was chosen to differ)
                     const bool s1 = f[1] == f[0], s2 = f[2] == f[1], s3 = f[3] == f[2];
                     const uint64_t M0 = __ballot(s0), M1 = __ballot(s1), M2 = __ballot(s2), M3 = __ballot(s3);
                     const uint32_t last3 = (uint32_t)__builtin_amdgcn_readlane((int)f[3], 63);

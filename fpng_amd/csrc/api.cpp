@@ -233,7 +233,6 @@ struct fpng_amd_encoder {
         PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
         PinnedBuf<Result> results;
         hipEvent_t in = nullptr;     // recorded on the caller's stream: the inputs are ready
-        hipEvent_t prepped = nullptr; // job records (2-pass: and the per-image tables) are on the device
         hipEvent_t walked = nullptr; // recorded after the row walk
         hipEvent_t done = nullptr;   // recorded on the lane: PNGs and result records are complete
         bool in_flight = false;
@@ -313,13 +312,8 @@ static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, 
         }
         e->own_stream = true;
     }
-    // FPNG_AMD_STREAM_PRIO=high|low: priority of the internal streams (A/B runs; default: the normal priority 0)
-    int prio_low = 0, prio_high = 0, prio = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    if (const char *v = getenv("FPNG_AMD_STREAM_PRIO")) prio = !strcmp(v, "high") ? prio_high : (!strcmp(v, "low") ? prio_low : 0);
-    for (int i = 0; i < fpng_amd_encoder::kLanes; i++) {
-        hipStream_t &ls = e->lane_stream[i];
-        hipError_t err = hipStreamCreateWithPriority(&ls, hipStreamNonBlocking, prio);
+    for (auto &ls : e->lane_stream) {
+        hipError_t err = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
         if (err != hipSuccess) {
             fpng_amd_encoder_destroy(e);
             return fail(FPNG_AMD_ERR_HIP, "hipStreamCreate (lane)", err);
@@ -368,7 +362,6 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.in) (void)hipEventDestroy(sl.in);
         if (sl.walked) (void)hipEventDestroy(sl.walked);
-        if (sl.prepped) (void)hipEventDestroy(sl.prepped);
     }
     for (auto &ls : e->lane_stream)
         if (ls) (void)hipStreamDestroy(ls);
@@ -516,7 +509,6 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     if (!slot.in) HIP_TRY(hipEventCreateWithFlags(&slot.in, hipEventDisableTiming));
     if (!slot.walked) HIP_TRY(hipEventCreateWithFlags(&slot.walked, hipEventDisableTiming));
-    if (!slot.prepped) HIP_TRY(hipEventCreateWithFlags(&slot.prepped, hipEventDisableTiming));
     if (slot.in_flight) {
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
@@ -526,37 +518,14 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const int n = v ? atoi(v) : 2;
         return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
     }();
-    // Schedules.
-    // lanes (default): whole chains alternate between FPNG_AMD_LANES (default 2) streams, each with its own scratch set.
-    // stages (FPNG_AMD_SCHED=stages; measured 8 % slower for 1-pass, 2 % faster for 2-pass): the three stages of a submission run on three streams -- prep (job records; 2-pass: histogram
-    //   walk and table build), walk (encode_rows) and place (stored fallback, assemble) -- linked by events, with a ring
-    //   of three scratch sets.  Walks of consecutive submissions then follow each other without a gap on the walk stream
-    //   (they are bound by instruction issue), while the memory-bound placement of submission k and the preparation of
-    //   k+2 run next to the walk of k+1.  An encoder with nothing in flight puts the whole chain on one stream: no
-    //   event hops in the latency of a single submission.
-    // Per-kernel profiling stays on one stream, which serialises it.
-    static const int sched_stages = [] {
-        const char *v = getenv("FPNG_AMD_SCHED");
-        return (v && !strcmp(v, "stages")) ? 1 : 0;
-    }();
-    int lane;
-    hipStream_t sp, s, sy;
-    if (e->profiling) {
-        lane = 0;
-        sp = s = sy = e->lane_stream[0];
-    } else if (sched_stages) {
-        lane = (int)(e->submitted % 3);
-        fpng_amd_encoder::Slot &prev = e->slots[e->submitted % fpng_amd_encoder::kSlots];
-        if (prev.in_flight && hipEventQuery(prev.done) == hipSuccess) prev.in_flight = false;
-        (void)hipGetLastError();
-        const bool idle = !prev.in_flight;
-        sp = idle ? e->lane_stream[1] : e->lane_stream[0];
-        s = e->lane_stream[1];
-        sy = idle ? e->lane_stream[1] : e->lane_stream[2];
-    } else {
-        lane = (int)(e->submitted % n_lanes);
-        sp = s = sy = e->lane_stream[lane];
-    }
+    // lane = internal stream + scratch set; whole chains alternate between FPNG_AMD_LANES (default 2) of them, so that the
+    // latency-bound tail of one submission (scan, stored fallback, finalize) and its memory-bound assemble run next to the
+    // row walk of the next one.  Per-kernel profiling stays on lane 0, which serialises it.
+    // (Measured on one box and dropped: the three stages of a submission on three streams linked by events -- prep, walk,
+    // place, the latter with high priority -- so that walks follow each other without a gap: 0.599 vs 0.555 ms per 8 x 8K
+    // step, +2 % for 2-pass only.)
+    const int lane = e->profiling ? 0 : (int)(e->submitted % n_lanes);
+    hipStream_t s = e->lane_stream[lane];
     fpng_amd_encoder::Scratch &sc = e->sc[lane];
     Submission sub;
     int rc = prepare_jobs(e, slot, sc, images, n, flags, sub);
@@ -591,19 +560,15 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     e->phases_recorded = 0;
     // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
     HIP_TRY(hipEventRecord(slot.in, e->stream));
-    HIP_TRY(hipStreamWaitEvent(sp, slot.in, 0));
-    if (sc.last_done) HIP_TRY(hipStreamWaitEvent(sp, sc.last_done, 0)); // the scratch set's previous user
-    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, sp));
-    if ((rc = mark(e, sp, 0))) return rc;
+    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
+    if (sc.last_done) HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    if ((rc = mark(e, s, 0))) return rc;
     if (two_pass) {
-        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), sp));
-        launch_hist(sp, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
-        launch_build_dynamic(sp, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
-        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, sp));
-    }
-    if (sp != s) {
-        HIP_TRY(hipEventRecord(slot.prepped, sp));
-        HIP_TRY(hipStreamWaitEvent(s, slot.prepped, 0));
+        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
+        launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
+        launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
+        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     }
     // 2-pass only: the row walk of this submission waits for the walk of the previous one (other lane), so that
     // its own histogram pass and table build run under that walk instead of next to the other lane's (+9 %, measured;
@@ -612,7 +577,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const char *v = getenv("FPNG_AMD_STAGGER");
         return v ? (v[0] == '1' ? 1 : 0) : -1;
     }();
-    const bool stagger = !sched_stages && (stagger_env < 0 ? two_pass : stagger_env == 1);
+    const bool stagger = stagger_env < 0 ? two_pass : stagger_env == 1;
     if (stagger && e->prev_walked && !e->profiling) HIP_TRY(hipStreamWaitEvent(s, e->prev_walked, 0));
     // five launches: rows, row scan (sizes, offsets, stored-or-compressed decision, stream head), stored fallback,
     // assemble (+ CRC partials), finalize (CRC fold, trailer, result record).  Folding the scan into the last row block and
@@ -622,19 +587,18 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     if ((rc = mark(e, s, 1))) return rc;
     HIP_TRY(hipEventRecord(slot.walked, s));
     e->prev_walked = slot.walked;
-    if (sy != s) HIP_TRY(hipStreamWaitEvent(sy, slot.walked, 0));
-    launch_scan(sy, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
-    if ((rc = mark(e, sy, 2))) return rc;
-    launch_stored(sy, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
-    if ((rc = mark(e, sy, 3))) return rc;
-    launch_assemble(sy, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-    if ((rc = mark(e, sy, 4))) return rc;
-    launch_finalize(sy, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
-    if ((rc = mark(e, sy, 5))) return rc;
+    launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+    if ((rc = mark(e, s, 2))) return rc;
+    launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+    if ((rc = mark(e, s, 3))) return rc;
+    launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
+    if ((rc = mark(e, s, 4))) return rc;
+    launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
+    if ((rc = mark(e, s, 5))) return rc;
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(slot.done, sy));
+    HIP_TRY(hipEventRecord(slot.done, s));
     sc.last_done = slot.done;
     slot.in_flight = true;
     if (ticket_out) *ticket_out = slot.ticket;

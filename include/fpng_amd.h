@@ -213,13 +213,15 @@ int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32
 /* ---- instrumentation for bench.py: per-kernel durations of the last submission measured with HIP
  *      events (ms).  With profiling enabled submissions use one lane, i.e. they do not overlap.
  *      fpng_amd_encoder_phase_names(): comma-separated names of the phases of the last submission's
- *      pipeline, e.g. "encode_image,stored,crc,finalize". ---- */
+ *      launch chain: "encode_rows,scan,stored,assemble,finalize". ---- */
 #define FPNG_AMD_NUM_PHASES 8
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *enc);
 
-/* Instrumentation: the first n_words control words (work-queue heads, diagnostics) of an internal lane's last launch. */
+/* Instrumentation of the timing build (libfpng_amd_timing.so, -DFPNG_BUILD_TIMING): n_words = 8 reads the cycle counters
+ * that build_dynamic_kernel left at the head of lane `lane`'s histogram scratch (dst[7] = 0xFEED selects the second page:
+ * the phases inside the table builder). */
 int fpng_amd_debug_peek(fpng_amd_encoder *enc, int lane, uint32_t *dst, uint32_t n_words);
 
 /* PMC calibration (instrumentation): stream `bytes` of d_buf once with 4- or 16-byte lanes, reading

@@ -1,3 +1,5 @@
+# Same-box comparison with the round-1 tree: mkdir r1tree && git archive 081c225 | tar -x -C r1tree && (cd r1tree && python -m fpng_amd.build)
+# (r1tree/ is git-ignored but travels to the GPU box); run through gpurun: bash tools/ab_r1.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 p() { python -c "
 import json,sys

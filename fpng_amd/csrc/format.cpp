@@ -282,6 +282,11 @@ void build_crc_device_tables(CrcDeviceTables *t)
     const uint64_t ord = 0xFFFFFFFFull; // multiplicative order of x divides 2^32-1 (P is irreducible)
     for (uint32_t p = 0; p < 16; p++) t->inv_pad[p] = gf2_xpow((ord - 8ull * p) % ord);
     t->inv_row = gf2_xpow((ord - 8ull * kCrcRowBytes % ord) % ord);
+    for (uint32_t p = 0; p < 16; p++) t->inv_row_pad[p] = gf2_mulmod(t->inv_row, t->inv_pad[p]);
+    for (uint32_t e = 12; e <= 24; e++)
+        for (uint64_t i = 0; i < 256; i++) t->fold[e - 12][i] = gf2_xpow8n(i << e);
+    for (uint32_t k = 0; k < 6; k++)
+        for (uint64_t b = 0; b < 256; b++) t->pow_byte[k][b] = gf2_xpow8n(b << (8 * k));
 }
 
 } // namespace fpng_amd

@@ -66,6 +66,9 @@ struct CrcDeviceTables {
     uint32_t inv_pad[16];      // x^(-8*p)
     uint32_t inv_row;          // x^(-8*kCrcRowBytes)
     uint32_t pad[15];
+    uint32_t inv_row_pad[16];  // x^(-8*(kCrcRowBytes + p)): inv_row * inv_pad[p]
+    uint32_t fold[13][256];    // fold[e-12][t] = x^(8 * 2^e * t), e = 12..24: thread t's group of partials -> the common end point
+    uint32_t pow_byte[6][256]; // pow_byte[k][b] = x^(8 * b * 256^k): x^(8n) is the product of six entries
 };
 void build_crc_device_tables(CrcDeviceTables *t);
 

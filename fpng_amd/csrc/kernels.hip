@@ -45,6 +45,8 @@ constexpr int kBlock = kWave * kWavesPerBlock;
 #define FPNG_ROW_WAVES 4
 #endif
 constexpr int kRowWaves = FPNG_ROW_WAVES;
+constexpr int kScanWaves = 4;              // scan_kernel: one block per job, its threads split the rows
+constexpr int kScanBlock = kWave * kScanWaves;
 constexpr int kHistWaves = 8;              // hist_kernel: one LDS histogram (36 KiB) and one round of global atomics per block
 constexpr int kHistBlock = kWave * kHistWaves;
 constexpr int kRowBlock = kWave * kRowWaves;
@@ -955,7 +957,7 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
 }
 
 __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
-                                         uint64_t (*wsum)[kWavesPerBlock] /* LDS [3][kWavesPerBlock] */)
+                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */)
 {
     const uint32_t t = threadIdx.x, lane = t & 63, wv = uniform(t >> 6);
     const TokenTable *tab = job.table;
@@ -971,17 +973,25 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     if (!force_stored) {
         // every thread owns a contiguous chunk of rows: local sums, one scan of the 256 chunk totals (per wave, then across
         // the four waves through LDS), then the chunk is walked again to hand out the row offsets
-        const uint32_t per = (job.nrows + kBlock - 1) / kBlock;
+        const uint32_t per = (job.nrows + kScanBlock - 1) / kScanBlock;
         const uint32_t r0 = t * per < job.nrows ? t * per : job.nrows, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
         uint64_t local = 0;
-        for (uint32_t r = r0; r < r1; r++) {
-            const u32x4 ri = rg[r];
-            const uint32_t s1 = ri.y, s2 = ri.z;
-            local += ri.x;
-            // S2 of the concatenation: every byte of this row is followed by the later rows
-            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
-            a_s1 += s1;
-            a_s2 += (s2 + after * s1) % kAdlerMod;
+        for (uint32_t rb = r0; rb < r1; rb += 8) { // eight records in flight per round trip
+            u32x4 ri[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) ri[k] = rg[rb + k < r1 ? rb + k : r1 - 1];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t r = rb + k;
+                if (r >= r1) break;
+                const uint32_t s1 = ri[k].y, s2 = ri[k].z; // < 65521
+                local += ri[k].x;
+                // S2 of the concatenation: every byte of this row is followed by the later rows.  All factors are below
+                // 65521, so the products (and 65520^2 + 65520) fit 32 bits
+                const uint32_t after = ((job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+                a_s1 += s1;
+                a_s2 += (s2 + after * s1) % kAdlerMod;
+            }
         }
         uint64_t wave_total;
         const uint64_t excl = wave_exclusive_sum_u64(local, lane, wave_total);
@@ -989,15 +999,22 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         __syncthreads();
         uint64_t before = 0, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kWavesPerBlock; k++) {
+        for (uint32_t k = 0; k < kScanWaves; k++) {
             const uint64_t v = wsum[0][k];
             if (k < wv) before += v;
             total += v;
         }
         uint64_t pos = first_bit + before + excl;
-        for (uint32_t r = r0; r < r1; r++) {
-            row_off[job.row_base + r] = pos;
-            pos += rg[r].x;
+        for (uint32_t rb = r0; rb < r1; rb += 4) {
+            uint32_t bits[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) bits[k] = rg[rb + k < r1 ? rb + k : r1 - 1].x;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (rb + k >= r1) break;
+                row_off[job.row_base + rb + k] = pos;
+                pos += bits[k];
+            }
         }
         s_last += total;
     }
@@ -1008,7 +1025,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     __syncthreads();
     uint64_t S1 = 0, S2 = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kWavesPerBlock; k++) S1 += wsum[1][k], S2 += wsum[2][k];
+    for (uint32_t k = 0; k < kScanWaves; k++) S1 += wsum[1][k], S2 += wsum[2][k];
     S1 %= kAdlerMod, S2 %= kAdlerMod;
 
     // --- compressed or stored?  (closed form of reference fpng.cpp:567-588) ---
@@ -1054,22 +1071,22 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     //     up to the next 16-byte boundary ---
     gptr_u8 out = to_global<gptr_u8>(job.out);
     if (job.whole_png)
-        for (uint32_t i = t; i < kPngHeaderBytes; i += kBlock)
+        for (uint32_t i = t; i < kPngHeaderBytes; i += kScanBlock)
             if (i < 50 || i >= 54) out[i] = job.png_header[i];
     gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
     if (!stored && job.is_first) {
         const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
-        for (uint32_t i = t; i < head_bytes; i += kBlock) zl[i] = tab->header[i];
+        for (uint32_t i = t; i < head_bytes; i += kScanBlock) zl[i] = tab->header[i];
         const uint32_t head_end = kPngHeaderBytes + head_bytes;
-        for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kBlock) out[i] = 0;
+        for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kScanBlock) out[i] = 0;
     }
     if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
 // scan_kernel: one block per job (whole images; row bands: counting phase and placement phase)
-__global__ __launch_bounds__(kBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    __shared__ uint64_t wsum[3][kWavesPerBlock];
+    __shared__ uint64_t wsum[3][kScanWaves];
     scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum);
 }
 
@@ -1299,6 +1316,20 @@ __global__ __launch_bounds__(kBlock) void crc_kernel(const Job *jobs, const JobS
 // ---------------------------------------------------------------------------------------------
 // finalize_kernel: one block per job
 // ---------------------------------------------------------------------------------------------
+// four independent products, interleaved (the single product is a chain of 32 dependent steps)
+__device__ __forceinline__ void dev_mulmod4(const uint32_t (&a)[4], const uint32_t (&b_in)[4], uint32_t (&r)[4])
+{
+    uint32_t b[4] = {b_in[0], b_in[1], b_in[2], b_in[3]};
+    r[0] = r[1] = r[2] = r[3] = 0;
+#pragma unroll 4
+    for (int i = 31; i >= 0; i--) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[k] ^= b[k] & (0u - ((a[k] >> i) & 1u));
+            b[k] = (b[k] >> 1) ^ (0xEDB88320u & (0u - (b[k] & 1u)));
+        }
+    }
+}
 __device__ __forceinline__ uint32_t dev_crc_byte(uint32_t c, uint32_t byte)
 {
     c ^= byte;
@@ -1363,47 +1394,50 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
     const uint32_t G = 1u << g;
     uint32_t v = 0;
     {
-        const uint32_t X = tabs->pow2[rl]; // x^(8*range)
-        for (int i = (int)G - 1; i >= 0; i--) {
-            const uint32_t j = t * G + (uint32_t)i;
-            if (v) v = dev_mulmod(v, X);
-            if (j < n_ranges) v ^= pj[j];
+        // partial i of the group times x^(8*range*i): independent multiplications, four at a time (a Horner chain would
+        // be G dependent ones: G = 32 for a 16384^2 image)
+        const uint32_t *xp = tabs->fold[rl - 12];
+        for (uint32_t i = 0; i < G; i += 4) {
+            uint32_t a[4], b[4], r[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t j = t * G + i + k;
+                a[k] = (i + k < G && j < n_ranges) ? pj[j] : 0u;
+                b[k] = xp[(i + k) & 255u];
+            }
+            dev_mulmod4(a, b, r);
+            v ^= r[0] ^ r[1] ^ r[2] ^ r[3];
         }
     }
-    red[t] = v;
+    // the thread's group starts t * G ranges before the common end point: one multiplication by a tabulated power, then
+    // the groups simply XOR together (no multiplications inside the reduction)
+    if (v && t) v = dev_mulmod(v, tabs->fold[rl + g - 12][t]);
+    v = wave_xor(v);
+    // x^(8*(zlib_size-4)): six tabulated factors (one per byte of the length), multiplied as a tree by lanes 0..7 of wave 0
+    uint32_t f = 0x80000000u; // 1
+    if (t < 6) f = tabs->pow_byte[t][((zlib_size - 4) >> (8 * t)) & 0xFF];
+    if (t < 64) {
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_down((int)f, o, 8);
+            f = dev_mulmod(f, other);
+        }
+    }
+    if ((t & 63) == 0) red[t >> 6] = v;
+    if (t == 0) red[kWavesPerBlock] = f;
     __syncthreads();
-    for (uint32_t l = 0; (1u << l) < kBlock; l++) {
-        if ((t & ((2u << l) - 1u)) == 0) {
-            const uint32_t other = red[t + (1u << l)];
-            if (other) red[t] ^= dev_mulmod(other, tabs->pow2[rl + g + l]);
-        }
-        __syncthreads();
-    }
-    const uint32_t folded = red[0];
-    __syncthreads();
-    // x^(8*(zlib_size-4)) as a product over the set bits of the exponent, multiplied as a tree
-    {
-        const uint64_t e = zlib_size - 4;
-        uint32_t f = 0x80000000u; // 1
-        if (t < 48 && ((e >> t) & 1)) f = tabs->pow2[t];
-        red[t] = f;
-        __syncthreads();
-        for (uint32_t o = 32; o > 0; o >>= 1) {
-            if (t < o) red[t] = dev_mulmod(red[t], red[t + o]);
-            __syncthreads();
-        }
-    }
+    const uint32_t folded = red[0] ^ red[1] ^ red[2] ^ red[3];
     if (t == 0) {
         gptr_u8 out = to_global<gptr_u8>(job.out);
         const uint32_t pad = (uint32_t)(end_aligned - data_end);
-        const uint32_t raw_data = dev_mulmod(dev_mulmod(folded, tabs->inv_row), tabs->inv_pad[pad]);
+        const uint32_t raw_data = dev_mulmod(folded, tabs->inv_row_pad[pad]);
         // running CRC state (init ~0) after "IDAT", advanced over the data, then the 4 Adler bytes
         uint32_t s = 0xFFFFFFFFu;
         s = dev_crc_byte(s, 'I');
         s = dev_crc_byte(s, 'D');
         s = dev_crc_byte(s, 'A');
         s = dev_crc_byte(s, 'T');
-        s = dev_mulmod(s, red[0]) ^ raw_data;
+        s = dev_mulmod(s, red[kWavesPerBlock]) ^ raw_data;
         gptr_u8 tail = out + kPngHeaderBytes + zlib_size - 4;
         store_be32(tail, adler); // reference fpng.cpp:1569-1577 / :851-863
         s = dev_crc_byte(s, adler >> 24);
@@ -2032,7 +2066,7 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 }
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, row_off, states);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
 {

@@ -201,16 +201,23 @@ struct PackedTables {
     uint32_t chunk[96];
 };
 
-__device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const TokenTable *src)
+template <int BLOCK> __device__ __forceinline__ void stage_packed_tables(PackedTables &dst, const TokenTable *src)
 {
-    for (int i = threadIdx.x; i < 288; i += blockDim.x) {
-        const uint32_t e = src->lit[i];
-        dst.lit[i] = (e & 0xFFFFu) | ((e >> 16) << 24);
+    // trip counts known at compile time: all of a thread's loads are issued before the first one is needed
+    uint32_t e[(288 + BLOCK - 1) / BLOCK], ch = 0;
+#pragma unroll
+    for (int k = 0; k < (288 + BLOCK - 1) / BLOCK; k++) {
+        const int i = (int)threadIdx.x + k * BLOCK;
+        e[k] = i < 288 ? src->lit[i] : 0u;
     }
-    for (int i = threadIdx.x; i < 96; i += blockDim.x) {
-        const uint32_t e = src->chunk[i];
-        dst.chunk[i] = (e >> 24) | ((e & 0xFFFFFFu) << 8);
+    static_assert(BLOCK >= 96, "one round for the chunk table");
+    if (threadIdx.x < 96) ch = src->chunk[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < (288 + BLOCK - 1) / BLOCK; k++) {
+        const int i = (int)threadIdx.x + k * BLOCK;
+        if (i < 288) dst.lit[i] = (e[k] & 0xFFFFu) | ((e[k] >> 16) << 24);
     }
+    if (threadIdx.x < 96) dst.chunk[threadIdx.x] = (ch >> 24) | ((ch & 0xFFFFFFu) << 8);
 }
 
 // packed literal entry: code in the low word, length in the top byte (both are SDWA operand selects)
@@ -899,7 +906,7 @@ __global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint3
     __shared__ uint32_t hist[288 * kHistReplicas];
     const Job &job = job_of_block(jobs);
     if (blockIdx.x * kHistWaves >= job.nrows) return;
-    stage_packed_tables(T, job.table);
+    stage_packed_tables<kHistBlock>(T, job.table);
     for (int i = threadIdx.x; i < 288 * kHistReplicas; i += kHistBlock) hist[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, r = blockIdx.x * kHistWaves + uniform(threadIdx.x >> 6);
@@ -1201,7 +1208,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     }
     const Job &job = jobs[by];
     if (job.c != C || bx * kRowWaves >= job.nrows) return;
-    stage_packed_tables(T, job.table);
+    stage_packed_tables<kRowBlock>(T, job.table);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), r = bx * kRowWaves + wv;
     if (r >= job.nrows) return;

@@ -667,10 +667,12 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     {
         constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
         constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
-        // super-windows that are followed by at least one more pixel of the row (the look-ahead pixel exists and
-        // the row's last pixel, which sets the final flush unit, is always left to phase B)
+        // NS super-windows are followed by at least one more pixel of the row.  A row that ENDS with a complete
+        // super-window (w a multiple of 256: 512, 3840, 7680 ...) takes that one here too when it is of a cheap tier: no
+        // look-ahead pixel, and the token of the row's last pixel is the final flush unit.
         const uint32_t NS = (w - 1) >> 8;
-        if (NS > 0) {
+        const uint32_t NSX = NS + (((w & 255u) == 0) ? 1u : 0u);
+        if (NSX > 0) {
             const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
                 // RGB: 16 aligned bytes that contain the lane's 12 (the resources start on a dword, the row begins
@@ -726,7 +728,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 const uint32_t comp = lane & 3;
                 return comp == 0 ? t0 : (comp == 1 ? t1 : (comp == 2 ? t2 : t3));
             };
-            uint32_t gen_streak = 1, done = 0, limit = NS; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
+            uint32_t gen_streak = 1, done = 0, limit = NSX; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
             for (uint32_t Sb = 0; Sb < limit; Sb += PF4) {
 #pragma unroll
                 for (int js = 0; js < PF4; js++) {
@@ -744,7 +746,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                     const bool s1 = f[1] == f[0], s2 = f[2] == f[1], s3 = f[3] == f[2];
                     const uint64_t M0 = __ballot(s0), M1 = __ballot(s1), M2 = __ballot(s2), M3 = __ballot(s3);
                     const uint32_t last3 = (uint32_t)__builtin_amdgcn_readlane((int)f[3], 63);
-                    const bool next0 = uniform(next_first) == last3; // does the next super-window start by repeating this one's last pixel?
+                    const bool row_end = S == NS; // (only with w % 256 == 0) the row's last super-window: nothing follows
+                    const bool next0 = !row_end && uniform(next_first) == last3; // does the next super-window start by repeating this one's last pixel?
                     const uint64_t any = M0 | M1 | M2 | M3;
                     const bool all_lits = (any == 0);
                     const bool sparse = !all_lits && rle.carry == 0 &&
@@ -793,6 +796,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                                 if (M2 && s2 && !(lit_test && c1_bits > n[2])) n[2] = c1_bits, t[2] = c1_code;
                                 if (M3 && s3 && !(lit_test && c1_bits > n[3])) n[3] = c1_bits, t[3] = c1_code;
                             }
+                            if (row_end) last_unit = (uint32_t)__builtin_amdgcn_readlane((int)n[3], 63);
                             const uint32_t nA = n[0] + n[1], nB = n[2] + n[3], nL = nA + nB;
                             const uint32_t incl = wave_inclusive_sum(nL);
                             const uint32_t pos = sink->fill + incl - nL;
@@ -813,11 +817,13 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                         }
                         rle.carry = sparse ? (uint32_t)(M3 >> 63) : 0u;
                     } else {
+                        if (row_end) { // the row's last windows need the masked body of phase B
+                            limit = S;
+                            break;
+                        }
                         // general case: replay the super-window as four 64-pixel windows of the per-pixel walk
                         gen_streak++;
-#ifndef FPNG_X1
                         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
-#endif
                         uint32_t fw = gather(0, f);
                         uint32_t carry_px = last_f;
 #pragma unroll 1
@@ -848,10 +854,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // =====================================================================================
     // Phase B: per-pixel walk (lane = pixel) of windows k0 .. nwin-1: everything for RGB, the row tail for RGBA
     // =====================================================================================
-    {
-#ifndef FPNG_X2
+    if (k0 < nwin) { // (phase A may have taken the whole row)
         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
-#endif
         Raw ring[PF];
         const Raw raw0 = px.load_raw(k0 << 6);
 #pragma unroll

@@ -177,6 +177,42 @@ def test_super_window_tiers(enc, c):
 
 
 @pytest.mark.parametrize("c", [3, 4])
+def test_rows_ending_on_a_super_window(enc, c):
+    """Rows whose width is a multiple of 256 end inside the 4-pixels-per-lane phase of the walk: the file, and the size of
+    the row's final flush unit (it feeds the reference's stored-or-compressed rule, reference fpng.cpp:567-588), for every
+    kind of row end -- literal, isolated repeat, run into the last pixel, run through the whole last super-window."""
+    import torch
+    from fpng_amd import sharded
+    from band_backend import OracleBandBackend
+    rng = np.random.default_rng(90 + c)
+    be = sharded.GpuBandBackend(enc)
+    for w in (256, 512, 768, 1024, 3840):
+        for end in ("literal", "repeat1", "repeat2", "run_cap", "solid_tail", "sparse"):
+            rows = rng.integers(0, 256, (3, w, c), dtype=np.uint8)
+            for r in rows:  # the FILTERED rows get the pattern: build them, then integrate over y
+                if end == "repeat1":
+                    r[w - 1] = r[w - 2]
+                elif end == "repeat2":
+                    r[w - 2:] = r[w - 3]
+                elif end == "run_cap":
+                    r[w - 64:] = r[w - 65]
+                elif end == "solid_tail":
+                    r[w - 256:] = 5
+                elif end == "sparse":
+                    for i in (3, 64, 200, w - 5, w - 1):
+                        r[i] = r[i - 1]
+            img = np.ascontiguousarray(np.cumsum(rows.astype(np.uint16), axis=0).astype(np.uint8))
+            for fl in (0, 1):
+                pngs, _ = _gpu_encode(enc, [img], fl)
+                _assert_same(pngs[0], oracle().encode(img, w, 3, c, fl), f"row end {end} {w}x3x{c} flags={fl}")
+            # one band = the whole image: its counts straight from the kernels
+            t = torch.from_numpy(img).cuda()
+            got = be.encode(t, None, w, c, 0, 3, 3, 0, None)
+            want = OracleBandBackend(img).encode(None, None, w, c, 0, 3, 3, 0, None)
+            assert (got.token_bits, got.last_unit_bits, got.s1, got.s2) == (want.token_bits, want.last_unit_bits, want.s1, want.s2), (end, w, c, got, want)
+
+
+@pytest.mark.parametrize("c", [3, 4])
 def test_maximum_width_rows(enc, c):
     """w = 2^24 (the reference's limit, fpng.cpp:1670): 48 / 64 MiB per row, two rows so that the Up filter runs.
     Mixed content: noisy stretches, long runs (thousands of chunks per row), a few isolated repeats."""

@@ -30,7 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {"8k": (7680, 4320, 4), "4k": (3840, 2160, 4), "1080p": (1920, 1080, 3), "512": (512, 512, 3), "16k": (16384, 16384, 4)}
+WORKLOADS = {"8k": (7680, 4320, 4), "4k": (3840, 2160, 4), "1080p": (1920, 1080, 3), "1080p4": (1920, 1080, 4), "512": (512, 512, 3), "16k": (16384, 16384, 4)}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 

@@ -178,7 +178,7 @@ def test_super_window_tiers(enc, c):
 
 @pytest.mark.parametrize("c", [3, 4])
 def test_rows_ending_on_a_super_window(enc, c):
-    """Rows whose width is a multiple of 256 end inside the 4-pixels-per-lane phase of the walk: the file, and the size of
+    """Rows of at least 256 pixels end inside the 4-pixels-per-lane phase of the walk: the file, and the size of
     the row's final flush unit (it feeds the reference's stored-or-compressed rule, reference fpng.cpp:567-588), for every
     kind of row end -- literal, isolated repeat, run into the last pixel, run through the whole last super-window."""
     import torch
@@ -186,7 +186,7 @@ def test_rows_ending_on_a_super_window(enc, c):
     from band_backend import OracleBandBackend
     rng = np.random.default_rng(90 + c)
     be = sharded.GpuBandBackend(enc)
-    for w in (256, 512, 768, 1024, 3840):
+    for w in (256, 257, 259, 300, 511, 512, 700, 768, 1000, 1024, 1920, 3840, 4099):   # the last super-window complete or partial
         for end in ("literal", "repeat1", "repeat2", "run_cap", "solid_tail", "sparse"):
             rows = rng.integers(0, 256, (3, w, c), dtype=np.uint8)
             for r in rows:  # the FILTERED rows get the pattern: build them, then integrate over y

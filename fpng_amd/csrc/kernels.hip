@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
             if (in_data && P + 128 > tok_begin && P < tok_end) { // (a band's window ends with the piece that holds its last bit)
                 u32x4 d; // (the last data piece also covers the bytes behind the data: finalize_kernel writes those afterwards)
                 d.x = w[0], d.y = w[1], d.z = w[2], d.w = w[3];
-                *(gptr_u128)(uintptr_t)(base + o) = d;
+                *(gptr_u128)(uintptr_t)(base + o) = d; // (non-temporal: 0.216 vs 0.190 ms)
             }
             if (r - pr >= 32) { // refill the look-ahead early: its latency hides behind this step's CRC
                 pr = r;

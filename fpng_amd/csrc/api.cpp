@@ -478,7 +478,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         // cover), + end-of-block; rows start 16-byte aligned and the 16-byte flush / assemble_kernel may touch up
         // to four dwords past the stream
         const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[im.num_chans];
-        j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
+        j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 31) & ~31ull); // whole 128-byte lines
         j.local_base = sub.local_dwords;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         sub.local_dwords += (uint64_t)j.local_stride * im.h;
@@ -933,7 +933,7 @@ static void band_job(fpng_amd_encoder *e, const fpng_amd_band *b, bool two_pass,
     j.is_last = b->y1 == b->h_total;
     j.bit_bias = (int64_t)kPngHeaderBytes * 8;
     const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[b->num_chans];
-    j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 3) & ~3ull);
+    j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 31) & ~31ull); // whole 128-byte lines
     j.table = two_pass ? e->sc[0].d_dyn.p : g_dev[e->device].one_pass[b->num_chans];
 }
 

@@ -413,7 +413,9 @@ __device__ __forceinline__ void sink_put_wide(EmitSink &s, uint64_t code, uint32
 __device__ __forceinline__ void sink_flush_exclusive(EmitSink &s, uint32_t lane, bool final)
 {
     wave_lds_fence();
-    const uint32_t n4 = final ? ((((s.fill + 31) >> 5) + 3u) >> 2) : (s.fill >> 7); // groups of four dwords to write out
+    // groups of four dwords to write out: everything at the end of the row, whole 128-byte lines in between (the rows'
+    // streams start on line boundaries, so no line of a stream is written in two pieces)
+    const uint32_t n4 = final ? ((((s.fill + 31) >> 5) + 3u) >> 2) : ((s.fill >> 7) & ~7u);
     u32x4 *st4 = (u32x4 *)s.stage;
     gptr_u128 dst4 = (gptr_u128)(uintptr_t)(s.out32 + s.base_dw);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -423,13 +425,13 @@ __device__ __forceinline__ void sink_flush_exclusive(EmitSink &s, uint32_t lane,
         if (!final) st4[j] = zero4;
     }
     if (!final && n4) {
-        // up to three complete dwords and the partial one stay: move them to the front of the window
+        // up to 31 complete dwords and the partial one stay: move them to the front of the window
         wave_lds_fence();
-        const uint32_t rem = (lane < 4) ? s.stage[4 * n4 + lane] : 0u;
+        const uint32_t rem = (lane < 32) ? s.stage[4 * n4 + lane] : 0u;
         wave_lds_fence();
-        if (lane < 4) s.stage[4 * n4 + lane] = 0u;
+        if (lane < 32) s.stage[4 * n4 + lane] = 0u;
         wave_lds_fence();
-        if (lane < 4) s.stage[lane] = rem;
+        if (lane < 32) s.stage[lane] = rem;
         s.base_dw += 4 * n4;
         s.fill -= 128u * n4;
         wave_lds_fence();
@@ -443,7 +445,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
         return;
     }
     wave_lds_fence();
-    const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5);
+    const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5); // (whole 128-byte lines only, as in the 16-byte flush: no gain here)
 #pragma unroll 1
     for (uint32_t j = lane; j < ndw; j += kWave) __builtin_nontemporal_store(s.stage[j], &s.out32[s.base_dw + j]);
     if (!final) {

@@ -196,7 +196,6 @@ struct fpng_amd_encoder {
     uint32_t phases_recorded = 0;
 
     PinnedBuf<Job> h_jobs;
-    PinnedBuf<Result> h_results;
     PinnedBuf<JobState> h_states;
     // Device scratch of one submission.  Batch submissions alternate between kLanes internal streams, each
     // with its own scratch, so that the tail of one submission (stored fallback, CRC, trailer) overlaps the
@@ -368,7 +367,6 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     for (auto &ev : e->band_copied)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &s : e->sc) s.release();
-    e->h_results.release();
     e->h_states.release();
     e->d_stage_in.release();
     e->d_stage_out.release();

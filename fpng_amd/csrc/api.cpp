@@ -223,6 +223,12 @@ struct fpng_amd_encoder {
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
+    // fpng_amd_encode_host_batch: ring of device staging buffers, one copy stream per direction
+    struct HostRing {
+        static constexpr int kDepth = 3;
+        DeviceBuf<uint8_t> d_in[kDepth], d_out[kDepth];
+        hipStream_t up = nullptr, down = nullptr;
+    } host;
     // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
     // records coming back) guarded by an event, so fpng_amd_encode_submit() never waits for the GPU unless all
     // slots are in flight.  A submission's ticket is its sequence number; its records stay readable until its
@@ -370,6 +376,10 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->h_states.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
+    for (auto &b : e->host.d_in) b.release();
+    for (auto &b : e->host.d_out) b.release();
+    if (e->host.up) (void)hipStreamDestroy(e->host.up);
+    if (e->host.down) (void)hipStreamDestroy(e->host.down);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -717,15 +727,6 @@ int fpng_amd_encode_host(fpng_amd_encoder *e, const void *pixels, uint32_t w, ui
 // downloader thread (D2H of frame k, then the optional file write on a pool of writer threads) -- so that the two PCIe
 // directions and the encoder overlap instead of taking turns as in fpng_amd_encode_host().
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct HostRing {
-    static constexpr int kDepth = 3;
-    DeviceBuf<uint8_t> d_in[kDepth], d_out[kDepth];
-    hipStream_t up = nullptr, down = nullptr;
-    hipEvent_t uploaded[kDepth] = {};
-};
-} // namespace
-
 int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *imgs, uint32_t n, uint32_t flags, int n_writer_threads)
 {
     if (!e || !imgs || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
@@ -736,13 +737,10 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
     }
     HIP_TRY(hipSetDevice(e->device));
     if ((rc = drain(e))) return rc;
-    static thread_local HostRing tl_ring; // (staging buffers are kept between calls; an encoder is used by one thread)
-    HostRing &ring = tl_ring;             // (the worker threads below must see THIS thread's ring, not their own)
-    if (!ring.up) {
-        HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
-        for (auto &ev : ring.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    using HostRing = fpng_amd_encoder::HostRing;
+    HostRing &ring = e->host; // (staging buffers are kept between calls)
+    if (!ring.up) HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
+    if (!ring.down) HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
     size_t max_in = 0, max_out = 0;
     for (uint32_t i = 0; i < n; i++) {
         max_in = std::max(max_in, (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans);
@@ -756,6 +754,7 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
     std::condition_variable cv;
     int state[HostRing::kDepth] = {0, 0, 0};
     uint64_t tickets[HostRing::kDepth] = {0, 0, 0};
+    std::mutex emu; // the encoder object is not thread-safe: the submitting thread and the downloader take turns
     std::atomic<int> failed{0};
     const int device = e->device;
     std::vector<size_t> sizes(n, 0);
@@ -797,7 +796,7 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
             if (failed) break;
             const size_t bytes = (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans;
             if (hipMemcpyAsync(ring.d_in[k].p, imgs[i].pixels, bytes, hipMemcpyHostToDevice, ring.up) != hipSuccess ||
-                hipEventRecord(ring.uploaded[k], ring.up) != hipSuccess || hipStreamSynchronize(ring.up) != hipSuccess)
+                hipStreamSynchronize(ring.up) != hipSuccess)
                 failed = FPNG_AMD_ERR_HIP;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -815,8 +814,23 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
                 cv.wait(lk, [&] { return state[k] == 2 || failed; });
             }
             if (failed) break;
-            fpng_amd_result res;
-            if (fpng_amd_encode_wait(e, tickets[k], &res, 1) != FPNG_AMD_OK || res.status) {
+            // wait for THIS frame's submission on its `done` event, outside the encoder lock (the next submit must not wait)
+            fpng_amd_result res = {0, 0, 1};
+            hipEvent_t done = nullptr;
+            fpng_amd_encoder::Slot *sl = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(emu);
+                sl = slot_of(e, tickets[k]);
+                if (sl) done = sl->done;
+            }
+            if (sl && hipEventSynchronize(done) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(emu);
+                res.png_size = sl->results.p[0].png_size;
+                res.mode = sl->results.p[0].mode;
+                res.status = sl->results.p[0].status;
+                sl->in_flight = false;
+            }
+            if (res.status) {
                 failed = FPNG_AMD_ERR_HIP;
             } else {
                 uint8_t *dst = imgs[i].out;
@@ -866,7 +880,10 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
         im.out_cap = ring.d_out[k].cap;
         // (the upload was waited for on the host: nothing more to order the submission against)
         uint64_t t = 0;
-        if ((rc = submit(e, &im, 1, flags, &t))) failed = rc;
+        {
+            std::lock_guard<std::mutex> lk(emu);
+            if ((rc = submit(e, &im, 1, flags, &t))) failed = rc;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             tickets[k] = t;

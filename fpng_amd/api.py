@@ -100,7 +100,7 @@ class Encoder:
         else:
             check(self.lib.fpng_amd_encoder_create_on_stream(C.byref(h), device, C.c_void_p(int(stream))))
         self.h = h
-        self._keep = []
+        self._keep = {}  # ticket -> buffers of that submission (at most 8 are in flight: the C side's slot ring)
 
     def _sync_stream(self):
         if self._follow_torch:
@@ -140,18 +140,22 @@ class Encoder:
         tensors with >= max_encoded_size bytes -- or images = a make_batch() descriptor and outs = None.
         Asynchronous; call finish() for the sizes."""
         batch = images if outs is None else self.make_batch(images, outs)
-        self._keep.append(batch)  # buffers of submissions in flight stay alive until finish()
         n = len(batch[2])
         self._sync_stream()
         t = C.c_uint64(0)
         check(self.lib.fpng_amd_encode_submit(self.h, batch[2], n, flags, C.byref(t)))
         self.last_ticket = t.value
+        # buffers of submissions in flight stay alive; a submission 8 tickets back has finished (its slot was reused)
+        self._keep[t.value] = batch
+        for old in [k for k in self._keep if k + 8 <= t.value]:
+            del self._keep[old]
         return n
 
     def wait(self, ticket, n):
         """Waits for the submission `ticket` (see last_ticket) only; returns its (png_size, mode, status) records."""
         res = (Result * n)()
         check(self.lib.fpng_amd_encode_wait(self.h, ticket, res, n))
+        self._keep.pop(ticket, None)
         return [(r.png_size, r.mode, r.status) for r in res]
 
     def query(self, ticket):
@@ -174,7 +178,7 @@ class Encoder:
         """Waits for ALL submissions in flight; returns (png_size, mode, status) of the last one's n images."""
         res = (Result * n)()
         check(self.lib.fpng_amd_encode_finish(self.h, res, n))
-        self._keep = []
+        self._keep = {}
         return [(r.png_size, r.mode, r.status) for r in res]
 
     def encode_tensors(self, images, flags=0):

@@ -255,6 +255,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # the first collective builds the communicator (tens of ms with the GPU idle): pay for it here, not in the barrier
+        # that opens the timed region, where it would let the clocks drop right before the timed steps
+        dist.barrier()
+        torch.cuda.synchronize()
     dev = torch.device("cuda", local_rank)
 
     import fpng_amd

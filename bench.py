@@ -224,7 +224,7 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
             pass
         png_bytes = int(png.numel())
         alg = w * h * c + png_bytes
-        print(json.dumps({
+        _RESULT.append(json.dumps({
             "metric": "encode megapixels/sec (whole node), 1-pass, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
             "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "prewarm": 0, "parity_checked": parity,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -356,12 +356,22 @@ def main():
         line["cpu_baseline"] = cpu_baseline(w, h, c, args.kind, args.flags, args.cpu_reps)
         line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 1)
     if rank == 0:
-        print(json.dumps(line))
+        _RESULT.append(json.dumps(line))
     enc.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
 
+_RESULT = []  # the one JSON line, printed LAST: RCCL writes its version banner to stdout through C stdio whenever it likes
+
+
 if __name__ == "__main__":
     main()
+    if _RESULT:
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(_RESULT[-1], flush=True)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "fpng_amd_band_place": (_int, [_vp, C.POINTER(Band), _u64, _u64, _vp, _sz, C.POINTER(_u64), C.POINTER(_sz)]),
     "fpng_amd_1pass_layout": (_int, [_u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "fpng_amd_wrap_png": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, C.POINTER(_sz)]),
+    "fpng_amd_wrap_png_crc": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _vp, _u32, C.POINTER(_sz)]),
+    "fpng_amd_band_crc_partials": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),

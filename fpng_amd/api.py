@@ -269,9 +269,24 @@ class Encoder:
                                            C.byref(off), C.byref(n)))
         return off.value, n.value
 
-    def wrap_png(self, png_buf, zlib_size, adler, w, h, num_chans):
+    def band_crc_partials(self, device):
+        """CRC partials (one uint32 per 64 KiB range of the file, as an int32 tensor) of the band placed last: XOR the
+        ranks' arrays and hand the result to wrap_png()."""
+        n = C.c_uint32(0)
+        check(self.lib.fpng_amd_band_crc_partials(self.h, None, 0, C.byref(n)))  # (asks for the count)
+        t = torch.empty(n.value, dtype=torch.int32, device=device)
+        check(self.lib.fpng_amd_band_crc_partials(self.h, t.data_ptr(), n.value, C.byref(n)))
+        return t
+
+    def wrap_png(self, png_buf, zlib_size, adler, w, h, num_chans, crc_partials=None):
         n = C.c_size_t(0)
-        check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, adler, w, h, num_chans, C.byref(n)))
+        if crc_partials is None:
+            check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, adler, w, h, num_chans, C.byref(n)))
+        else:
+            crc_partials = crc_partials.contiguous()
+            self._keep_partials = crc_partials  # (asynchronous: keep it alive until the next call)
+            check(self.lib.fpng_amd_wrap_png_crc(self.h, png_buf.data_ptr(), zlib_size, adler, w, h, num_chans,
+                                                 crc_partials.data_ptr(), crc_partials.numel(), C.byref(n)))
         return n.value
 
     # ---- instrumentation ----

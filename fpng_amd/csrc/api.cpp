@@ -248,6 +248,7 @@ struct fpng_amd_encoder {
     uint64_t band_token_bits = 0; // row bands: what fpng_amd_band_encode() left for fpng_amd_band_place()
     uint32_t band_eob_bits = 0;
     bool band_two_pass = false;
+    uint32_t band_crc_ranges = 0; // fpng_amd_band_place(): number of 64 KiB CRC ranges of the image
     hipEvent_t band_copied[4] = {}; // the pinned job record h_jobs[k] of an asynchronous band call has been uploaded
 };
 
@@ -911,6 +912,15 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
 // the encoder's local streams, counts to the host: the one exchange step) -> place (the streams shifted to the band's
 // bit position inside a window that shares the file's 16-byte geometry).  Same kernels as whole images.
 // ------------------------------------------------------------------------------------------------
+// number of 64 KiB CRC ranges of a file whose zlib stream has zlib_size bytes (ranges end at the 16-byte-aligned end of the
+// data; the same arithmetic as finalize_kernel)
+static uint32_t crc_ranges_of(uint64_t zlib_size)
+{
+    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    return (uint32_t)((end_aligned - 48 + (1ll << 16) - 1) >> 16);
+}
+
 static int band_check(fpng_amd_encoder *e, const fpng_amd_band *b)
 {
     if (!e || !b || !b->d_rows) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
@@ -1054,21 +1064,37 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
     j.out = d_window - wb0;    // file byte 0 as the window sees it (only bytes >= wb0 are ever touched)
     j.out_cap = window_cap + wb0;
     j.crc_blocks = (uint32_t)((kPngHeaderBytes + zlib_size + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
-    if ((rc = sc.d_partials.ensure(((size_t)j.crc_blocks) << 4))) return rc; // (ranges may be as small as 4 KiB)
+    if ((rc = sc.d_partials.ensure(j.crc_blocks))) return rc;
     hipStream_t s = e->stream;
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p + 3, &j, sizeof(Job), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(e->band_copied[3], s));
+    // ranges the band does not touch contribute nothing to the CRC (fpng_amd_band_crc_partials)
+    HIP_TRY(hipMemsetAsync(sc.d_partials.p, 0, (size_t)j.crc_blocks * sizeof(uint32_t), s));
     launch_scan(s, sc.d_jobs.p + 3, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // absolute row offsets, stream head
-    launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks << 4, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
+    launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
                     sc.d_partials.p);
     HIP_TRY(hipGetLastError());
+    e->band_crc_ranges = crc_ranges_of(zlib_size);
     return FPNG_AMD_OK;
 }
 
-int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h, uint32_t c,
-                      size_t *png_size)
+int fpng_amd_band_crc_partials(fpng_amd_encoder *e, uint32_t *d_partials, uint32_t cap, uint32_t *n_partials)
+{
+    if (!e || !n_partials) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (!e->band_crc_ranges) return fail(FPNG_AMD_ERR_INVALID_ARG, "no fpng_amd_band_place() before");
+    *n_partials = e->band_crc_ranges;
+    if (!d_partials) return FPNG_AMD_OK; // (size query)
+    if (cap < e->band_crc_ranges) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "partials buffer too small");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(d_partials, e->sc[0].d_partials.p, (size_t)e->band_crc_ranges * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    return FPNG_AMD_OK;
+}
+
+static int wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h, uint32_t c,
+                    const uint32_t *d_crc_partials, uint32_t n_partials, size_t *png_size)
 {
     if (!e || !d_png || !png_size || zlib_size < 6) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
+    if (d_crc_partials && n_partials != crc_ranges_of(zlib_size)) return fail(FPNG_AMD_ERR_INVALID_ARG, "wrong number of CRC partials for this stream size");
     if ((uintptr_t)d_png & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_png must be 16-byte aligned");
     int rc = check_dims(w, h, c);
     if (rc) return rc;
@@ -1098,11 +1124,27 @@ int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uin
     HIP_TRY(hipMemcpyAsync(sc.d_states.p, &st, sizeof(JobState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_png, j.png_header, kPngHeaderBytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(e->band_copied[0], s));
-    launch_crc(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p);
+    if (d_crc_partials) // the bands' partials, already XOR-ed together: no pass over the file
+        HIP_TRY(hipMemcpyAsync(sc.d_partials.p, d_crc_partials, (size_t)n_partials * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    else
+        launch_crc(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p);
     launch_finalize(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_rows.p, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p, sc.d_results.p);
     HIP_TRY(hipGetLastError());
     *png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes; // asynchronous: complete when the encoder's stream gets there
     return FPNG_AMD_OK;
+}
+
+int fpng_amd_wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h, uint32_t c,
+                      size_t *png_size)
+{
+    return wrap_png(e, d_png, zlib_size, adler, w, h, c, nullptr, 0, png_size);
+}
+
+int fpng_amd_wrap_png_crc(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h, uint32_t c,
+                          const uint32_t *d_crc_partials, uint32_t n_partials, size_t *png_size)
+{
+    if (!d_crc_partials) return fail(FPNG_AMD_ERR_INVALID_ARG, "null partials");
+    return wrap_png(e, d_png, zlib_size, adler, w, h, c, d_crc_partials, n_partials, png_size);
 }
 
 int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n_words)

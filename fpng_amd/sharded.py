@@ -114,8 +114,13 @@ class GpuBandBackend:
         off, n = self.enc.band_place(self._band, start_bit, zlib_size, win)
         return off, win[:n]
 
-    def wrap(self, png_buf, zlib_size, adler, w, h, c):
-        n = self.enc.wrap_png(png_buf, zlib_size, adler, w, h, c)
+    def crc_partials(self, device):
+        """The placed band's contribution to the IDAT CRC: one int32 per 64 KiB range of the file (XOR over the bands =
+        the file's partials; a raw CRC is linear and a window is zero where other bands' bits are)."""
+        return self.enc.band_crc_partials(device)
+
+    def wrap(self, png_buf, zlib_size, adler, w, h, c, crc_partials=None):
+        n = self.enc.wrap_png(png_buf, zlib_size, adler, w, h, c, crc_partials)
         return png_buf[:n]
 
     def encode_whole(self, image, w, h, c, flags):
@@ -155,11 +160,15 @@ def encode_image_bands_local(backend, image, cuts, flags=0):
     if plan.stored:
         return backend.encode_whole(image, w, h, c, 2)
     png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=image.device)
+    crc = None
     for i, (y0, y1) in enumerate(bands):
         backend.encode(image[y0:y1], above(y0), w, c, y0, y1, h, flags, hist)
         off, win = backend.place(plan.start_bits[i], plan.zlib_size, stats[i].token_bits, image.device)
         merge_window(png_buf, off, win, i == 0, plan.start_bits[i])
-    return bytes(backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c).cpu().numpy())
+        part = backend.crc_partials(image.device)  # None: this backend leaves the CRC to wrap()
+        if part is not None:
+            crc = part if crc is None else torch.bitwise_xor(crc, part)
+    return bytes(backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c, crc).cpu().numpy())
 
 
 def _all_gather_records(rec, group, device):
@@ -209,9 +218,22 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
         import numpy as np
         return torch.from_numpy(np.frombuffer(png, dtype=np.uint8).copy())
 
-    win, off = None, 0
+    win, off, crc = None, 0, None
     if nrows > 0:
         off, win = backend.place(plan.start_bits[my_pos], plan.zlib_size, st.token_bits, device)
+        crc = backend.crc_partials(device)
+    # the IDAT CRC, sharded like the rows: every rank's per-range partials (a few KiB), XOR-ed on the root
+    have_crc = _all_gather_records([0 if (nrows > 0 and crc is None) else 1, 0 if crc is None else int(crc.numel())], group, device)
+    crc_all = None
+    if all(rec[0] for rec in have_crc):
+        n_part = max(rec[1] for rec in have_crc)
+        mine = crc if crc is not None else torch.zeros(n_part, dtype=torch.int32, device=device)
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == root else None
+        dist.gather(mine, parts, dst=_global_rank(group, root), group=group)
+        if rank == root:
+            crc_all = parts[0]
+            for p_ in parts[1:]:
+                crc_all = torch.bitwise_xor(crc_all, p_)
 
     # ---- step 5: windows to the root; the offsets follow from the plan, the sizes are exchanged ----
     geo = _all_gather_records([off, 0 if win is None else int(win.numel())], group, device)
@@ -229,7 +251,7 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
             wins[r] = tmp
         for r in non_empty:  # in row order: a window's first piece is OR-ed onto its predecessor's last one
             merge_window(png_buf, geo[r][0], wins[r], r == non_empty[0], plan.start_bits[order.index(r)])
-        return backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c)
+        return backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c, crc_all)
     if win is not None:
         dist.send(win.contiguous(), dst=_global_rank(group, root), group=group)
     return None

@@ -199,6 +199,17 @@ int fpng_amd_band_place(fpng_amd_encoder *enc, const fpng_amd_band *band, uint64
 int fpng_amd_wrap_png(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h,
                       uint32_t num_chans, size_t *png_size);
 
+/* CRC-32 of the IDAT sharded like the rows: a raw CRC is linear, and a band's window is zero wherever other bands' bits
+ * are, so the per-64-KiB-range CRC partials that fpng_amd_band_place() computes while it writes the window XOR together
+ * across the bands to the partials of the whole file.  fpng_amd_band_crc_partials() copies this band's *n_partials
+ * values (the same count on every rank: it depends on zlib_size only; d_partials = NULL just reports it) to device memory,
+ * asynchronously on the encoder's stream; the caller XORs the ranks' arrays element-wise (a gather of a few KiB) and hands the result to
+ * fpng_amd_wrap_png_crc(), which then finishes the file without reading it (fpng_amd_wrap_png() runs a CRC pass over
+ * the whole file instead). */
+int fpng_amd_band_crc_partials(fpng_amd_encoder *enc, uint32_t *d_partials, uint32_t cap, uint32_t *n_partials);
+int fpng_amd_wrap_png_crc(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h,
+                          uint32_t num_chans, const uint32_t *d_crc_partials, uint32_t n_partials, size_t *png_size);
+
 /* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);

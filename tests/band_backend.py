@@ -61,7 +61,10 @@ class OracleBandBackend:
             win[:58] = 0xEE  # undefined bytes: the merge must not use them
         return wb0, torch.from_numpy(win)
 
-    def wrap(self, png_buf, zlib_size, adler, w, h, c):
+    def crc_partials(self, device):
+        return None  # the stand-in leaves the CRC to wrap()
+
+    def wrap(self, png_buf, zlib_size, adler, w, h, c, crc_partials=None):
         z = bytes(png_buf[58:58 + zlib_size - 4].numpy()) + adler.to_bytes(4, "big")
         whole = oracle().encode(self.image, w, h, c, 0)  # container bytes (header) from the oracle
         hdr = bytearray(whole[:58])

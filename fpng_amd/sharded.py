@@ -235,25 +235,50 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
             for p_ in parts[1:]:
                 crc_all = torch.bitwise_xor(crc_all, p_)
 
-    # ---- step 5: windows to the root; the offsets follow from the plan, the sizes are exchanged ----
+    # ---- step 5: windows to the root; the offsets follow from the plan, the sizes are exchanged.  A remote window is
+    #      received straight into its place in the file, except its first 16-byte piece when the band shares that piece with
+    #      its predecessor (both wrote zeros where the other's bits are): that piece travels on its own and is OR-ed in ----
     geo = _all_gather_records([off, 0 if win is None else int(win.numel())], group, device)
+
+    def shared_head(r):  # bytes of band r's window that overlap its predecessor's window
+        if r == non_empty[0]:
+            return 0
+        return min(16, geo[r][1]) if (58 * 8 + plan.start_bits[order.index(r)]) % 128 else 0
+
     if rank == root:
         png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=device)
-        pending = []
+        pending, heads = [], {}
         for r in non_empty:
             if r == root:
                 continue
-            tmp = torch.empty(geo[r][1], dtype=torch.uint8, device=device)
-            pending.append((dist.irecv(tmp, src=_global_rank(group, r), group=group), r, tmp))
-        wins = {root: win} if win is not None else {}
-        for req, r, tmp in pending:
+            o, n, hd = geo[r][0], geo[r][1], shared_head(r)
+            if hd:
+                heads[r] = torch.empty(hd, dtype=torch.uint8, device=device)
+                pending.append(dist.irecv(heads[r], src=_global_rank(group, r), group=group))
+            if n > hd:
+                pending.append(dist.irecv(png_buf[o + hd:o + n], src=_global_rank(group, r), group=group))
+        if win is not None:  # the root's own band: everything but a shared first piece is copied now
+            hd = shared_head(root)
+            heads[root] = win[:hd]
+            if off == 0:
+                png_buf[58:win.numel()] = win[58:]  # (the PNG header's bytes of the first window are undefined: wrap() writes them)
+            else:
+                png_buf[off + hd:off + win.numel()] = win[hd:]
+        for req in pending:
             req.wait()
-            wins[r] = tmp
-        for r in non_empty:  # in row order: a window's first piece is OR-ed onto its predecessor's last one
-            merge_window(png_buf, geo[r][0], wins[r], r == non_empty[0], plan.start_bits[order.index(r)])
+        for r in non_empty:  # the shared pieces: OR-ed onto what the predecessor's window put there
+            hd = shared_head(r)
+            if hd:
+                view = png_buf[geo[r][0]:geo[r][0] + hd]
+                torch.bitwise_or(view, heads[r], out=view)
         return backend.wrap(png_buf, plan.zlib_size, plan.adler, w, h, c, crc_all)
     if win is not None:
-        dist.send(win.contiguous(), dst=_global_rank(group, root), group=group)
+        hd = shared_head(rank)
+        win = win.contiguous()
+        if hd:
+            dist.send(win[:hd].clone(), dst=_global_rank(group, root), group=group)
+        if win.numel() > hd:
+            dist.send(win[hd:], dst=_global_rank(group, root), group=group)
     return None
 
 

@@ -18,9 +18,9 @@
 //   finalize_kernel  folds the CRC partials, writes Adler / IDAT CRC / IEND and the result record
 //                    (reference fpng.cpp:1764-1800).
 //
-// Row bands (multi-GPU single image) and images whose local streams would not fit the scratch budget use
-// count_kernel -> scan_kernel -> emit_kernel -> crc_kernel: two walks, tokens emitted at their final bit position
-// with the seam dwords OR-merged.
+// Row bands (multi-GPU single image) use the same kernels: encode_rows_kernel + scan_kernel in counting mode, then
+// scan_kernel + assemble_kernel into a window of the file (bits of other bands stay zero); crc_kernel is the CRC pass of
+// fpng_amd_wrap_png() for callers that do not hand over the bands' CRC partials.
 //
 // Integer / byte work throughout, bounded by VALU issue and HBM traffic: no MFMA.
 #include "kernels.h"

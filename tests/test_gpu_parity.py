@@ -418,7 +418,7 @@ def test_two_pass_skewed_histogram_quirk(enc):
 
 
 def test_row_bands_stitched_at_bit_granularity(enc):
-    """The multi-GPU row-band path (fpng_amd_band_count / _band_emit / _wrap_png) driven band after
+    """The multi-GPU row-band path (fpng_amd_band_hist / _band_encode / _band_place / _band_crc_partials / _wrap_png_crc) driven band after
     band on one GPU: one IDAT, one Deflate block, byte-identical to the whole-image encoding."""
     import torch
     import fpng_amd

@@ -107,12 +107,14 @@ class GpuBandBackend:
         st = self.enc.band_encode(self._band, flags, hist)
         return BandStats(st.token_bits, st.adler_s1, st.adler_s2, st.adler_len, st.last_unit_bits, st.first_token_bit, st.eob_bits)
 
-    def place(self, start_bit, zlib_size, token_bits, device):
-        """-> (file offset of the window, window tensor): 16-byte pieces of the file, foreign bits zero."""
-        cap = ((token_bits + 7) >> 3) + 64 + 512
-        win = torch.empty((cap + 15) & ~15, dtype=torch.uint8, device=device)
-        off, n = self.enc.band_place(self._band, start_bit, zlib_size, win)
-        return off, win[:n]
+    def place(self, start_bit, zlib_size, token_bits, device, out=None):
+        """-> (file offset of the window, window tensor): 16-byte pieces of the file, foreign bits zero.
+        out: storage for the window (16-byte aligned uint8 tensor, e.g. the file buffer from window_offset() on)."""
+        if out is None:
+            cap = ((token_bits + 7) >> 3) + 64 + 512
+            out = torch.empty((cap + 15) & ~15, dtype=torch.uint8, device=device)
+        off, n = self.enc.band_place(self._band, start_bit, zlib_size, out)
+        return off, out[:n]
 
     def crc_partials(self, device):
         """The placed band's contribution to the IDAT CRC: one int32 per 64 KiB range of the file (XOR over the bands =
@@ -126,6 +128,12 @@ class GpuBandBackend:
     def encode_whole(self, image, w, h, c, flags):
         pngs, _ = self.enc.encode_tensors([image], flags)
         return pngs[0]
+
+
+def window_offset(first, start_bit):
+    """File offset of a band's window: the 16-byte piece holding its first token bit (0 for the image's first band, whose
+    window also carries the stream's head) -- the rule of fpng_amd_band_place()."""
+    return 0 if first else ((58 * 8 + start_bit) >> 3) & ~15
 
 
 def merge_window(png_buf, file_off, win, first, start_bit):
@@ -218,9 +226,15 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
         import numpy as np
         return torch.from_numpy(np.frombuffer(png, dtype=np.uint8).copy())
 
-    win, off, crc = None, 0, None
+    win, off, crc, png_buf = None, 0, None, None
+    if rank == root:
+        png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=device)
     if nrows > 0:
-        off, win = backend.place(plan.start_bits[my_pos], plan.zlib_size, st.token_bits, device)
+        # the root places its own band straight into the file buffer; the others into a window that is sent over
+        dest = None
+        if rank == root:
+            dest = png_buf[window_offset(rank == non_empty[0], plan.start_bits[my_pos]):]
+        off, win = backend.place(plan.start_bits[my_pos], plan.zlib_size, st.token_bits, device, out=dest)
         crc = backend.crc_partials(device)
     # the IDAT CRC, sharded like the rows: every rank's per-range partials (a few KiB), XOR-ed on the root
     have_crc = _all_gather_records([0 if (nrows > 0 and crc is None) else 1, 0 if crc is None else int(crc.numel())], group, device)
@@ -246,8 +260,11 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
         return min(16, geo[r][1]) if (58 * 8 + plan.start_bits[order.index(r)]) % 128 else 0
 
     if rank == root:
-        png_buf = torch.empty(((58 + plan.zlib_size + 16 + 15) & ~15) + 16, dtype=torch.uint8, device=device)
         pending, heads = [], {}
+        if win is not None:  # the root's own band is in place already; a shared first piece is set aside: the predecessor's
+            hd = shared_head(root)  # window (received below) overwrites it, then it is OR-ed back in
+            if hd:
+                heads[root] = win[:hd].clone()
         for r in non_empty:
             if r == root:
                 continue
@@ -257,13 +274,6 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
                 pending.append(dist.irecv(heads[r], src=_global_rank(group, r), group=group))
             if n > hd:
                 pending.append(dist.irecv(png_buf[o + hd:o + n], src=_global_rank(group, r), group=group))
-        if win is not None:  # the root's own band: everything but a shared first piece is copied now
-            hd = shared_head(root)
-            heads[root] = win[:hd]
-            if off == 0:
-                png_buf[58:win.numel()] = win[58:]  # (the PNG header's bytes of the first window are undefined: wrap() writes them)
-            else:
-                png_buf[off + hd:off + win.numel()] = win[hd:]
         for req in pending:
             req.wait()
         for r in non_empty:  # the shared pieces: OR-ed onto what the predecessor's window put there

@@ -43,7 +43,14 @@ class OracleBandBackend:
                           ftb=ftb.value, eob_bits=eobb.value, eob_code=eobc.value, hdr=hdr)
         return BandStats(int(bits), s1.value, s2.value, ln.value, lu.value, ftb.value, eobb.value)
 
-    def place(self, start_bit, zlib_size, token_bits, device):
+    def place(self, start_bit, zlib_size, token_bits, device, out=None):
+        off, win = self._place(start_bit, zlib_size, token_bits, device)
+        if out is not None:
+            out[:win.numel()] = win
+            win = out[:win.numel()]
+        return off, win
+
+    def _place(self, start_bit, zlib_size, token_bits, device):
         b = self._band
         fb0 = 58 * 8 + start_bit
         wb0 = 0 if b["first"] else (fb0 >> 3) & ~15

@@ -91,7 +91,9 @@ def plan_bands(stats, w, h, c, first_token_bit, eob_bits, one_pass=True):
 
 
 class GpuBandBackend:
-    """Per-band work on this rank's GPU through the C ABI (fpng_amd_band_hist / _encode / _place / _wrap_png)."""
+    """Per-band work on this rank's GPU through the C ABI (fpng_amd_band_hist / _encode / _place / _crc_partials / _wrap_png)."""
+    has_crc_partials = True
+
 
     def __init__(self, encoder):
         self.enc = encoder
@@ -134,6 +136,14 @@ def window_offset(first, start_bit):
     """File offset of a band's window: the 16-byte piece holding its first token bit (0 for the image's first band, whose
     window also carries the stream's head) -- the rule of fpng_amd_band_place()."""
     return 0 if first else ((58 * 8 + start_bit) >> 3) & ~15
+
+
+def window_extent(first, last, start_bit, token_bits, eob_bits):
+    """(file offset, bytes) of a band's window -- every rank can work out every band's from the gathered records."""
+    fb0 = 58 * 8 + start_bit
+    fb1 = fb0 + token_bits + (eob_bits if last else 0)
+    wb0 = window_offset(first, start_bit)
+    return wb0, ((((fb1 + 7) >> 3) + 15) & ~15) - wb0
 
 
 def merge_window(png_buf, file_off, win, first, start_bit):
@@ -236,11 +246,12 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
             dest = png_buf[window_offset(rank == non_empty[0], plan.start_bits[my_pos]):]
         off, win = backend.place(plan.start_bits[my_pos], plan.zlib_size, st.token_bits, device, out=dest)
         crc = backend.crc_partials(device)
-    # the IDAT CRC, sharded like the rows: every rank's per-range partials (a few KiB), XOR-ed on the root
-    have_crc = _all_gather_records([0 if (nrows > 0 and crc is None) else 1, 0 if crc is None else int(crc.numel())], group, device)
+    # the IDAT CRC, sharded like the rows: every rank's per-range partials (a few KiB), XOR-ed on the root.  Whether the
+    # backend produces them is a property of its class (the same on every rank); their number follows from zlib_size.
     crc_all = None
-    if all(rec[0] for rec in have_crc):
-        n_part = max(rec[1] for rec in have_crc)
+    if getattr(backend, "has_crc_partials", False):
+        n_part = ((((58 + plan.zlib_size - 4) + 15) & ~15) - 48 + 65535) >> 16
+        assert crc is None or int(crc.numel()) == n_part
         mine = crc if crc is not None else torch.zeros(n_part, dtype=torch.int32, device=device)
         parts = [torch.empty_like(mine) for _ in range(world)] if rank == root else None
         dist.gather(mine, parts, dst=_global_rank(group, root), group=group)
@@ -252,7 +263,12 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
     # ---- step 5: windows to the root; the offsets follow from the plan, the sizes are exchanged.  A remote window is
     #      received straight into its place in the file, except its first 16-byte piece when the band shares that piece with
     #      its predecessor (both wrote zeros where the other's bits are): that piece travels on its own and is OR-ed in ----
-    geo = _all_gather_records([off, 0 if win is None else int(win.numel())], group, device)
+    geo = [None] * world  # (file offset, bytes) of every band's window: from the plan, no exchange
+    for pos, r in enumerate(order):
+        geo[r] = (0, 0)
+        if recs[r][8] > recs[r][7]:
+            geo[r] = window_extent(r == non_empty[0], recs[r][8] == h, plan.start_bits[pos], recs[r][0], eob)
+    assert win is None or geo[rank] == (off, int(win.numel())), (geo[rank], off, win.numel())
 
     def shared_head(r):  # bytes of band r's window that overlap its predecessor's window
         if r == non_empty[0]:

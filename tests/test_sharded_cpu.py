@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, seed, n_cases, q):
+def _worker(rank, world, port, seed, n_cases, q, root=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,8 +42,9 @@ def _worker(rank, world, port, seed, n_cases, q):
         rows = torch.from_numpy(img[y0:y1].copy())
         above = torch.from_numpy(img[y0 - 1].copy()) if y0 > 0 else None
         fl = i % 2  # 1-pass and 2-pass (histogram all_reduce, dynamic table) alternate
-        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1, fl)
-        if rank == 0:
+        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1, fl, root=root)
+        assert (png is None) == (rank != root)
+        if rank == root:
             exp = oracle().encode(img, w, h, c, fl)
             got = bytes(png.numpy())
             stored += (exp[60] >> 1) & 3 == 0
@@ -54,18 +55,27 @@ def _worker(rank, world, port, seed, n_cases, q):
     mine = sharded.shard_batch(len(imgs), rank, world)
     pngs = [oracle().encode(*imgs[i]) for i in mine]
     allp = sharded.gather_pngs(pngs, device="cpu")
+    ok_batch = allp == [oracle().encode(*im) for im in imgs] if rank == 0 else None
+    if root != 0:  # the row-band results live on `root`, the batch check on rank 0: pass the former on
+        if rank == root:
+            dist.send(torch.tensor([len(bad), stored], dtype=torch.int64), dst=0)
+        elif rank == 0:
+            t = torch.zeros(2, dtype=torch.int64)
+            dist.recv(t, src=root)
+            bad, stored = [("on root", int(t[0]))] if int(t[0]) else [], int(t[1])
     if rank == 0:
-        ok_batch = allp == [oracle().encode(*im) for im in imgs]
         q.put((bad, stored, ok_batch))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_image_and_batch_gather(world):
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 0), (3, 1), (2, 1)])
+def test_row_sharded_image_and_batch_gather(world, root):
+    """root != 0: the root's own band is not the image's first one, so its window shares its first 16-byte piece with the
+    predecessor's window, which arrives from another rank and is received straight into the file buffer."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 77 + world, 60, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 77 + world, 60, q, root)) for r in range(world)]
     for p in procs:
         p.start()
     bad, stored, ok_batch = q.get(timeout=300)

@@ -12,6 +12,11 @@ from fpng_amd.sharded import BandStats
 
 
 class OracleBandBackend:
+    # The stand-in shards the IDAT CRC like the GPU backend does, in its own geometry: the LINEAR part of CRC-32,
+    # lin(M) = crc32(M) ^ crc32(zeros(len M)), of the band's window laid over an otherwise zero stream goes into
+    # partial 0 (the other entries stay 0); XOR-ed over the bands that must be lin(whole stream), which wrap() checks.
+    has_crc_partials = True
+
     def __init__(self, image):
         self.image = np.ascontiguousarray(image)  # the whole image (the oracle filters from it directly)
         self.h, self.w, self.c = self.image.shape
@@ -45,6 +50,7 @@ class OracleBandBackend:
 
     def place(self, start_bit, zlib_size, token_bits, device, out=None):
         off, win = self._place(start_bit, zlib_size, token_bits, device)
+        self._placed = (off, win.clone(), zlib_size)
         if out is not None:
             out[:win.numel()] = win
             win = out[:win.numel()]
@@ -68,10 +74,28 @@ class OracleBandBackend:
             win[:58] = 0xEE  # undefined bytes: the merge must not use them
         return wb0, torch.from_numpy(win)
 
+    @staticmethod
+    def _lin_crc(data):
+        return zlib.crc32(data) ^ zlib.crc32(bytes(len(data)))
+
     def crc_partials(self, device):
-        return None  # the stand-in leaves the CRC to wrap()
+        off, win, zlib_size = self._placed
+        n_data = zlib_size - 4
+        buf = np.zeros(n_data, dtype=np.uint8)  # the stream without its Adler-32, zero where other bands' bits are
+        w = win.numpy()
+        lo, hi = max(off, 58), min(off + len(w), 58 + n_data)
+        if hi > lo:
+            buf[lo - 58:hi - 58] = w[lo - off:hi - off]
+        n_part = ((((58 + zlib_size - 4) + 15) & ~15) - 48 + 65535) >> 16
+        part = np.zeros(n_part, dtype=np.uint32)
+        part[0] = self._lin_crc(buf.tobytes())
+        return torch.from_numpy(part.view(np.int32).copy())
 
     def wrap(self, png_buf, zlib_size, adler, w, h, c, crc_partials=None):
+        if crc_partials is not None:  # the bands' shares, XOR-ed by the orchestration
+            got = int(crc_partials.numpy().view(np.uint32)[0])
+            assert got == self._lin_crc(bytes(png_buf[58:58 + zlib_size - 4].numpy())), "sharded CRC does not add up"
+            assert not crc_partials.numpy()[1:].any()
         z = bytes(png_buf[58:58 + zlib_size - 4].numpy()) + adler.to_bytes(4, "big")
         whole = oracle().encode(self.image, w, h, c, 0)  # container bytes (header) from the oracle
         hdr = bytearray(whole[:58])

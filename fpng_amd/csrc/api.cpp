@@ -413,10 +413,12 @@ int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *e, float ms[FPNG_AMD_NUM_PH
 
 namespace {
 
+constexpr uint64_t kLocalFrontPad = 32; // dwords (one 128-byte line)
+
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
     uint64_t total_rows = 0;
-    uint64_t local_dwords = 0; // rows pipeline: scratch for the rows' local streams
+    uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
 };
 
@@ -959,6 +961,7 @@ static void band_job(fpng_amd_encoder *e, const fpng_amd_band *b, bool two_pass,
     j.bit_bias = (int64_t)kPngHeaderBytes * 8;
     const uint64_t bits_per_byte = two_pass ? 12u : g_1pass_bits_per_byte[b->num_chans];
     j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 31) & ~31ull); // whole 128-byte lines
+    j.local_base = kLocalFrontPad;
     j.table = two_pass ? e->sc[0].d_dyn.p : g_dev[e->device].one_pass[b->num_chans];
 }
 
@@ -998,7 +1001,7 @@ int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t f
     Job &j = e->h_jobs.p[0];
     band_job(e, b, two_pass, j);
     if ((rc = sc.d_rows.ensure(j.nrows)) || (rc = sc.d_row_off.ensure(j.nrows)) || (rc = sc.d_states.ensure(1)) ||
-        (rc = sc.d_local.ensure((uint64_t)j.local_stride * j.nrows + 16)))
+        (rc = sc.d_local.ensure(kLocalFrontPad + (uint64_t)j.local_stride * j.nrows + 16)))
         return rc;
     hipStream_t s = e->stream;
     if (two_pass) { // the table every rank builds from the same (all-reduced) histogram

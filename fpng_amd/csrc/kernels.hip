@@ -1614,11 +1614,24 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
                     const int32_t iA = pA >> 5, iB = pB >> 5;        // floor
                     const uint32_t ndwA = ((uint32_t)(nn - aa) + 31u) >> 5, ndwB = second ? ((uint32_t)(nn2 - nn) + 31u) >> 5 : 0u;
                     gptr_cu32 srcB = src + stride;
+                    // five consecutive dwords per row and lane, loaded unconditionally (an index clamped to [-4, ndw] stays
+                    // inside the scratch: streams have four dwords of slack behind them and a line of padding in front of
+                    // the first one) and masked afterwards: two load instructions per row instead of five predicated ones
                     uint32_t sA[5], sB[5];
+                    {
+                        const int32_t cA = iA < -4 ? -4 : (iA > (int32_t)ndwA ? (int32_t)ndwA : iA);
+                        const int32_t cB = iB < -4 ? -4 : (iB > (int32_t)ndwB ? (int32_t)ndwB : iB);
+                        gptr_cu32 qA = src + cA, qB = srcB + cB;
+                        uint32_t lA[5], lB[5];
 #pragma unroll
-                    for (int t = 0; t < 5; t++) sA[t] = ((uint32_t)(iA + t) < ndwA) ? src[iA + t] : 0u;
+                        for (int t = 0; t < 5; t++) lA[t] = qA[t];
 #pragma unroll
-                    for (int t = 0; t < 5; t++) sB[t] = ((uint32_t)(iB + t) < ndwB) ? srcB[iB + t] : 0u;
+                        for (int t = 0; t < 5; t++) lB[t] = qB[t];
+#pragma unroll
+                        for (int t = 0; t < 5; t++) sA[t] = ((uint32_t)(iA + t) < ndwA) ? lA[t] : 0u;
+#pragma unroll
+                        for (int t = 0; t < 5; t++) sB[t] = ((uint32_t)(iB + t) < ndwB) ? lB[t] : 0u;
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++)
                         w[kk] |= __builtin_amdgcn_alignbit(sA[kk + 1], sA[kk], (uint32_t)pA & 31u) |

@@ -761,9 +761,9 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
     std::atomic<int> failed{0};
     const int device = e->device;
     std::vector<size_t> sizes(n, 0);
-    std::vector<std::vector<uint8_t>> file_bufs; // frames that go to files without a caller buffer
+    std::vector<std::vector<uint8_t>> file_bufs(n); // frames that go to files without a caller buffer (freed once written)
     // writer pool: finished files are handed to n_writer_threads threads (reference fpng.cpp:1806-1828 writes inline)
-    struct WriteJob { const char *path; const uint8_t *data; size_t size; };
+    struct WriteJob { const char *path; const uint8_t *data; size_t size; uint32_t idx; };
     std::vector<WriteJob> wq;
     size_t wq_head = 0;
     bool wq_closed = false;
@@ -784,9 +784,9 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
                 FILE *f = fopen(job.path, "wb");
                 if (!f || fwrite(job.data, 1, job.size, f) != job.size) failed = FPNG_AMD_ERR_INVALID_ARG;
                 if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+                std::vector<uint8_t>().swap(file_bufs[job.idx]); // (a frame without a caller buffer: its bytes are on disk now)
             }
         });
-    file_bufs.resize(n);
 
     std::thread uploader([&] {
         (void)hipSetDevice(device);
@@ -851,13 +851,14 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
                     if (nw) {
                         {
                             std::lock_guard<std::mutex> lk(wmu);
-                            wq.push_back({imgs[i].path, dst, (size_t)res.png_size});
+                            wq.push_back({imgs[i].path, dst, (size_t)res.png_size, i});
                         }
                         wcv.notify_one();
                     } else {
                         FILE *f = fopen(imgs[i].path, "wb");
                         if (!f || fwrite(dst, 1, res.png_size, f) != res.png_size) failed = FPNG_AMD_ERR_INVALID_ARG;
                         if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+                        std::vector<uint8_t>().swap(file_bufs[i]);
                     }
                 }
             }

@@ -19,9 +19,12 @@ Two regimes:
        reference's "ran out of buffer -> stored blocks" decision (closed form)
     4. every rank shifts its band to its bit position inside a WINDOW of whole 16-byte pieces of the
        file (foreign bits 0)
-    5. windows go to the root; neighbouring windows share one 16-byte piece, which is OR-merged, the
-       rest is copied
-    6. the root wraps the stream: PNG header, Adler-32, IDAT CRC-32, IEND.
+    5. windows go to the root, which receives them straight into the file buffer (its own band is
+       placed there directly); neighbouring windows share at most one 16-byte piece: a window's first
+       piece travels on its own when it is shared and is OR-ed onto the predecessor's last piece
+    6. the IDAT CRC-32 is sharded too: the per-64-KiB partials each rank's placement kernel computes
+       XOR together (a raw CRC is linear, windows are zero in foreign bits); one gather of a few KiB
+    7. the root wraps the stream: PNG header, Adler-32, CRC fold, IEND -- without reading the file.
 
 The arithmetic of steps 2-5 is plain Python here; the per-band work is done by a "band backend":
 the HIP encoder on GPUs (`GpuBandBackend`), or a CPU stand-in injected by the gloo tests.
@@ -94,8 +97,11 @@ class GpuBandBackend:
     """Per-band work on this rank's GPU through the C ABI (fpng_amd_band_hist / _encode / _place / _crc_partials / _wrap_png)."""
     has_crc_partials = True
 
-
     def __init__(self, encoder):
+        # the band calls are asynchronous on the encoder's stream and their results (windows, histograms, CRC partials) are
+        # consumed by torch ops and collectives: both must be the same stream
+        if not getattr(encoder, "_follow_torch", False):
+            raise ValueError('GpuBandBackend needs an Encoder(stream="torch"): its outputs are consumed on torch\'s current stream')
         self.enc = encoder
 
     def hist(self, rows, row_above, w, c, y0, y1, h):

@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {"8k": (7680, 4320, 4), "4k": (3840, 2160, 4), "1080p": (1920, 1080, 3), "1080p4": (1920, 1080, 4), "512": (512, 512, 3), "16k": (16384, 16384, 4)}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+PASS_NAME = {0: "1-pass", 1: "2-pass (FPNG_ENCODE_SLOWER)", 2: "stored (FPNG_FORCE_UNCOMPRESSED)"}
 
 
 def parse():
@@ -49,17 +50,36 @@ def parse():
     ap.add_argument("--mode", default="batch", choices=["batch", "rowband"],
                     help="batch: every rank encodes its own images (BASELINE configs 2/3/5, the headline); rowband: ONE image "
                          "sharded by rows over the ranks, one IDAT, windows gathered to rank 0 over RCCL (BASELINE config 4)")
+    ap.add_argument("--regions", type=int, default=3,
+                    help="timed regions per run, each EXACTLY --steps steps between two barriers; value = the median region, "
+                         "`runs` / `spread` report all of them (a single 10 ms region cannot show a 5 %% change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
     return ap.parse_args()
 
 
-def committed_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.txt, produced by
-    tools/gpu_profile_round.sh + tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
-    of this command).  PMC counters cannot be collected from inside the timed process."""
+def workload_tag(args):
+    """Name of this command in profiles/: r03_<tag>_pmc_traffic.txt etc. (tools/gpu_profile_round.sh <round>_<tag> <args>)."""
+    defaults = {"8k": 8}
+    tag = args.workload + ("" if defaults.get(args.workload, args.batch) == args.batch else f"_b{args.batch}")
+    if args.flags:
+        tag += {1: "_2pass", 2: "_stored"}.get(args.flags, f"_f{args.flags}")
+    if args.kind != "grad":
+        tag += "_" + args.kind
+    return tag
+
+
+def committed_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS command (profiles/*_<tag>_pmc_traffic.txt,
+    produced by tools/gpu_profile_round.sh + tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs; files without a workload tag are the default 8k command).  PMC counters cannot be collected from inside the timed
+    process."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")), reverse=True):
+    import re
+    paths = glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}_pmc_traffic.txt"))
+    if tag == "8k":
+        paths += [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")) if re.fullmatch(r"r\d\d_[a-z]_pmc_traffic\.txt", os.path.basename(p))]
+    for path in sorted(paths, key=os.path.basename, reverse=True):
         for line in open(path):
             f = line.split()
             if len(f) == 5 and f[0] == kernel:
@@ -67,31 +87,35 @@ def committed_traffic(kernel):
     return None, None
 
 
-def verify_first_output(args, rank, w, h, c, out, size):
-    """sha256 of image 0 (seed 12345 on rank 0) vs the golden vectors produced by the unmodified reference.
-    Returns True/False when a golden vector exists for this input, None otherwise."""
+def verify_outputs(args, rank, w, h, c, outs, sizes):
+    """sha256 of EVERY image of the last timed submission (seeds 12345+i on rank 0) vs the golden vectors produced by the
+    unmodified reference (tests/golden/batches.json holds whole batches, kat.json single images with seed 12345).
+    Returns the number of images checked (all of them must have a golden vector), or None when there is none for this input."""
     import hashlib
-    if rank != 0 or args.kind != "grad" or args.flags not in (0, 1):
+    if rank != 0 or args.flags not in (0, 1, 2):
         return None
-    want = None
+    want = {}
     try:
         with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
             for e in json.load(f):
-                if (e["w"], e["h"], e["c"], e["kind"]) == (w, h, c, args.kind):
-                    want = e["flags"][str(args.flags)]["sha256"]
-        if want is None:
-            with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
-                for e in json.load(f).values():
-                    if (e["w"], e["h"], e["c"], e["kind"], e["seed0"]) == (w, h, c, args.kind, 12345) and str(args.flags) in e["flags"]:
-                        want = e["flags"][str(args.flags)]["sha256"][0]
+                if (e["w"], e["h"], e["c"], e["kind"]) == (w, h, c, args.kind) and str(args.flags) in e["flags"]:
+                    want[0] = e["flags"][str(args.flags)]["sha256"]
+        with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+            for e in json.load(f).values():
+                if (e["w"], e["h"], e["c"], e["kind"], e["seed0"]) == (w, h, c, args.kind, 12345) and str(args.flags) in e["flags"]:
+                    for i, sha in enumerate(e["flags"][str(args.flags)]["sha256"]):
+                        want[i] = sha
     except OSError:
         return None
-    if want is None:
-        return None
-    got = hashlib.sha256(out[:size].cpu().numpy().tobytes()).hexdigest()
-    if got != want:
-        raise SystemExit(f"bench.py: PARITY FAILURE, image 0 sha256 {got} != reference {want}")
-    return True
+    n = 0
+    for i, (out, size) in enumerate(zip(outs, sizes)):
+        if i not in want:
+            continue
+        got = hashlib.sha256(out[:size].cpu().numpy().tobytes()).hexdigest()
+        if got != want[i]:
+            raise SystemExit(f"bench.py: PARITY FAILURE, image {i} sha256 {got} != reference {want[i]}")
+        n += 1
+    return n or None
 
 
 def _cpu_worker(task):
@@ -215,9 +239,9 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
         try:
             with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
                 g = json.load(f)["c4"]
-            if (w, h, c, args.kind, args.flags) == (g["w"], g["h"], g["c"], g["kind"], 0):
+            if (w, h, c, args.kind) == (g["w"], g["h"], g["c"], g["kind"]) and str(args.flags) in g["flags"]:
                 got = hashlib.sha256(png.cpu().numpy().tobytes()).hexdigest()
-                if got != g["flags"]["0"]["sha256"][0]:
+                if got != g["flags"][str(args.flags)]["sha256"][0]:
                     raise SystemExit(f"bench.py: PARITY FAILURE, row-band file sha256 {got}")
                 parity = True
         except OSError:
@@ -225,7 +249,7 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
         png_bytes = int(png.numel())
         alg = w * h * c + png_bytes
         _RESULT.append(json.dumps({
-            "metric": "encode megapixels/sec (whole node), 1-pass, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
+            "metric": f"encode megapixels/sec (whole node), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
             "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "prewarm": 0, "parity_checked": parity,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -292,27 +316,33 @@ def main():
         enc.submit(batches[i & 3], None, args.flags)
     if args.prewarm + args.warmup:
         res = enc.finish(B)
-    barrier()
-    t0 = time.perf_counter()
-    # K steps are enqueued back to back (the encoder pipelines submissions through a ring of pinned
-    # slots); the closing finish()/barrier waits for all of them, so exactly K steps are timed.
-    for i in range(args.steps):
-        enc.submit(batches[i & 3], None, args.flags)
-    res = enc.finish(B)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # `regions` timed regions, each EXACTLY K steps enqueued back to back (the encoder pipelines submissions through a ring
+    # of pinned slots) between a barrier + synchronize on both sides; per region the max over ranks counts.  The reported
+    # value is the MEDIAN region; all of them are in `runs` (boxes and clocks wander by a few per cent within a run).
+    runs = []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            enc.submit(batches[i & 3], None, args.flags)
+        res = enc.finish(B)
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        runs.append(el)
+    elapsed = sorted(runs)[len(runs) // 2]
 
     png_bytes = sum(r[0] for r in res)
     assert all(r[2] == 0 for r in res)
-    # self-check: image 0 of the last timed submission's output set against the reference's bytes
+    # self-check: EVERY image of the last timed submission's output set against the reference's bytes
     # (tests/golden/batches.json / kat.json: sha256 of the unmodified reference encoder's file for this input)
-    parity_checked = verify_first_output(args, rank, w, h, c, out_sets[(args.steps - 1) & 3][0], res[0][0])
+    parity_checked = verify_outputs(args, rank, w, h, c, out_sets[(args.steps - 1) & 3], [r[0] for r in res])
     pixels_per_step = B * w * h
     value = world * pixels_per_step * args.steps / elapsed / 1e6
+    run_values = [round(world * pixels_per_step * args.steps / r / 1e6, 1) for r in runs]
 
     # ---- per-kernel durations with HIP events on the encoder's own stream (untimed extra steps) ----
     enc.set_profiling(True)
@@ -326,13 +356,11 @@ def main():
     names = enc.phase_names()
     phase_ms = {n: round(float(phases[i]), 4) for i, n in enumerate(names)}
     alg_bytes = B * w * h * c + png_bytes  # input read once + PNG written once
-    dom = max((k for k in names if k in ("encode_rows", "assemble", "encode", "count", "emit", "crc")), key=lambda k: phase_ms[k])
+    dom = max((k for k in names if k in ("encode_rows", "assemble", "hist", "stored")), key=lambda k: phase_ms[k])
     dom_s = phase_ms[dom] / 1e3
     achieved = alg_bytes / dom_s / 1e9
     kernels_s = sum(phase_ms[k] for k in names) / 1e3
-    traffic, traffic_src = (None, None)
-    if (args.workload, B, args.flags, args.kind) == ("8k", 8, 0, "grad"):  # the command the committed PMC passes ran
-        traffic, traffic_src = committed_traffic(f"{dom}_kernel")
+    traffic, traffic_src = committed_traffic(f"{dom}_kernel", workload_tag(args))  # PMC passes of THIS command, if committed
     roofline = {"bound": "hbm", "kernel": f"{dom}_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": phase_ms[dom],
@@ -340,9 +368,11 @@ def main():
                 "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": phase_ms}
 
     line = {
-        "metric": "encode megapixels/sec (whole node), 1-pass, device-resident",
+        "metric": f"encode megapixels/sec (whole node), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident",
         "value": round(value, 1), "unit": "MP/s", "value_MiPs": round(value * 1e6 / 2 ** 20, 1), "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "prewarm": args.prewarm, "parity_checked": parity_checked,
+        "warmup": args.warmup, "prewarm": args.prewarm, "parity_checked": bool(parity_checked) if parity_checked is not None else None,
+        "parity_images": parity_checked, "runs": run_values,
+        "spread": round((max(run_values) - min(run_values)) / value, 4) if len(run_values) > 1 else None,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{B} x {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' frames per GPU per step, "

@@ -6,4 +6,5 @@ the `fpng::` C++ drop-in; this package is the Python door to the same C ABI.
 from .api import (FPNG_ADLER32_INIT, FPNG_CRC32_INIT, FPNG_ENCODE_SLOWER, FPNG_FORCE_UNCOMPRESSED, MODE_COMPRESSED,  # noqa: F401
                   MODE_STORED, Encoder, FpngAmdError, adler32_combine, crc32_combine, fpng_adler32,
                   fpng_cpu_supports_sse41, fpng_crc32, fpng_encode_image_to_file, fpng_encode_image_to_memory,
-                  fpng_init, layout_1pass, max_encoded_size, synth_image)
+                  fpng_init, layout_1pass, max_encoded_size, synth_image, Node, plan_bands, band_window, idat_crc_from_bands,
+                  png_head, png_tail, pin_host_memory, unpin_host_memory)

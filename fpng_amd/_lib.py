@@ -41,6 +41,12 @@ class BandStats(C.Structure):
                 ("eob_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class BandPlan(C.Structure):
+    _fields_ = [("end_bit", C.c_uint64), ("zlib_size", C.c_uint64), ("adler", C.c_uint32), ("stored", C.c_uint32)]
+
+
+RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
 # every symbol include/fpng_amd.h declares: (restype, argtypes)
 _u32, _u64, _sz, _vp, _int = C.c_uint32, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int
 SIGNATURES = {
@@ -75,6 +81,19 @@ SIGNATURES = {
     "fpng_amd_wrap_png": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, C.POINTER(_sz)]),
     "fpng_amd_wrap_png_crc": (_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _vp, _u32, C.POINTER(_sz)]),
     "fpng_amd_band_crc_partials": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
+    "fpng_amd_band_crc": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u64)]),
+    "fpng_amd_plan_bands": (_int, [C.POINTER(BandStats), _u32, _u32, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(BandPlan)]),
+    "fpng_amd_band_window": (_int, [_int, _int, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_sz), C.POINTER(_u32)]),
+    "fpng_amd_idat_crc_from_bands": (_u32, [C.POINTER(_u32), C.POINTER(_u64), _u32, _u64, _u32]),
+    "fpng_amd_png_head": (_int, [_u32, _u32, _u32, _u64, _vp]),
+    "fpng_amd_png_tail": (None, [_u32, _u32, _vp]),
+    "fpng_amd_encode_host_to": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, RESERVE_FN, _vp, C.POINTER(_sz)]),
+    "fpng_amd_pin_host_memory": (_int, [_vp, _sz]),
+    "fpng_amd_unpin_host_memory": (_int, [_vp]),
+    "fpng_amd_node_create": (_int, [C.POINTER(_vp), C.POINTER(_int), _u32]),
+    "fpng_amd_node_destroy": (None, [_vp]),
+    "fpng_amd_node_size": (_u32, [_vp]),
+    "fpng_amd_node_encode_host_batch": (_int, [_vp, C.POINTER(HostImage), _u32, _u32, _int]),
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),

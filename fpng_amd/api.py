@@ -72,6 +72,102 @@ def layout_1pass(num_chans):
     return a.value, b.value, c.value
 
 
+def pin_host_memory(arr):
+    """Page-lock a numpy array's memory (fpng_amd_pin_host_memory): host frames in page-locked memory are streamed through
+    the GPU in row bands (upload, encode and download overlapped).  Unpin before the array is freed."""
+    check(_lib.load().fpng_amd_pin_host_memory(arr.ctypes.data, arr.nbytes))
+
+
+def unpin_host_memory(arr):
+    check(_lib.load().fpng_amd_unpin_host_memory(arr.ctypes.data))
+
+
+def plan_bands(stats, w, h, num_chans, flags=0):
+    """fpng_amd_plan_bands: stats = list of _lib.BandStats in row order -> (start_bits, BandPlan)."""
+    n = len(stats)
+    arr = (_lib.BandStats * n)(*stats)
+    starts = (C.c_uint64 * n)()
+    plan = _lib.BandPlan()
+    check(_lib.load().fpng_amd_plan_bands(arr, n, w, h, num_chans, flags, starts, C.byref(plan)))
+    return list(starts), plan
+
+
+def band_window(is_first, is_last, start_bit, token_bits, eob_bits):
+    """-> (file offset, bytes, shared head bytes) of the window fpng_amd_band_place() writes."""
+    off, n, hd = C.c_uint64(0), C.c_size_t(0), C.c_uint32(0)
+    check(_lib.load().fpng_amd_band_window(int(is_first), int(is_last), start_bit, token_bits, eob_bits, C.byref(off), C.byref(n), C.byref(hd)))
+    return off.value, n.value, hd.value
+
+
+def idat_crc_from_bands(raw, ends, zlib_size, adler):
+    n = len(raw)
+    return _lib.load().fpng_amd_idat_crc_from_bands((C.c_uint32 * n)(*raw), (C.c_uint64 * n)(*ends), n, zlib_size, adler)
+
+
+def png_head(w, h, num_chans, zlib_size):
+    b = (C.c_uint8 * 58)()
+    check(_lib.load().fpng_amd_png_head(w, h, num_chans, zlib_size, b))
+    return bytes(b)
+
+
+def png_tail(adler, idat_crc):
+    b = (C.c_uint8 * 20)()
+    _lib.load().fpng_amd_png_tail(adler, idat_crc, b)
+    return bytes(b)
+
+
+class Node:
+    """fpng_amd_node: one process, one encoder + staging ring per listed device, host batches dealt round-robin."""
+
+    def __init__(self, devices):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        check(self.lib.fpng_amd_node_create(C.byref(h), arr, len(devices)))
+        self.h = h
+
+    def size(self):
+        return self.lib.fpng_amd_node_size(self.h)
+
+    def encode_host_batch(self, images, flags=0, outs=None, paths=None, writer_threads=0):
+        arr, sizes, keep = _host_batch_records(images, outs, paths)
+        check(self.lib.fpng_amd_node_encode_host_batch(self.h, arr, len(images), flags, writer_threads))
+        return [int(s) for s in sizes]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fpng_amd_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _host_batch_records(images, outs, paths):
+    n = len(images)
+    arr = (HostImage * n)()
+    sizes = (C.c_size_t * n)()
+    keep = []
+    for i, im in enumerate(images):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        keep.append(im)
+        h, w, c = im.shape
+        arr[i].pixels = im.ctypes.data
+        arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
+        if outs is not None:
+            arr[i].out = outs[i].ctypes.data
+            arr[i].out_cap = outs[i].size
+        arr[i].out_size = C.cast(C.byref(sizes, i * C.sizeof(C.c_size_t)), C.POINTER(C.c_size_t))
+        if paths is not None:
+            p = paths[i].encode() if isinstance(paths[i], str) else paths[i]
+            keep.append(p)
+            arr[i].path = p
+    return arr, sizes, keep
+
+
 def synth_image(kind, w, h, num_chans, seed=12345):
     """Deterministic test image as a uint8 array of shape (h, w, num_chans)."""
     out = np.empty(w * h * num_chans, dtype=np.uint8)
@@ -202,6 +298,7 @@ class Encoder:
         cap = max_encoded_size(w, h, num_chans) if (w and h and num_chans in (3, 4)) else 64
         out = np.empty(cap, dtype=np.uint8)
         n = C.c_size_t(0)
+        self._sync_stream()
         check(self.lib.fpng_amd_encode_host(self.h, b.ctypes.data, w, h, num_chans, flags, out.ctypes.data, cap,
                                             C.byref(n)))
         return out[: n.value].tobytes()
@@ -215,6 +312,7 @@ class Encoder:
             raise ValueError("image buffer smaller than w*h*num_chans")
         assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
         n = C.c_size_t(0)
+        self._sync_stream()
         check(self.lib.fpng_amd_encode_host(self.h, b.ctypes.data, w, h, num_chans, flags, out.ctypes.data, out.size,
                                             C.byref(n)))
         return n.value
@@ -223,30 +321,40 @@ class Encoder:
         """Many host frames (uint8 arrays shaped (h, w, c)): uploads, encodes, downloads and file writes of consecutive
         frames overlap (fpng_amd_encode_host_batch).  outs: caller-owned uint8 arrays (>= max_encoded_size) or None when
         every frame goes to a file; paths: file names or None.  Returns the PNG sizes."""
-        n = len(images)
-        arr = (HostImage * n)()
-        sizes = (C.c_size_t * n)()
-        keep = []
-        for i, im in enumerate(images):
-            im = np.ascontiguousarray(im, dtype=np.uint8)
-            keep.append(im)
-            h, w, c = im.shape
-            arr[i].pixels = im.ctypes.data
-            arr[i].w, arr[i].h, arr[i].num_chans = w, h, c
-            if outs is not None:
-                arr[i].out = outs[i].ctypes.data
-                arr[i].out_cap = outs[i].size
-            arr[i].out_size = C.cast(C.byref(sizes, i * C.sizeof(C.c_size_t)), C.POINTER(C.c_size_t))
-            if paths is not None:
-                p = paths[i].encode() if isinstance(paths[i], str) else paths[i]
-                keep.append(p)
-                arr[i].path = p
-        check(self.lib.fpng_amd_encode_host_batch(self.h, arr, n, flags, writer_threads))
+        arr, sizes, keep = _host_batch_records(images, outs, paths)
+        check(self.lib.fpng_amd_encode_host_batch(self.h, arr, len(images), flags, writer_threads))
         return [int(s) for s in sizes]
+
+    def encode_host_growing(self, image, w, h, num_chans, flags=0):
+        """fpng_amd_encode_host_to() with a growing bytearray as the output allocator (what the fpng:: drop-in does with
+        its std::vector): returns (png bytes, list of the sizes the encoder asked for)."""
+        b = _as_u8(image)
+        buf = bytearray()
+        asked = []
+        hold = []
+
+        def reserve(_user, nbytes):
+            asked.append(nbytes)
+            hold[:] = []  # (a bytearray cannot grow while a ctypes view of it is alive)
+            if len(buf) < nbytes:
+                buf.extend(bytes(nbytes - len(buf)))
+            hold[:] = [(C.c_uint8 * len(buf)).from_buffer(buf)]
+            return C.addressof(hold[0])
+
+        cb = _lib.RESERVE_FN(reserve)
+        n = C.c_size_t(0)
+        self._sync_stream()
+        rc = self.lib.fpng_amd_encode_host_to(self.h, b.ctypes.data, w, h, num_chans, flags, cb, None, C.byref(n))
+        hold[:] = []
+        check(rc)
+        return bytes(buf[: n.value]), asked
 
     # ---- row bands (multi-GPU, one image): see include/fpng_amd.h ----
     @staticmethod
     def _band(rows, row_above, w, num_chans, y0, y1, h_total):
+        for t in (rows, row_above):
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous(), "band rows must be contiguous uint8 CUDA tensors"
         b = Band()
         b.d_rows = rows.data_ptr()
         b.d_row_above = row_above.data_ptr() if row_above is not None else None
@@ -265,6 +373,7 @@ class Encoder:
 
     def band_place(self, band, start_bit, zlib_size, window):
         off, n = C.c_uint64(0), C.c_size_t(0)
+        self._sync_stream()
         check(self.lib.fpng_amd_band_place(self.h, C.byref(band), start_bit, zlib_size, window.data_ptr(), window.numel(),
                                            C.byref(off), C.byref(n)))
         return off.value, n.value
@@ -273,6 +382,7 @@ class Encoder:
         """CRC partials (one uint32 per 64 KiB range of the file, as an int32 tensor) of the band placed last: XOR the
         ranks' arrays and hand the result to wrap_png()."""
         n = C.c_uint32(0)
+        self._sync_stream()
         check(self.lib.fpng_amd_band_crc_partials(self.h, None, 0, C.byref(n)))  # (asks for the count)
         t = torch.empty(n.value, dtype=torch.int32, device=device)
         check(self.lib.fpng_amd_band_crc_partials(self.h, t.data_ptr(), n.value, C.byref(n)))
@@ -280,6 +390,7 @@ class Encoder:
 
     def wrap_png(self, png_buf, zlib_size, adler, w, h, num_chans, crc_partials=None):
         n = C.c_size_t(0)
+        self._sync_stream()
         if crc_partials is None:
             check(self.lib.fpng_amd_wrap_png(self.h, png_buf.data_ptr(), zlib_size, adler, w, h, num_chans, C.byref(n)))
         else:

@@ -3,10 +3,7 @@
 // Host-side orchestration only: argument rules of the reference's fpng_encode_image_to_memory
 // (reference src/fpng.cpp:1662-1680), job descriptors, scratch management, kernel launches on one
 // stream.  There is no CPU implementation of the encode path in this library.
-#include "fpng_amd.h"
-#include "kernels.h"
-
-#include <hip/hip_runtime.h>
+#include "encoder.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -19,13 +16,11 @@
 #include <thread>
 #include <vector>
 
-using namespace fpng_amd;
-
 namespace {
-
 thread_local std::string g_last_error;
+}
 
-int fail(int code, const char *what, hipError_t e = hipSuccess)
+int fpng_amd::fail(int code, const char *what, hipError_t e)
 {
     char buf[512];
     if (e != hipSuccess)
@@ -36,11 +31,7 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
     return code;
 }
 
-#define HIP_TRY(expr)                                                      \
-    do {                                                                   \
-        hipError_t e_ = (expr);                                            \
-        if (e_ != hipSuccess) return fail(FPNG_AMD_ERR_HIP, #expr, e_);    \
-    } while (0)
+namespace {
 
 // per-device immutable tables
 struct DeviceTables {
@@ -103,57 +94,10 @@ int ensure_device_tables(int dev)
     return FPNG_AMD_OK;
 }
 
-template <typename T> struct DeviceBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    bool fresh = false; // set when ensure() (re)allocated: the contents are undefined
-    // (hipFree waits for the device: growing a buffer that a submission in flight still uses is safe, merely a stall;
-    // capacities grow geometrically so that it stops happening after the first few submissions)
-    int ensure(size_t n)
-    {
-        if (n <= cap) return FPNG_AMD_OK;
-        const size_t want = std::max(n, cap + cap / 2);
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, want * sizeof(T));
-        if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipMalloc scratch", e);
-        cap = want;
-        fresh = true;
-        return FPNG_AMD_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-template <typename T> struct PinnedBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t n)
-    {
-        if (n <= cap) return FPNG_AMD_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        n = std::max(n, (size_t)16);
-        hipError_t e = hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault);
-        if (e != hipSuccess) return fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipHostMalloc", e);
-        cap = n;
-        return FPNG_AMD_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
+} // namespace
 
 // reference src/fpng.cpp:1670-1680 plus the 32-bit arithmetic limit of :1682-1705
-int check_dims(uint32_t w, uint32_t h, uint32_t c)
+int fpng_amd::check_dims(uint32_t w, uint32_t h, uint32_t c)
 {
     if (w < 1 || h < 1 || (uint64_t)w * h > 0xFFFFFFFFull || w > (1u << 24) || h > (1u << 24))
         return fail(FPNG_AMD_ERR_INVALID_ARG, "invalid image dimensions");
@@ -163,7 +107,7 @@ int check_dims(uint32_t w, uint32_t h, uint32_t c)
     return FPNG_AMD_OK;
 }
 
-void make_png_header(uint8_t *hdr, uint32_t w, uint32_t h, uint32_t c)
+void fpng_amd::make_png_header(uint8_t *hdr, uint32_t w, uint32_t h, uint32_t c)
 {
     // reference src/fpng.cpp:1767-1791.  Only the low 16 bits of each dimension are stored there
     // (":1773-1774"); reproduced, not fixed.  The IDAT length (bytes 50..53) is patched on device.
@@ -183,74 +127,10 @@ void make_png_header(uint8_t *hdr, uint32_t w, uint32_t h, uint32_t c)
     std::memcpy(hdr + 54, "IDAT", 4);
 }
 
-} // namespace
-
-struct fpng_amd_encoder {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    bool profiling = false;
-    hipEvent_t ev[FPNG_AMD_NUM_PHASES + 1] = {};
-    bool ev_ready = false;
-    float phase_ms[FPNG_AMD_NUM_PHASES] = {};
-    uint32_t phases_recorded = 0;
-
-    PinnedBuf<Job> h_jobs;
-    PinnedBuf<JobState> h_states;
-    // Device scratch of one submission.  Batch submissions alternate between kLanes internal streams, each
-    // with its own scratch, so that the tail of one submission (stored fallback, CRC, trailer) overlaps the
-    // VALU-bound encode kernel of the next one.  Set 0 also serves the synchronous entry points (bands, wrap_png),
-    // which drain the lanes first.
-    struct Scratch {
-        DeviceBuf<Job> d_jobs;
-        DeviceBuf<RowInfo> d_rows;
-        DeviceBuf<uint64_t> d_row_off;
-        DeviceBuf<JobState> d_states;
-        DeviceBuf<Result> d_results;
-        DeviceBuf<uint32_t> d_partials;
-        DeviceBuf<uint32_t> d_hist;
-        DeviceBuf<TokenTable> d_dyn;
-        DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
-        hipEvent_t last_done = nullptr; // `done` event (owned by a slot) of the last submission that used this set
-        void release()
-        {
-            d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
-            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
-        }
-    };
-    static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
-    Scratch sc[kLanes];
-    hipStream_t lane_stream[kLanes] = {};
-    hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)
-    DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
-    // fpng_amd_encode_host_batch: ring of device staging buffers, one copy stream per direction
-    struct HostRing {
-        static constexpr int kDepth = 3;
-        DeviceBuf<uint8_t> d_in[kDepth], d_out[kDepth];
-        hipStream_t up = nullptr, down = nullptr;
-    } host;
-    // Submissions are pipelined: each one owns a slot of pinned host memory (job records going down, result
-    // records coming back) guarded by an event, so fpng_amd_encode_submit() never waits for the GPU unless all
-    // slots are in flight.  A submission's ticket is its sequence number; its records stay readable until its
-    // slot is reused, kSlots submissions later.
-    static constexpr int kSlots = 8;
-    struct Slot {
-        PinnedBuf<Job> jobs, jobs2; // jobs2: the second upload of 2-pass (tables patched)
-        PinnedBuf<Result> results;
-        hipEvent_t in = nullptr;     // recorded on the caller's stream: the inputs are ready
-        hipEvent_t walked = nullptr; // recorded after the row walk
-        hipEvent_t done = nullptr;   // recorded on the lane: PNGs and result records are complete
-        bool in_flight = false;
-        uint32_t n = 0;
-        uint64_t ticket = 0;
-    } slots[kSlots];
-    uint64_t submitted = 0; // tickets handed out so far
-    uint64_t band_token_bits = 0; // row bands: what fpng_amd_band_encode() left for fpng_amd_band_place()
-    uint32_t band_eob_bits = 0;
-    bool band_two_pass = false;
-    uint32_t band_crc_ranges = 0; // fpng_amd_band_place(): number of 64 KiB CRC ranges of the image
-    hipEvent_t band_copied[4] = {}; // the pinned job record h_jobs[k] of an asynchronous band call has been uploaded
-};
+const TokenTable *fpng_amd::host_1pass_table(uint32_t c)
+{
+    return ((c == 3 || c == 4) && host_tables()) ? &g_host_1pass[c] : nullptr;
+}
 
 extern "C" {
 
@@ -355,6 +235,7 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    destroy_host_workers(e);
     for (auto &ls : e->lane_stream)
         if (ls) (void)hipStreamSynchronize(ls);
     if (e->own_stream) (void)hipStreamSynchronize(e->stream);
@@ -375,6 +256,8 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &s : e->sc) s.release();
     e->h_states.release();
+    e->h_partials.release();
+    e->d_stream_partials.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
     for (auto &b : e->host.d_in) b.release();
@@ -431,8 +314,10 @@ int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
     return FPNG_AMD_OK;
 }
 
+} // namespace
+
 // Host-side wait for every submission in flight on the lanes.
-int drain(fpng_amd_encoder *e)
+int fpng_amd::drain(fpng_amd_encoder *e)
 {
     for (auto &sl : e->slots)
         if (sl.in_flight) {
@@ -441,6 +326,8 @@ int drain(fpng_amd_encoder *e)
         }
     return FPNG_AMD_OK;
 }
+
+namespace {
 
 // Fills slot.jobs[0..n) for whole-image jobs and sizes the scratch buffers.  Only `slot` (which is free) and
 // the lane's device scratch are touched: the records of submissions in flight stay where they are.
@@ -564,22 +451,26 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
             slot.jobs.p[i].table = dt.symbols[slot.jobs.p[i].c];
         }
     }
-    // ---- the batch is valid: from here on the submission exists ----
-    e->submitted++;
-    slot.ticket = e->submitted;
-    slot.n = n;
+    // ---- the batch is valid.  The ticket is committed at the very end, after the last HIP call that can fail: a failed
+    //      submit hands out no ticket and the next one reuses this slot and lane (stream order keeps whatever was launched
+    //      apart from it) ----
+    slot.ticket = 0;
     e->phases_recorded = 0;
+    e->last_two_pass = two_pass;
     // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
     HIP_TRY(hipEventRecord(slot.in, e->stream));
     HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
     if (sc.last_done) HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
+    uint32_t ph = 0; // index of the last phase mark
     if (two_pass) {
         HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
         launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
+        if ((rc = mark(e, s, ++ph))) return rc;
         launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
         HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+        if ((rc = mark(e, s, ++ph))) return rc;
     }
     // 2-pass only: the row walk of this submission waits for the walk of the previous one (other lane), so that
     // its own histogram pass and table build run under that walk instead of next to the other lane's (+9 %, measured;
@@ -595,22 +486,25 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // the finalize step into the last assemble block (three launches) was measured on the same box: 11 % less throughput
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
     if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
-    if ((rc = mark(e, s, 1))) return rc;
+    if ((rc = mark(e, s, ++ph))) return rc;
     HIP_TRY(hipEventRecord(slot.walked, s));
     e->prev_walked = slot.walked;
     launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
-    if ((rc = mark(e, s, 2))) return rc;
+    if ((rc = mark(e, s, ++ph))) return rc;
     launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
-    if ((rc = mark(e, s, 3))) return rc;
+    if ((rc = mark(e, s, ++ph))) return rc;
     launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-    if ((rc = mark(e, s, 4))) return rc;
+    if ((rc = mark(e, s, ++ph))) return rc;
     launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
-    if ((rc = mark(e, s, 5))) return rc;
+    if ((rc = mark(e, s, ++ph))) return rc;
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, s));
     sc.last_done = slot.done;
+    e->submitted++;
+    slot.ticket = e->submitted;
+    slot.n = n;
     slot.in_flight = true;
     if (ticket_out) *ticket_out = slot.ticket;
     return FPNG_AMD_OK;
@@ -672,8 +566,7 @@ int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    (void)e;
-    return "encode_rows,scan,stored,assemble,finalize";
+    return (e && e->last_two_pass) ? "hist,build_dynamic,encode_rows,scan,stored,assemble,finalize" : "encode_rows,scan,stored,assemble,finalize";
 }
 
 int fpng_amd_encoder_join(fpng_amd_encoder *e)
@@ -695,32 +588,6 @@ int fpng_amd_encode_finish(fpng_amd_encoder *e, fpng_amd_result *results, uint32
         if (!e->submitted) return fail(FPNG_AMD_ERR_INVALID_ARG, "nothing was submitted");
         return fpng_amd_encode_wait(e, e->submitted, results, n);
     }
-    return FPNG_AMD_OK;
-}
-
-int fpng_amd_encode_host(fpng_amd_encoder *e, const void *pixels, uint32_t w, uint32_t h, uint32_t c, uint32_t flags,
-                         uint8_t *out, size_t out_cap, size_t *out_size)
-{
-    if (!e || !pixels || !out_size) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
-    int rc = check_dims(w, h, c);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(e->device));
-    const size_t in_bytes = (size_t)w * h * c, max_out = fpng_amd_max_encoded_size(w, h, c);
-    if ((rc = e->d_stage_in.ensure(in_bytes + 16))) return rc;
-    if ((rc = e->d_stage_out.ensure(max_out + 64))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_stage_in.p, pixels, in_bytes, hipMemcpyHostToDevice, e->stream));
-    fpng_amd_image im;
-    im.d_pixels = e->d_stage_in.p;
-    im.w = w, im.h = h, im.num_chans = c;
-    im.d_out = e->d_stage_out.p;
-    im.out_cap = max_out + 64;
-    if ((rc = fpng_amd_encode_batch_async(e, &im, 1, flags))) return rc;
-    fpng_amd_result res;
-    if ((rc = fpng_amd_encode_finish(e, &res, 1))) return rc;
-    if (res.status) return fail(FPNG_AMD_ERR_HIP, "device reported an encode failure");
-    *out_size = (size_t)res.png_size;
-    if (!out || out_cap < res.png_size) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "output buffer too small");
-    HIP_TRY(hipMemcpy(out, e->d_stage_out.p, res.png_size, hipMemcpyDeviceToHost));
     return FPNG_AMD_OK;
 }
 
@@ -765,7 +632,7 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
     // writer pool: finished files are handed to n_writer_threads threads (reference fpng.cpp:1806-1828 writes inline)
     struct WriteJob { const char *path; const uint8_t *data; size_t size; uint32_t idx; };
     std::vector<WriteJob> wq;
-    size_t wq_head = 0;
+    size_t wq_head = 0, wq_done = 0; // taken / written; at most 2 x writers + 2 frames wait in between (back-pressure on the downloader)
     bool wq_closed = false;
     std::mutex wmu;
     std::condition_variable wcv;
@@ -782,9 +649,14 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
                     job = wq[wq_head++];
                 }
                 FILE *f = fopen(job.path, "wb");
-                if (!f || fwrite(job.data, 1, job.size, f) != job.size) failed = FPNG_AMD_ERR_INVALID_ARG;
-                if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+                if (!f || fwrite(job.data, 1, job.size, f) != job.size) failed = FPNG_AMD_ERR_IO;
+                if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_IO;
                 std::vector<uint8_t>().swap(file_bufs[job.idx]); // (a frame without a caller buffer: its bytes are on disk now)
+                {
+                    std::lock_guard<std::mutex> lk(wmu);
+                    wq_done++;
+                }
+                wcv.notify_all(); // the downloader may be waiting for room in the queue; a failure is seen at once
             }
         });
 
@@ -850,14 +722,16 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
                 if (!failed && imgs[i].path) {
                     if (nw) {
                         {
-                            std::lock_guard<std::mutex> lk(wmu);
+                            // a disk slower than the GPU must not let finished frames pile up in host memory
+                            std::unique_lock<std::mutex> lk(wmu);
+                            wcv.wait(lk, [&] { return wq.size() - wq_done < (size_t)(2 * nw + 2) || failed; });
                             wq.push_back({imgs[i].path, dst, (size_t)res.png_size, i});
                         }
-                        wcv.notify_one();
+                        wcv.notify_all();
                     } else {
                         FILE *f = fopen(imgs[i].path, "wb");
-                        if (!f || fwrite(dst, 1, res.png_size, f) != res.png_size) failed = FPNG_AMD_ERR_INVALID_ARG;
-                        if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_INVALID_ARG;
+                        if (!f || fwrite(dst, 1, res.png_size, f) != res.png_size) failed = FPNG_AMD_ERR_IO;
+                        if (f && fclose(f) == EOF) failed = FPNG_AMD_ERR_IO;
                         std::vector<uint8_t>().swap(file_bufs[i]);
                     }
                 }
@@ -1046,11 +920,11 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
 {
     int rc = band_check(e, b);
     if (rc) return rc;
-    if (!d_window || !window_file_offset || !window_bytes || zlib_size < 6) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
+    if (!d_window || !window_file_offset || !window_bytes || (zlib_size && zlib_size < 6)) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
     if ((uintptr_t)d_window & 15) return fail(FPNG_AMD_ERR_INVALID_ARG, "d_window must be 16-byte aligned");
     HIP_TRY(hipSetDevice(e->device));
     fpng_amd_encoder::Scratch &sc = e->sc[0];
-    if ((rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = band_record_free(e, 3))) return rc;
+    if ((rc = drain(e)) || (rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = band_record_free(e, 3))) return rc;
     Job &j = e->h_jobs.p[3];
     band_job(e, b, e->band_two_pass, j);
     // the window: whole 16-byte pieces of the FILE from the piece holding the band's first bit to the one holding its last
@@ -1062,6 +936,10 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
     *window_file_offset = wb0;
     *window_bytes = (size_t)(wb1 - wb0);
     if (window_cap < wb1 - wb0) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "band window too small");
+    // zlib_size == 0 ("not known yet"): the band pretends that the data ends with its window; its CRC partials then
+    // describe [58, wb1) with foreign bits zero, and fpng_amd_band_crc() folds them to one value positioned at wb1
+    e->band_self_end = zlib_size ? 0 : wb1;
+    if (!zlib_size) zlib_size = wb1 - kPngHeaderBytes + 4;
     j.start_bit = start_bit;
     j.flags = 0x100u | 0x200u; // band placement through scan_kernel + assemble_kernel
     j.band_zlib_size = zlib_size;
@@ -1090,6 +968,8 @@ int fpng_amd_band_crc_partials(fpng_amd_encoder *e, uint32_t *d_partials, uint32
     if (!d_partials) return FPNG_AMD_OK; // (size query)
     if (cap < e->band_crc_ranges) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "partials buffer too small");
     HIP_TRY(hipSetDevice(e->device));
+    int rc = drain(e);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_partials, e->sc[0].d_partials.p, (size_t)e->band_crc_ranges * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
     return FPNG_AMD_OK;
 }
@@ -1103,8 +983,8 @@ static int wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint3
     int rc = check_dims(w, h, c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    fpng_amd_encoder::Scratch &sc = e->sc[0];
-    if ((rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = sc.d_states.ensure(1)) || (rc = e->h_states.ensure(2)) ||
+    fpng_amd_encoder::Scratch &sc = e->sc[0]; // (lane 0's scratch: whole-image submissions in flight must be done with it)
+    if ((rc = drain(e)) || (rc = e->h_jobs.ensure(4)) || (rc = sc.d_jobs.ensure(4)) || (rc = sc.d_states.ensure(1)) || (rc = e->h_states.ensure(2)) ||
         (rc = sc.d_results.ensure(1)) || (rc = sc.d_rows.ensure(1)))
         return rc;
     if ((rc = band_record_free(e, 0))) return rc;

@@ -1,7 +1,7 @@
 // fpng_dropin.cpp -- `namespace fpng` (include/fpng.h) on top of the C ABI of libfpng_amd.so.
 //
 // Built by g++ into libfpng.so; it contains no HIP code and no encoder of its own: every encode call
-// goes through fpng_amd_encode_host() (H2D copy -> HIP kernels -> D2H copy).  Each thread gets its own
+// goes through fpng_amd_encode_host_to() (H2D copies, HIP kernels and D2H copies, streamed in row bands for large frames).  Each thread gets its own
 // encoder object, so the functions stay re-entrant like the reference's.
 //
 // Decoding (fpng_get_info / fpng_decode_memory / fpng_decode_file) is a serial Huffman stream and
@@ -48,10 +48,18 @@ bool fpng_encode_image_to_memory(const void *pImage, uint32_t w, uint32_t h, uin
     if ((num_chans != 3) && (num_chans != 4)) return false;
     fpng_amd_encoder *enc = t_encoder.get();
     if (!enc) return false;
-    const size_t cap = fpng_amd_max_encoded_size(w, h, num_chans);
-    out_buf.resize(cap);
+    // The vector is the output allocator: the encoder asks for room as the file's size becomes known (once, up front, for
+    // an estimate; once at the end for the exact size), so nothing is sized for the worst case and zero-filled (the
+    // reference resizes to the worst case, src/fpng.cpp:1686-1691, then shrinks) -- a vector reused from frame to frame, as
+    // in the reference's own timing loop (fpng_test.cpp:1198-1209), is not touched at all until the bytes arrive.
     size_t size = 0;
-    if (fpng_amd_encode_host(enc, pImage, w, h, num_chans, flags, out_buf.data(), cap, &size) != FPNG_AMD_OK) {
+    if (fpng_amd_encode_host_to(enc, pImage, w, h, num_chans, flags,
+                                [](void *user, size_t bytes) -> uint8_t * {
+                                    auto *v = static_cast<std::vector<uint8_t> *>(user);
+                                    if (v->size() < bytes) v->resize(bytes);
+                                    return v->data();
+                                },
+                                &out_buf, &size) != FPNG_AMD_OK) {
         out_buf.resize(0);
         return false;
     }

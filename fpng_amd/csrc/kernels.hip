@@ -51,6 +51,19 @@ constexpr int kHistWaves = 8;              // hist_kernel: one LDS histogram (36
 constexpr int kHistBlock = kWave * kHistWaves;
 constexpr int kRowBlock = kWave * kRowWaves;
 constexpr int kStageDwords = 1024;         // per-wave LDS staging window of the output bit stream
+// Local-stream stores carry the non-temporal hint (build with -DFPNG_LOCAL_NT=0 to A/B it: the hint decides whether the
+// streams are kept in L2 / Infinity Cache for assemble_kernel)
+#ifndef FPNG_LOCAL_NT
+#define FPNG_LOCAL_NT 1
+#endif
+template <typename T, typename P> __device__ __forceinline__ void local_store(const T &v, P p)
+{
+#if FPNG_LOCAL_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 constexpr int kStageFlushAt = kStageDwords - 136; // a 64-pixel window adds at most 64*60 bits = 120 dwords
 
 // ---------------------------------------------------------------------------------------------
@@ -421,7 +434,7 @@ __device__ __forceinline__ void sink_flush_exclusive(EmitSink &s, uint32_t lane,
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll 1
     for (uint32_t j = lane; j < n4; j += kWave) {
-        __builtin_nontemporal_store(st4[j], &dst4[j]); // written once, read much later by another kernel: not worth L2 space (+2 %)
+        local_store(st4[j], &dst4[j]); // written once, read much later by another kernel: not worth L2 space (+2 %)
         if (!final) st4[j] = zero4;
     }
     if (!final && n4) {
@@ -447,7 +460,7 @@ __device__ __forceinline__ void sink_flush(EmitSink &s, uint32_t lane, bool fina
     wave_lds_fence();
     const uint32_t ndw = final ? ((s.fill + 31) >> 5) : (s.fill >> 5); // (whole 128-byte lines only, as in the 16-byte flush: no gain here)
 #pragma unroll 1
-    for (uint32_t j = lane; j < ndw; j += kWave) __builtin_nontemporal_store(s.stage[j], &s.out32[s.base_dw + j]);
+    for (uint32_t j = lane; j < ndw; j += kWave) local_store(s.stage[j], &s.out32[s.base_dw + j]);
     if (!final) {
         const uint32_t rem = s.stage[ndw]; // partial dword, uniform address
         wave_lds_fence();

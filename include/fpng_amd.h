@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPNG_AMD_ABI_VERSION 2
+#define FPNG_AMD_ABI_VERSION 3
 
 /* ---- status codes ---- */
 #define FPNG_AMD_OK 0
@@ -36,6 +36,7 @@ extern "C" {
 #define FPNG_AMD_ERR_BUFFER_TOO_SMALL (-4)
 #define FPNG_AMD_ERR_OUT_OF_MEMORY (-5)
 #define FPNG_AMD_ERR_UNSUPPORTED (-6)      /* > 4 GiB of filtered bytes: undefined in the reference (src/fpng.cpp:1682-1705) */
+#define FPNG_AMD_ERR_IO (-7)               /* a file could not be written (reference src/fpng.cpp:1818-1827 returns false) */
 
 /* ---- encode flags: same bit values as reference src/fpng.h:34-42 ---- */
 #define FPNG_AMD_ENCODE_SLOWER 1u      /* 2-pass: per-image dynamic Huffman table */
@@ -71,6 +72,16 @@ uint32_t fpng_amd_adler32_combine(uint32_t adler_x, uint32_t adler_y, uint64_t l
 /* Largest possible output of any encode call for these dimensions (= the stored-block size,
  * reference src/fpng.cpp:1747, + container).  d_out capacities must be >= this. */
 size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
+
+/* ---- environment knobs (read once per process, for A/B measurements; the defaults are the measured optimum):
+ *      FPNG_AMD_LANES=1..4          internal streams that take submissions in turn (default 2; 1 serialises everything)
+ *      FPNG_AMD_LOCAL_LIMIT_MB=n    cap on the scratch for the rows' local streams (default 98304); a submission that would
+ *                                   need more is refused with FPNG_AMD_ERR_OUT_OF_MEMORY before anything is launched
+ *      FPNG_AMD_STAGGER=0|1         2-pass: make a submission's row walk wait for the previous submission's walk
+ *                                   (default: on for FPNG_AMD_ENCODE_SLOWER, off otherwise)
+ *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline, also
+ *                                   for pageable pixels (default: by image size and only for page-locked pixels; 1 = serial)
+ *      FPNG_AMD_TRACE=1             fpng_amd_encode_host(): per-band timeline of the streamed path on stderr ---- */
 
 /* ---- encoder object: the caller's HIP stream (ordering point) + two internal streams ("lanes") with
  *      reusable device scratch.  Not thread-safe; create one per thread (the reference is re-entrant,
@@ -117,7 +128,8 @@ int fpng_amd_encode_batch_async(fpng_amd_encoder *enc, const fpng_amd_image *ima
 /* The same call handing back a TICKET for this submission, so that a pipeline with several submissions in flight can
  * collect each one's result records: fpng_amd_encode_wait() waits for that submission only (later ones keep
  * running) and copies out its n records; fpng_amd_encode_query() polls (1 done, 0 running).  Records stay
- * retrievable until 8 further submissions have been made.  A failed submit leaves the encoder unchanged. */
+ * retrievable until 8 further submissions have been made.  A failed submit hands out no ticket and leaves the encoder as it
+ * was (the ticket is committed after the last call that can fail). */
 int fpng_amd_encode_submit(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t flags, uint64_t *ticket);
 int fpng_amd_encode_wait(fpng_amd_encoder *enc, uint64_t ticket, fpng_amd_result *results, uint32_t n);
 int fpng_amd_encode_query(fpng_amd_encoder *enc, uint64_t ticket);
@@ -134,6 +146,22 @@ int fpng_amd_encode_finish(fpng_amd_encoder *enc, fpng_amd_result *results, uint
 int fpng_amd_encode_host(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
                          uint32_t flags, uint8_t *out, size_t out_cap, size_t *out_size);
 
+/* The same with the OUTPUT ALLOCATOR in the caller's hands -- what a std::vector-based caller (the fpng:: drop-in) needs so
+ * that nothing is zero-filled or copied twice: `reserve(user, bytes)` must return a buffer of at least `bytes` bytes that
+ * still holds everything written so far (NULL = give up: FPNG_AMD_ERR_BUFFER_TOO_SMALL); it is called with growing sizes, only
+ * while the call runs and never concurrently, possibly from a helper thread.  Large 1-pass frames are STREAMED: the frame is
+ * cut into row bands, band k+1 is uploaded while band k is encoded and placed and band k-1's piece of the file is downloaded,
+ * so a call takes about max(upload, download) instead of their sum (one 8K RGBA frame: 2.8 instead of 3.6 ms).
+ * Streaming needs PAGE-LOCKED pixels: on this platform copies from pageable memory in the two directions take turns instead
+ * of overlapping, so frames in ordinary malloc'ed memory take the serial path (upload, encode, size, download).  A capture
+ * loop that reuses its frame buffer page-locks it once with fpng_amd_pin_host_memory() (= hipHostRegister; undo with
+ * fpng_amd_unpin_host_memory() BEFORE freeing the buffer). */
+typedef uint8_t *(*fpng_amd_reserve_fn)(void *user, size_t bytes);
+int fpng_amd_encode_host_to(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
+                            uint32_t flags, fpng_amd_reserve_fn reserve, void *user, size_t *out_size);
+int fpng_amd_pin_host_memory(void *p, size_t bytes);
+int fpng_amd_unpin_host_memory(void *p);
+
 /* fpng_encode_image_to_memory() / fpng_encode_image_to_file() (reference src/fpng.h:48-52, src/fpng.cpp:1806-1828) for MANY
  * frames in host memory: uploads, encodes, downloads and file writes of consecutive frames overlap (a ring of device
  * staging buffers, an uploader and a downloader thread, n_writer_threads file writers; 0 = the downloader writes).
@@ -148,6 +176,16 @@ typedef struct fpng_amd_host_image {
 } fpng_amd_host_image;
 int fpng_amd_encode_host_batch(fpng_amd_encoder *enc, const fpng_amd_host_image *images, uint32_t n, uint32_t flags,
                                int n_writer_threads);
+
+/* ---- whole node from ONE process (SURVEY 8b "a multi-GPU form"): one encoder + staging ring per listed device, the frames
+ *      of a host batch are dealt round-robin to the devices, every device runs fpng_amd_encode_host_batch() on its share from
+ *      its own thread.  `devices` may name a device more than once (two pipelines on one GPU). ---- */
+typedef struct fpng_amd_node fpng_amd_node;
+int fpng_amd_node_create(fpng_amd_node **node, const int *devices, uint32_t n_devices);
+void fpng_amd_node_destroy(fpng_amd_node *node);
+uint32_t fpng_amd_node_size(const fpng_amd_node *node);
+int fpng_amd_node_encode_host_batch(fpng_amd_node *node, const fpng_amd_host_image *images, uint32_t n, uint32_t flags,
+                                    int n_writer_threads_per_device);
 
 /* ---- row-band interface: one image sharded by rows over several GPUs.
  *      The stream stays ONE IDAT / ONE Deflate block; bands are stitched at bit granularity. ---- */
@@ -189,7 +227,10 @@ int fpng_amd_band_encode(fpng_amd_encoder *enc, const fpng_amd_band *band, uint3
  * WINDOW of whole 16-byte pieces of the file: d_window[0] is file byte *window_file_offset (a multiple of 16; 0 for the
  * first band, whose window also receives the stream's head), *window_bytes bytes are defined; bits that belong to other
  * bands are 0, so neighbouring windows are merged by OR-ing their one shared 16-byte piece.  The image's last band
- * (y1 == h_total) appends the end-of-block code.  PNG header, Adler-32, CRC and IEND are fpng_amd_wrap_png()'s. */
+ * (y1 == h_total) appends the end-of-block code.  PNG header, Adler-32, CRC and IEND are fpng_amd_wrap_png()'s.
+ * zlib_size == 0: the size of the stream is not known yet (bands placed one after another while later ones are still being
+ * uploaded or encoded): the CRC ranges are then laid out from the window's own end and fpng_amd_band_crc() turns them into
+ * ONE raw CRC value per band, which fpng_amd_idat_crc_from_bands() combines once the last band is in. */
 int fpng_amd_band_place(fpng_amd_encoder *enc, const fpng_amd_band *band, uint64_t start_bit, uint64_t zlib_size,
                         uint8_t *d_window, size_t window_cap, uint64_t *window_file_offset, size_t *window_bytes);
 
@@ -210,6 +251,35 @@ int fpng_amd_band_crc_partials(fpng_amd_encoder *enc, uint32_t *d_partials, uint
 int fpng_amd_wrap_png_crc(fpng_amd_encoder *enc, uint8_t *d_png, size_t zlib_size, uint32_t adler, uint32_t w, uint32_t h,
                           uint32_t num_chans, const uint32_t *d_crc_partials, uint32_t n_partials, size_t *png_size);
 
+/* The raw CRC-32 (init 0, no final xor) of the window of the band placed last with zlib_size == 0, foreign bits counting as
+ * zero, as if the file ended at *end_offset (the window's end).  Waits for the placement. */
+int fpng_amd_band_crc(fpng_amd_encoder *enc, uint32_t *raw_crc, uint64_t *end_offset);
+
+/* ---- host-side arithmetic of the band path (no GPU needed): what every rank -- or one host streaming bands through one GPU
+ *      -- derives from the bands' records.  Bands in row order; a band without rows has adler_len == 0. ---- */
+typedef struct fpng_amd_band_plan {
+    uint64_t end_bit;   /* zlib bit position after the last row token */
+    uint64_t zlib_size; /* bytes of the compressed zlib stream incl. the Adler-32 */
+    uint32_t adler;     /* Adler-32 of the image's filtered bytes */
+    uint32_t stored;    /* 1: the reference's coder would have run out of buffer (src/fpng.cpp:567-588): encode the image whole,
+                           it becomes stored blocks */
+} fpng_amd_band_plan;
+/* start_bits[k] = zlib bit where band k's tokens begin (exclusive prefix sum from stats[0].first_token_bit); flags: 0 or
+ * FPNG_AMD_ENCODE_SLOWER (the failure rule differs, reference src/fpng.cpp:1169 / :1455). */
+int fpng_amd_plan_bands(const fpng_amd_band_stats *stats, uint32_t n_bands, uint32_t w, uint32_t h, uint32_t num_chans,
+                        uint32_t flags, uint64_t *start_bits, fpng_amd_band_plan *plan);
+/* The window fpng_amd_band_place() writes for a band: whole 16-byte pieces of the file; *shared_head = 16 when its first
+ * piece is also the last piece of the previous band's window (OR the two), else 0. */
+int fpng_amd_band_window(int is_first, int is_last, uint64_t start_bit, uint64_t token_bits, uint32_t eob_bits,
+                         uint64_t *file_offset, size_t *bytes, uint32_t *shared_head);
+/* IDAT chunk CRC-32 (reference src/fpng.cpp:1797-1800) from the bands' raw window CRCs (fpng_amd_band_crc). */
+uint32_t fpng_amd_idat_crc_from_bands(const uint32_t *raw_crc, const uint64_t *end_offset, uint32_t n_bands, uint64_t zlib_size,
+                                      uint32_t adler);
+/* The 58 bytes in front of the zlib stream (signature, IHDR, fdEC, IDAT length + type; reference src/fpng.cpp:1767-1791) and
+ * the 20 bytes behind its tokens (Adler-32 big-endian = the stream's last 4 bytes, IDAT CRC-32, IEND). */
+int fpng_amd_png_head(uint32_t w, uint32_t h, uint32_t num_chans, uint64_t zlib_size, uint8_t head[58]);
+void fpng_amd_png_tail(uint32_t adler, uint32_t idat_crc, uint8_t tail[20]);
+
 /* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
@@ -224,7 +294,8 @@ int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32
 /* ---- instrumentation for bench.py: per-kernel durations of the last submission measured with HIP
  *      events (ms).  With profiling enabled submissions use one lane, i.e. they do not overlap.
  *      fpng_amd_encoder_phase_names(): comma-separated names of the phases of the last submission's
- *      launch chain: "encode_rows,scan,stored,assemble,finalize". ---- */
+ *      launch chain: "encode_rows,scan,stored,assemble,finalize", with "hist,build_dynamic," in front for
+ *      FPNG_AMD_ENCODE_SLOWER submissions. ---- */
 #define FPNG_AMD_NUM_PHASES 8
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);

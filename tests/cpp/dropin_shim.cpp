@@ -1,7 +1,27 @@
 // Test-only C shim so Python can call the `namespace fpng` drop-in (std::vector API) via ctypes.
 #include "fpng.h"
 #include <string.h>
+#include <chrono>
 extern "C" {
+// Timed loop through the drop-in exactly as the reference's harness times its encoder (fpng_test.cpp:1198-1209): `reps` calls
+// of fpng::fpng_encode_image_to_memory into ONE reused vector (reuse = 1) or into a fresh vector per call (reuse = 0, the
+// vector's construction and growth inside the timed region); best seconds per call.
+double shim_time_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int reps, int reuse, size_t *size)
+{
+    std::vector<uint8_t> keep;
+    double best = 1e30;
+    for (int i = 0; i < reps; i++) {
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint8_t> fresh;
+        std::vector<uint8_t> &v = reuse ? keep : fresh;
+        if (!fpng::fpng_encode_image_to_memory(img, w, h, c, v, flags)) return -1.0;
+        auto t1 = std::chrono::steady_clock::now();
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        if (s < best) best = s;
+        if (size) *size = v.size();
+    }
+    return best;
+}
 int shim_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, uint8_t *out, size_t cap, size_t *size)
 {
     std::vector<uint8_t> v;

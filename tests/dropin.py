@@ -30,6 +30,8 @@ def shim():
     L.shim_get_info.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.shim_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
     L.shim_decode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
+    L.shim_time_encode.restype = C.c_double
+    L.shim_time_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.shim_crc32.restype = C.c_uint32
     L.shim_crc32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
     L.shim_adler32.restype = C.c_uint32
@@ -68,3 +70,15 @@ def encode(img, w, h, c, flags=0):
     n = C.c_size_t(0)
     ok = L.shim_encode(a.ctypes.data, w, h, c, flags, out.ctypes.data, cap, C.byref(n))
     return out[: n.value].tobytes() if ok else None
+
+
+def time_encode(img, w, h, c, flags=0, reps=5, reuse=True):
+    """Best seconds per fpng::fpng_encode_image_to_memory() call through libfpng.so, timed in C++ like the reference's
+    harness (fpng_test.cpp:1198-1209); reuse: one std::vector across the calls / a fresh one per call."""
+    L = shim()
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    n = C.c_size_t(0)
+    t = L.shim_time_encode(a.ctypes.data, w, h, c, flags, reps, int(reuse), C.byref(n))
+    if t < 0:
+        raise RuntimeError("fpng::fpng_encode_image_to_memory failed")
+    return t, n.value

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fpng_amd.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert lib.fpng_amd_abi_version() == 2
+    assert lib.fpng_amd_abi_version() == 3
 
 
 def test_format_tables_self_check(built_lib):
@@ -64,3 +64,71 @@ def test_no_silent_cpu_fallback(built_lib):
     with pytest.raises(Exception):
         fpng_amd.fpng_encode_image_to_memory(img, 4, 4, 3)
     assert fpng_amd.fpng_cpu_supports_sse41() is False
+
+
+def _raw_crc(data):
+    """CRC-32 with init 0 and no final xor (what the kernels' partials are made of): crc32 is affine in the message."""
+    return zlib.crc32(data) ^ zlib.crc32(bytes(len(data)))
+
+
+def test_band_plan_matches_the_python_mirror(built_lib):
+    """fpng_amd_plan_bands / fpng_amd_band_window (C, what C++ callers and the streamed host path use) against
+    fpng_amd/sharded.py's plan_bands / window_extent on random band records, incl. empty bands and stored outcomes."""
+    import fpng_amd
+    from fpng_amd import _lib, sharded
+    rng = np.random.default_rng(5)
+    n_stored = 0
+    for trial in range(300):
+        c = int(rng.integers(3, 5))
+        w, h = int(rng.integers(1, 5000)), int(rng.integers(1, 3000))
+        nb = int(rng.integers(1, 9))
+        cuts = sorted(int(v) for v in rng.integers(0, h + 1, nb - 1))
+        cuts = [0] + cuts + [h]
+        one_pass = bool(rng.integers(0, 2))
+        ftb = fpng_amd.layout_1pass(c)[0] if one_pass else int(rng.integers(300, 900))
+        scale = float(rng.choice([0.3, 0.9, 1.0, 1.01, 1.2]))
+        py, cs = [], []
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            nbytes = (w * c + 1) * (y1 - y0)
+            bits = int(nbytes * 8 * scale * rng.random()) if nbytes else 0
+            s1, s2, lu = (int(rng.integers(0, 65521)), int(rng.integers(0, 65521)), int(rng.integers(1, 60))) if nbytes else (0, 0, 0)
+            py.append(sharded.BandStats(bits, s1, s2, nbytes, lu, ftb, 12))
+            cs.append(_lib.BandStats(bits, s1, s2, nbytes, lu, ftb, 12, 0))
+        want = sharded.plan_bands(py, w, h, c, ftb, 12, one_pass)
+        starts, plan = fpng_amd.plan_bands(cs, w, h, c, 0 if one_pass else 1)
+        assert starts == want.start_bits and plan.end_bit == want.end_bit and plan.adler == want.adler
+        assert bool(plan.stored) == want.stored and plan.zlib_size == want.zlib_size
+        n_stored += want.stored
+        non_empty = [k for k in range(nb) if py[k].nbytes]
+        for k in non_empty:
+            first, last = k == non_empty[0], cuts[k + 1] == h
+            off, nbytes, head = fpng_amd.band_window(first, last, starts[k], py[k].token_bits, 12)
+            assert (off, nbytes) == sharded.window_extent(first, last, starts[k], py[k].token_bits, 12)
+            assert head == (0 if first else (min(16, nbytes) if (58 * 8 + starts[k]) % 128 else 0))
+    assert 0 < n_stored < 300
+
+
+def test_container_from_band_crcs(built_lib):
+    """fpng_amd_idat_crc_from_bands / fpng_amd_png_head / fpng_amd_png_tail rebuild a reference file's container from raw CRCs
+    of arbitrary windows of its zlib stream (what the streamed host path and the sharded path do with the GPU's values)."""
+    import fpng_amd
+    rng = np.random.default_rng(6)
+    for (kind, w, h, c) in [("grad", 97, 41, 3), ("blocks", 300, 77, 4), ("grad", 640, 360, 4)]:
+        img = fpng_amd.synth_image(kind, w, h, c)
+        png = oracle().encode(img, w, h, c, 0)
+        zlib_size = len(png) - 58 - 16
+        adler = int.from_bytes(png[58 + zlib_size - 4:58 + zlib_size], "big")
+        assert fpng_amd.png_head(w, h, c, zlib_size) == png[:58]
+        data_end = 58 + zlib_size - 4
+        for trial in range(10):
+            nb = int(rng.integers(1, 6))
+            # windows end on 16-byte pieces of the FILE (the last one may end behind the data, zero padded)
+            ends = sorted(set(int(v) & ~15 for v in rng.integers(80, data_end, nb - 1))) + [(data_end + 15) & ~15]
+            raw, begin = [], 58
+            for e in ends:
+                seg = png[begin:min(e, data_end)]
+                # raw CRC of bytes [58, e) with everything outside [begin, e) zero
+                raw.append(_raw_crc(bytes(begin - 58) + seg + bytes(e - begin - len(seg))))
+                begin = e
+            crc = fpng_amd.idat_crc_from_bands(raw, ends, zlib_size, adler)
+            assert fpng_amd.png_tail(adler, crc) == png[58 + zlib_size - 4:]

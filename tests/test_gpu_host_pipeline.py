@@ -1,0 +1,146 @@
+"""Host-buffer pipelines (-m gpu): fpng_amd_encode_host_to() streamed in row bands (upload | encode + place | download
+overlapped), the fpng:: drop-in on top of it, and the whole-node form -- all against the reference's bytes."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import dropin
+import real_image
+from cpu_ref import ROOT, oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _kat(kind, w, h, c, flags):
+    with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+        for e in json.load(f):
+            if (e["w"], e["h"], e["c"], e["kind"]) == (w, h, c, kind):
+                return e["flags"][str(flags)]
+    raise KeyError((kind, w, h, c))
+
+
+@pytest.fixture(scope="module")
+def enc(built_lib):
+    import torch
+    import fpng_amd
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    e = fpng_amd.Encoder(device=0, stream="own")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("dims", [(7680, 4320, 4), (3840, 2160, 4)])
+def test_streamed_frames_vs_reference(enc, dims):
+    """8K RGBA (8 bands) and 4K RGBA (3 bands by the size rule): golden sha256 of the unmodified reference."""
+    import fpng_amd
+    w, h, c = dims
+    for kind in ("grad", "blocks"):
+        img = fpng_amd.synth_image(kind, w, h, c)
+        exp = _kat(kind, w, h, c, 0)
+        png, asked = enc.encode_host_growing(img, w, h, c, 0)
+        assert len(png) == exp["size"] and hashlib.sha256(png).hexdigest() == exp["sha256"], (kind, dims)
+        assert asked == [exp["size"]]  # pageable pixels: the serial path knows the size before it asks for room
+        fpng_amd.pin_host_memory(img)  # page-locked pixels are streamed in row bands
+        try:
+            png, asked = enc.encode_host_growing(img, w, h, c, 0)
+            assert len(png) == exp["size"] and hashlib.sha256(png).hexdigest() == exp["sha256"], (kind, dims)
+            assert len(asked) >= 3 and asked[-1] == exp["size"]  # streamed: room was asked for window by window
+            assert max(asked) <= fpng_amd.max_encoded_size(w, h, c)
+            assert enc.encode_host(img, w, h, c, 0) == png  # the fixed-buffer form
+        finally:
+            fpng_amd.unpin_host_memory(img)
+
+
+def test_streamed_incompressible_frame_ends_up_stored(enc):
+    import fpng_amd
+    w, h, c = 3840, 2160, 4
+    img = fpng_amd.synth_image("noise", w, h, c)
+    exp = _kat("noise", w, h, c, 0)
+    fpng_amd.pin_host_memory(img)
+    try:
+        png, asked = enc.encode_host_growing(img, w, h, c, 0)
+    finally:
+        fpng_amd.unpin_host_memory(img)
+    assert len(asked) > 1
+    assert exp["btype"] == 0 and len(png) == exp["size"] and hashlib.sha256(png).hexdigest() == exp["sha256"]
+
+
+def test_half_compressible_frame_crosses_the_budget_mid_stream(enc):
+    """Rows that compress first, noise afterwards: the stored outcome is only known several bands into the stream."""
+    import fpng_amd
+    w, h, c = 4096, 2048, 4
+    img = fpng_amd.synth_image("grad", w, h, c).copy()
+    img[h // 3:] = fpng_amd.synth_image("noise", w, h - h // 3, c)
+    exp = oracle().encode(img, w, h, c, 0)
+    fpng_amd.pin_host_memory(img)
+    try:
+        png, asked = enc.encode_host_growing(img, w, h, c, 0)
+    finally:
+        fpng_amd.unpin_host_memory(img)
+    assert len(asked) > 2 and png == exp
+
+
+def test_band_counts_and_the_natural_image(built_lib):
+    """FPNG_AMD_HOST_BANDS = 1, 2, 5, 16 in fresh processes (the knob is read once): every cut of the tiled photograph and
+    of an RGB frame whose rows do not divide evenly gives the reference's file."""
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, "tests")
+import numpy as np
+import fpng_amd, dropin, real_image
+imgs = real_image.variants(real_image.rgb_pixels(dropin.decode))
+g = real_image.gold()["variants"]
+enc = fpng_amd.Encoder(device=0, stream="own")
+for k in ("rgb_t4", "rgba_ga_t4", "rgb"):
+    h, w, c = imgs[k].shape
+    for fl in (0, 1, 2):
+        png, asked = enc.encode_host_growing(imgs[k], w, h, c, fl)
+        assert hashlib.sha256(png).hexdigest() == g[k]["flags"][str(fl)]["sha256"], (k, fl)
+print("ok")
+'''
+    for nb in (1, 2, 5, 16):
+        env = dict(os.environ, FPNG_AMD_HOST_BANDS=str(nb))
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ok" in out.stdout, (nb, out.stderr[-800:])
+
+
+def test_cpp_dropin_pageable_and_page_locked_frames(built_lib):
+    import fpng_amd
+    w, h, c = 7680, 4320, 4
+    img = fpng_amd.synth_image("grad", w, h, c)
+    exp = _kat("grad", w, h, c, 0)
+    for pinned in (False, True):
+        if pinned:
+            fpng_amd.pin_host_memory(img)
+        try:
+            for _ in range(2):
+                png = dropin.encode(img, w, h, c, 0)
+                assert len(png) == exp["size"] and hashlib.sha256(png).hexdigest() == exp["sha256"]
+        finally:
+            if pinned:
+                fpng_amd.unpin_host_memory(img)
+    exp1 = _kat("grad", w, h, c, 1)
+    assert hashlib.sha256(dropin.encode(img, w, h, c, 1)).hexdigest() == exp1["sha256"]
+
+
+def test_node_host_batch_two_pipelines_on_one_gpu(built_lib, tmp_path):
+    """fpng_amd_node_*: device 0 listed twice = two encoders with their own rings and threads; frames dealt round-robin,
+    to memory and to files."""
+    import fpng_amd
+    node = fpng_amd.Node([0, 0])
+    assert node.size() == 2
+    frames = [fpng_amd.synth_image("grad", 1920, 1080, 3, seed=12345 + i) for i in range(7)]
+    with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+        g = json.load(f)["c3"]["flags"]["0"]
+    outs = [np.empty(fpng_amd.max_encoded_size(1920, 1080, 3), dtype=np.uint8) for _ in frames]
+    paths = [str(tmp_path / f"n{i}.png") for i in range(len(frames))]
+    sizes = node.encode_host_batch(frames, 0, outs=outs, paths=paths, writer_threads=2)
+    for i, (o, n) in enumerate(zip(outs, sizes)):
+        assert n == g["sizes"][i] and hashlib.sha256(o[:n].tobytes()).hexdigest() == g["sha256"][i]
+        assert open(paths[i], "rb").read() == o[:n].tobytes()
+    node.close()

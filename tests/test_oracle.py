@@ -148,3 +148,20 @@ def test_oracle_band_concatenation_equals_whole():
             bits_total += bits
         wbits, wbuf, _, _, _ = oracle().band_1pass(img, w, h, c, 0, h)
         assert bits_total == wbits and ints == int.from_bytes(wbuf.tobytes(), "little")
+
+
+def test_oracle_on_the_natural_image():
+    """The restatement against the reference's bytes on a photograph (tests/golden/real.json, made by
+    oracle/make_golden_real.py from the reference's example.png): every variant, flags 0/1/2."""
+    import hashlib
+    import real_image
+    r = ref() if have_ref() else None
+    dec = r.decode if r else __import__("dropin").decode
+    imgs = real_image.variants(real_image.rgb_pixels(dec))
+    g = real_image.gold()["variants"]
+    for k, img in imgs.items():
+        h, w, c = img.shape
+        for fl in (0, 1, 2):
+            png = oracle().encode(img, w, h, c, fl)
+            assert len(png) == g[k]["flags"][str(fl)]["size"]
+            assert hashlib.sha256(png).hexdigest() == g[k]["flags"][str(fl)]["sha256"], (k, fl)

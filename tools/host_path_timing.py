@@ -1,25 +1,40 @@
 #!/usr/bin/env python
-"""PCIe-inclusive timing of the host-buffer entry point (what the fpng:: drop-in pays): H2D + kernels + D2H."""
+"""PCIe-inclusive timing of the host-buffer entry points (what a user of the reference's API pays): host pixels in, host PNG
+out.  Pageable pixels take the serial path (upload, encode, size, download); page-locked pixels (fpng_amd_pin_host_memory) are
+streamed through the GPU in row bands.  FPNG_AMD_HOST_BANDS=n forces n bands also for pageable pixels (read once per process)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, fpng_amd
-enc = fpng_amd.Encoder(device=0)
-for (w, h, c) in [(3840, 2160, 4), (7680, 4320, 4), (1920, 1080, 3)]:
-    img = fpng_amd.synth_image("grad", w, h, c)
-    mp = w * h / 1e6
+import dropin
+enc = fpng_amd.Encoder(device=0, stream="own")
+print("FPNG_AMD_HOST_BANDS =", os.environ.get("FPNG_AMD_HOST_BANDS", "(by size, page-locked pixels only)"))
 
-    def best_of(fn, n=5):
-        fn()
-        b = 1e9
-        for _ in range(n):
-            t0 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t0)
-        return b, r
 
-    # (a) the Python door as a one-shot call: fresh 'max size' output array + bytes copy on top of the transfers
-    ta, png = best_of(lambda: enc.encode_host(img, w, h, c, 0))
-    # (b) caller-owned, reused output buffer (what the C++ drop-in's std::vector amounts to when it is reused)
-    out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)
-    tb, n = best_of(lambda: enc.encode_host_into(img, w, h, c, out, 0))
-    assert bytes(out[:n]) == png
-    print(f"{w}x{h}x{c}: one-shot {ta*1e3:.2f} ms ({mp/ta/1e3:.1f} GP/s) | reused out buffer {tb*1e3:.2f} ms ({mp/tb/1e3:.1f} GP/s)   png {len(png)} B"
-          "   (page-locking both buffers with hipHostRegister measured the same as the reused pageable ones)")
+def best_of(fn, n=7):
+    fn()
+    b = 1e9
+    for _ in range(n):
+        t0 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t0)
+    return b, r
+
+
+for (w, h, c) in [(1920, 1080, 3), (3840, 2160, 4), (7680, 4320, 4)]:
+    for flags in (0, 1):
+        img = fpng_amd.synth_image("grad", w, h, c)
+        mp = w * h / 1e6
+        out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)
+        res = {}
+        res["C ABI pageable"], n = best_of(lambda: enc.encode_host_into(img, w, h, c, out, flags))
+        res["fpng:: pageable, reused vector"], nd = dropin.time_encode(img, w, h, c, flags, reps=8, reuse=True)
+        res["fpng:: pageable, fresh vector"], _ = dropin.time_encode(img, w, h, c, flags, reps=4, reuse=False)
+        fpng_amd.pin_host_memory(img)
+        res["C ABI pixels page-locked"], n2 = best_of(lambda: enc.encode_host_into(img, w, h, c, out, flags))
+        res["fpng:: pixels page-locked, reused vector"], _ = dropin.time_encode(img, w, h, c, flags, reps=8, reuse=True)
+        fpng_amd.pin_host_memory(out)
+        res["C ABI pixels and output page-locked"], n3 = best_of(lambda: enc.encode_host_into(img, w, h, c, out, flags))
+        fpng_amd.unpin_host_memory(out)
+        fpng_amd.unpin_host_memory(img)
+        assert n == nd == n2 == n3
+        print(f"{w}x{h}x{c} flags={flags} png {n} B: " + " | ".join(f"{k} {v*1e3:.2f} ms ({mp/v/1e3:.1f} GP/s)" for k, v in res.items()))

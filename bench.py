@@ -214,12 +214,17 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
     above = torch.from_numpy(img[y0 - 1]).to(dev) if y0 else None
     del img
     enc = fpng_amd.Encoder(device=local_rank)
-    be = sharded.GpuBandBackend(enc)
+    # the exchange runs behind the C ABI (fpng_amd_encode_image_sharded over the built-in RCCL transport); torch.distributed
+    # only carries RCCL's 128-byte id to the ranks and the barriers around the timed region
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(sharded.CppRowSharded.rccl_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, 0)
+    sh = sharded.CppRowSharded(enc, rank, world, bytes(uid.cpu().numpy()), local_rank)
+    out = torch.empty(fpng_amd.max_encoded_size(w, h, c) + 64, dtype=torch.uint8, device=dev) if rank == 0 else None
 
     def step():
-        png = sharded.encode_image_row_sharded(be, rows, above, w, h, c, y0, y1, args.flags)
-        torch.cuda.synchronize()
-        return png
+        return sh.encode(rows, above, w, h, c, y0, y1, args.flags, 0, out)  # (returns when the file is complete on rank 0)
 
     for _ in range(max(1, args.warmup)):
         png = step()
@@ -255,13 +260,15 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"ONE {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' image as {world} row band(s), one IDAT, "
                                    f"flags={args.flags}, windows gathered to rank 0, bit-exact fpng PNG output", "width": w, "height": h,
-                       "channels": c, "png_bytes": png_bytes, "parallelism": f"rows sharded over {world} GPU(s); exchange: "
-                       "all_gather of one 72-byte record per rank (+ all_reduce of 288 counters for 2-pass), windows sent to rank 0"},
+                       "channels": c, "png_bytes": png_bytes, "parallelism": f"rows sharded over {world} GPU(s) behind the C ABI "
+                       "(fpng_amd_encode_image_sharded, RCCL transport): all_gather of a 64-byte and a 16-byte record per rank "
+                       "(+ all_reduce of 288 counters for 2-pass), windows sent to rank 0"},
             "roofline": {"bound": "hbm", "kernel": "whole step (band encode + exchange + place + gather + wrap)",
                          "achieved": round(alg / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(alg / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg},
         }))
+    sh.close()
     enc.close()
     dist.barrier()
     dist.destroy_process_group()

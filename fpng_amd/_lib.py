@@ -47,6 +47,17 @@ class BandPlan(C.Structure):
 
 RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
+
+class Transport(C.Structure):
+    """fpng_amd_transport: the exchange functions fpng_amd_encode_image_sharded() calls (all on the encoder's stream)."""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int),
+                ("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)),
+                ("all_reduce_sum_u32", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)),
+                ("group_begin", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("send", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)),
+                ("recv", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)),
+                ("group_end", C.CFUNCTYPE(C.c_int, C.c_void_p))]
+
 # every symbol include/fpng_amd.h declares: (restype, argtypes)
 _u32, _u64, _sz, _vp, _int = C.c_uint32, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int
 SIGNATURES = {
@@ -88,6 +99,10 @@ SIGNATURES = {
     "fpng_amd_png_head": (_int, [_u32, _u32, _u32, _u64, _vp]),
     "fpng_amd_png_tail": (None, [_u32, _u32, _vp]),
     "fpng_amd_encode_host_to": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, RESERVE_FN, _vp, C.POINTER(_sz)]),
+    "fpng_amd_rccl_unique_id": (_int, [_vp]),
+    "fpng_amd_rccl_transport_create": (_int, [C.POINTER(C.POINTER(Transport)), _vp, _int, _int, _int]),
+    "fpng_amd_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
+    "fpng_amd_encode_image_sharded": (_int, [_vp, C.POINTER(Transport), C.POINTER(Band), _u32, _int, _vp, _sz, C.POINTER(_sz)]),
     "fpng_amd_pin_host_memory": (_int, [_vp, _sz]),
     "fpng_amd_unpin_host_memory": (_int, [_vp]),
     "fpng_amd_node_create": (_int, [C.POINTER(_vp), C.POINTER(_int), _u32]),

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfpng_amd.so")
 DROPIN_LIB = os.path.join(LIB_DIR, "libfpng.so")
-SOURCES = ["kernels.hip", "api.cpp", "pipeline.cpp", "format.cpp", "synth.cpp"]
+SOURCES = ["kernels.hip", "api.cpp", "pipeline.cpp", "sharded.cpp", "format.cpp", "synth.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "encoder.h"),
            os.path.join(ROOT, "include", "fpng_amd.h")]
 ARCH = "gfx950"
@@ -43,7 +43,7 @@ def build_variant(name, defines, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     out = os.path.join(LIB_DIR, f"libfpng_amd_{name}.so")
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall",
-           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + [f"-D{d}" for d in defines]
+           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out, "-ldl"] + [f"-D{d}" for d in defines]
     for s in SOURCES:
         cmd += ["-x", "hip", os.path.join(CSRC, s)]
     if verbose:
@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if force or _stale(LIB, srcs + HEADERS):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-               "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB]
+               "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB, "-ldl"]
         for s in srcs:
             cmd += ["-x", "hip", s]
         if verbose:

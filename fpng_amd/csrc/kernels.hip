@@ -2078,6 +2078,8 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
     }
 }
 
+__global__ void or_piece_kernel(uint32_t *dst, const uint32_t *src) { dst[threadIdx.x] |= src[threadIdx.x]; }
+
 // stored-block fallback as its own launch: the whole-image pipeline decides after encoding (scan_kernel)
 __global__ __launch_bounds__(kRowBlock) void stored_kernel(const Job *jobs, RowInfo *rows_io, const JobState *states)
 {
@@ -2146,6 +2148,10 @@ void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max
     const uint32_t row_blocks = (max_rows + kRowWaves - 1) / kRowWaves;
     const uint32_t per_job = std::max(1u, std::min(row_blocks, 2048u / std::max(1u, n_jobs)));
     hipLaunchKernelGGL(stored_kernel, dim3(per_job, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
+}
+void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src)
+{
+    hipLaunchKernelGGL(or_piece_kernel, dim3(1), dim3(4), 0, s, (uint32_t *)dst, (const uint32_t *)src);
 }
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
 {

@@ -314,6 +314,49 @@ def encode_image_row_sharded(backend, rows, row_above, w, h, c, y0, y1, flags=0,
     return None
 
 
+class CppRowSharded:
+    """The same exchange behind the C ABI (fpng_amd_encode_image_sharded, fpng_amd/csrc/sharded.cpp) over the built-in RCCL
+    transport -- what a C++ host uses; no torch.distributed on the data path.  The 128-byte RCCL id is made on rank 0
+    (`rccl_unique_id()`) and must reach every rank before construction (here: any torch.distributed broadcast)."""
+
+    def __init__(self, encoder, rank, world, unique_id, device):
+        import ctypes as C
+        from . import _lib
+        self.enc, self.rank, self.world = encoder, rank, world
+        self.lib = _lib.load()
+        self.t = C.POINTER(_lib.Transport)()
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(self.lib.fpng_amd_rccl_transport_create(C.byref(self.t), idb, rank, world, device))
+
+    @staticmethod
+    def rccl_unique_id():
+        import ctypes as C
+        from . import _lib
+        b = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().fpng_amd_rccl_unique_id(b))
+        return bytes(b)
+
+    def encode(self, rows, row_above, w, h, c, y0, y1, flags=0, root=0, out=None):
+        """rows: uint8 CUDA tensor (y1-y0, w, c) (may be empty), out: uint8 CUDA tensor of >= max_encoded_size + 64 bytes on the
+        root.  Returns the PNG as a view of `out` on the root, None elsewhere."""
+        import ctypes as C
+        from . import _lib
+        self.enc._sync_stream()
+        b = _lib.Band()
+        b.d_rows = rows.data_ptr() if y1 > y0 else None
+        b.d_row_above = row_above.data_ptr() if (row_above is not None and y0 > 0) else None
+        b.w, b.num_chans, b.y0, b.y1, b.h_total = w, c, y0, y1, h
+        n = C.c_size_t(0)
+        _lib.check(self.lib.fpng_amd_encode_image_sharded(self.enc.h, self.t, C.byref(b), flags, root,
+                                                          out.data_ptr() if out is not None else None, out.numel() if out is not None else 0, C.byref(n)))
+        return out[: n.value] if self.rank == root else None
+
+    def close(self):
+        if self.t:
+            self.lib.fpng_amd_rccl_transport_destroy(self.t)
+            self.t = None
+
+
 def _global_rank(group, r):
     return r if group is None else dist.get_global_rank(group, r)
 

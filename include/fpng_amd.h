@@ -280,6 +280,37 @@ uint32_t fpng_amd_idat_crc_from_bands(const uint32_t *raw_crc, const uint64_t *e
 int fpng_amd_png_head(uint32_t w, uint32_t h, uint32_t num_chans, uint64_t zlib_size, uint8_t head[58]);
 void fpng_amd_png_tail(uint32_t adler, uint32_t idat_crc, uint8_t tail[20]);
 
+/* ---- ONE image over several GPUs from C/C++ (SURVEY 8b "a multi-GPU form", 8e): the same steps as fpng_amd/sharded.py on
+ *      top of a TRANSPORT the caller provides (MPI, a custom fabric ...) or the built-in RCCL one.  One process (or thread)
+ *      per GPU, each with its own encoder and the rows [y0, y1) of the image; the finished .png appears in `d_png` on rank
+ *      `root`.  Exchanges: (2-pass: one all-reduce of 288 counters,) one all-gather of a 64-byte record, one of a 16-byte
+ *      record, and every non-root band's window (its share of the file) sent to the root -- no pixel leaves its GPU unless
+ *      the image turns out incompressible (the reference's stored-block outcome: the rows are then collected on the root).
+ *      All buffers are device pointers; every call is made on `stream` (the encoder's) ---- */
+typedef struct fpng_amd_transport {
+    void *ctx;
+    int rank, world;
+    int (*all_gather)(void *ctx, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+    int (*all_reduce_sum_u32)(void *ctx, void *d_buf, size_t count, void *stream); /* in place */
+    int (*group_begin)(void *ctx); /* the sends / receives up to group_end() may complete in any order */
+    int (*send)(void *ctx, const void *d_buf, size_t bytes, int peer, void *stream);
+    int (*recv)(void *ctx, void *d_buf, size_t bytes, int peer, void *stream);
+    int (*group_end)(void *ctx);
+} fpng_amd_transport;
+
+/* The built-in transport: RCCL (librccl.so.1 is loaded at run time, so libfpng_amd.so itself does not depend on it).  Rank 0
+ * makes the 128-byte id, the caller gets it to the other ranks (a file, a socket, MPI_Bcast, torch.distributed ...), then
+ * every rank creates its transport; `device` = the HIP device of this rank's encoder. */
+int fpng_amd_rccl_unique_id(uint8_t id[128]);
+int fpng_amd_rccl_transport_create(fpng_amd_transport **t, const uint8_t id[128], int rank, int world, int device);
+void fpng_amd_rccl_transport_destroy(fpng_amd_transport *t);
+
+/* band: this rank's rows (y1 == y0 allowed: a rank without rows still takes part in the collectives); flags: 0 or
+ * FPNG_AMD_ENCODE_SLOWER; d_png / png_cap (>= fpng_amd_max_encoded_size() + 64) / png_size matter on the root only.  Returns
+ * when the file is complete on the root (the other ranks return when their sends are enqueued and the stream is drained). */
+int fpng_amd_encode_image_sharded(fpng_amd_encoder *enc, const fpng_amd_transport *t, const fpng_amd_band *band, uint32_t flags,
+                                  int root, uint8_t *d_png, size_t png_cap, size_t *png_size);
+
 /* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);

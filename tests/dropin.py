@@ -82,3 +82,47 @@ def time_encode(img, w, h, c, flags=0, reps=5, reuse=True):
     if t < 0:
         raise RuntimeError("fpng::fpng_encode_image_to_memory failed")
     return t, n.value
+
+
+_sharded = None
+
+
+def sharded_local():
+    """tests/cpp/sharded_local.cpp: fpng_amd_encode_image_sharded() driven by N threads of this process over an in-process
+    transport (the multi-rank logic on a one-GPU box)."""
+    global _sharded
+    if _sharded is not None:
+        return _sharded
+    from fpng_amd import build
+    build.build()
+    lib_dir = os.path.join(ROOT, "fpng_amd", "lib")
+    src = os.path.join(ROOT, "tests", "cpp", "sharded_local.cpp")
+    so = os.path.join(lib_dir, "libfpng_test_sharded.so")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    deps = [src, os.path.join(lib_dir, "libfpng_amd.so"), os.path.join(ROOT, "include", "fpng_amd.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(rocm, "include"), src, "-o", so, "-L", lib_dir, "-lfpng_amd", "-L", os.path.join(rocm, "lib"),
+                               "-lamdhip64", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+    L = C.CDLL(so)
+    L.shim_sharded_local.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    _sharded = L
+    return L
+
+
+def encode_sharded_local(img, cuts, flags=0, root=0):
+    """img: uint8 (h, w, c); cuts: row boundaries [0, ..., h] (one band per rank) -> PNG bytes from rank `root`."""
+    L = sharded_local()
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = a.shape
+    world = len(cuts) - 1
+    n_f = (w * c + 1) * h
+    cap = 58 + 6 + n_f + 5 * ((n_f + 65534) // 65535) + 16 + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = L.shim_sharded_local(world, (C.c_uint32 * (world + 1))(*cuts), a.ctypes.data, w, h, c, flags, root, out.ctypes.data, cap, C.byref(n), err, 512)
+    if rc:
+        raise RuntimeError(f"sharded_local rc={rc}: {err.value.decode(errors='replace')}")
+    return out[: n.value].tobytes()

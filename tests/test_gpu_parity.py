@@ -529,6 +529,38 @@ def test_command_line_harness(tmp_path):
     assert "decode verified" in run("-u", "-o", out, out)      # a file written by fpng as input, no judge: round trip only
 
 
+def test_command_line_harness_on_ordinary_png_files(tmp_path):
+    """The reference's corpus workflow (fpng_test.cpp:1116-1190): ANY PNG in, alpha from -a or from a second file, 24 or 32 bpp
+    by content, every output identical to the CPU encoder's; and the six kinds of fuzz damage on a photograph, incl. the byte
+    runs that are not pixel-aligned."""
+    import subprocess
+    import sys
+    exe = os.path.join(ROOT, "fpng_amd", "lib", "fpng_amd_test")
+    judge = os.path.join(ROOT, "oracle", "_ref", "libfpng_ref.so") if have_ref() else os.path.join(ROOT, "oracle", "libfpng_oracle.so")
+    corpus = str(tmp_path / "corpus")
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_corpus.py"), corpus], env=dict(env, FPNG_CORPUS_DROPIN="1"))
+    csv = str(tmp_path / "corpus.csv")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_corpus.sh"), corpus, csv], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in open(csv).read().splitlines() if ln and not ln.startswith("#")]
+    assert r.returncode == 0 and "corpus rc=0" in r.stdout, (r.stdout[-600:], r.stderr[-600:], lines[-3:])
+    assert len(lines) == 2 * 9 + 2 and not any("FAILED" in ln for ln in lines)
+    chans = {ln.split(",")[0].split("/")[-1]: int(ln.split(",")[3]) for ln in lines}
+    assert chans["photo_rgba.png"] == 4 and chans["photo_grey.png"] == 3 and chans["photo_palette64.png"] == 3
+    assert int(lines[-1].split(",")[3]) == 4 and int(lines[-2].split(",")[3]) == 4   # alpha file / -a: 32 bpp
+
+    def run(*args):
+        q = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900, env=env)
+        assert q.returncode == 0, (args, q.stdout[-800:], q.stderr[-800:])
+        return q.stdout
+    photo = os.path.join(corpus, "photo_half.png")
+    txt = run("--judge", judge, "-e", "-n", "150", photo)
+    assert "trials ok (byte-identical" in txt
+    for kind in ("color fill runs", "fill runs", "corrupt runs", "bits flipped"):
+        assert kind in txt, kind
+    assert "trials ok (byte-identical" in run("--judge", judge, "-e", "-s", "-a", "-n", "60", photo)
+
+
 def test_pipelined_submissions_without_intermediate_finish(enc):
     """fpng_amd_encode_batch_async() may be called repeatedly before fpng_amd_encode_finish(): submissions
     go through a ring of pinned slots and alternate between the encoder's two lanes."""

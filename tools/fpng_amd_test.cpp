@@ -1,8 +1,11 @@
 // fpng_amd_test -- the fpng_test workflow (reference src/fpng_test.cpp:975-1639) pointed at the MI355X path.
 //
-//   fpng_amd_test [options] <input>
+//   fpng_amd_test [options] <input> [alpha source .png]
 //     <input>   synth:<noise|solid|grad|blocks>:<W>x<H>x<C>[:seed]   (SURVEY.md B.1 generators)
-//               or a .png written by fpng (decoded with fpng::fpng_decode_file; no other PNG loader here)
+//               or ANY non-interlaced .png (tools/png_loader.h: the role lodepng plays in the reference's harness,
+//               fpng_test.cpp:1116-1122).  As there: the image is encoded with 4 channels if any alpha value is below 255,
+//               else with 3; a second file name supplies the alpha channel from its GREEN channel (fpng_test.cpp:1124-1145)
+//     -a        alpha = green (fpng_test.cpp:1147-1152)
 //     -s        2-pass compression (FPNG_ENCODE_SLOWER)            reference fpng_test.cpp:1027
 //     -u        stored Deflate blocks (FPNG_FORCE_UNCOMPRESSED)    reference fpng_test.cpp:1031
 //     -c        one line of comma separated values                 reference fpng_test.cpp:1608-1633
@@ -21,6 +24,7 @@
 // second like the reference prints (fpng_test.cpp:1212) with the 10^6 figure next to it.
 #include "fpng.h"
 #include "fpng_amd.h"
+#include "png_loader.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -38,9 +42,9 @@ namespace {
 typedef int (*judge_fn)(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *, size_t, size_t *);
 
 struct Options {
-    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false;
+    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false, green_to_alpha = false;
     uint32_t trials = 1000, max_dim = 8193, batch = 0, cpu_threads = 0;
-    const char *input = nullptr, *out = "fpng.png", *judge_path = nullptr;
+    const char *input = nullptr, *alpha_input = nullptr, *out = "fpng.png", *judge_path = nullptr;
 };
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -57,8 +61,9 @@ struct Rng { // xorshift32, as the synthetic generators
     double unit() { return next() / 4294967296.0; }
 };
 
-bool load_input(const char *spec, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, uint32_t &c)
+bool load_input(const Options &o, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, uint32_t &c)
 {
+    const char *spec = o.input;
     if (!strncmp(spec, "synth:", 6)) {
         char kind[16] = {0};
         unsigned seed = 12345;
@@ -68,14 +73,34 @@ bool load_input(const char *spec, std::vector<uint8_t> &px, uint32_t &w, uint32_
         px.resize((size_t)w * h * c);
         return fpng_amd_synth_image(k, seed, w, h, c, px.data()) == 0;
     }
-    uint32_t cf = 0;
-    if (fpng::fpng_decode_file(spec, px, w, h, cf, 4) != fpng::FPNG_DECODE_SUCCESS) return false;
-    if (cf == 3) { // keep the file's channel count, like the reference's 24 bpp path
-        std::vector<uint8_t> p3((size_t)w * h * 3);
-        for (size_t i = 0; i < (size_t)w * h; i++) memcpy(&p3[i * 3], &px[i * 4], 3);
-        px.swap(p3);
+    // any PNG -> RGBA8 (reference fpng_test.cpp:1116-1122)
+    std::vector<uint8_t> file, rgba;
+    std::string err;
+    if (!png_loader::read_file(spec, file) || !png_loader::load_rgba(file.data(), file.size(), rgba, w, h, err)) {
+        fprintf(stderr, "Failed unpacking source file \"%s\"%s%s\n", spec, err.empty() ? "" : ": ", err.c_str());
+        return false;
     }
-    c = cf;
+    if (o.alpha_input) { // alpha from the green channel of a second image (fpng_test.cpp:1124-1145)
+        std::vector<uint8_t> afile, a;
+        uint32_t aw = 0, ah = 0;
+        if (!png_loader::read_file(o.alpha_input, afile) || !png_loader::load_rgba(afile.data(), afile.size(), a, aw, ah, err)) {
+            fprintf(stderr, "Failed unpacking alpha source file \"%s\"\n", o.alpha_input);
+            return false;
+        }
+        for (uint32_t y = 0; y < std::min(ah, h); y++)
+            for (uint32_t x = 0; x < std::min(aw, w); x++) rgba[((size_t)y * w + x) * 4 + 3] = a[((size_t)y * aw + x) * 4 + 1];
+    } else if (o.green_to_alpha) { // fpng_test.cpp:1147-1152
+        for (size_t i = 0; i < (size_t)w * h; i++) rgba[i * 4 + 3] = rgba[i * 4 + 1];
+    }
+    bool has_alpha = false; // fpng_test.cpp:1154-1166: 32 bpp only if some pixel is not opaque
+    for (size_t i = 0; i < (size_t)w * h && !has_alpha; i++) has_alpha = rgba[i * 4 + 3] < 255;
+    c = has_alpha ? 4 : 3;
+    if (has_alpha)
+        px.swap(rgba);
+    else {
+        px.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++) memcpy(&px[i * 3], &rgba[i * 4], 3);
+    }
     return true;
 }
 
@@ -108,43 +133,69 @@ bool encode_checked(const uint8_t *px, uint32_t w, uint32_t h, uint32_t c, uint3
 int fuzz_encoder(const std::vector<uint8_t> &src, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, const Options &o, judge_fn judge)
 {
     std::vector<uint8_t> tmp, png;
+    std::vector<std::pair<std::string, uint32_t>> kinds;
     for (uint32_t trial = 0; trial < o.trials; trial++) {
         Rng r(trial + 1);
         tmp = src;
-        const double u = r.unit();
+        // the reference's six kinds of damage with its probabilities (fpng_test.cpp:403-515); runs that are NOT pixel-aligned
+        // (byte fill / byte xor) are what stresses the 3- and 4-byte pixel compare of the run finder
+        const double rand_fract = 0.000001 + r.unit() * 0.099999;
         const char *kind;
-        if (u < 0.05) { // colour fill runs over the whole image
-            kind = "colour fill runs";
+        if (r.unit() < 0.05) { // colour fill runs over the whole image, 1..32 pixels each
+            kind = "color fill runs";
             for (size_t ofs = 0; ofs < tmp.size();) {
-                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, (left < 32 ? left : 32) + 1);
+                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, std::min(left, 32u) + 1);
                 uint8_t lit[4] = {(uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next()};
                 for (uint32_t i = 0; i < run; i++, ofs += c) memcpy(&tmp[ofs], lit, c);
             }
-        } else if (u < 0.10) { // runs that are xor-ed, filled or skipped
-            kind = "mixed runs";
+        } else if (r.unit() < 0.05) { // colour runs, one in five xor-ed with a colour, the others left alone
+            kind = "color corrupt runs";
             for (size_t ofs = 0; ofs < tmp.size();) {
-                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, (left < 32 ? left : 32) + 1);
+                const uint32_t left = (uint32_t)((tmp.size() - ofs) / c), run = r.range(1, std::min(left, 32u) + 1);
                 uint8_t lit[4] = {(uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next(), (uint8_t)r.next()};
-                const double v = r.unit();
+                const bool hit = r.unit() > 0.8;
                 for (uint32_t i = 0; i < run; i++, ofs += c)
-                    for (uint32_t j = 0; j < c; j++) {
-                        if (v > 0.8)
-                            tmp[ofs + j] ^= lit[j];
-                        else if (v > 0.4)
-                            tmp[ofs + j] = lit[j];
-                    }
+                    for (uint32_t j = 0; j < c && hit; j++) tmp[ofs + j] ^= lit[j];
             }
-        } else { // sparse random byte damage
-            kind = "random bytes";
-            const double fract = 0.000001 + r.unit() * 0.1;
+        } else if (r.unit() < 0.05) { // BYTE fill runs of 1..258 bytes
+            kind = "fill runs";
+            for (size_t ofs = 0; ofs < tmp.size();) {
+                const uint32_t left = (uint32_t)std::min<size_t>(tmp.size() - ofs, 258), run = r.range(1, left + 1);
+                memset(&tmp[ofs], (int)(r.next() & 0xFF), run);
+                ofs += run;
+            }
+        } else if (r.unit() < 0.15) { // BYTE runs of 1..32 bytes, nine in ten xor-ed with a value
+            kind = "corrupt runs";
+            for (size_t ofs = 0; ofs < tmp.size();) {
+                const uint32_t left = (uint32_t)std::min<size_t>(tmp.size() - ofs, 32), run = r.range(1, left + 1);
+                if (r.unit() > 0.1) {
+                    const uint8_t v = (uint8_t)r.next();
+                    for (uint32_t i = 0; i < run; i++) tmp[ofs + i] ^= v;
+                }
+                ofs += run;
+            }
+        } else if (r.unit() < 0.005) {
+            kind = "full random";
+            for (auto &b : tmp) b = (uint8_t)r.next();
+        } else { // every bit flipped with probability rand_fract
+            kind = "bits flipped";
+            const uint32_t thresh = (uint32_t)(4294967295.0 * rand_fract);
             for (auto &b : tmp)
-                if (r.unit() < fract) b = (uint8_t)r.next();
+                for (int j = 0; j < 8; j++)
+                    if (r.next() <= thresh) b ^= (uint8_t)(1 << j);
         }
         char what[96];
         snprintf(what, sizeof what, "fuzz trial %u (%s)", trial, kind);
         if (!encode_checked(tmp.data(), w, h, c, flags, judge, png, what)) return EXIT_FAILURE;
         if (trial % 50 == 0) printf("%u: %s, %zu bytes ok\n", trial, kind, png.size());
+        bool seen = false;
+        for (auto &k : kinds)
+            if (k.first == kind) k.second++, seen = true;
+        if (!seen) kinds.push_back({kind, 1u});
     }
+    printf("kinds of damage:");
+    for (auto &k : kinds) printf(" %s x %u;", k.first.c_str(), k.second);
+    printf("\n");
     printf("fuzz_test_encoder: %u trials ok%s\n", o.trials, judge ? " (byte-identical to the CPU encoder)" : "");
     return EXIT_SUCCESS;
 }
@@ -226,6 +277,7 @@ int main(int argc, char **argv)
             case 's': o.slower = true; break;
             case 'u': o.uncompressed = true; break;
             case 'c': o.csv = true; break;
+            case 'a': o.green_to_alpha = true; break;
             case 'e': o.fuzz = true; break;
             case 'E': o.fuzz2 = true; break;
             case 'n': o.trials = (uint32_t)atoi(argv[++i]); break;
@@ -235,12 +287,14 @@ int main(int argc, char **argv)
             case 'o': o.out = argv[++i]; break;
             default: fprintf(stderr, "Unrecognized option: %s\n", a); return EXIT_FAILURE;
             }
-        } else
+        } else if (!o.input)
             o.input = a;
+        else
+            o.alpha_input = a;
     }
     if (!o.input && !o.fuzz2) {
-        printf("Usage: fpng_amd_test [-s] [-u] [-c] [-e] [-E] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
-               "[--judge cpu_encoder.so] <synth:kind:WxHxC[:seed] | file written by fpng>\n");
+        printf("Usage: fpng_amd_test [-s] [-u] [-a] [-c] [-e] [-E] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
+               "[--judge cpu_encoder.so] <synth:kind:WxHxC[:seed] | file.png> [alpha_file.png]\n");
         return EXIT_FAILURE;
     }
     fpng::fpng_init();
@@ -266,7 +320,7 @@ int main(int argc, char **argv)
 
     std::vector<uint8_t> px;
     uint32_t w = 0, h = 0, c = 0;
-    if (!load_input(o.input, px, w, h, c)) {
+    if (!load_input(o, px, w, h, c)) {
         fprintf(stderr, "Failed loading %s\n", o.input);
         return EXIT_FAILURE;
     }

@@ -290,6 +290,25 @@ class Encoder:
             pngs.append(bytes(out[:size].cpu().numpy()))
         return pngs, [m for _, m, _ in res]
 
+    def train_tables(self, images):
+        """fpng_amd_train_tables: a new 1-pass table from a corpus of uint8 CUDA tensors (h, w, c), all with the same c, in the
+        form the reference's training mode prints it (block prefix bytes as hex, pending bits, codes, code sizes)."""
+        n = len(images)
+        c = images[0].shape[2]
+        arr = (Image * n)()
+        for i, im in enumerate(images):
+            assert im.is_cuda and im.dtype == torch.uint8 and im.is_contiguous() and im.dim() == 3
+            arr[i].d_pixels = im.data_ptr()
+            arr[i].w, arr[i].h, arr[i].num_chans = im.shape[1], im.shape[0], im.shape[2]
+        prefix = (C.c_uint8 * 512)()
+        nb, bb, bbs = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0)
+        codes = (C.c_uint32 * 288)()
+        sizes = (C.c_uint8 * 288)()
+        self._sync_stream()
+        check(self.lib.fpng_amd_train_tables(self.h, arr, n, c, prefix, 512, C.byref(nb), C.byref(bb), C.byref(bbs), codes, sizes))
+        return {"prefix": bytes(prefix[: nb.value]).hex(), "bit_buf": bb.value, "bit_buf_size": bbs.value, "codes": list(codes),
+                "code_sizes": list(sizes)}
+
     # ---- host buffers: what fpng_encode_image_to_memory() does ----
     def encode_host(self, image, w, h, num_chans, flags=0):
         b = _as_u8(image)

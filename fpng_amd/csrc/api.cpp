@@ -1031,6 +1031,80 @@ int fpng_amd_wrap_png_crc(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size,
     return wrap_png(e, d_png, zlib_size, adler, w, h, c, d_crc_partials, n_partials, png_size);
 }
 
+int fpng_amd_train_tables(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32_t c, uint8_t *prefix, size_t prefix_cap,
+                          size_t *prefix_bytes, uint32_t *bit_buf, uint32_t *bit_buf_size, uint32_t codes[288], uint8_t code_sizes[288])
+{
+    if (!e || !images || !n || !prefix || !prefix_bytes || !bit_buf || !bit_buf_size || !codes || !code_sizes)
+        return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (c != 3 && c != 4) return fail(FPNG_AMD_ERR_INVALID_ARG, "num_chans must be 3 or 4");
+    if (n > 65535) return fail(FPNG_AMD_ERR_INVALID_ARG, "corpus larger than 65535 images (the sums are 32-bit in the reference)");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = drain(e);
+    if (rc) return rc;
+    fpng_amd_encoder::Scratch &sc = e->sc[0];
+    const DeviceTables &dt = g_dev[e->device];
+    // jobs: the images under the symbol table of the histogram pass (no output buffers)
+    PinnedBuf<Job> &hj = e->slots[0].jobs;
+    if ((rc = hj.ensure(n + 1)) || (rc = sc.d_jobs.ensure(n + 1)) || (rc = sc.d_hist.ensure(((size_t)n + 3) * 288)) || (rc = sc.d_dyn.ensure(1)) ||
+        (rc = e->h_states.ensure(16)))
+        return rc;
+    uint32_t max_rows = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const fpng_amd_image &im = images[i];
+        if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
+        if (im.num_chans != c) return fail(FPNG_AMD_ERR_INVALID_ARG, "every image of the corpus must have num_chans channels");
+        if (!im.d_pixels || (c == 4 && ((uintptr_t)im.d_pixels & 3))) return fail(FPNG_AMD_ERR_INVALID_ARG, "null / misaligned pixel pointer");
+        Job &j = hj.p[i];
+        std::memset(&j, 0, sizeof j);
+        j.rows = (const uint8_t *)im.d_pixels;
+        j.w = im.w, j.c = c, j.bpl = im.w * c, j.nrows = j.h_total = im.h;
+        j.flags = FPNG_AMD_ENCODE_SLOWER;
+        j.whole_png = j.is_first = j.is_last = 1;
+        j.table = dt.symbols[c];
+        max_rows = std::max(max_rows, im.h);
+    }
+    Job &jt = hj.p[n]; // the builder's job: corpus sums in, table out
+    std::memset(&jt, 0, sizeof jt);
+    jt.c = c, jt.flags = FPNG_AMD_ENCODE_SLOWER | 0x400u, jt.table = dt.symbols[c];
+    hipStream_t s = e->stream;
+    uint32_t *d_hist = sc.d_hist.p;                       // n x 288 counters
+    uint64_t *d_sums = (uint64_t *)(d_hist + (size_t)n * 288); // 288 x u64 (n * 288 * 4 is a multiple of 8)
+    uint32_t *d_freq = d_hist + (size_t)n * 288 + 576;    // the corpus histogram the builder reads
+    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, hj.p, (n + 1) * sizeof(Job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, ((size_t)n + 3) * 288 * sizeof(uint32_t), s));
+    launch_hist(s, sc.d_jobs.p, n, max_rows, d_hist);
+    launch_train_accumulate(s, d_hist, n, d_sums);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> sums(288);
+    HIP_TRY(hipMemcpyAsync(sums.data(), d_sums, 288 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // every literal, the end-of-block symbol and every length a multiple-of-c match can have must be codable
+    // (reference fpng.cpp:941-952)
+    std::vector<uint32_t> freq(288);
+    for (int i = 0; i < 288; i++) freq[i] = (uint32_t)sums[i];
+    for (int i = 0; i <= 256; i++)
+        if (!freq[i]) freq[i] = 1;
+    for (uint32_t len = c; len <= 258; len += c) {
+        uint32_t sym, extra;
+        deflate_length_symbol(len - 3, &sym, &extra);
+        if (!freq[sym]) freq[sym] = 1;
+    }
+    HIP_TRY(hipMemcpyAsync(d_freq, freq.data(), 288 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    launch_build_dynamic(s, sc.d_jobs.p + n, 1, d_freq, sc.d_dyn.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<TokenTable> tab(1);
+    HIP_TRY(hipMemcpyAsync(tab.data(), sc.d_dyn.p, sizeof(TokenTable), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t bits = tab[0].header_bits, nbytes = bits / 8;
+    *prefix_bytes = nbytes;
+    if (prefix_cap < nbytes) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "prefix buffer too small");
+    std::memcpy(prefix, tab[0].header, nbytes);
+    *bit_buf_size = bits % 8;
+    *bit_buf = tab[0].header[nbytes] & ((1u << (bits % 8)) - 1u);
+    for (int i = 0; i < 288; i++) codes[i] = lit_code(tab[0].lit[i]), code_sizes[i] = (uint8_t)lit_len(tab[0].lit[i]);
+    return FPNG_AMD_OK;
+}
+
 int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n_words)
 {
     if (!e || lane < 0 || lane >= fpng_amd_encoder::kLanes || !dst) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");

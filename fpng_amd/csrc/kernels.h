@@ -84,6 +84,8 @@ void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_cr
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
                      JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
 void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states);
+// table training: sums[0..288) += the 16-bit adjusted histogram of every image (hist_all: 288 counters per image)
+void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n_images, uint64_t *sums);
 // dst[0..16) |= src[0..16): the 16-byte piece two neighbouring band windows share (each holds zeros where the other's bits are)
 void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src);
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);

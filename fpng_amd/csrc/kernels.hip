@@ -1894,11 +1894,14 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, u
 
     // ---- adjust_freq32 (reference fpng.cpp:868-907): scale to 16 bits, never to zero.  Its
     //      ">65535" repair loop only rewrites the 32-bit input, which nothing reads afterwards. ----
+    // (table training, job flag 0x400: the corpus sums come with their own end-of-block count, reference fpng.cpp:932-954;
+    // an image's histogram has it set to 1, :1092 / :1371)
+    const bool corpus = (job.flags & 0x400u) != 0;
     uint32_t part = 0;
-    for (uint32_t i = lane; i < 288; i += kWave) part += (i == 256) ? 1u : hist[i];
+    for (uint32_t i = lane; i < 288; i += kWave) part += (i == 256 && !corpus) ? 1u : hist[i];
     const uint32_t total = wave_sum(part); // uint32 wrap-around like the reference's total_freq
     for (uint32_t i = lane; i < 288; i += kWave) {
-        const uint32_t f = (i == 256) ? 1u : hist[i];
+        const uint32_t f = (i == 256 && !corpus) ? 1u : hist[i];
         uint32_t v = 0;
         if (f && total) {
             v = (uint32_t)(((uint64_t)f * 65535ull) / total);
@@ -2078,6 +2081,23 @@ template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kern
     }
 }
 
+// Table training, per image of the corpus (one wave each): its histogram adjusted to 16 bits as it enters the reference's block
+// writer (fpng.cpp:868-907 with lit_freq[256] = 1; summed at :751-755, BEFORE the end-of-block count is forced to 1).
+__global__ __launch_bounds__(kWave) void train_accumulate_kernel(const uint32_t *hist_all, unsigned long long *sums)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *hist = hist_all + (size_t)blockIdx.x * 288;
+    uint32_t part = 0;
+    for (uint32_t i = lane; i < 288; i += kWave) part += (i == 256) ? 1u : hist[i];
+    const uint32_t total = wave_sum(part);
+    for (uint32_t i = lane; i < 288; i += kWave) {
+        const uint32_t f = (i == 256) ? 1u : hist[i];
+        if (!f || !total) continue;
+        const uint32_t v = (uint32_t)(((uint64_t)f * 65535ull) / total);
+        atomicAdd(&sums[i], (unsigned long long)(v ? v : 1u));
+    }
+}
+
 __global__ void or_piece_kernel(uint32_t *dst, const uint32_t *src) { dst[threadIdx.x] |= src[threadIdx.x]; }
 
 // stored-block fallback as its own launch: the whole-image pipeline decides after encoding (scan_kernel)
@@ -2148,6 +2168,10 @@ void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max
     const uint32_t row_blocks = (max_rows + kRowWaves - 1) / kRowWaves;
     const uint32_t per_job = std::max(1u, std::min(row_blocks, 2048u / std::max(1u, n_jobs)));
     hipLaunchKernelGGL(stored_kernel, dim3(per_job, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
+}
+void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n_images, uint64_t *sums)
+{
+    hipLaunchKernelGGL(train_accumulate_kernel, dim3(n_images), dim3(kWave), 0, s, hist_all, (unsigned long long *)sums);
 }
 void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src)
 {

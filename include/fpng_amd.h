@@ -315,6 +315,17 @@ int fpng_amd_encode_image_sharded(fpng_amd_encoder *enc, const fpng_amd_transpor
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
 
+/* ---- table training (reference src/fpng_test.cpp:766-973 "-t" + src/fpng.cpp:909-988, both only in builds of the reference with
+ *      FPNG_TRAIN_HUFFMAN_TABLES=1): from a corpus of `n` device-resident images, all with num_chans channels (the reference's
+ *      harness trains the 24 bpp and the 32 bpp table on the opaque and the translucent files separately), to a new 1-pass
+ *      table in the form the reference prints it: the Deflate block prefix (whole bytes + `bit_buf_size` pending bits) and the
+ *      288 code / code size pairs of g_dyn_huff_{3|4}_codes.  Histograms, their 16-bit adjustment and the table builder run
+ *      on the device.  d_out / out_cap of the images are not used.  Note: a table trained here is a DIFFERENT FORMAT TABLE --
+ *      files written with it are valid PNGs but not byte-identical to the stock fpng encoder's. ---- */
+int fpng_amd_train_tables(fpng_amd_encoder *enc, const fpng_amd_image *images, uint32_t n, uint32_t num_chans, uint8_t *prefix,
+                          size_t prefix_cap, size_t *prefix_bytes, uint32_t *bit_buf, uint32_t *bit_buf_size, uint32_t codes[288],
+                          uint8_t code_sizes[288]);
+
 /* ---- synthetic inputs for tests/bench, host memory ---- */
 #define FPNG_AMD_SYNTH_NOISE 0
 #define FPNG_AMD_SYNTH_SOLID 1

@@ -491,20 +491,14 @@ static void build_table(const uint16_t *count, unsigned n, unsigned max_len, uin
     canonical_codes(len, n, max_len, code);
 }
 
-uint32_t fpo_build_dynamic_table(const uint32_t lit_freq_in[288], uint32_t num_chans, uint8_t len_out[288],
-                                 uint16_t code_out[288], uint8_t *hdr)
+/* adjust_freq32 (src/fpng.cpp:868-907): scale to 16 bits, never to zero.  The reference's
+ * "total > 65535" repair loop only rewrites the 32-bit input array, which nobody reads
+ * afterwards, so it has no observable effect and is not restated. */
+static void adjust_freq(const uint32_t freq[288], uint16_t c0[288])
 {
-    ensure_init();
-    /* adjust_freq32 (src/fpng.cpp:868-907): scale to 16 bits, never to zero.  The reference's
-     * "total > 65535" repair loop only rewrites the 32-bit input array, which nobody reads
-     * afterwards, so it has no observable effect and is not restated. */
-    uint32_t freq[288];
-    memcpy(freq, lit_freq_in, sizeof freq);
-    freq[256] = 1; /* src/fpng.cpp:1092 / :1371 */
     uint64_t total = 0;
     for (unsigned i = 0; i < 288; i++) total += freq[i];
     total &= 0xFFFFFFFFu; /* total_freq is uint32_t there */
-    uint16_t c0[288], c1[32], c2[19];
     for (unsigned i = 0; i < 288; i++) {
         if (!freq[i] || !total) {
             c0[i] = 0;
@@ -513,6 +507,56 @@ uint32_t fpo_build_dynamic_table(const uint32_t lit_freq_in[288], uint32_t num_c
         uint32_t s = (uint32_t)(((uint64_t)freq[i] * 65535u) / total);
         c0[i] = (uint16_t)(s ? s : 1);
     }
+}
+
+static uint32_t build_dynamic_from_counts(uint16_t c0[288], uint32_t num_chans, uint8_t len_out[288], uint16_t code_out[288], uint8_t *hdr);
+
+uint32_t fpo_build_dynamic_table(const uint32_t lit_freq_in[288], uint32_t num_chans, uint8_t len_out[288],
+                                 uint16_t code_out[288], uint8_t *hdr)
+{
+    ensure_init();
+    uint32_t freq[288];
+    memcpy(freq, lit_freq_in, sizeof freq);
+    freq[256] = 1; /* src/fpng.cpp:1092 / :1371 */
+    uint16_t c0[288];
+    adjust_freq(freq, c0);
+    return build_dynamic_from_counts(c0, num_chans, len_out, code_out, hdr);
+}
+
+/* Table training (src/fpng_test.cpp:766-973 training_mode + src/fpng.cpp:909-988 create_dynamic_block_prefix, both under
+ * FPNG_TRAIN_HUFFMAN_TABLES): every image of the corpus (all with num_chans channels) is encoded 2-pass; what is summed is
+ * its 16-bit ADJUSTED histogram as it enters defl_start_dynamic_block (src/fpng.cpp:751-755: before the end-of-block count is
+ * forced to 1).  The sums (truncated to 32 bits, :932) get every literal, the end-of-block symbol and every length symbol a
+ * multiple-of-num_chans match can use set to at least 1 (:941-952), are adjusted to 16 bits again (:954) and go through the
+ * same builder and header writer as a 2-pass image.  Returns the header length in bits like fpo_build_dynamic_table. */
+uint32_t fpo_train_tables(const void *const *images, const uint32_t *w, const uint32_t *h, uint32_t n, uint32_t num_chans,
+                          uint8_t len_out[288], uint16_t code_out[288], uint8_t *hdr)
+{
+    ensure_init();
+    uint64_t sum[288];
+    memset(sum, 0, sizeof sum);
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t freq[288];
+        uint16_t c0[288];
+        fpo_band_hist(images[k], w[k], h[k], num_chans, 0, h[k], freq);
+        freq[256] = 1; /* src/fpng.cpp:1092 / :1371 */
+        adjust_freq(freq, c0);
+        for (unsigned i = 0; i < 288; i++) sum[i] += c0[i];
+    }
+    uint32_t lit_freq[288];
+    for (unsigned i = 0; i < 288; i++) lit_freq[i] = (uint32_t)sum[i];
+    for (unsigned i = 0; i <= 256; i++)
+        if (!lit_freq[i]) lit_freq[i] = 1;
+    for (uint32_t len = num_chans; len <= 258; len += num_chans)
+        if (!lit_freq[g_len_sym[len - 3]]) lit_freq[g_len_sym[len - 3]] = 1;
+    uint16_t c0[288];
+    adjust_freq(lit_freq, c0);
+    return build_dynamic_from_counts(c0, num_chans, len_out, code_out, hdr);
+}
+
+static uint32_t build_dynamic_from_counts(uint16_t c0[288], uint32_t num_chans, uint8_t len_out[288], uint16_t code_out[288], uint8_t *hdr)
+{
+    uint16_t c1[32], c2[19];
     c0[256] = 1; /* src/fpng.cpp:757 */
     memset(c1, 0, sizeof c1);
     c1[num_chans - 1] = 1; /* distance symbol of distance 3 / 4 (src/fpng.cpp:1019, :1097-1098) */

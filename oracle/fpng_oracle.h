@@ -74,6 +74,14 @@ void fpo_get_len_tables(uint16_t len_sym[256], uint8_t len_extra[256]);
 uint32_t fpo_build_dynamic_table(const uint32_t lit_freq[288], uint32_t num_chans,
                                  uint8_t len_out[288], uint16_t code_out[288], uint8_t *hdr);
 
+/*
+ * Table training (src/fpng_test.cpp:766-973 + src/fpng.cpp:909-988, FPNG_TRAIN_HUFFMAN_TABLES builds of the reference): from a
+ * corpus of images with num_chans channels to the code lengths / codes / block prefix of a new 1-pass table.  Same outputs as
+ * fpo_build_dynamic_table.
+ */
+uint32_t fpo_train_tables(const void *const *images, const uint32_t *w, const uint32_t *h, uint32_t n, uint32_t num_chans,
+                          uint8_t len_out[288], uint16_t code_out[288], uint8_t *hdr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,4 +65,30 @@ double ref_time_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint
     return best;
 }
 
+#if FPNG_TRAIN_HUFFMAN_TABLES
+// The reference's training mode (src/fpng_test.cpp:766-973) for images in memory: every image encoded with FPNG_ENCODE_SLOWER,
+// fpng::g_huff_counts summed, then fpng::create_dynamic_block_prefix (src/fpng.cpp:910-988).  Built only into
+// _ref/libfpng_ref_train.so (-DFPNG_TRAIN_HUFFMAN_TABLES=1).
+int ref_train(const void *const *images, const uint32_t *w, const uint32_t *h, uint32_t n, uint32_t c, uint8_t *prefix, uint32_t prefix_cap,
+              uint32_t *prefix_len, uint32_t *bit_buf, uint32_t *bit_buf_size, uint32_t codes[288], uint8_t code_sizes[288])
+{
+    uint64_t freq[fpng::HUFF_COUNTS_SIZE];
+    memset(freq, 0, sizeof freq);
+    for (uint32_t k = 0; k < n; k++) {
+        memset(fpng::g_huff_counts, 0, sizeof(fpng::g_huff_counts));
+        std::vector<uint8_t> v;
+        if (!fpng::fpng_encode_image_to_memory(images[k], w[k], h[k], c, v, fpng::FPNG_ENCODE_SLOWER)) return 0;
+        for (uint32_t i = 0; i < fpng::HUFF_COUNTS_SIZE; i++) freq[i] += fpng::g_huff_counts[i];
+    }
+    std::vector<uint8_t> p;
+    uint64_t bb = 0;
+    int bbs = 0;
+    if (!fpng::create_dynamic_block_prefix(freq, c, p, bb, bbs, codes, code_sizes)) return 0;
+    if (p.size() > prefix_cap) return 0;
+    memcpy(prefix, p.data(), p.size());
+    *prefix_len = (uint32_t)p.size(), *bit_buf = (uint32_t)bb, *bit_buf_size = (uint32_t)bbs;
+    return 1;
+}
+#endif
+
 } // extern "C"

@@ -46,6 +46,8 @@ class _Oracle:
         L.fpo_get_len_tables.argtypes = [C.c_void_p, C.c_void_p]
         L.fpo_build_dynamic_table.restype = C.c_uint32
         L.fpo_build_dynamic_table.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fpo_train_tables.restype = C.c_uint32
+        L.fpo_train_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L = L
 
     def crc32(self, data, prev=0):
@@ -100,6 +102,28 @@ class _Oracle:
         hdr = np.zeros(400, dtype=np.uint8)
         bits = self.L.fpo_build_dynamic_table(hist.ctypes.data, c, lens.ctypes.data, codes.ctypes.data, hdr.ctypes.data)
         return lens, codes, hdr, bits
+
+
+    def train_tables(self, imgs, c):
+        """-> dict like tests/golden/train.json: prefix bytes (hex), pending bits, codes, code sizes."""
+        imgs = [np.ascontiguousarray(i, dtype=np.uint8) for i in imgs]
+        n = len(imgs)
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        ws = (C.c_uint32 * n)(*[i.shape[1] for i in imgs])
+        hs = (C.c_uint32 * n)(*[i.shape[0] for i in imgs])
+        lens = np.zeros(288, dtype=np.uint8)
+        codes = np.zeros(288, dtype=np.uint16)
+        hdr = np.zeros(400, dtype=np.uint8)
+        bits = self.L.fpo_train_tables(ptrs, ws, hs, n, c, lens.ctypes.data, codes.ctypes.data, hdr.ctypes.data)
+        return table_record(hdr, bits, codes, lens)
+
+
+def table_record(hdr, bits, codes, lens):
+    """Header bytes + bit count of a block prefix in the form the reference's training mode prints it (src/fpng_test.cpp:905-925):
+    whole bytes, then the pending bits."""
+    nb = bits // 8
+    return {"prefix": bytes(hdr[:nb]).hex(), "bit_buf": int(hdr[nb]) & ((1 << (bits % 8)) - 1), "bit_buf_size": bits % 8,
+            "codes": [int(v) for v in codes], "code_sizes": [int(v) for v in lens]}
 
 
 class _Ref:

@@ -6,6 +6,8 @@
 //               fpng_test.cpp:1116-1122).  As there: the image is encoded with 4 channels if any alpha value is below 255,
 //               else with 3; a second file name supplies the alpha channel from its GREEN channel (fpng_test.cpp:1124-1145)
 //     -a        alpha = green (fpng_test.cpp:1147-1152)
+//     -t        training mode: <input> = @filelist.txt (one .png per line); prints new 1-pass tables for the opaque and the
+//               translucent files in the reference's format (fpng_test.cpp:766-973; there only in FPNG_TRAIN_HUFFMAN_TABLES builds)
 //     -s        2-pass compression (FPNG_ENCODE_SLOWER)            reference fpng_test.cpp:1027
 //     -u        stored Deflate blocks (FPNG_FORCE_UNCOMPRESSED)    reference fpng_test.cpp:1031
 //     -c        one line of comma separated values                 reference fpng_test.cpp:1608-1633
@@ -42,7 +44,7 @@ namespace {
 typedef int (*judge_fn)(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *, size_t, size_t *);
 
 struct Options {
-    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false, green_to_alpha = false;
+    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false, green_to_alpha = false, train = false;
     uint32_t trials = 1000, max_dim = 8193, batch = 0, cpu_threads = 0;
     const char *input = nullptr, *alpha_input = nullptr, *out = "fpng.png", *judge_path = nullptr;
 };
@@ -263,6 +265,70 @@ void batch_rates(const std::vector<uint8_t> &px, uint32_t w, uint32_t h, uint32_
     fpng_amd_encoder_destroy(enc);
 }
 
+// reference training_mode (fpng_test.cpp:766-973): the files of @list, split into opaque (24 bpp) and translucent (32 bpp) ones,
+// each class through fpng_amd_train_tables (histograms, adjustment and table builder on the GPU); output in the reference's form
+int training_mode(const Options &o)
+{
+    if (!o.input || o.input[0] != '@') {
+        fprintf(stderr, "Must specify list of files to read using @filelist.txt\n");
+        return EXIT_FAILURE;
+    }
+    FILE *lf = fopen(o.input + 1, "r");
+    if (!lf) {
+        fprintf(stderr, "Failed opening listing file %s\n", o.input + 1);
+        return EXIT_FAILURE;
+    }
+    struct Dev { void *p; uint32_t w, h; };
+    std::vector<Dev> cls[5];
+    uint32_t failed = 0;
+    char line[4096];
+    while (fgets(line, sizeof line, lf)) {
+        std::string name(line);
+        while (!name.empty() && (name.back() == '\n' || name.back() == '\r' || name.back() == ' ')) name.pop_back();
+        if (name.empty()) continue;
+        printf("Processing file \"%s\"\n", name.c_str());
+        Options one = o;
+        one.input = name.c_str();
+        std::vector<uint8_t> px;
+        uint32_t w = 0, h = 0, c = 0;
+        if (!load_input(one, px, w, h, c)) {
+            fprintf(stderr, "WARNING: Failed unpacking source file \"%s\"! Skipping.\n", name.c_str());
+            failed++;
+            continue;
+        }
+        printf("Dimensions: %ux%u, Has Alpha: %u\n", w, h, c == 4);
+        Dev d = {nullptr, w, h};
+        if (hipMalloc(&d.p, px.size()) != hipSuccess || hipMemcpy(d.p, px.data(), px.size(), hipMemcpyHostToDevice) != hipSuccess) return EXIT_FAILURE;
+        cls[c].push_back(d);
+    }
+    fclose(lf);
+    printf("Total alpha files: %zu\nTotal opaque files: %zu\nTotal failed loading: %u\n", cls[4].size(), cls[3].size(), failed);
+    if (cls[3].empty() && cls[4].empty()) return EXIT_FAILURE;
+    fpng_amd_encoder *enc = nullptr;
+    if (fpng_amd_encoder_create(&enc, -1, nullptr)) return EXIT_FAILURE;
+    for (uint32_t c = 3; c <= 4; c++) {
+        if (cls[c].empty()) continue;
+        std::vector<fpng_amd_image> im(cls[c].size());
+        for (size_t i = 0; i < im.size(); i++) im[i] = {cls[c][i].p, cls[c][i].w, cls[c][i].h, c, nullptr, 0};
+        uint8_t prefix[512];
+        size_t nb = 0;
+        uint32_t bb = 0, bbs = 0, codes[288];
+        uint8_t sizes[288];
+        if (fpng_amd_train_tables(enc, im.data(), (uint32_t)im.size(), c, prefix, sizeof prefix, &nb, &bb, &bbs, codes, sizes)) {
+            fprintf(stderr, "fpng_amd_train_tables() failed: %s\n", fpng_amd_last_error());
+            return EXIT_FAILURE;
+        }
+        printf("\nstatic const uint8_t g_dyn_huff_%u[] = {\n", c);
+        for (size_t i = 0; i < nb; i++) printf("%u%c %s", prefix[i], i + 1 != nb ? ',' : ' ', (i & 31) == 31 ? "\n" : "");
+        printf("};\nconst uint32_t DYN_HUFF_%u_BITBUF = %u, DYN_HUFF_%u_BITBUF_SIZE = %u;\n", c, bb, c, bbs);
+        printf("static const struct { uint8_t m_code_size; uint16_t m_code; } g_dyn_huff_%u_codes[288] = {\n", c);
+        for (uint32_t i = 0; i < 288; i++) printf("{%u,%u}%c%s", sizes[i], codes[i], i != 287 ? ',' : ' ', (i & 31) == 31 ? "\n" : "");
+        printf("};\n");
+    }
+    fpng_amd_encoder_destroy(enc);
+    return EXIT_SUCCESS;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -278,6 +344,7 @@ int main(int argc, char **argv)
             case 'u': o.uncompressed = true; break;
             case 'c': o.csv = true; break;
             case 'a': o.green_to_alpha = true; break;
+            case 't': o.train = true; break;
             case 'e': o.fuzz = true; break;
             case 'E': o.fuzz2 = true; break;
             case 'n': o.trials = (uint32_t)atoi(argv[++i]); break;
@@ -293,7 +360,7 @@ int main(int argc, char **argv)
             o.alpha_input = a;
     }
     if (!o.input && !o.fuzz2) {
-        printf("Usage: fpng_amd_test [-s] [-u] [-a] [-c] [-e] [-E] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
+        printf("Usage: fpng_amd_test [-s] [-u] [-a] [-c] [-e] [-E] [-t @filelist.txt] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
                "[--judge cpu_encoder.so] <synth:kind:WxHxC[:seed] | file.png> [alpha_file.png]\n");
         return EXIT_FAILURE;
     }
@@ -316,6 +383,7 @@ int main(int argc, char **argv)
         }
     }
     const uint32_t flags = (o.slower ? fpng::FPNG_ENCODE_SLOWER : 0) | (o.uncompressed ? fpng::FPNG_FORCE_UNCOMPRESSED : 0);
+    if (o.train) return training_mode(o);
     if (o.fuzz2) return fuzz_encoder2(flags, o, judge);
 
     std::vector<uint8_t> px;

@@ -461,6 +461,10 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     HIP_TRY(hipEventRecord(slot.in, e->stream));
     HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
     if (sc.last_done) HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
+    // (Measured and dropped, profiles/r03_latency.txt: letting one- and two-frame submissions read their job records straight from
+    // the slot's pinned host memory instead of uploading them -- the upload is a blit kernel + a dispatch gap, ~7 us -- costs
+    // 7 us MORE per chain: every kernel's first touch of the record goes over PCIe.)
+    const Job *d_jobs = sc.d_jobs.p;
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
     uint32_t ph = 0; // index of the last phase mark
@@ -485,17 +489,19 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // assemble (+ CRC partials), finalize (CRC fold, trailer, result record).  Folding the scan into the last row block and
     // the finalize step into the last assemble block (three launches) was measured on the same box: 11 % less throughput
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
-    if (!force_stored) launch_encode_rows(s, sc.d_jobs.p, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    if (!force_stored) launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;
-    HIP_TRY(hipEventRecord(slot.walked, s));
-    e->prev_walked = slot.walked;
-    launch_scan(s, sc.d_jobs.p, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+    if (two_pass || stagger_env == 1) { // (only the staggered 2-pass walks wait for it)
+        HIP_TRY(hipEventRecord(slot.walked, s));
+        e->prev_walked = slot.walked;
+    }
+    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
     if ((rc = mark(e, s, ++ph))) return rc;
-    launch_stored(s, sc.d_jobs.p, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+    launch_stored(s, d_jobs, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
     if ((rc = mark(e, s, ++ph))) return rc;
-    launch_assemble(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
+    launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
     if ((rc = mark(e, s, ++ph))) return rc;
-    launch_finalize(s, sc.d_jobs.p, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
+    launch_finalize(s, d_jobs, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
     if ((rc = mark(e, s, ++ph))) return rc;
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event

@@ -60,7 +60,7 @@ def parse():
 
 def workload_tag(args):
     """Name of this command in profiles/: r03_<tag>_pmc_traffic.txt etc. (tools/gpu_profile_round.sh <round>_<tag> <args>)."""
-    defaults = {"8k": 8}
+    defaults = {"8k": 8, "4k": 16, "1080p": 256, "512": 1024, "16k": 1}
     tag = args.workload + ("" if defaults.get(args.workload, args.batch) == args.batch else f"_b{args.batch}")
     if args.flags:
         tag += {1: "_2pass", 2: "_stored"}.get(args.flags, f"_f{args.flags}")

@@ -12,6 +12,6 @@ cd /tmp && export TMPDIR=/tmp
 FPNG_AMD_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$C -o cal -- python $R/tools/pmc_calibrate.py > $OUT/cal_$C.log 2>&1
+  [ -z "$SKIP_CAL" ] && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$C -o cal -- python $R/tools/pmc_calibrate.py > $OUT/cal_$C.log 2>&1
 done
 find $OUT -name "*.csv" | head -40

@@ -5,7 +5,9 @@ import collections, csv, json, shutil, sys, os
 
 tag = sys.argv[1]
 alg = int(sys.argv[2]) if len(sys.argv) > 2 else None
+cal_tag = sys.argv[3] if len(sys.argv) > 3 else tag  # the run that holds the calibration streams (one per session is enough)
 base = f"gpurun_out/prof_{tag}"
+cal_base = f"gpurun_out/prof_{cal_tag}"
 shutil.copy(f"{base}/trace/trace_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 
 
@@ -19,12 +21,13 @@ def load(path):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-cal_f, cal_w = load(f"{base}/cal_FETCH_SIZE/cal_counter_collection.csv"), load(f"{base}/cal_WRITE_SIZE/cal_counter_collection.csv")
+cal_f, cal_w = load(f"{cal_base}/cal_FETCH_SIZE/cal_counter_collection.csv"), load(f"{cal_base}/cal_WRITE_SIZE/cal_counter_collection.csv")
 f, w = load(f"{base}/pmc_FETCH_SIZE/pmc_counter_collection.csv"), load(f"{base}/pmc_WRITE_SIZE/pmc_counter_collection.csv")
 GiB = 1 << 30
 fscale = GiB / [v for k, v in cal_f.items() if "calib_read_kernel<unsigned int>" in k][0]
 wscale = GiB / [v for k, v in cal_w.items() if "calib_write_kernel<unsigned int>" in k][0]
-lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+args = " ".join(sys.argv[4:])
+lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline {args}".rstrip(),
          f"# calibration (tools/pmc_calibrate.py, 1 GiB streams with 4-byte lanes): FETCH_SIZE unit = {fscale:.1f} B, WRITE_SIZE unit = {wscale:.1f} B",
          f"{'kernel':<22} {'FETCH_SIZE':>12} {'fetch_MB':>10} {'WRITE_SIZE':>12} {'write_MB':>10}"]
 tot = 0

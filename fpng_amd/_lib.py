@@ -41,6 +41,14 @@ class BandStats(C.Structure):
                 ("eob_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class PngIn(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_uint32), ("reserved", C.c_uint32), ("d_pixels", C.c_void_p), ("pixels_cap", C.c_size_t)]
+
+
+class DecodeResult(C.Structure):
+    _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("channels_in_file", C.c_uint32), ("status", C.c_int32)]
+
+
 class BandPlan(C.Structure):
     _fields_ = [("end_bit", C.c_uint64), ("zlib_size", C.c_uint64), ("adler", C.c_uint32), ("stored", C.c_uint32)]
 
@@ -109,6 +117,7 @@ SIGNATURES = {
     "fpng_amd_node_destroy": (None, [_vp]),
     "fpng_amd_node_size": (_u32, [_vp]),
     "fpng_amd_node_encode_host_batch": (_int, [_vp, C.POINTER(HostImage), _u32, _u32, _int]),
+    "fpng_amd_decode_batch": (_int, [_vp, C.POINTER(PngIn), _u32, _u32, C.POINTER(DecodeResult)]),
     "fpng_amd_train_tables": (_int, [_vp, C.POINTER(Image), _u32, _u32, _vp, _sz, C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32), _vp, _vp]),
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),

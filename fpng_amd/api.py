@@ -290,6 +290,34 @@ class Encoder:
             pngs.append(bytes(out[:size].cpu().numpy()))
         return pngs, [m for _, m, _ in res]
 
+    def decode_batch(self, pngs, desired_chans, dims=None):
+        """fpng_amd_decode_batch: list of fpng-written files (bytes) -> list of (status, uint8 CUDA tensor (h, w, desired_chans)
+        or None, channels_in_file).  Output buffers are sized from the files' headers (dims: optional list of (w, h) to skip that)."""
+        import struct
+        n = len(pngs)
+        arr = (_lib.PngIn * n)()
+        res = (_lib.DecodeResult * n)()
+        keep, outs = [], []
+        for i, p in enumerate(pngs):
+            b = np.frombuffer(bytes(p), dtype=np.uint8)
+            keep.append(b)
+            w, h = dims[i] if dims else ((struct.unpack(">II", bytes(p[16:24]))) if len(p) >= 24 else (0, 0))
+            cap = w * h * desired_chans if 0 < w <= (1 << 24) and 0 < h <= (1 << 24) and w * h <= (1 << 30) else 0
+            t = torch.empty(max(cap, 16), dtype=torch.uint8, device=f"cuda:{self.device}")
+            outs.append(t)
+            arr[i].data = b.ctypes.data if b.size else None
+            arr[i].size = b.size
+            arr[i].d_pixels = t.data_ptr()
+            arr[i].pixels_cap = t.numel()
+        self._sync_stream()
+        check(self.lib.fpng_amd_decode_batch(self.h, arr, n, desired_chans, res))
+        out = []
+        for i in range(n):
+            r = res[i]
+            ok = r.status == 0
+            out.append((r.status, outs[i][: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
+        return out
+
     def train_tables(self, images):
         """fpng_amd_train_tables: a new 1-pass table from a corpus of uint8 CUDA tensors (h, w, c), all with the same c, in the
         form the reference's training mode prints it (block prefix bytes as hex, pending bits, codes, code sizes)."""

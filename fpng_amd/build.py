@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfpng_amd.so")
 DROPIN_LIB = os.path.join(LIB_DIR, "libfpng.so")
-SOURCES = ["kernels.hip", "api.cpp", "pipeline.cpp", "sharded.cpp", "format.cpp", "synth.cpp"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "encoder.h"),
+SOURCES = ["kernels.hip", "decode.hip", "api.cpp", "pipeline.cpp", "sharded.cpp", "decode_api.cpp", "format.cpp", "synth.cpp"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "encoder.h"), os.path.join(CSRC, "decode.h"), os.path.join(CSRC, "png_parse.h"),
            os.path.join(ROOT, "include", "fpng_amd.h")]
 ARCH = "gfx950"
 
@@ -64,9 +64,9 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     dropin_srcs = [os.path.join(CSRC, "fpng_dropin.cpp"), os.path.join(CSRC, "fpng_decode.cpp")]
-    if force or _stale(DROPIN_LIB, dropin_srcs + [LIB, os.path.join(ROOT, "include", "fpng.h")]):
+    if force or _stale(DROPIN_LIB, dropin_srcs + [LIB, os.path.join(ROOT, "include", "fpng.h"), os.path.join(CSRC, "png_parse.h")]):
         # the `namespace fpng` drop-in: plain C++ over the C ABI, no HIP in it
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include")] + dropin_srcs + [
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + dropin_srcs + [
             "-o", DROPIN_LIB, "-L", LIB_DIR, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -258,6 +258,7 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->h_states.release();
     e->h_partials.release();
     e->d_stream_partials.release();
+    e->d_decode.release();
     e->d_stage_in.release();
     e->d_stage_out.release();
     for (auto &b : e->host.d_in) b.release();

@@ -1,0 +1,36 @@
+// decode.h -- host/device shared structures of the GPU batch decoder (decode.hip, decode_api.cpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace fpng_amd {
+
+constexpr uint32_t kSubBits = 1024; // token bits per subsequence (one thread each)
+enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecSawEob = 0x100u };
+
+struct DecJob {
+    const uint8_t *z;         // device: the zlib stream (16-byte aligned copy), z[0] = 0x78
+    const uint8_t *z_aligned; // == z
+    uint64_t z_offset;        // 0 (bit positions count from z)
+    uint64_t z_bytes;         // length of the IDAT payload
+    uint64_t first_bit;       // first row token (behind the dynamic block header)
+    uint64_t end_limit_bit;   // (z_bytes - 4) * 8: no token may start here or later
+    const uint16_t *lut;      // device: 4096 x (symbol | code length << 9), 0 = no such code
+    uint8_t *filt;            // device scratch: (bpl + 1) * h filtered bytes
+    uint32_t *runmask;        // device scratch, zeroed: one bit per pixel, rows padded to 32 pixels
+    uint8_t *out;             // device: w * h * dst_c pixels
+    uint32_t w, h, src_c, dst_c, bpl;
+    uint32_t n_sub;           // subsequences of the file
+    uint32_t sub_base;        // index of its first subsequence (a multiple of the block size: one file per workgroup)
+    uint32_t mode;            // 0 one dynamic block, 1 stored blocks
+};
+
+void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in, const uint32_t *flags_in,
+                     uint64_t *start, uint64_t *end_out, uint32_t *bytes, uint32_t *flags_out, uint32_t *changed);
+void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes, const uint32_t *flags,
+                        uint64_t *off, uint32_t *status, uint32_t *eob_index);
+void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *eob_index, const uint64_t *off,
+                     uint32_t *status);
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status);
+
+} // namespace fpng_amd

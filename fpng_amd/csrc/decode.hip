@@ -1,0 +1,384 @@
+// decode.hip -- GPU batch decoder of fpng-written PNG files (reference src/fpng.cpp:2209-2901 decodes the same
+// streams serially).  A PROTOTYPE of the data-parallel form: the container and the Deflate block header are parsed on the host
+// (a few hundred bytes per file, decode_api.cpp); everything that touches the pixel stream runs here.
+//
+// An fpng stream is ONE Huffman-coded bit string with no restart points, but Huffman decoders SELF-SYNCHRONISE: started at a
+// wrong bit, a decoder falls into step with the true token sequence after a few dozen bits.  So the token bits are cut into
+// subsequences of kSubBits bits, one thread each:
+//   dec_sync_kernel    round 0: every thread decodes its subsequence from its nominal first bit and notes where it crossed
+//                      into the next one; rounds 1..R: every thread restarts where its predecessor ended if that differs from
+//                      where it started before.  After a round without changes the ends form the TRUE chain from the stream's
+//                      first token (the host gives up on the GPU path for the file if that takes more than R rounds).
+//   dec_offsets_kernel per file: exclusive scan of the subsequences' output byte counts -> where each one writes
+//   dec_emit_kernel    decodes again, now for real: literals go to the filtered image; a match (always "repeat the previous
+//                      pixel", reference fpng.cpp:2273-2330) only marks its pixels in a bit mask; every rule of the reference's
+//                      decoder is checked (filter literal 0 then 2, matches whole pixels inside a row, exact total, EOB, the
+//                      stream ends 4 bytes before the IDAT does)
+//   dec_fill_kernel    one wave per row: marked pixels take the value of the nearest unmarked pixel to their left
+//   dec_unfilter_kernel one thread per byte column: running sum over the rows (the Up filter), channel count conversion
+//   dec_stored_kernel  files that are stored blocks (reference fpng.cpp:2107-2207): a strided copy
+#include "decode.h"
+
+#include <hip/hip_runtime.h>
+
+namespace fpng_amd {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kDecBlock = 256;
+
+__device__ __forceinline__ uint32_t dec_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// LSB-first reader over device memory (dword loads; positions are absolute bits from z)
+struct DevBits {
+    const uint32_t *w; // z aligned down to 4 bytes
+    uint64_t pos;      // absolute bit position (from w)
+    uint64_t limit;    // no token may start at or behind this bit
+    uint64_t buf;
+    uint32_t have;     // valid bits in buf
+    __device__ __forceinline__ void seek(uint64_t p)
+    {
+        pos = p;
+        const uint64_t d = p >> 5;
+        const uint32_t lo = w[d], hi = w[d + 1];
+        buf = (((uint64_t)hi << 32) | lo) >> (p & 31);
+        have = 64 - (uint32_t)(p & 31);
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t k) // k <= 32
+    {
+        if (have < k) seek(pos);
+        return (uint32_t)(buf & ((1ull << k) - 1));
+    }
+    __device__ __forceinline__ void skip(uint32_t k)
+    {
+        if (have < k) seek(pos);
+        buf >>= k;
+        have -= k;
+        pos += k;
+    }
+};
+
+__device__ __constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+
+enum : uint32_t { kSubEob = 1u, kSubInvalid = 4u };
+
+// one token: returns its kind and advances.  kind: 0..255 literal, 256 end of block, 257.. match with `run` bytes; -1 invalid
+__device__ __forceinline__ int next_token(DevBits &in, const uint16_t *lut, uint32_t &run)
+{
+    const uint32_t e = lut[in.peek(12)];
+    const uint32_t len = e >> 9;
+    if (!len) return -1;
+    in.skip(len);
+    const uint32_t sym = e & 511u;
+    if (sym <= 256) return (int)sym;
+    if (sym > 285) return -1;
+    const uint32_t xb = kLenExtra[sym - 257];
+    run = kLenBase[sym - 257] + (xb ? in.peek(xb) : 0u);
+    in.skip(xb + 1); // extra bits + the 1-bit distance code ("previous pixel")
+    return (int)sym;
+}
+
+__device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t n_jobs, uint32_t g, uint32_t &local)
+{
+    // binary search over sub_base (jobs are few; subsequences many)
+    uint32_t lo = 0, hi = n_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].sub_base <= g) lo = mid; else hi = mid;
+    }
+    local = g - jobs[lo].sub_base;
+    return jobs[lo];
+}
+
+// ---- synchronisation rounds ----
+__global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in,
+                                                             const uint32_t *flags_in, uint64_t *start, uint64_t *end_out, uint32_t *bytes,
+                                                             uint32_t *flags_out, uint32_t *changed)
+{
+    __shared__ uint16_t lut[4096];
+    const uint32_t g0 = blockIdx.x * kDecBlock;
+    if (g0 >= total_subs) return;
+    // all subsequences of a block belong to one job (sub_base is padded to kDecBlock by the host)
+    uint32_t local0;
+    const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+    for (int i = threadIdx.x; i < 4096; i += kDecBlock) lut[i] = job.lut[i];
+    __syncthreads();
+    const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
+    if (i >= job.n_sub) return;
+    const uint64_t nominal = job.first_bit + (uint64_t)i * kSubBits, boundary = nominal + kSubBits;
+    uint64_t s;
+    if (round == 0) {
+        s = nominal;
+    } else {
+        s = i ? end_in[g - 1] : job.first_bit;
+        if (s == start[g]) { // nothing new: carry the result over
+            end_out[g] = end_in[g], flags_out[g] = flags_in[g];
+            return;
+        }
+        atomicOr(changed, 1u);
+    }
+    start[g] = s;
+    DevBits in;
+    in.w = (const uint32_t *)job.z_aligned;
+    in.limit = job.end_limit_bit;
+    in.seek(s);
+    uint32_t nbytes = 0, fl = 0;
+    while (in.pos < boundary) {
+        if (in.pos >= in.limit) { // ran off the data without an end-of-block symbol
+            fl = kSubInvalid;
+            break;
+        }
+        uint32_t run = 0;
+        const int t = next_token(in, lut, run);
+        if (t < 0) {
+            fl = kSubInvalid;
+            break;
+        }
+        if (t == 256) {
+            fl = kSubEob;
+            break;
+        }
+        nbytes += t < 256 ? 1u : run;
+    }
+    // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
+    // end-of-block symbols, and letting those stop their successors would cost one round per subsequence to undo.  Which
+    // end-of-block symbol is the true one is settled afterwards: the first one of the converged chain (dec_offsets_kernel).
+    end_out[g] = fl ? boundary : in.pos;
+    bytes[g] = nbytes;
+    flags_out[g] = fl;
+}
+
+// ---- per file: exclusive scan of the byte counts of its subsequences, consistency of the chain, total ----
+__global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes,
+                                                                const uint32_t *flags, uint64_t *off, uint32_t *status, uint32_t *eob_index)
+{
+    __shared__ uint64_t sums[kDecBlock];
+    __shared__ uint32_t bad, first_eob;
+    const DecJob &job = jobs[blockIdx.x];
+    if (job.mode != 0) return;
+    const uint32_t t = threadIdx.x, n = job.n_sub, per = (n + kDecBlock - 1) / kDecBlock;
+    const uint32_t i0 = t * per < n ? t * per : n, i1 = i0 + per < n ? i0 + per : n;
+    if (t == 0) bad = 0, first_eob = n;
+    __syncthreads();
+    // the stream ends with the FIRST end-of-block symbol of the chain (everything in front of it is the true token sequence
+    // once the chain holds; what lies behind it is padding and the Adler-32, decoded as garbage by their threads)
+    for (uint32_t i = i0; i < i1; i++)
+        if (flags[job.sub_base + i] & kSubEob) {
+            atomicMin(&first_eob, i);
+            break;
+        }
+    __syncthreads();
+    const uint32_t last = first_eob; // subsequences 0..last make up the stream
+    uint64_t local = 0;
+    uint32_t b = 0;
+    for (uint32_t i = i0; i < i1 && i <= last; i++) {
+        const uint32_t g = job.sub_base + i;
+        local += bytes[g];
+        // the chain must hold: every subsequence starts where its predecessor ended
+        const uint64_t want = i ? end[g - 1] : job.first_bit;
+        if (start[g] != want) b |= kDecNotConverged;
+        if (flags[g] & kSubInvalid) b |= kDecBadStream;
+    }
+    if (t == 0) {
+        eob_index[blockIdx.x] = last;
+        if (last == n) b |= kDecBadStream; // the stream never ends
+    }
+    sums[t] = local;
+    if (b) atomicOr(&bad, b);
+    __syncthreads();
+    if (t == 0) {
+        uint64_t acc = 0;
+        for (int k = 0; k < kDecBlock; k++) {
+            const uint64_t v = sums[k];
+            sums[k] = acc;
+            acc += v;
+        }
+        uint32_t st = bad;
+        if (acc != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
+        if (st) atomicOr(&status[blockIdx.x], st);
+    }
+    __syncthreads();
+    uint64_t o = sums[t];
+    for (uint32_t i = i0; i < i1 && i <= last; i++) {
+        off[job.sub_base + i] = o;
+        o += bytes[job.sub_base + i];
+    }
+}
+
+// ---- the real decode ----
+__global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start,
+                                                             const uint32_t *eob_index, const uint64_t *off, uint32_t *status)
+{
+    __shared__ uint16_t lut[4096];
+    const uint32_t g0 = blockIdx.x * kDecBlock;
+    if (g0 >= total_subs) return;
+    uint32_t local0;
+    const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+    const uint32_t job_index = (uint32_t)(&job - jobs);
+    if (status[job_index] & ~kDecSawEob) return; // (uniform per block: one file per block)
+    for (int i = threadIdx.x; i < 4096; i += kDecBlock) lut[i] = job.lut[i];
+    __syncthreads();
+    const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
+    if (i >= job.n_sub || i > eob_index[job_index]) return;
+    const uint64_t boundary = job.first_bit + (uint64_t)(i + 1) * kSubBits, total = (uint64_t)(job.bpl + 1) * job.h;
+    const uint32_t stride = job.bpl + 1, c = job.src_c, wpr = (job.w + 31) >> 5;
+    DevBits in;
+    in.w = (const uint32_t *)job.z_aligned;
+    in.limit = job.end_limit_bit;
+    in.seek(start[g]);
+    uint64_t o = off[g];
+    uint32_t row = (uint32_t)(o / stride), col = (uint32_t)(o - (uint64_t)row * stride);
+    uint8_t *F = job.filt;
+    uint32_t err = 0;
+    while (in.pos < boundary) {
+        if (in.pos >= in.limit) {
+            err = kDecBadStream;
+            break;
+        }
+        uint32_t run = 0;
+        const int t = next_token(in, lut, run);
+        if (t < 0) {
+            err = kDecBadStream;
+            break;
+        }
+        if (t == 256) { // end of block: every pixel must be there, and the stream must end 4 bytes (the Adler-32) before the IDAT does
+            if (o != total || ((in.pos + 7) >> 3) + 4 != job.z_bytes) err = kDecBadStream;
+            atomicOr(&status[job_index], kDecSawEob);
+            break;
+        }
+        if (t < 256) {
+            if (o >= total || (col == 0 && (uint32_t)t != (row ? 2u : 0u))) { // the row's filter literal: 0, then 2 (Up)
+                err = kDecBadStream;
+                break;
+            }
+            F[o] = (uint8_t)t;
+            o++;
+            if (++col == stride) col = 0, row++;
+        } else {
+            // a match repeats the previous pixel: whole pixels, inside the row (reference fpng.cpp:2301-2330)
+            const uint32_t x = (col - 1) / c, npix = run / c;
+            if (col == 0 || (col - 1) % c || run % c || !npix || x + npix > job.w || o + run > total) {
+                err = kDecBadStream;
+                break;
+            }
+            uint32_t *m = job.runmask + (size_t)row * wpr;
+            for (uint32_t p = x; p < x + npix;) { // set bits [x, x + npix)
+                const uint32_t wd = p >> 5, b0 = p & 31, cnt = min(32u - b0, x + npix - p);
+                atomicOr(&m[wd], (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b0);
+                p += cnt;
+            }
+            o += run;
+            col += run;
+            if (col == stride) col = 0, row++;
+        }
+    }
+    if (err) atomicOr(&status[job_index], err);
+}
+
+// ---- runs: every marked pixel takes the filtered value of the nearest unmarked pixel to its left (zero if there is none) ----
+__global__ __launch_bounds__(kDecBlock) void dec_fill_kernel(const DecJob *jobs, const uint32_t *status)
+{
+    const DecJob &job = jobs[blockIdx.y];
+    if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
+    const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * (kDecBlock / kWave) + dec_uniform(threadIdx.x >> 6);
+    if (row >= job.h) return;
+    const uint32_t c = job.src_c, wpr = (job.w + 31) >> 5;
+    uint8_t *F = job.filt + (size_t)row * (job.bpl + 1) + 1;
+    const uint32_t *m = job.runmask + (size_t)row * wpr;
+    uint32_t carry = 0; // value of the last pixel of the previous window (filtered bytes, packed)
+    for (uint32_t x0 = 0; x0 < job.w; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        const bool valid = x < job.w;
+        uint32_t v = 0;
+        bool is_run = false;
+        if (valid) {
+            is_run = (m[x >> 5] >> (x & 31)) & 1;
+            if (!is_run) {
+                const uint8_t *p = F + (size_t)x * c;
+                v = p[0] | (p[1] << 8) | (p[2] << 16) | (c == 4 ? (uint32_t)p[3] << 24 : 0u);
+            }
+        }
+        const uint64_t lit = __ballot(valid && !is_run);
+        const uint64_t le = (2ull << lane) - 1ull;
+        const uint64_t below = lit & le;
+        const int src = below ? 63 - __builtin_clzll(below) : -1; // nearest literal pixel at or below this lane
+        const uint32_t got = (uint32_t)__shfl((int)v, src < 0 ? 0 : src, kWave);
+        const uint32_t val = src < 0 ? carry : got;
+        if (valid && is_run) {
+            uint8_t *p = F + (size_t)x * c;
+            p[0] = (uint8_t)val, p[1] = (uint8_t)(val >> 8), p[2] = (uint8_t)(val >> 16);
+            if (c == 4) p[3] = (uint8_t)(val >> 24);
+        }
+        carry = (uint32_t)__shfl((int)val, 63, kWave); // (lanes past the row end are not read again)
+    }
+}
+
+// ---- Up filter undone: out[y] = out[y-1] + filtered[y] per byte column; 3 <-> 4 channels on the way out ----
+__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, const uint32_t *status)
+{
+    const DecJob &job = jobs[blockIdx.y];
+    if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
+    const uint32_t j = blockIdx.x * kDecBlock + threadIdx.x; // byte column of the file's rows
+    if (j >= job.bpl) return;
+    const uint32_t sc = job.src_c, dc = job.dst_c, px = j / sc, ch = j - px * sc;
+    if (ch >= dc) return; // alpha dropped
+    const uint8_t *F = job.filt + 1 + j;
+    const size_t fs = job.bpl + 1, os = (size_t)job.w * dc;
+    uint8_t *out = job.out + (size_t)px * dc + ch;
+    const bool add_alpha = dc == 4 && sc == 3 && ch == 2;
+    uint32_t acc = 0;
+    for (uint32_t y = 0; y < job.h; y++) {
+        acc = (acc + F[(size_t)y * fs]) & 255u;
+        out[(size_t)y * os] = (uint8_t)acc;
+        if (add_alpha) out[(size_t)y * os + 1] = 0xFF;
+    }
+}
+
+// ---- stored files: the filter-0 stream sits in stored blocks of 65535 bytes (the host checked their headers and the filter bytes) ----
+__global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *jobs)
+{
+    const DecJob &job = jobs[blockIdx.y];
+    if (job.mode != 1) return;
+    const uint64_t n = (uint64_t)job.w * job.h * job.dst_c;
+    for (uint64_t k = (uint64_t)blockIdx.x * kDecBlock + threadIdx.x; k < n; k += (uint64_t)gridDim.x * kDecBlock) {
+        const uint64_t pixel = k / job.dst_c;
+        const uint32_t ch = (uint32_t)(k - pixel * job.dst_c);
+        uint8_t v = 0xFF;
+        if (ch < job.src_c) {
+            const uint64_t y = pixel / job.w, x = pixel - y * job.w;
+            const uint64_t s = y * (job.bpl + 1) + 1 + x * job.src_c + ch; // stream byte
+            v = job.z[2 + 5 * (s / 65535 + 1) + s];
+        }
+        job.out[k] = v;
+    }
+}
+
+} // namespace
+
+void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in, const uint32_t *flags_in,
+                     uint64_t *start, uint64_t *end_out, uint32_t *bytes, uint32_t *flags_out, uint32_t *changed)
+{
+    hipLaunchKernelGGL(dec_sync_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, round, end_in, flags_in,
+                       start, end_out, bytes, flags_out, changed);
+}
+void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes, const uint32_t *flags,
+                        uint64_t *off, uint32_t *status, uint32_t *eob_index)
+{
+    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_jobs), dim3(kDecBlock), 0, s, jobs, start, end, bytes, flags, off, status, eob_index);
+}
+void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *eob_index, const uint64_t *off,
+                     uint32_t *status)
+{
+    hipLaunchKernelGGL(dec_emit_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, eob_index, off, status);
+}
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status)
+{
+    const uint32_t rows_per_block = kDecBlock / kWave;
+    hipLaunchKernelGGL(dec_fill_kernel, dim3((max_rows + rows_per_block - 1) / rows_per_block, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
+    hipLaunchKernelGGL(dec_unfilter_kernel, dim3((max_bpl + kDecBlock - 1) / kDecBlock, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
+    hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, n_jobs), dim3(kDecBlock), 0, s, jobs);
+}
+
+} // namespace fpng_amd

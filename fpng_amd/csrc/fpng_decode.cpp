@@ -15,9 +15,7 @@
 //                            the end of the IDAT payload
 //   stored blocks .......... reference src/fpng.cpp:2107-2207
 // Any violation inside the zlib stream maps to FPNG_DECODE_NOT_FPNG (reference :3131-3136).
-#include "fpng.h"
-
-#include "fpng_amd.h"
+#include "png_parse.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -26,182 +24,7 @@ namespace fpng {
 
 namespace {
 
-const uint32_t kMaxDim = 1u << 24;
-
-uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-
-int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint32_t &h, uint32_t &chans, uint32_t &idat_ofs,
-                    uint32_t &idat_len)
-{
-    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
-    w = h = chans = idat_ofs = idat_len = 0;
-    // signature + IHDR chunk (25) + chunk prefix (8) + 1 + crc (4) + IEND (12)
-    if (size < 8 + 25 + 8 + 1 + 4 + 12) return FPNG_DECODE_FAILED_NOT_PNG;
-    if (memcmp(png, sig, 8) != 0) return FPNG_DECODE_FAILED_NOT_PNG;
-    const uint8_t *ihdr = png + 8;
-    if (be32(ihdr) != 13) return FPNG_DECODE_FAILED_NOT_PNG;
-    if (fpng_amd_crc32(ihdr + 4, 4 + 13, 0) != be32(ihdr + 21)) return FPNG_DECODE_FAILED_HEADER_CRC32;
-    w = be32(ihdr + 8);
-    h = be32(ihdr + 12);
-    if (!w || !h || w > kMaxDim || h > kMaxDim) return FPNG_DECODE_FAILED_INVALID_DIMENSIONS;
-    if ((uint64_t)w * h > (1u << 30)) return FPNG_DECODE_FAILED_INVALID_DIMENSIONS;
-    if (ihdr[18] || ihdr[19] || ihdr[20] || ihdr[16] != 8) return FPNG_DECODE_NOT_FPNG;
-    if (ihdr[17] == 2)
-        chans = 3;
-    else if (ihdr[17] == 6)
-        chans = 4;
-    else
-        return FPNG_DECODE_NOT_FPNG;
-
-    bool have_fdec = false;
-    size_t ofs = 8 + 25;
-    for (;;) {
-        if (ofs >= size) return FPNG_DECODE_FAILED_CHUNK_PARSING;
-        if (size - ofs < 12) return FPNG_DECODE_FAILED_CHUNK_PARSING;
-        const uint8_t *ck = png + ofs;
-        const uint32_t len = be32(ck);
-        if (ofs + 8 + (uint64_t)len + 4 > size) return FPNG_DECODE_FAILED_CHUNK_PARSING;
-        for (int i = 0; i < 4; i++) {
-            const uint8_t c = ck[4 + i];
-            if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))) return FPNG_DECODE_FAILED_CHUNK_PARSING;
-        }
-        const bool is_idat = memcmp(ck + 4, "IDAT", 4) == 0;
-        if (!is_idat && fpng_amd_crc32(ck + 4, 4 + len, 0) != be32(ck + 8 + len)) return FPNG_DECODE_FAILED_HEADER_CRC32;
-        const uint8_t *data = ck + 8;
-        if (memcmp(ck + 4, "IEND", 4) == 0) break;
-        if (is_idat) {
-            if (idat_ofs || !have_fdec) return FPNG_DECODE_NOT_FPNG; // second IDAT, or IDAT before the marker
-            idat_ofs = (uint32_t)ofs;
-            idat_len = len;
-            if (idat_len < 7) return FPNG_DECODE_FAILED_INVALID_IDAT;
-        } else if (memcmp(ck + 4, "fdEC", 4) == 0) {
-            if (have_fdec || len != 5) return FPNG_DECODE_NOT_FPNG;
-            if (data[0] != 82 || data[1] != 36 || data[2] != 147 || data[3] != 227 || data[4] != 0) return FPNG_DECODE_NOT_FPNG;
-            have_fdec = true;
-        } else if ((ck[4] & 32) == 0) {
-            return FPNG_DECODE_NOT_FPNG; // unknown critical chunk
-        }
-        ofs += 8 + (size_t)len + 4;
-    }
-    if (!have_fdec || !idat_ofs) return FPNG_DECODE_NOT_FPNG;
-    return FPNG_DECODE_SUCCESS;
-}
-
-// LSB-first bit reader confined to the zlib payload
-struct Bits {
-    const uint8_t *p;
-    size_t n;      // bytes available
-    size_t byte;   // next byte to load
-    uint64_t buf;
-    uint32_t cnt;
-    bool overrun;
-    void fill()
-    {
-        while (cnt <= 56) {
-            uint64_t b = 0;
-            if (byte < n)
-                b = p[byte];
-            byte++;
-            buf |= b << cnt;
-            cnt += 8;
-        }
-    }
-    uint32_t peek(uint32_t k)
-    {
-        if (cnt < k) fill();
-        return (uint32_t)(buf & ((1ull << k) - 1));
-    }
-    void skip(uint32_t k)
-    {
-        if (cnt < k) fill();
-        buf >>= k;
-        cnt -= k;
-    }
-    uint32_t get(uint32_t k)
-    {
-        const uint32_t v = peek(k);
-        skip(k);
-        return v;
-    }
-    // position of the next unread bit
-    size_t bitpos() const { return byte * 8 - cnt; }
-};
-
-const uint32_t kTableBits = 12;
-
-// 12-bit direct lookup: sym | len << 9 (0 = invalid)
-bool build_lookup(const uint8_t *len, uint32_t n, uint32_t *table)
-{
-    uint32_t per_len[16] = {0};
-    for (uint32_t i = 0; i < n; i++) per_len[len[i]]++;
-    per_len[0] = 0;
-    uint32_t kraft = 0, used = 0;
-    for (uint32_t l = 1; l <= 15; l++) {
-        kraft += per_len[l] << (15 - l);
-        used += per_len[l];
-    }
-    if (kraft != (1u << 15) && used != 1) return false; // complete code, or the single-code special case
-    uint32_t first[16] = {0}, code = 0;
-    for (uint32_t l = 1; l <= 15; l++) {
-        code = (code + per_len[l - 1]) << 1;
-        first[l] = code;
-    }
-    memset(table, 0, sizeof(uint32_t) << kTableBits);
-    for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = len[s];
-        if (!l) continue;
-        uint32_t c = first[l]++, r = 0;
-        for (uint32_t i = 0; i < l; i++, c >>= 1) r = (r << 1) | (c & 1);
-        for (; r < (1u << kTableBits); r += 1u << l) table[r] = s | (l << 9);
-    }
-    return true;
-}
-
-bool read_dynamic_header(Bits &in, uint32_t chans, uint32_t *lit_table)
-{
-    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    const uint32_t n_lit = in.get(5) + 257, n_dist = in.get(5) + 1, total = n_lit + n_dist;
-    if (total > 288 + 32) return false;
-    const uint32_t n_clc = in.get(4) + 4;
-    uint8_t clc[19] = {0};
-    for (uint32_t i = 0; i < n_clc; i++) clc[order[i]] = (uint8_t)in.get(3);
-    static thread_local uint32_t clc_table[1u << kTableBits];
-    if (!build_lookup(clc, 19, clc_table)) return false;
-    uint8_t sizes[288 + 32];
-    memset(sizes, 0, sizeof sizes);
-    for (uint32_t cur = 0; cur < total;) {
-        const uint32_t e = clc_table[in.peek(kTableBits)];
-        if (!(e >> 9)) return false;
-        in.skip(e >> 9);
-        const uint32_t sym = e & 511;
-        if (sym <= 15) {
-            if (sym > kTableBits) return false; // fpng never emits codes longer than 12 bits
-            sizes[cur++] = (uint8_t)sym;
-            continue;
-        }
-        uint32_t rep, val = 0;
-        if (sym == 16) {
-            rep = in.get(2) + 3;
-            if (!cur) return false;
-            val = sizes[cur - 1];
-        } else if (sym == 17)
-            rep = in.get(3) + 3;
-        else
-            rep = in.get(7) + 11;
-        if (cur + rep > total) return false;
-        while (rep--) sizes[cur++] = (uint8_t)val;
-    }
-    // distance tree: one or two 1-bit codes, the pixel distance among them
-    uint32_t one_bit = 0;
-    for (uint32_t i = 0; i < n_dist; i++) one_bit += sizes[n_lit + i] == 1;
-    if (one_bit < 1 || one_bit > 2) return false;
-    if (sizes[n_lit + chans - 1] != 1) return false;
-    if (one_bit == 2 && sizes[n_lit + chans] != 1) return false;
-    uint8_t lit[288];
-    memcpy(lit, sizes, n_lit);
-    memset(lit + n_lit, 0, 288 - n_lit);
-    return build_lookup(lit, n_lit, lit_table);
-}
+using namespace parse;
 
 bool inflate_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t *dst, uint32_t w, uint32_t h, uint32_t src_chans,
                     uint32_t dst_chans)

@@ -315,6 +315,29 @@ int fpng_amd_encode_image_sharded(fpng_amd_encoder *enc, const fpng_amd_transpor
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
 
+/* ---- GPU batch DECODE of fpng-written files (reference src/fpng.h:55-111 fpng_decode_memory; src/fpng.cpp:2209-2901), a
+ *      prototype of the data-parallel form: container and block header are parsed on the host, the pixel stream is decoded by
+ *      thousands of threads that find the token boundaries through the self-synchronisation of Huffman codes (decode.hip).
+ *      `data` is a HOST pointer to the whole .png; the pixels (desired_chans = 3 or 4 per pixel, like the reference's
+ *      desired_channels) appear in DEVICE memory.  status = the reference's fpng::FPNG_DECODE_* code for this file (0 = success);
+ *      FPNG_AMD_DECODE_UNDECIDED: the GPU path could not settle the file (its token boundaries did not synchronise in the
+ *      allotted rounds) -- decode it with fpng::fpng_decode_memory() instead; never reported for a file the CPU decoder
+ *      would reject with a different code than FPNG_DECODE_NOT_FPNG. ---- */
+#define FPNG_AMD_DECODE_UNDECIDED 64
+typedef struct fpng_amd_png {
+    const void *data; /* HOST: the file */
+    uint32_t size;
+    uint32_t reserved;
+    uint8_t *d_pixels; /* DEVICE: receives w * h * desired_chans bytes */
+    size_t pixels_cap;
+} fpng_amd_png;
+typedef struct fpng_amd_decode_result {
+    uint32_t w, h, channels_in_file;
+    int32_t status;
+} fpng_amd_decode_result;
+int fpng_amd_decode_batch(fpng_amd_encoder *enc, const fpng_amd_png *files, uint32_t n, uint32_t desired_chans,
+                          fpng_amd_decode_result *results);
+
 /* ---- table training (reference src/fpng_test.cpp:766-973 "-t" + src/fpng.cpp:909-988, both only in builds of the reference with
  *      FPNG_TRAIN_HUFFMAN_TABLES=1): from a corpus of `n` device-resident images, all with num_chans channels (the reference's
  *      harness trains the 24 bpp and the 32 bpp table on the opaque and the translucent files separately), to a new 1-pass

@@ -1,0 +1,112 @@
+"""GPU batch decoder of fpng-written files (-m gpu; fpng_amd_decode_batch, fpng_amd/csrc/decode.hip): pixels identical to the
+drop-in's CPU decoder (itself checked against the reference's, tests/test_dropin_decode.py), the reference's status codes on
+damaged files; FPNG_AMD_DECODE_UNDECIDED (= use the CPU decoder) is allowed only where the CPU decoder does not succeed either
+... or, for valid files, never in this suite."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import dropin
+import real_image
+from cpu_ref import ROOT, fuzz_image, oracle
+
+pytestmark = pytest.mark.gpu
+UNDECIDED = 64
+
+
+@pytest.fixture(scope="module")
+def enc(built_lib):
+    import torch
+    import fpng_amd
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    e = fpng_amd.Encoder(device=0)
+    yield e
+    e.close()
+
+
+def _check(enc, pngs, desired):
+    got = enc.decode_batch(pngs, desired)
+    for i, (png, (st, px, cf)) in enumerate(zip(pngs, got)):
+        cst, cpx, w, h, c = dropin.decode(png, desired)
+        assert st == cst, (i, st, cst)
+        if st == 0:
+            assert cf == c and tuple(px.shape) == (h, w, desired)
+            assert np.array_equal(px.cpu().numpy().reshape(-1), cpx), i
+
+
+@pytest.mark.parametrize("desired", [3, 4])
+def test_small_images_every_mode(enc, desired):
+    """The fuzz recipe's images (runs, vertical copies, noise; ~40 % end up as stored blocks) encoded 1-pass, 2-pass and stored,
+    decoded as one batch, to 3 and to 4 channels."""
+    rng = np.random.default_rng(11)
+    pngs = []
+    for _ in range(150):
+        img, w, h, c = fuzz_image(rng)
+        for fl in (0, 1, 2):
+            pngs.append(oracle().encode(img, w, h, c, fl))
+    _check(enc, pngs, desired)
+
+
+def test_natural_image_and_synthetic_frames(enc):
+    import torch
+    import fpng_amd
+    imgs = real_image.variants(real_image.rgb_pixels(dropin.decode))
+    ts = [torch.from_numpy(imgs[k]).cuda() for k in ("rgb", "rgba_ga", "rgb_t4")]
+    ts += [torch.from_numpy(fpng_amd.synth_image(kind, 3840, 2160, 4)).cuda() for kind in ("grad", "blocks", "noise", "solid")]
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors(ts, flags)
+        got = enc.decode_batch(pngs, 4)
+        for t, (st, px, cf) in zip(ts, got):
+            assert st == 0 and cf == t.shape[2]
+            want = t if t.shape[2] == 4 else torch.cat([t, torch.full_like(t[:, :, :1], 255)], dim=2)
+            assert torch.equal(px, want)
+        got3 = enc.decode_batch(pngs[:3], 3)
+        for t, (st, px, cf) in zip(ts[:3], got3):
+            assert st == 0 and torch.equal(px, t[:, :, :3])
+
+
+def test_8k_frame_round_trip(enc):
+    import torch
+    import fpng_amd
+    t = torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4)).cuda()
+    (png,), _ = enc.encode_tensors([t], 0)
+    ((st, px, cf),) = enc.decode_batch([png], 4)
+    assert st == 0 and cf == 4 and torch.equal(px, t)
+
+
+def test_damaged_files_get_the_reference_status(enc):
+    """Truncations, bit flips in the container and in the pixel stream, a wrong block type, a second IDAT: the status is the
+    CPU decoder's (= the reference's, tests/test_dropin_decode.py) or UNDECIDED where that one fails too; pixels equal wherever
+    both succeed (a flipped bit inside a literal still decodes)."""
+    import fpng_amd
+    rng = np.random.default_rng(12)
+    base = [oracle().encode(fpng_amd.synth_image("grad", 300, 200, 4), 300, 200, 4, 0),
+            oracle().encode(fpng_amd.synth_image("blocks", 257, 190, 3), 257, 190, 3, 1),
+            oracle().encode(fpng_amd.synth_image("noise", 64, 64, 3), 64, 64, 3, 0)]
+    pngs = []
+    for b in base:
+        pngs += [b[:n] for n in (0, 7, 30, 57, 70, len(b) // 2, len(b) - 17, len(b) - 1)]
+        for _ in range(40):
+            d = bytearray(b)
+            for _ in range(int(rng.integers(1, 4))):
+                d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            pngs.append(bytes(d))
+        d = bytearray(b)
+        d[60] ^= 0x06  # block type bits
+        pngs.append(bytes(d))
+    got = enc.decode_batch(pngs, 4)
+    n_ok = n_bad = 0
+    for i, (png, (st, px, cf)) in enumerate(zip(pngs, got)):
+        cst, cpx, w, h, c = dropin.decode(png, 4)
+        if st == UNDECIDED:
+            assert cst != 0, i
+            continue
+        assert st == cst, (i, st, cst)
+        if st == 0:
+            assert np.array_equal(px.cpu().numpy().reshape(-1), cpx), i
+            n_ok += 1
+        else:
+            n_bad += 1
+    assert n_ok > 3 and n_bad > 60

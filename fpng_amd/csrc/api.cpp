@@ -390,7 +390,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
     if ((rc = sc.d_states.ensure(n))) return rc;
     if ((rc = sc.d_results.ensure(n))) return rc;
-    if ((rc = sc.d_partials.ensure((size_t)n * sub.max_crc_blocks))) return rc;
+    if ((rc = sc.d_partials.ensure(3 * (size_t)n * sub.max_crc_blocks))) return rc; // CRC partials + two Adler words per range (stored images)
     if (two_pass) {
         if ((rc = sc.d_hist.ensure((size_t)n * 288))) return rc;
         if ((rc = sc.d_dyn.ensure(n))) return rc;
@@ -486,8 +486,8 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     }();
     const bool stagger = stagger_env < 0 ? two_pass : stagger_env == 1;
     if (stagger && e->prev_walked && !e->profiling) HIP_TRY(hipStreamWaitEvent(s, e->prev_walked, 0));
-    // five launches: rows, row scan (sizes, offsets, stored-or-compressed decision, stream head), stored fallback,
-    // assemble (+ CRC partials), finalize (CRC fold, trailer, result record).  Folding the scan into the last row block and
+    // four launches: rows, row scan (sizes, offsets, stored-or-compressed decision, stream head), assemble (rows into place or,
+    // for an image that fell back, the stored blocks; + CRC partials), finalize (CRC fold, Adler, trailer, result record).  Folding the scan into the last row block and
     // the finalize step into the last assemble block (three launches) was measured on the same box: 11 % less throughput
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
     if (!force_stored) launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
@@ -498,11 +498,10 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     }
     launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
     if ((rc = mark(e, s, ++ph))) return rc;
-    launch_stored(s, d_jobs, n, sub.max_rows, sc.d_rows.p, sc.d_states.p); // only jobs that fell back do work
+    uint32_t *adler_parts = sc.d_partials.p + (size_t)n * sub.max_crc_blocks;
+    launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, adler_parts);
     if ((rc = mark(e, s, ++ph))) return rc;
-    launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p);
-    if ((rc = mark(e, s, ++ph))) return rc;
-    launch_finalize(s, d_jobs, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, slot.results.p);
+    launch_finalize(s, d_jobs, n, sub.max_crc_blocks, sc.d_rows.p, sc.d_states.p, dt.crc, sc.d_partials.p, adler_parts, slot.results.p);
     if ((rc = mark(e, s, ++ph))) return rc;
     // the result records go straight into the slot's pinned host memory (device-visible): no copy kernel at the
     // end of the chain; they are read by the host after the `done` event
@@ -573,7 +572,7 @@ int fpng_amd_encode_wait(fpng_amd_encoder *e, uint64_t ticket, fpng_amd_result *
 
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *e)
 {
-    return (e && e->last_two_pass) ? "hist,build_dynamic,encode_rows,scan,stored,assemble,finalize" : "encode_rows,scan,stored,assemble,finalize";
+    return (e && e->last_two_pass) ? "hist,build_dynamic,encode_rows,scan,assemble,finalize" : "encode_rows,scan,assemble,finalize";
 }
 
 int fpng_amd_encoder_join(fpng_amd_encoder *e)
@@ -961,7 +960,7 @@ int fpng_amd_band_place(fpng_amd_encoder *e, const fpng_amd_band *b, uint64_t st
     HIP_TRY(hipMemsetAsync(sc.d_partials.p, 0, (size_t)j.crc_blocks * sizeof(uint32_t), s));
     launch_scan(s, sc.d_jobs.p + 3, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // absolute row offsets, stream head
     launch_assemble(s, sc.d_jobs.p + 3, 1, j.crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, g_dev[e->device].crc,
-                    sc.d_partials.p);
+                    sc.d_partials.p, nullptr);
     HIP_TRY(hipGetLastError());
     e->band_crc_ranges = crc_ranges_of(zlib_size);
     return FPNG_AMD_OK;
@@ -1019,7 +1018,7 @@ static int wrap_png(fpng_amd_encoder *e, uint8_t *d_png, size_t zlib_size, uint3
         HIP_TRY(hipMemcpyAsync(sc.d_partials.p, d_crc_partials, (size_t)n_partials * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     else
         launch_crc(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p);
-    launch_finalize(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_rows.p, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p, sc.d_results.p);
+    launch_finalize(s, sc.d_jobs.p, 1, j.crc_blocks, sc.d_rows.p, sc.d_states.p, g_dev[e->device].crc, sc.d_partials.p, nullptr, sc.d_results.p);
     HIP_TRY(hipGetLastError());
     *png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes; // asynchronous: complete when the encoder's stream gets there
     return FPNG_AMD_OK;

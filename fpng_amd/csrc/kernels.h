@@ -77,13 +77,14 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);
+// adler_parts (whole images; two words per CRC range and job, or NULL for row bands): where the workgroups of an image that
+// fell back to stored blocks leave their range's share of the Adler-32
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials);
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials, uint32_t *adler_parts);
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials);
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
-                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results);
-void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states);
+                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, const uint32_t *adler_parts, Result *results);
 // table training: sums[0..288) += the 16-bit adjusted histogram of every image (hist_all: 288 counters per image)
 void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n_images, uint64_t *sums);
 // dst[0..16) |= src[0..16): the 16-byte piece two neighbouring band windows share (each holds zeros where the other's bits are)

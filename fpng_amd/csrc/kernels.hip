@@ -11,10 +11,10 @@
 //   scan_kernel      per image: exclusive scan of row bits -> absolute bit offset of every row, Adler combine,
 //                    closed-form "did the coder run out of buffer" decision (reference fpng.cpp:567-588),
 //                    PNG header + Deflate prefix.
-//   stored_kernel    only images that fell back: stored blocks (reference fpng.cpp:818-866).
 //   assemble_kernel  shifts the local streams to their bit positions (rows meet inside a dword), stores the
 //                    file 16 bytes per lane and takes the CRC-32 of the same bytes: slice-by-16 from LDS, lane
-//                    stripes folded with GF(2) constants (reference fpng.cpp:234-292).
+//                    stripes folded with GF(2) constants (reference fpng.cpp:234-292).  Images that fell back get
+//                    their stored blocks here instead (reference fpng.cpp:818-866), straight from the pixels.
 //   finalize_kernel  folds the CRC partials, writes Adler / IDAT CRC / IEND and the result record
 //                    (reference fpng.cpp:1764-1800).
 //
@@ -1120,91 +1120,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stored-block fallback
-// ---------------------------------------------------------------------------------------------
-// Stored-block fallback, one row per wave (reference fpng.cpp:818-866 over the filter-0 stream,
-// :1728-1758).  Stream byte s of the filter-0 image sits at zlib offset 2 + 5*(s/65535+1) + s.
-__device__ void stored_row(const Job &job, uint32_t r, uint32_t lane, RowInfo *rows_out)
-{
-    const uint32_t bpl = job.bpl, n_row = bpl + 1;
-    gptr_cu8 src = to_global<gptr_cu8>(job.rows) + (size_t)r * bpl;
-    gptr_u8 z = to_global<gptr_u8>(job.out) + kPngHeaderBytes;
-    const uint64_t n_filtered = (uint64_t)n_row * job.nrows;
-    const uint64_t s0 = (uint64_t)r * n_row, s_end = s0 + n_row;
-    if (r == 0 && lane == 0) {
-        z[0] = 0x78;
-        z[1] = 0x01;
-    }
-    // Adler partial sums as in walk_row: byte sum, (bytes to the row end) x (dword byte sum), in-dword offsets
-    uint32_t acc_a = 0, acc_j = 0;
-    uint64_t acc_w = 0;
-    // The row's stream bytes [s0, s_end) = filter byte 0 + pixels.  Between stored-block boundaries the file is a
-    // shifted copy of the stream: one piece per stored block the row touches (wave-uniform loop).
-    for (uint64_t s = s0; s < s_end;) {
-        const uint64_t blk = s / kStoredBlockMax;
-        const uint64_t blk_end = (blk + 1) * kStoredBlockMax;
-        const uint64_t e = blk_end < s_end ? blk_end : s_end;
-        const uint64_t shift = 2 + 5 * (blk + 1); // file position (from the zlib header) = stream position + shift
-        if (s == blk * kStoredBlockMax && lane == 0) { // first byte of a stored block: write its 5-byte header
-            const uint64_t remaining = n_filtered - s;
-            const uint32_t len = remaining < kStoredBlockMax ? (uint32_t)remaining : kStoredBlockMax;
-            gptr_u8 h = z + s + shift - 5;
-            h[0] = (remaining <= kStoredBlockMax) ? 1 : 0;
-            h[1] = (uint8_t)len;
-            h[2] = (uint8_t)(len >> 8);
-            h[3] = (uint8_t)~len;
-            h[4] = (uint8_t)(~len >> 8);
-        }
-        uint64_t a = s;
-        if (a == s0) { // the filter-type byte
-            if (lane == 0) z[a + shift] = 0;
-            a++;
-        }
-        if (a < e) {
-            // pixels: stream bytes [a, e) = src[idx0 - 1 ...), idx0 = index in the row's stream
-            const uint32_t len = (uint32_t)(e - a), idx0 = (uint32_t)(a - s0);
-            gptr_u8 dst = z + a + shift;
-            gptr_cu8 sp = src + (idx0 - 1);
-            uint32_t head = (uint32_t)(0u - (uint32_t)(uintptr_t)dst) & 3u; // bytes up to the next destination dword
-            if (head > len) head = len;
-            const uint32_t body = (len - head) >> 2, tail = (len - head) & 3u;
-            if (lane < head + tail) { // the few unaligned bytes at both ends, one per lane
-                const uint32_t o = lane < head ? lane : head + 4 * body + (lane - head);
-                const uint32_t v = sp[o];
-                dst[o] = (uint8_t)v;
-                acc_a += v;
-                acc_w += (uint64_t)(n_row - (idx0 + o)) * v;
-            }
-            // destination-aligned dwords; the source is read as aligned dwords too and re-aligned with v_alignbyte
-            gptr_u32 d32 = (gptr_u32)(uintptr_t)(dst + head);
-            const uint32_t m = (uint32_t)(uintptr_t)(sp + head) & 3u;
-            gptr_cu32 s32 = (gptr_cu32)(uintptr_t)(sp + head - m);
-            for (uint32_t i = lane; i < body; i += kWave) {
-                const uint32_t lo = s32[i];
-                const uint32_t hi = m ? s32[i + 1] : 0u; // both words hold bytes of the piece: never outside the image's pages
-                const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, m);
-                d32[i] = v;
-                const uint32_t bs = __builtin_amdgcn_sad_u8(v, 0u, 0u);
-                acc_a += bs;
-                acc_w += (uint64_t)(n_row - (idx0 + head + 4 * i)) * bs;
-                acc_j = __builtin_amdgcn_udot4(v, 0x03020100u, acc_j, false);
-            }
-        }
-        s = e;
-    }
-    const uint32_t s1 = wave_sum(acc_a % kAdlerMod) % kAdlerMod;
-    const uint32_t s2 = wave_sum((uint32_t)((acc_w - acc_j) % kAdlerMod)) % kAdlerMod;
-    if (lane == 0) {
-        RowInfo ri;
-        ri.bits = 0;
-        ri.s1 = s1;
-        ri.s2 = s2;
-        ri.pad = 0;
-        rows_out[job.row_base + r] = ri; // overwrites the compressed-mode partials: finalize recombines
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // encode_rows_kernel: grid (ceil(max_rows/8), n_jobs).  ONE walk over the pixels of a whole image: each wave
 // encodes its row into the row's private, dword-aligned local stream (plain coalesced stores, nothing is
 // shared between rows) and records the row's token bits and Adler sums for scan_kernel.
@@ -1383,7 +1298,7 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *red64)
 // One block (kBlock threads) finishes one image: CRC fold, Adler, IDAT CRC, IEND, result record.  `partials` of a
 // launch that calls this from its own last block were written by other workgroups: granule-style loads.
 __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows, JobState &st, const CrcDeviceTables *tabs,
-                                             const uint32_t *pj, Result &result, uint32_t *red, uint64_t *red64)
+                                             const uint32_t *pj, const uint32_t *aj, Result &result, uint32_t *red, uint64_t *red64)
 {
     const uint32_t t = threadIdx.x;
     if (!job.whole_png) {
@@ -1394,17 +1309,17 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
         }
         return;
     }
+    const uint64_t zlib_size = st.zlib_size;
+    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
+    const int64_t end_aligned = (data_end + 15) & ~15ll;
+    const uint32_t rl = crc_range_log2(st);
+    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
     uint32_t adler = st.adler;
-    if (st.mode == 1u) {
-        // stored mode: Adler of the filter-0 stream from the per-row partials written by stored_row
-        const uint32_t n_row_mod = (job.bpl + 1u) % kAdlerMod;
+    if (st.mode == 1u && aj) {
+        // stored mode: Adler-32 of the filter-0 stream from the ranges' sums (assemble_stored): byte sums, and sums weighted with
+        // the bytes from each byte to the end of the stream
         uint64_t s1 = 0, s2 = 0;
-        for (uint32_t r = t; r < job.nrows; r += kBlock) {
-            const RowInfo ri = rows[job.row_base + r];
-            const uint64_t after = ((uint64_t)(job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
-            s1 += ri.s1;
-            s2 += (ri.s2 + after * ri.s1) % kAdlerMod;
-        }
+        for (uint32_t j = t; j < n_ranges; j += kBlock) s1 += aj[2 * j], s2 += aj[2 * j + 1];
         const uint64_t S1 = block_sum_u64(s1 % kAdlerMod, red64) % kAdlerMod;
         const uint64_t S2 = block_sum_u64(s2 % kAdlerMod, red64) % kAdlerMod;
         const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
@@ -1413,11 +1328,6 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
 
     // ---- fold the CRC partials.  Partial j sits (j ranges + one block row) before the common end
     //      point, so  T = XOR_j p_j * X^j  with X = x^(8*64Ki); all needed constants are x^(8*2^i). ----
-    const uint64_t zlib_size = st.zlib_size;
-    const int64_t data_end = (int64_t)(kPngHeaderBytes + zlib_size - 4);
-    const int64_t end_aligned = (data_end + 15) & ~15ll;
-    const uint32_t rl = crc_range_log2(st);
-    const uint32_t n_ranges = (uint32_t)((end_aligned - 48 + (1ll << rl) - 1) >> rl);
     uint32_t g = 0; // each thread folds G = 2^g consecutive partials
     while (((uint64_t)kBlock << g) < n_ranges) g++;
     const uint32_t G = 1u << g;
@@ -1486,12 +1396,13 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
 }
 
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const RowInfo *rows, JobState *states,
-                                                         const CrcDeviceTables *tabs, const uint32_t *partials,
+                                                         const CrcDeviceTables *tabs, const uint32_t *partials, const uint32_t *adler_parts,
                                                          uint32_t max_crc_blocks, Result *results)
 {
     __shared__ uint32_t red[kBlock];
     __shared__ uint64_t red64[kBlock];
-    finalize_job(jobs[blockIdx.x], rows, states[blockIdx.x], tabs, partials + (size_t)blockIdx.x * max_crc_blocks, results[blockIdx.x], red, red64);
+    finalize_job(jobs[blockIdx.x], rows, states[blockIdx.x], tabs, partials + (size_t)blockIdx.x * max_crc_blocks,
+                 adler_parts ? adler_parts + 2 * (size_t)blockIdx.x * max_crc_blocks : nullptr, results[blockIdx.x], red, red64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1502,12 +1413,145 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const Job *jobs, const
 // written twice, so the rows need no atomics and no zeroed seams.  Stored-mode jobs only take the CRC.
 // ---------------------------------------------------------------------------------------------
 
+// Stored-block fallback (reference fpng.cpp:818-866 over the filter-0 stream, :1728-1758), done by the same workgroups that
+// would otherwise place the compressed rows: the block's range of the FILE is produced straight from the pixels --
+//   zlib offset z:  0,1 = 78 01;  stored block k: header at 2 + 65540 k (BFINAL, LEN, ~LEN), data = stream bytes
+//   [65535 k, ...) behind it;  stream byte s = filter byte 0 (s % (bpl+1) == 0) or pixel byte (row s / (bpl+1), s % (bpl+1) - 1)
+// -- together with its CRC partial and its share of the Adler-32 (byte sum, position-weighted sum: finalize_kernel adds the
+// ranges up).  A piece of 16 file bytes that lies inside one stored block and one row is 16 consecutive pixel bytes (5 aligned
+// loads + v_alignbyte); pieces with a block header, a filter byte or the ends of the stream are built byte by byte.
+__device__ __forceinline__ uint32_t stored_stream_byte(const Job &job, gptr_cu8 px, uint32_t s)
+{
+    const uint32_t stride = job.bpl + 1, row = s / stride, col = s - row * stride;
+    return col ? (uint32_t)px[(size_t)row * job.bpl + col - 1] : 0u;
+}
+
+__device__ __forceinline__ void assemble_stored(const Job &job, const JobState &st, int64_t range_begin, uint32_t range_bytes, int32_t db, int32_t de,
+                                                uint32_t (*tab)[256], uint32_t *red, const CrcDeviceTables *tabs, uint32_t *crc_out, uint32_t *adler_out)
+{
+    const uint32_t tid = threadIdx.x, stride = job.bpl + 1;
+    const uint32_t n_filtered = stride * job.nrows; // (< 2^32: check_dims)
+    gptr_cu8 px = to_global<gptr_cu8>(job.rows);
+    gptr_u8 file = to_global<gptr_u8>(job.out);
+    // the lane's position in the stored-block structure, kept up from step to step (one step = 4096 file bytes further)
+    int64_t z = range_begin + (int64_t)tid * 16 - kPngHeaderBytes; // zlib offset of the lane's piece
+    uint64_t k = 0;
+    uint32_t w = 0; // z = 2 + 65540 k + w  (valid when z >= 2)
+    if (z >= 2) k = (uint64_t)(z - 2) / 65540u, w = (uint32_t)((uint64_t)(z - 2) - k * 65540u);
+    uint32_t c = 0;
+    uint64_t a_sum = 0, w_sum = 0;
+    for (uint32_t row = 0; row < range_bytes / kCrcRowBytes; row++) {
+        const int32_t o = (int32_t)(row * kCrcRowBytes + tid * 16);
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (o + 16 > db && o < de) {
+            const int64_t fo = range_begin + o;
+            bool fast = false;
+            if (z >= 7 && w >= 5 && w <= 65540u - 16u) {
+                const uint64_t s0 = k * 65535u + (w - 5);
+                if (s0 + 16 <= n_filtered) {
+                    const uint32_t s32 = (uint32_t)s0, r = s32 / stride, col = s32 - r * stride;
+                    if (col >= 1 && col + 16 <= stride) { // 16 consecutive pixel bytes
+                        fast = true;
+                        gptr_cu8 p = px + (size_t)r * job.bpl + (col - 1);
+                        const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
+                        gptr_cu32 q = (gptr_cu32)(uintptr_t)(p - m);
+                        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = m ? q[4] : 0u; // (never outside the image's bytes' words)
+                        v[0] = __builtin_amdgcn_alignbyte(q1, q0, m), v[1] = __builtin_amdgcn_alignbyte(q2, q1, m);
+                        v[2] = __builtin_amdgcn_alignbyte(q3, q2, m), v[3] = __builtin_amdgcn_alignbyte(q4, q3, m);
+                        uint32_t a = 0, dj = 0;
+                        constexpr uint32_t kOffs[4] = {0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu};
+#pragma unroll
+                        for (int t = 0; t < 4; t++) a = __builtin_amdgcn_sad_u8(v[t], 0u, a), dj = __builtin_amdgcn_udot4(v[t], kOffs[t], dj, false);
+                        a_sum += a;
+                        w_sum += (uint64_t)(n_filtered - s32) * a - dj; // weight of stream byte s: bytes from it to the end of the stream
+                    }
+                }
+            }
+            if (!fast) {
+                uint64_t kk = k;
+                uint32_t ww = w;
+                for (int j = 0; j < 16; j++) {
+                    const int64_t zj = z + j;
+                    uint32_t b = 0;
+                    if (zj == 0)
+                        b = 0x78;
+                    else if (zj == 1)
+                        b = 0x01;
+                    else if (zj >= 2) {
+                        if (zj == 2) kk = 0, ww = 0;
+                        if (ww < 5) { // header of stored block kk
+                            const uint64_t done = kk * 65535u;
+                            if (done < n_filtered) {
+                                const uint32_t remaining = n_filtered - (uint32_t)done, len = remaining < kStoredBlockMax ? remaining : kStoredBlockMax;
+                                b = ww == 0 ? (remaining <= kStoredBlockMax ? 1u : 0u) : ww == 1 ? (len & 0xFF) : ww == 2 ? (len >> 8) : ww == 3 ? (~len & 0xFF) : ((~len >> 8) & 0xFF);
+                            }
+                        } else {
+                            const uint64_t sj = kk * 65535u + (ww - 5);
+                            if (sj < n_filtered) {
+                                b = stored_stream_byte(job, px, (uint32_t)sj);
+                                a_sum += b;
+                                w_sum += (uint64_t)(n_filtered - (uint32_t)sj) * b;
+                            }
+                        }
+                        if (++ww == 65540u) ww = 0, kk++;
+                    }
+                    v[j >> 2] |= b << (8 * (j & 3));
+                }
+            }
+            if (fo >= 64) { // (a whole piece behind the PNG header; bytes behind the data are finalize_kernel's, written afterwards)
+                u32x4 d;
+                d.x = v[0], d.y = v[1], d.z = v[2], d.w = v[3];
+                *(gptr_u128)(uintptr_t)(file + fo) = d;
+            } else {
+                for (int j = 0; j < 16; j++)
+                    if (fo + j >= (int64_t)kPngHeaderBytes) file[fo + j] = (uint8_t)(v[j >> 2] >> (8 * (j & 3)));
+            }
+            if (o < db || o + 16 > de) { // the CRC covers [data_begin, data_end)
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) {
+                    uint32_t msk = 0;
+#pragma unroll
+                    for (int bq = 0; bq < 4; bq++) {
+                        const int32_t pos = o + 4 * kq + bq;
+                        if (pos >= db && pos < de) msk |= 0xFFu << (8 * bq);
+                    }
+                    v[kq] &= msk;
+                }
+            }
+        }
+        v[0] ^= c;
+        uint32_t nx = 0;
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++)
+            nx ^= tab[4 * kq + 0][v[kq] & 0xFF] ^ tab[4 * kq + 1][(v[kq] >> 8) & 0xFF] ^ tab[4 * kq + 2][(v[kq] >> 16) & 0xFF] ^ tab[4 * kq + 3][v[kq] >> 24];
+        c = nx;
+        // one step further in the file
+        z += kCrcRowBytes;
+        if (z >= 2) {
+            if (z - (int64_t)kCrcRowBytes < 2)
+                k = (uint64_t)(z - 2) / 65540u, w = (uint32_t)((uint64_t)(z - 2) - k * 65540u);
+            else if ((w += kCrcRowBytes) >= 65540u)
+                w -= 65540u, k++;
+        }
+    }
+    c = wave_xor(dev_mulmod(c, tabs->lane_fix[tid]));
+    const uint32_t s1 = wave_sum((uint32_t)(a_sum % kAdlerMod)), s2 = wave_sum((uint32_t)(w_sum % kAdlerMod));
+    if ((tid & 63) == 0) red[tid >> 6] = c, red[kWavesPerBlock + (tid >> 6)] = s1, red[2 * kWavesPerBlock + (tid >> 6)] = s2;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t x = 0, t1 = 0, t2 = 0;
+        for (int q = 0; q < kWavesPerBlock; q++) x ^= red[q], t1 += red[kWavesPerBlock + q], t2 += red[2 * kWavesPerBlock + q];
+        *crc_out = x;
+        adler_out[0] = t1 % kAdlerMod, adler_out[1] = t2 % kAdlerMod;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
-                                                         uint32_t max_crc_blocks)
+                                                         uint32_t *adler_parts, uint32_t max_crc_blocks)
 {
     __shared__ uint32_t tab[16][256];
-    __shared__ uint32_t red[kWavesPerBlock];
+    __shared__ uint32_t red[3 * kWavesPerBlock];
     const Job &job = job_of_block(jobs);
     JobState &st = states[blockIdx.y];
     // row bands (flag 0x100): the rows of a band land in a private window that shares the whole file's geometry
@@ -1537,6 +1581,11 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
     gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
 
     const bool gather = uniform(st.mode) == 0u;
+    if (!gather && job.whole_png && adler_parts) { // the image fell back to stored blocks: this workgroup writes its range of them
+        const size_t slot = (size_t)blockIdx.y * max_crc_blocks + blockIdx.x;
+        assemble_stored(job, st, range_begin, range_bytes, db, de, tab, red, tabs, &partials[slot], &adler_parts[2 * slot]);
+        return;
+    }
     const int64_t bit0 = range_begin * 8 - job.bit_bias; // zlib bit position of relative bit 0
     const uint32_t R = uniform(job.nrows);
     const uint32_t stride = uniform(job.local_stride);
@@ -2100,20 +2149,6 @@ __global__ __launch_bounds__(kWave) void train_accumulate_kernel(const uint32_t 
 
 __global__ void or_piece_kernel(uint32_t *dst, const uint32_t *src) { dst[threadIdx.x] |= src[threadIdx.x]; }
 
-// stored-block fallback as its own launch: the whole-image pipeline decides after encoding (scan_kernel)
-__global__ __launch_bounds__(kRowBlock) void stored_kernel(const Job *jobs, RowInfo *rows_io, const JobState *states)
-{
-    // a small grid that strides over the row blocks: in the common case (nothing fell back) the launch costs a
-    // handful of workgroups instead of one per 8 rows, which matters when another stream keeps the dispatcher busy
-    const Job &job = job_of_block(jobs);
-    if (states[blockIdx.y].mode != 1u) return;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t rb = blockIdx.x; rb * kRowWaves < job.nrows; rb += gridDim.x) {
-        const uint32_t r = rb * kRowWaves + wv;
-        if (r < job.nrows) stored_row(job, r, lane, rows_io);
-    }
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2145,10 +2180,10 @@ void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_
         hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
 }
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
-                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials)
+                     const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials, uint32_t *adler_parts)
 {
     hipLaunchKernelGGL(assemble_kernel, dim3(max_crc_blocks, n_jobs), dim3(kBlock), 0, s, jobs, states, row_off, local, tabs,
-                       partials, max_crc_blocks);
+                       partials, adler_parts, max_crc_blocks);
 }
 void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const JobState *states,
                 const CrcDeviceTables *tabs, uint32_t *partials)
@@ -2157,18 +2192,12 @@ void launch_crc(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_cr
                        max_crc_blocks);
 }
 void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, const RowInfo *rows,
-                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, Result *results)
+                     JobState *states, const CrcDeviceTables *tabs, const uint32_t *partials, const uint32_t *adler_parts, Result *results)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, states, tabs, partials, max_crc_blocks,
+    hipLaunchKernelGGL(finalize_kernel, dim3(n_jobs), dim3(kBlock), 0, s, jobs, rows, states, tabs, partials, adler_parts, max_crc_blocks,
                        results);
 }
 
-void launch_stored(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, RowInfo *rows, const JobState *states)
-{
-    const uint32_t row_blocks = (max_rows + kRowWaves - 1) / kRowWaves;
-    const uint32_t per_job = std::max(1u, std::min(row_blocks, 2048u / std::max(1u, n_jobs)));
-    hipLaunchKernelGGL(stored_kernel, dim3(per_job, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states);
-}
 void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n_images, uint64_t *sums)
 {
     hipLaunchKernelGGL(train_accumulate_kernel, dim3(n_images), dim3(kWave), 0, s, hist_all, (unsigned long long *)sums);

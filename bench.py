@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="8k")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--kind", default="grad")
@@ -54,6 +54,8 @@ def parse():
                     help="timed regions per run, each EXACTLY --steps steps between two barriers; value = the median region, "
                          "`runs` / `spread` report all of them (a single 10 ms region cannot show a 5 %% change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object for --workload WxHxC and exit")
+    ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--cpu-reps", type=int, default=5)
     return ap.parse_args()
 
@@ -133,6 +135,21 @@ def _cpu_worker(task):
 
 
 def end_to_end(enc_device, w, h, c, kind, flags):
+    """The host-pixel paths in a FRESH process (a user of the reference's API has no other GPU work in its process; and how
+    the runtime overlaps pageable copies turned out to depend on what the process did before, profiles/r03_host_path.txt)."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--end-to-end-only", "--workload", f"{w}x{h}x{c}", "--kind", kind,
+                              "--flags", str(flags), "--device", str(enc_device)], capture_output=True, text=True, timeout=600)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": (out.stderr or out.stdout)[-200:]}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
+def end_to_end_here(enc_device, w, h, c, kind, flags):
     """The drop-in's view (SURVEY 8d timing 2): host pixels in, host PNG out, PCIe inclusive -- one blocking call per frame
     (what fpng::fpng_encode_image_to_memory does) and the many-frames form whose copies overlap.  Never `value`."""
     import fpng_amd
@@ -148,11 +165,40 @@ def end_to_end(enc_device, w, h, c, kind, flags):
         t0 = time.perf_counter()
         enc.encode_host_batch(imgs, flags, outs=outs)
         bestn = min(bestn, (time.perf_counter() - t0) / n)
+    # the same frame in PAGE-LOCKED memory (fpng_amd_pin_host_memory): streamed through the GPU in row bands, upload | encode |
+    # download overlapped
+    bestp = None
+    try:
+        fpng_amd.pin_host_memory(imgs[0])
+        bestp = 1e30
+        for _ in range(4):
+            t0 = time.perf_counter()
+            enc.encode_host_into(imgs[0], w, h, c, outs[0], flags)
+            bestp = min(bestp, time.perf_counter() - t0)
+        fpng_amd.unpin_host_memory(imgs[0])
+    except Exception:
+        bestp = None
     enc.close()
     mp = w * h / 1e6
-    return {"single_call_ms": round(best1 * 1e3, 3), "single_call_MPs": round(mp / best1, 1), "frames_per_batch_call": n,
-            "batch_ms_per_frame": round(bestn * 1e3, 3), "batch_MPs": round(mp / bestn, 1),
-            "note": "host pixels -> host PNG through the C ABI the fpng:: drop-in uses, pageable memory, PCIe inclusive"}
+    out = {"single_call_ms": round(best1 * 1e3, 3), "single_call_MPs": round(mp / best1, 1), "frames_per_batch_call": n,
+           "batch_ms_per_frame": round(bestn * 1e3, 3), "batch_MPs": round(mp / bestn, 1),
+           "note": "host pixels -> host PNG through the C ABI the fpng:: drop-in uses, pageable memory, PCIe inclusive"}
+    if bestp:
+        out["single_call_page_locked_ms"] = round(bestp * 1e3, 3)
+        out["single_call_page_locked_MPs"] = round(mp / bestp, 1)
+    # ... and through libfpng.so itself: fpng::fpng_encode_image_to_memory() into one reused std::vector, timed in C++ like the
+    # reference's harness does (fpng_test.cpp:1198-1209; SURVEY 8d timing 2 "incl. vector resize")
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import dropin
+        t, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=6, reuse=True)
+        tf, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=3, reuse=False)
+        out["dropin_ms"] = round(t * 1e3, 3)
+        out["dropin_MPs"] = round(mp / t, 1)
+        out["dropin_fresh_vector_ms"] = round(tf * 1e3, 3)
+    except Exception as e:  # (needs g++ for the test shim)
+        out["dropin_error"] = str(e)[:80]
+    return out
 
 
 def cpu_baseline(w, h, c, kind, flags, reps):
@@ -276,6 +322,13 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
 
 def main():
     args = parse()
+    if args.end_to_end_only:
+        w, h, c = (int(v) for v in args.workload.split("x"))
+        torch.cuda.set_device(args.device)
+        print(json.dumps(end_to_end_here(args.device, w, h, c, args.kind, args.flags)), flush=True)
+        return
+    if args.workload not in WORKLOADS:
+        raise SystemExit(f"--workload: one of {sorted(WORKLOADS)}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -129,6 +129,10 @@ class Node:
     def size(self):
         return self.lib.fpng_amd_node_size(self.h)
 
+    def last_host_bands(self):
+        """Row bands the last encode_host*() call was streamed in (1 = upload, encode, download one after the other)."""
+        return self.lib.fpng_amd_encoder_last_host_bands(self.h)
+
     def encode_host_batch(self, images, flags=0, outs=None, paths=None, writer_threads=0):
         arr, sizes, keep = _host_batch_records(images, outs, paths)
         check(self.lib.fpng_amd_node_encode_host_batch(self.h, arr, len(images), flags, writer_threads))
@@ -363,6 +367,10 @@ class Encoder:
         check(self.lib.fpng_amd_encode_host(self.h, b.ctypes.data, w, h, num_chans, flags, out.ctypes.data, out.size,
                                             C.byref(n)))
         return n.value
+
+    def last_host_bands(self):
+        """Row bands the last encode_host*() call was streamed in (1 = upload, encode, download one after the other)."""
+        return self.lib.fpng_amd_encoder_last_host_bands(self.h)
 
     def encode_host_batch(self, images, flags=0, outs=None, paths=None, writer_threads=0):
         """Many host frames (uint8 arrays shaped (h, w, c)): uploads, encodes, downloads and file writes of consecutive

@@ -150,6 +150,8 @@ struct fpng_amd_encoder {
     uint64_t band_self_end = 0;   // placement with zlib_size == 0: file offset of the window's end (the CRC ranges hang off it)
     PinnedBuf<uint32_t> h_partials; // fpng_amd_band_crc(): the band's partials on their way to the host-side fold
     DeviceBuf<uint32_t> d_stream_partials; // fpng_amd_encode_host_to(): partials of all bands of the frame
+    uint32_t last_host_bands = 0;  // row bands of the last fpng_amd_encode_host*() call (1 = the serial path)
+    size_t last_host_png_size = 0; // fpng_amd_encode_host_to(): size of the previous file (the next call's estimate)
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
     struct HostWorkers *workers = nullptr; // fpng_amd_encode_host_to(): the uploader and downloader threads (pipeline.cpp)
     hipEvent_t band_copied[4] = {}; // the pinned job record h_jobs[k] of an asynchronous band call has been uploaded

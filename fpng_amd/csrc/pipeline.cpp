@@ -220,6 +220,47 @@ void fpng_amd::destroy_host_workers(fpng_amd_encoder *e)
 
 namespace {
 
+// Host ranges that have been through the SERIAL path once (or were page-locked through fpng_amd_pin_host_memory).  Measured
+// (profiles/r03_host_path.txt): whether the runtime overlaps copies from / to a pageable buffer in the two directions is decided
+// by how that buffer was copied the FIRST time -- after one plain upload + download on a single stream it overlaps from then
+// on (8K RGBA: 2.8 ms per streamed call), first touched by overlapping copies it never does (3.55 ms, the same as the serial
+// path, which is why a stale entry -- a freed buffer's address handed out again -- costs nothing but the gain).  A capture
+// loop reuses its buffers, so its second frame is streamed.  (hipPointerGetAttributes() is NOT used to recognise page-locked
+// memory: asked about a pageable pointer it leaves that buffer in the never-overlapping state.)
+struct KnownRanges {
+    std::mutex mu;
+    struct R { uintptr_t p; size_t n; uint32_t seen; };
+    std::vector<R> r;
+    bool has(const void *p, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : r)
+            if ((uintptr_t)p >= e.p && (uintptr_t)p + n <= e.p + e.n) return true;
+        return false;
+    }
+    void remove(const void *p)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < r.size(); i++)
+            if (r[i].p == (uintptr_t)p) {
+                r.erase(r.begin() + i);
+                return;
+            }
+    }
+    void add(const void *p, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : r)
+            if (e.p == (uintptr_t)p) {
+                e.n = std::max(e.n, n);
+                e.seen++;
+                return;
+            }
+        if (r.size() >= 64) r.erase(r.begin());
+        r.push_back({(uintptr_t)p, n, 1u});
+    }
+} g_known;
+
 struct FixedOut {
     uint8_t *p;
     size_t cap;
@@ -252,6 +293,9 @@ int encode_host_serial(fpng_amd_encoder *e, const void *pixels, bool uploaded, u
     uint8_t *out = reserve(user, (size_t)res.png_size); // the size is known before a single output byte moves
     if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "output buffer too small");
     HIP_TRY(hipMemcpy(out, e->d_stage_out.p, res.png_size, hipMemcpyDeviceToHost));
+    if (!uploaded) g_known.add(pixels, in_bytes); // both buffers have now been copied once, one direction at a time
+    g_known.add(out, (size_t)res.png_size);
+    e->last_host_png_size = (size_t)res.png_size;
     return FPNG_AMD_OK;
 }
 
@@ -262,17 +306,6 @@ int host_bands_forced()
         return v ? atoi(v) : 0;
     }();
     return forced;
-}
-
-bool is_page_locked(const void *p)
-{
-    hipPointerAttribute_t a;
-    std::memset(&a, 0, sizeof a);
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError(); // (plain malloc'ed memory: not an error of ours)
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
 }
 
 uint32_t host_bands_for(size_t in_bytes, uint32_t h)
@@ -297,8 +330,21 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     // pageable memory in the two directions take turns on this platform (measured per 8K band: 16.6 MB up + 7.3 MB down
     // 428 + 425 us side by side instead of 306 + 170; profiles/r03_host_path.txt), so such frames go the serial way.
     uint32_t nb = 1;
-    if (!(flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED)) && (host_bands_forced() || is_page_locked(pixels)))
+    if (!(flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED))) {
         nb = host_bands_for(in_bytes, h);
+        if (nb >= 2 && !host_bands_forced()) {
+            // only buffers that have been through the serial path before, or were page-locked through
+            // fpng_amd_pin_host_memory() (see KnownRanges); the output buffer is asked for up front with the size of the
+            // previous file as the estimate
+            bool ok = g_known.has(pixels, in_bytes) && e->last_host_png_size;
+            if (ok) {
+                const uint8_t *o = reserve(user, std::min(e->last_host_png_size, max_out));
+                ok = o && g_known.has(o, std::min(e->last_host_png_size, max_out));
+            }
+            if (!ok) nb = 1;
+        }
+    }
+    e->last_host_bands = nb;
     if (nb < 2) return encode_host_serial(e, pixels, false, w, h, c, flags, reserve, user, out_size);
 
     // ---- streamed: band k+1 goes up while band k is encoded and placed and band k-1's window comes down ----
@@ -477,7 +523,7 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
         stored = plan.stored != 0;
     }
     if (stored) // incompressible: the reference's stored-block outcome, decided and written by the whole-image path
-        return encode_host_serial(e, pixels, true, w, h, c, flags, reserve, user, out_size);
+        return e->last_host_bands = 1, encode_host_serial(e, pixels, true, w, h, c, flags, reserve, user, out_size);
 
     // ---- the container around the windows (reference src/fpng.cpp:1764-1800), a few dozen bytes on the host ----
     HIP_TRY(hipMemcpyAsync(e->h_partials.p, e->d_stream_partials.p, (size_t)nb * rec_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -503,19 +549,24 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     std::memcpy(out, head, kPngHeaderBytes);
     std::memcpy(out + kPngHeaderBytes + plan.zlib_size - 4, tail, 20);
     *out_size = png_size;
+    e->last_host_png_size = png_size;
     return FPNG_AMD_OK;
 }
+
+extern "C" int fpng_amd_encoder_last_host_bands(fpng_amd_encoder *e) { return e ? (int)e->last_host_bands : 0; }
 
 extern "C" int fpng_amd_pin_host_memory(void *p, size_t bytes)
 {
     if (!p || !bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty range");
     HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    g_known.add(p, bytes); // page-locked memory overlaps from its first copy on
     return FPNG_AMD_OK;
 }
 
 extern "C" int fpng_amd_unpin_host_memory(void *p)
 {
     if (!p) return fail(FPNG_AMD_ERR_INVALID_ARG, "null pointer");
+    g_known.remove(p);
     HIP_TRY(hipHostUnregister(p));
     return FPNG_AMD_OK;
 }

@@ -79,8 +79,8 @@ size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
  *                                   need more is refused with FPNG_AMD_ERR_OUT_OF_MEMORY before anything is launched
  *      FPNG_AMD_STAGGER=0|1         2-pass: make a submission's row walk wait for the previous submission's walk
  *                                   (default: on for FPNG_AMD_ENCODE_SLOWER, off otherwise)
- *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline, also
- *                                   for pageable pixels (default: by image size and only for page-locked pixels; 1 = serial)
+ *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline for every
+ *                                   1-pass frame (default: by image size, for page-locked or previously seen buffers; 1 = serial)
  *      FPNG_AMD_TRACE=1             fpng_amd_encode_host(): per-band timeline of the streamed path on stderr ---- */
 
 /* ---- encoder object: the caller's HIP stream (ordering point) + two internal streams ("lanes") with
@@ -152,13 +152,16 @@ int fpng_amd_encode_host(fpng_amd_encoder *enc, const void *pixels, uint32_t w, 
  * while the call runs and never concurrently, possibly from a helper thread.  Large 1-pass frames are STREAMED: the frame is
  * cut into row bands, band k+1 is uploaded while band k is encoded and placed and band k-1's piece of the file is downloaded,
  * so a call takes about max(upload, download) instead of their sum (one 8K RGBA frame: 2.8 instead of 3.6 ms).
- * Streaming needs PAGE-LOCKED pixels: on this platform copies from pageable memory in the two directions take turns instead
- * of overlapping, so frames in ordinary malloc'ed memory take the serial path (upload, encode, size, download).  A capture
- * loop that reuses its frame buffer page-locks it once with fpng_amd_pin_host_memory() (= hipHostRegister; undo with
- * fpng_amd_unpin_host_memory() BEFORE freeing the buffer). */
+ * Which frames are streamed: buffers page-locked with fpng_amd_pin_host_memory() (= hipHostRegister; undo with
+ * fpng_amd_unpin_host_memory() BEFORE freeing the buffer) always; ordinary (pageable) buffers from the SECOND call with the
+ * same pixel and output buffers on -- the first call takes the serial path (upload, encode, size, download), because on this platform copies
+ * from / to a pageable buffer only overlap in the two directions if the buffer's first copies did not (measured,
+ * profiles/r03_host_path.txt).  A capture loop reuses its buffers, so all frames but its first are streamed. */
 typedef uint8_t *(*fpng_amd_reserve_fn)(void *user, size_t bytes);
 int fpng_amd_encode_host_to(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
                             uint32_t flags, fpng_amd_reserve_fn reserve, void *user, size_t *out_size);
+/* Row bands the last fpng_amd_encode_host() / _host_to() call of this encoder was streamed in (1 = the serial path). */
+int fpng_amd_encoder_last_host_bands(fpng_amd_encoder *enc);
 int fpng_amd_pin_host_memory(void *p, size_t bytes);
 int fpng_amd_unpin_host_memory(void *p);
 

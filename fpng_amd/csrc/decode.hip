@@ -231,6 +231,20 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
     uint64_t o = off[g];
     uint32_t row = (uint32_t)(o / stride), col = (uint32_t)(o - (uint64_t)row * stride);
     uint8_t *F = job.filt;
+    const uint32_t fstride = job.fstride;
+    // literals are collected into the dword they fall in and stored with one instruction when all four of its bytes are
+    // literals of THIS thread; bytes of run pixels are dec_fill_kernel's, a dword shared with the neighbouring thread or broken
+    // by a run is stored byte by byte (buffer byte of stream position (row, col): row * fstride + 3 + col)
+    size_t cur = ~(size_t)0; // dword (byte address / 4) being collected
+    uint32_t acc = 0, have = 0;
+    auto flush = [&]() {
+        if (have == 0xFu)
+            *(uint32_t *)(F + cur * 4) = acc;
+        else
+            for (uint32_t k = 0; k < 4; k++)
+                if (have & (1u << k)) F[cur * 4 + k] = (uint8_t)(acc >> (8 * k));
+        have = 0, acc = 0;
+    };
     uint32_t err = 0;
     while (in.pos < boundary) {
         if (in.pos >= in.limit) {
@@ -253,7 +267,14 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
                 err = kDecBadStream;
                 break;
             }
-            F[o] = (uint8_t)t;
+            if (col) { // (the filter literal itself is not kept)
+                const size_t a = (size_t)row * fstride + 3 + col;
+                if ((a >> 2) != cur) {
+                    if (have) flush();
+                    cur = a >> 2;
+                }
+                acc |= (uint32_t)t << (8 * (a & 3)), have |= 1u << (a & 3);
+            }
             o++;
             if (++col == stride) col = 0, row++;
         } else {
@@ -274,6 +295,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
             if (col == stride) col = 0, row++;
         }
     }
+    if (have) flush();
     if (err) atomicOr(&status[job_index], err);
 }
 
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_fill_kernel(const DecJob *jobs,
     const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * (kDecBlock / kWave) + dec_uniform(threadIdx.x >> 6);
     if (row >= job.h) return;
     const uint32_t c = job.src_c, wpr = (job.w + 31) >> 5;
-    uint8_t *F = job.filt + (size_t)row * (job.bpl + 1) + 1;
+    uint8_t *F = job.filt + (size_t)row * job.fstride + 4;
     const uint32_t *m = job.runmask + (size_t)row * wpr;
     uint32_t carry = 0; // value of the last pixel of the previous window (filtered bytes, packed)
     for (uint32_t x0 = 0; x0 < job.w; x0 += 64) {
@@ -315,24 +337,35 @@ __global__ __launch_bounds__(kDecBlock) void dec_fill_kernel(const DecJob *jobs,
     }
 }
 
-// ---- Up filter undone: out[y] = out[y-1] + filtered[y] per byte column; 3 <-> 4 channels on the way out ----
+// ---- Up filter undone: out[y] = out[y-1] + filtered[y]; one thread per DWORD column (four byte columns: packed byte adds),
+//      3 <-> 4 channels on the way out ----
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)
+{
+    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+}
 __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, const uint32_t *status)
 {
     const DecJob &job = jobs[blockIdx.y];
     if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
-    const uint32_t j = blockIdx.x * kDecBlock + threadIdx.x; // byte column of the file's rows
-    if (j >= job.bpl) return;
-    const uint32_t sc = job.src_c, dc = job.dst_c, px = j / sc, ch = j - px * sc;
-    if (ch >= dc) return; // alpha dropped
-    const uint8_t *F = job.filt + 1 + j;
-    const size_t fs = job.bpl + 1, os = (size_t)job.w * dc;
-    uint8_t *out = job.out + (size_t)px * dc + ch;
-    const bool add_alpha = dc == 4 && sc == 3 && ch == 2;
+    const uint32_t j4 = blockIdx.x * kDecBlock + threadIdx.x; // dword column of the file's rows
+    if (j4 * 4 >= job.bpl) return;
+    const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4);
+    const uint32_t *F = (const uint32_t *)(job.filt + 4) + j4;
+    const size_t fs4 = job.fstride / 4, os = (size_t)job.w * dc;
+    const bool whole = sc == dc && nb == 4 && (os & 3) == 0 && (((uintptr_t)job.out) & 3) == 0; // aligned dword stores
     uint32_t acc = 0;
     for (uint32_t y = 0; y < job.h; y++) {
-        acc = (acc + F[(size_t)y * fs]) & 255u;
-        out[(size_t)y * os] = (uint8_t)acc;
-        if (add_alpha) out[(size_t)y * os + 1] = 0xFF;
+        acc = add_bytes(acc, F[(size_t)y * fs4]);
+        uint8_t *orow = job.out + (size_t)y * os;
+        if (whole)
+            *(uint32_t *)(orow + (size_t)j4 * 4) = acc;
+        else
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t j = j4 * 4 + k, px = j / sc, ch = j - px * sc;
+                if (ch >= dc) continue; // alpha dropped
+                orow[(size_t)px * dc + ch] = (uint8_t)(acc >> (8 * k));
+                if (dc == 4 && sc == 3 && ch == 2) orow[(size_t)px * dc + 3] = 0xFF;
+            }
     }
 }
 
@@ -377,7 +410,7 @@ void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint3
 {
     const uint32_t rows_per_block = kDecBlock / kWave;
     hipLaunchKernelGGL(dec_fill_kernel, dim3((max_rows + rows_per_block - 1) / rows_per_block, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
-    hipLaunchKernelGGL(dec_unfilter_kernel, dim3((max_bpl + kDecBlock - 1) / kDecBlock, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
+    hipLaunchKernelGGL(dec_unfilter_kernel, dim3(((max_bpl + 3) / 4 + kDecBlock - 1) / kDecBlock, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
     hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, n_jobs), dim3(kDecBlock), 0, s, jobs);
 }
 

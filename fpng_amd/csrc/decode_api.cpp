@@ -121,7 +121,8 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             // offsets into the shared scratch (pointers are patched once the buffers exist)
             j.filt = (uint8_t *)(uintptr_t)filt_total;
             j.runmask = (uint32_t *)(uintptr_t)mask_total;
-            filt_total += ((size_t)(j.bpl + 1) * j.h + 15) & ~(size_t)15;
+            j.fstride = ((j.bpl + 3u) & ~3u) + 4u;
+            filt_total += ((size_t)j.fstride * j.h + 15) & ~(size_t)15;
             mask_total += (size_t)((p.w + 31) / 32) * p.h;
             max_rows = std::max(max_rows, p.h), max_bpl = std::max(max_bpl, j.bpl);
         }

@@ -153,6 +153,8 @@ struct fpng_amd_encoder {
     uint32_t last_host_bands = 0;  // row bands of the last fpng_amd_encode_host*() call (1 = the serial path)
     size_t last_host_png_size = 0; // fpng_amd_encode_host_to(): size of the previous file (the next call's estimate)
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
+    DeviceBuf<uint8_t> d_xchg;    // fpng_amd_encode_image_sharded(): the records it exchanges, and their pinned mirror
+    PinnedBuf<uint8_t> h_xchg;
     struct HostWorkers *workers = nullptr; // fpng_amd_encode_host_to(): the uploader and downloader threads (pipeline.cpp)
     hipEvent_t band_copied[4] = {}; // the pinned job record h_jobs[k] of an asynchronous band call has been uploaded
 };
@@ -163,4 +165,7 @@ namespace fpng_amd {
 int drain(fpng_amd_encoder *e);
 // stops and joins the encoder's copy threads (no-op when there are none)
 void destroy_host_workers(fpng_amd_encoder *e);
+// has this host range been copied one direction at a time before (or page-locked through fpng_amd_pin_host_memory)?
+// (pipeline.cpp: KnownRanges)
+bool host_range_known(const void *p, size_t bytes);
 } // namespace fpng_amd

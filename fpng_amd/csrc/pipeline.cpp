@@ -261,6 +261,10 @@ struct KnownRanges {
     }
 } g_known;
 
+} // namespace
+bool fpng_amd::host_range_known(const void *p, size_t bytes) { return g_known.has(p, bytes); }
+namespace {
+
 struct FixedOut {
     uint8_t *p;
     size_t cap;

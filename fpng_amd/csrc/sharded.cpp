@@ -44,13 +44,6 @@ struct CrcRecord { // step 3
         if (rc_) return rc_ < 0 ? rc_ : fail(FPNG_AMD_ERR_HIP, "transport call failed: " #expr); \
     } while (0)
 
-// small exchange buffers of one sharded call: device records + their pinned host mirrors
-struct Exchange {
-    DeviceBuf<uint8_t> d;
-    PinnedBuf<uint8_t> h;
-};
-thread_local Exchange t_xchg; // (one encoder per thread: the scratch follows the thread)
-
 } // namespace
 
 extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd_transport *t, const fpng_amd_band *band, uint32_t flags,
@@ -81,9 +74,8 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
     // exchange scratch: [hist 288 u32][my record][all records][my crc record][all crc records][heads 16 B x world]
     const size_t o_hist = 0, o_rec = o_hist + 288 * 4, o_recs = o_rec + sizeof(Record), o_crc = o_recs + sizeof(Record) * world,
                  o_crcs = o_crc + sizeof(CrcRecord), o_heads = o_crcs + sizeof(CrcRecord) * world, total = o_heads + 16 * (size_t)world + 128;
-    Exchange &x = t_xchg;
-    if ((rc = x.d.ensure(total)) || (rc = x.h.ensure(total))) return rc;
-    uint8_t *dx = x.d.p, *hx = x.h.p;
+    if ((rc = e->d_xchg.ensure(total)) || (rc = e->h_xchg.ensure(total))) return rc;
+    uint8_t *dx = e->d_xchg.p, *hx = e->h_xchg.p;
 
     // ---- 0/1: histogram all-reduce (2-pass), encode the band ----
     uint32_t *d_hist = nullptr;

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -28,9 +29,10 @@ struct Hub {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t gen = 0;
+    bool failed = false; // a rank gave up: nobody waits for it any more
     uint8_t *d_slots = nullptr; // world x 8 KiB
     std::map<std::pair<int, int>, std::deque<Post *>> box; // (src, dst) -> posts in order
-    void barrier()
+    bool barrier() // false: a rank failed (or two minutes passed) -- the caller reports a transport error
     {
         std::unique_lock<std::mutex> lk(mu);
         const uint64_t g = gen;
@@ -38,8 +40,17 @@ struct Hub {
             arrived = 0;
             gen++;
             cv.notify_all();
-        } else
-            cv.wait(lk, [&] { return gen != g; });
+            return !failed;
+        }
+        return cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || failed; }) && !failed;
+    }
+    void give_up()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            failed = true;
+        }
+        cv.notify_all();
     }
 };
 struct Rank {
@@ -58,12 +69,11 @@ int l_all_gather(void *ctx, const void *snd, void *rcv, size_t bytes, void *stre
     if (bytes > kSlot) return 1;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(h->d_slots + r->rank * kSlot, snd, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 1;
-    h->barrier();
+    if (!h->barrier()) return 1;
     for (int k = 0; k < h->world; k++)
         if (hipMemcpyAsync((uint8_t *)rcv + k * bytes, h->d_slots + k * kSlot, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
-    h->barrier();
-    return 0;
+    return h->barrier() ? 0 : 1;
 }
 int l_all_reduce(void *ctx, void *buf, size_t count, void *stream)
 {
@@ -72,15 +82,14 @@ int l_all_reduce(void *ctx, void *buf, size_t count, void *stream)
     if (count * 4 > kSlot) return 1;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(h->d_slots + r->rank * kSlot, buf, count * 4, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 1;
-    h->barrier();
+    if (!h->barrier()) return 1;
     std::vector<uint32_t> sum(count, 0), part(count);
     for (int k = 0; k < h->world; k++) {
         if (hipMemcpy(part.data(), h->d_slots + k * kSlot, count * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
         for (size_t i = 0; i < count; i++) sum[i] += part[i];
     }
     if (hipMemcpy(buf, sum.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    h->barrier();
-    return 0;
+    return h->barrier() ? 0 : 1;
 }
 int l_group_begin(void *) { return 0; }
 int l_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream)
@@ -109,7 +118,7 @@ int l_group_end_s(Rank *r, hipStream_t s)
         {
             std::unique_lock<std::mutex> lk(h->mu);
             auto &dq = h->box[{q.peer, r->rank}];
-            h->cv.wait(lk, [&] { return !dq.empty(); });
+            if (!h->cv.wait_for(lk, std::chrono::seconds(120), [&] { return !dq.empty() || h->failed; }) || dq.empty()) return 1;
             p = dq.front();
             dq.pop_front();
         }
@@ -126,7 +135,7 @@ int l_group_end_s(Rank *r, hipStream_t s)
     r->recvs.clear();
     for (Post *p : r->sends) { // a sender's buffer is its own again once the receiver has copied it
         std::unique_lock<std::mutex> lk(h->mu);
-        h->cv.wait(lk, [&] { return p->taken; });
+        if (!h->cv.wait_for(lk, std::chrono::seconds(120), [&] { return p->taken || h->failed; }) || !p->taken) return 1;
         lk.unlock();
         (void)hipEventDestroy(p->ready);
         delete p;
@@ -173,6 +182,7 @@ extern "C" int shim_sharded_local(int world, const uint32_t *cuts, const uint8_t
                 fpng_amd_band b = {d_rows, d_above, w, c, y0, y1, h, 0};
                 rc = fpng_amd_encode_image_sharded(enc, &t, &b, flags, root, d_png, png_cap, &n);
                 if (rc) {
+                    hub.give_up(); // (the other ranks must not wait for this one)
                     std::lock_guard<std::mutex> lk(emu);
                     snprintf(err, err_cap, "rank %d: %s", r, fpng_amd_last_error());
                 }
@@ -182,6 +192,7 @@ extern "C" int shim_sharded_local(int world, const uint32_t *cuts, const uint8_t
                 rc = (n > cap) ? -101 : (hipMemcpy(out, d_png, n, hipMemcpyDeviceToHost) != hipSuccess);
             }
             rcs[r] = rc;
+            if (rc) hub.give_up(); // (whatever went wrong: the other ranks must not wait for this one)
             (void)hipFree(d_rows), (void)hipFree(d_above), (void)hipFree(d_png);
             if (enc) fpng_amd_encoder_destroy(enc);
         });

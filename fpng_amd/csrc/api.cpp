@@ -615,45 +615,6 @@ int fpng_amd_encode_host_batch(fpng_amd_encoder *e, const fpng_amd_host_image *i
         if ((rc = check_dims(imgs[i].w, imgs[i].h, imgs[i].num_chans))) return rc;
         if (!imgs[i].pixels || (!imgs[i].out && !imgs[i].path)) return fail(FPNG_AMD_ERR_INVALID_ARG, "image without pixels or destination");
     }
-    // Measured, not explained (profiles/r03_host_path.txt, tools/host_batch_order_probe.py): whether the ring's two copy streams
-    // overlap the two directions is settled by their first copies, for the rest of the process -- 2.59 or 3.43 ms per 8K frame.
-    // The one recipe that gave the overlapping state in every run when the batch is the process's first host copy: the batch's
-    // first frame goes through the one-frame path (one direction at a time), then the two new streams move 1 MiB of that frame's
-    // buffers at the same time, then the ring takes over.  (16 MiB or whole frames as the first copies, or the two small copies
-    // one after the other: the other state.  A wrong guess costs the difference, never correctness.)
-    if (n >= 2 && !e->host.up && !host_range_known(imgs[0].pixels, (size_t)imgs[0].w * imgs[0].h * imgs[0].num_chans)) {
-        const fpng_amd_host_image &f = imgs[0];
-        std::vector<uint8_t> tmp;
-        uint8_t *out = f.out;
-        size_t cap = f.out_cap, size = 0;
-        if (!out) {
-            tmp.resize(fpng_amd_max_encoded_size(f.w, f.h, f.num_chans));
-            out = tmp.data(), cap = tmp.size();
-        }
-        if ((rc = fpng_amd_encode_host(e, f.pixels, f.w, f.h, f.num_chans, flags, out, cap, &size))) return rc;
-        if (f.out_size) *f.out_size = size;
-        {
-            using HostRing = fpng_amd_encoder::HostRing;
-            HostRing &ring = e->host;
-            HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
-            const size_t in_bytes = (size_t)f.w * f.h * f.num_chans, nu = std::min<size_t>(in_bytes, 1u << 20), nd = std::min<size_t>(size, 1u << 20);
-            if ((rc = ring.d_in[0].ensure(in_bytes + 16))) return rc;
-            HIP_TRY(hipMemcpyAsync(ring.d_in[0].p, f.pixels, nu, hipMemcpyHostToDevice, ring.up));
-            HIP_TRY(hipMemcpyAsync(out, e->d_stage_out.p, nd, hipMemcpyDeviceToHost, ring.down)); // (the same bytes once more: the frame's file is still there)
-            HIP_TRY(hipStreamSynchronize(ring.up));
-            HIP_TRY(hipStreamSynchronize(ring.down));
-        }
-        if (f.path) {
-            FILE *fp = fopen(f.path, "wb");
-            if (!fp || fwrite(out, 1, size, fp) != size) {
-                if (fp) fclose(fp);
-                return fail(FPNG_AMD_ERR_IO, "could not write a frame's file");
-            }
-            if (fclose(fp) == EOF) return fail(FPNG_AMD_ERR_IO, "could not write a frame's file");
-        }
-        return host_batch_ring(e, imgs + 1, n - 1, flags, n_writer_threads);
-    }
     return host_batch_ring(e, imgs, n, flags, n_writer_threads);
 }
 
@@ -664,8 +625,7 @@ static int host_batch_ring(fpng_amd_encoder *e, const fpng_amd_host_image *imgs,
     if ((rc = drain(e))) return rc;
     using HostRing = fpng_amd_encoder::HostRing;
     HostRing &ring = e->host; // (staging buffers are kept between calls)
-    if (!ring.up) HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
-    if (!ring.down) HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
+    if ((rc = ensure_copy_streams(e))) return rc;
     size_t max_in = 0, max_out = 0;
     for (uint32_t i = 0; i < n; i++) {
         max_in = std::max(max_in, (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 namespace fpng_amd {
@@ -82,6 +83,19 @@ const TokenTable *host_1pass_table(uint32_t num_chans);
 
 using namespace fpng_amd;
 
+// A stream for one of the host paths' two copy directions.  The runtime serves all HIP streams of one priority from a pool of four
+// hardware queues (its log: "maximum per priority is: 4"; an encoder alone makes five ordinary streams), and a copy it cannot
+// give to an SDMA engine becomes a blit kernel on its stream's queue; streams of another priority come from another pool, so
+// the copy streams ask for the highest one and never share a queue with the lanes' kernels.  (A precaution: with the two
+// directions on two engines -- ensure_copy_streams() in pipeline.cpp -- we measured no difference.)
+inline hipError_t create_copy_stream(hipStream_t *s)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least)
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 struct fpng_amd_encoder {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -151,7 +165,6 @@ struct fpng_amd_encoder {
     PinnedBuf<uint32_t> h_partials; // fpng_amd_band_crc(): the band's partials on their way to the host-side fold
     DeviceBuf<uint32_t> d_stream_partials; // fpng_amd_encode_host_to(): partials of all bands of the frame
     uint32_t last_host_bands = 0;  // row bands of the last fpng_amd_encode_host*() call (1 = the serial path)
-    size_t last_host_png_size = 0; // fpng_amd_encode_host_to(): size of the previous file (the next call's estimate)
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
     DeviceBuf<uint8_t> d_xchg;    // fpng_amd_encode_image_sharded(): the records it exchanges, and their pinned mirror
     PinnedBuf<uint8_t> h_xchg;
@@ -166,6 +179,5 @@ int drain(fpng_amd_encoder *e);
 // stops and joins the encoder's copy threads (no-op when there are none)
 void destroy_host_workers(fpng_amd_encoder *e);
 // has this host range been copied one direction at a time before (or page-locked through fpng_amd_pin_host_memory)?
-// (pipeline.cpp: KnownRanges)
-bool host_range_known(const void *p, size_t bytes);
+int ensure_copy_streams(fpng_amd_encoder *e); // pipeline.cpp: the two copy streams of the host paths, on two copy engines
 } // namespace fpng_amd

@@ -218,51 +218,72 @@ void fpng_amd::destroy_host_workers(fpng_amd_encoder *e)
     e->workers = nullptr;
 }
 
-namespace {
-
-// Host ranges that have been through the SERIAL path once (or were page-locked through fpng_amd_pin_host_memory).  Measured
-// (profiles/r03_host_path.txt): whether the runtime overlaps copies from / to a pageable buffer in the two directions is decided
-// by how that buffer was copied the FIRST time -- after one plain upload + download on a single stream it overlaps from then
-// on (8K RGBA: 2.8 ms per streamed call), first touched by overlapping copies it never does (3.55 ms, the same as the serial
-// path, which is why a stale entry -- a freed buffer's address handed out again -- costs nothing but the gain).  A capture
-// loop reuses its buffers, so its second frame is streamed.  (hipPointerGetAttributes() is NOT used to recognise page-locked
-// memory: asked about a pageable pointer it leaves that buffer in the never-overlapping state.)
-struct KnownRanges {
-    std::mutex mu;
-    struct R { uintptr_t p; size_t n; uint32_t seen; };
-    std::vector<R> r;
-    bool has(const void *p, size_t n)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto &e : r)
-            if ((uintptr_t)p >= e.p && (uintptr_t)p + n <= e.p + e.n) return true;
-        return false;
+// The host paths' two copy streams, made so that the two PCIe directions run on DIFFERENT copy engines.
+//
+// What the runtime does (its own log, AMD_LOG_LEVEL=4, "HSA Copy copy_engine=0x1 ... engineType=2", tools/gpu_host_state_log.sh):
+// a stream's FIRST copy asks which SDMA engines are idle at that instant, takes the lowest one and keeps it for the stream's
+// life.  The upload stream takes engine 1.  The download stream's first copy used to be issued by the downloader thread whenever
+// the first frame or band was encoded -- if that fell between two of the uploader's 32 MiB chunks (the runtime pins pageable
+// memory chunk by chunk; ~80 us of idle engine between chunks), it took engine 1 as well, and from then on every download of
+// the process queued behind the uploads: 3.43-3.58 ms per 8K frame instead of 2.59-2.85, in roughly one process in ten on one
+// box and in every process on another (profiles/r03_host_path.txt).  So the first download is issued here, from this thread,
+// right behind an 8 MiB upload that is still in flight (pinned source: the call returns at once and the engine is busy for
+// ~150 us), and the outcome is measured: both directions together must take clearly less than one after the other; if not the
+// download stream is made anew and the step repeated.
+//
+// Not covered: a SECOND encoder made in a process after the first one was destroyed downloads at 23 GB/s instead of 54 whatever
+// streams it uses (its own, made anew, or the first encoder's: all measured, tools/host_state_probe.py) -- 3.7 instead of 2.9 ms
+// per one-frame call, 2.78 instead of 2.59 per batch frame.  Keep one encoder per device for the life of the process.
+int fpng_amd::ensure_copy_streams(fpng_amd_encoder *e)
+{
+    auto &ring = e->host;
+    if (ring.up && ring.down) return FPNG_AMD_OK;
+    static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
+    constexpr size_t kBytes = 8u << 20;
+    PinnedBuf<uint8_t> h;
+    DeviceBuf<uint8_t> d;
+    int rc;
+    if ((rc = h.ensure(2 * kBytes)) || (rc = d.ensure(2 * kBytes))) return rc;
+    struct Free {
+        PinnedBuf<uint8_t> &h;
+        DeviceBuf<uint8_t> &d;
+        ~Free() { h.release(), d.release(); }
+    } free_them{h, d};
+    memset(h.p, 0, kBytes);
+    if (!ring.up) HIP_TRY(create_copy_stream(&ring.up));
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (!ring.down) HIP_TRY(create_copy_stream(&ring.down));
+        double t_up = 1e30, t_down = 1e30, t_both = 1e30;
+        for (int rep = 0; rep < 2; rep++) {
+            // (the very first pass through here is the one that settles the download stream's engine: upload in flight, download behind it)
+            auto t0 = clk::now();
+            HIP_TRY(hipMemcpyAsync(d.p, h.p, kBytes, hipMemcpyHostToDevice, ring.up));
+            HIP_TRY(hipMemcpyAsync(h.p + kBytes, d.p + kBytes, kBytes, hipMemcpyDeviceToHost, ring.down));
+            HIP_TRY(hipStreamSynchronize(ring.up));
+            HIP_TRY(hipStreamSynchronize(ring.down));
+            t_both = std::min(t_both, us(t0));
+            t0 = clk::now();
+            HIP_TRY(hipMemcpyAsync(d.p, h.p, kBytes, hipMemcpyHostToDevice, ring.up));
+            HIP_TRY(hipStreamSynchronize(ring.up));
+            t_up = std::min(t_up, us(t0));
+            t0 = clk::now();
+            HIP_TRY(hipMemcpyAsync(h.p + kBytes, d.p + kBytes, kBytes, hipMemcpyDeviceToHost, ring.down));
+            HIP_TRY(hipStreamSynchronize(ring.down));
+            t_down = std::min(t_down, us(t0));
+        }
+        const bool apart = t_both < 0.8 * (t_up + t_down);
+        if (trace)
+            fprintf(stderr, "fpng_amd: copy streams, attempt %d: up %.0f us, down %.0f us, both %.0f us -> %s\n", attempt, t_up, t_down, t_both,
+                    apart ? "two engines" : "one engine, again");
+        if (apart) break;
+        if (attempt == 3) break; // (keep the last pair: the path is correct either way, only slower)
+        (void)hipStreamDestroy(ring.down);
+        ring.down = nullptr;
     }
-    void remove(const void *p)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (size_t i = 0; i < r.size(); i++)
-            if (r[i].p == (uintptr_t)p) {
-                r.erase(r.begin() + i);
-                return;
-            }
-    }
-    void add(const void *p, size_t n)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto &e : r)
-            if (e.p == (uintptr_t)p) {
-                e.n = std::max(e.n, n);
-                e.seen++;
-                return;
-            }
-        if (r.size() >= 64) r.erase(r.begin());
-        r.push_back({(uintptr_t)p, n, 1u});
-    }
-} g_known;
-
-} // namespace
-bool fpng_amd::host_range_known(const void *p, size_t bytes) { return g_known.has(p, bytes); }
+    return FPNG_AMD_OK;
+}
 namespace {
 
 struct FixedOut {
@@ -297,9 +318,6 @@ int encode_host_serial(fpng_amd_encoder *e, const void *pixels, bool uploaded, u
     uint8_t *out = reserve(user, (size_t)res.png_size); // the size is known before a single output byte moves
     if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "output buffer too small");
     HIP_TRY(hipMemcpy(out, e->d_stage_out.p, res.png_size, hipMemcpyDeviceToHost));
-    if (!uploaded) g_known.add(pixels, in_bytes); // both buffers have now been copied once, one direction at a time
-    g_known.add(out, (size_t)res.png_size);
-    e->last_host_png_size = (size_t)res.png_size;
     return FPNG_AMD_OK;
 }
 
@@ -330,24 +348,10 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     const size_t bpl = (size_t)w * c, in_bytes = bpl * h, max_out = fpng_amd_max_encoded_size(w, h, c);
-    // Streaming pays only for PAGE-LOCKED pixels (fpng_amd_pin_host_memory / hipHostRegister / hipHostMalloc): copies from
-    // pageable memory in the two directions take turns on this platform (measured per 8K band: 16.6 MB up + 7.3 MB down
-    // 428 + 425 us side by side instead of 306 + 170; profiles/r03_host_path.txt), so such frames go the serial way.
+    // Frames of 16 MiB of pixels and more are streamed in row bands (pageable or page-locked memory alike, seen before or not:
+    // tools/gpu_stream_always.sh); 2-pass and forced-stored frames need the whole image's counts first and go the serial way.
     uint32_t nb = 1;
-    if (!(flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED))) {
-        nb = host_bands_for(in_bytes, h);
-        if (nb >= 2 && !host_bands_forced()) {
-            // only buffers that have been through the serial path before, or were page-locked through
-            // fpng_amd_pin_host_memory() (see KnownRanges); the output buffer is asked for up front with the size of the
-            // previous file as the estimate
-            bool ok = g_known.has(pixels, in_bytes) && e->last_host_png_size;
-            if (ok) {
-                const uint8_t *o = reserve(user, std::min(e->last_host_png_size, max_out));
-                ok = o && g_known.has(o, std::min(e->last_host_png_size, max_out));
-            }
-            if (!ok) nb = 1;
-        }
-    }
+    if (!(flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED))) nb = host_bands_for(in_bytes, h);
     e->last_host_bands = nb;
     if (nb < 2) return encode_host_serial(e, pixels, false, w, h, c, flags, reserve, user, out_size);
 
@@ -387,8 +391,7 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     for (auto &r : runs)
         if (hipEventCreateWithFlags(&r.placed, hipEventDisableTiming) != hipSuccess) failed = FPNG_AMD_ERR_HIP;
 
-    if (!ring.up) HIP_TRY(hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
-    if (!ring.down) HIP_TRY(hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
+    if (int rc_streams = ensure_copy_streams(e)) return rc_streams;
     hipStream_t s_up = ring.up, s_down = ring.down;
     // The two copy threads live as long as the encoder (no thread start per call).
     if (!e->workers) e->workers = new HostWorkers();
@@ -553,7 +556,6 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     std::memcpy(out, head, kPngHeaderBytes);
     std::memcpy(out + kPngHeaderBytes + plan.zlib_size - 4, tail, 20);
     *out_size = png_size;
-    e->last_host_png_size = png_size;
     return FPNG_AMD_OK;
 }
 
@@ -563,14 +565,12 @@ extern "C" int fpng_amd_pin_host_memory(void *p, size_t bytes)
 {
     if (!p || !bytes) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty range");
     HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
-    g_known.add(p, bytes); // page-locked memory overlaps from its first copy on
     return FPNG_AMD_OK;
 }
 
 extern "C" int fpng_amd_unpin_host_memory(void *p)
 {
     if (!p) return fail(FPNG_AMD_ERR_INVALID_ARG, "null pointer");
-    g_known.remove(p);
     HIP_TRY(hipHostUnregister(p));
     return FPNG_AMD_OK;
 }

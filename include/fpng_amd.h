@@ -152,11 +152,9 @@ int fpng_amd_encode_host(fpng_amd_encoder *enc, const void *pixels, uint32_t w, 
  * while the call runs and never concurrently, possibly from a helper thread.  Large 1-pass frames are STREAMED: the frame is
  * cut into row bands, band k+1 is uploaded while band k is encoded and placed and band k-1's piece of the file is downloaded,
  * so a call takes about max(upload, download) instead of their sum (one 8K RGBA frame: 2.8 instead of 3.6 ms).
- * Which frames are streamed: buffers page-locked with fpng_amd_pin_host_memory() (= hipHostRegister; undo with
- * fpng_amd_unpin_host_memory() BEFORE freeing the buffer) always; ordinary (pageable) buffers from the SECOND call with the
- * same pixel and output buffers on -- the first call takes the serial path (upload, encode, size, download), because on this platform copies
- * from / to a pageable buffer only overlap in the two directions if the buffer's first copies did not (measured,
- * profiles/r03_host_path.txt).  A capture loop reuses its buffers, so all frames but its first are streamed. */
+ * Which frames are streamed: 1-pass frames of 16 MiB of pixels and more, in pageable or page-locked memory alike.
+ * fpng_amd_pin_host_memory() (= hipHostRegister; undo with fpng_amd_unpin_host_memory() BEFORE freeing the buffer) saves the
+ * runtime's pinning of each chunk it copies (8K RGBA: 2.80 instead of 2.85 ms), nothing more. */
 typedef uint8_t *(*fpng_amd_reserve_fn)(void *user, size_t bytes);
 int fpng_amd_encode_host_to(fpng_amd_encoder *enc, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans,
                             uint32_t flags, fpng_amd_reserve_fn reserve, void *user, size_t *out_size);

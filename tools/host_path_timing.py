@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """PCIe-inclusive timing of the host-buffer entry points (what a user of the reference's API pays): host pixels in, host PNG
-out.  Pageable pixels take the serial path (upload, encode, size, download); page-locked pixels (fpng_amd_pin_host_memory) are
-streamed through the GPU in row bands.  FPNG_AMD_HOST_BANDS=n forces n bands also for pageable pixels (read once per process)."""
+out.  1-pass frames of 16 MiB of pixels and more are streamed through the GPU in row bands, pageable or page-locked
+(fpng_amd_pin_host_memory) alike; FPNG_AMD_HOST_BANDS=n forces n bands (1 = one direction at a time; read once per process)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, fpng_amd
 import dropin
 enc = fpng_amd.Encoder(device=0, stream="own")
-print("FPNG_AMD_HOST_BANDS =", os.environ.get("FPNG_AMD_HOST_BANDS", "(by size, page-locked pixels only)"))
+print("FPNG_AMD_HOST_BANDS =", os.environ.get("FPNG_AMD_HOST_BANDS", "(by size)"))
 
 
 def best_of(fn, n=7):

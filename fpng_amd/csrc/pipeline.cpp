@@ -352,6 +352,19 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     // tools/gpu_stream_always.sh); 2-pass and forced-stored frames need the whole image's counts first and go the serial way.
     uint32_t nb = 1;
     if (!(flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED))) nb = host_bands_for(in_bytes, h);
+    // Band k covers rows ys[k] .. ys[k+1].  What a call costs beyond its uploads is the LAST band's walk (one row's latency
+    // whatever the band's size) + placement + download, so the last of the equal bands is cut once more, 3/4 + 1/4: the
+    // final download shrinks to a quarter while the 3/4 piece's upload still covers the quarter's turn on the calling thread
+    // (~110 us per band).  8K RGBA: the tail after the last upload 300 -> ~210 us.
+    std::vector<uint32_t> ys;
+    {
+        const uint32_t rows_per = (h + nb - 1) / nb;
+        for (uint32_t y = 0; y < h; y += rows_per) ys.push_back(y);
+        const uint32_t y0 = ys.back(), n = h - y0;
+        if (nb >= 2 && !host_bands_forced() && n >= 64 && (size_t)n * bpl >= (8u << 20)) ys.push_back(y0 + n - n / 4);
+        ys.push_back(h);
+        nb = (uint32_t)ys.size() - 1;
+    }
     e->last_host_bands = nb;
     if (nb < 2) return encode_host_serial(e, pixels, false, w, h, c, flags, reserve, user, out_size);
 
@@ -364,7 +377,6 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     if ((rc = e->d_stage_in.ensure(in_bytes + 16)) || (rc = e->d_stage_out.ensure(out_cap)) ||
         (rc = e->d_stream_partials.ensure((size_t)nb * rec_words)) || (rc = e->h_partials.ensure((size_t)nb * rec_words)))
         return rc;
-    const uint32_t rows_per = (h + nb - 1) / nb;
     struct BandRun {
         uint32_t y0 = 0, y1 = 0;
         uint64_t file_off = 0;   // of the window
@@ -399,7 +411,7 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     wk.up.start([&] {
         (void)hipSetDevice(device);
         for (uint32_t k = 0; k < nb && !failed; k++) {
-            const uint32_t y0 = k * rows_per, y1 = std::min(h, y0 + rows_per);
+            const uint32_t y0 = ys[k], y1 = ys[k + 1];
             if (trace) tl[k * 6 + 0] = now_us();
             if (y1 > y0 && (hipMemcpyAsync(d_in + (size_t)y0 * bpl, (const uint8_t *)pixels + (size_t)y0 * bpl, (size_t)(y1 - y0) * bpl, hipMemcpyHostToDevice, s_up) != hipSuccess ||
                             hipStreamSynchronize(s_up) != hipSuccess))
@@ -464,7 +476,7 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
         }
         if (failed) break;
         BandRun &r = runs[k];
-        r.y0 = k * rows_per, r.y1 = std::min(h, r.y0 + rows_per);
+        r.y0 = ys[k], r.y1 = ys[k + 1];
         std::memset(&stats[k], 0, sizeof stats[k]);
         if (r.y1 > r.y0) {
             fpng_amd_band band;

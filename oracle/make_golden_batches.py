@@ -9,6 +9,11 @@ Run in the dev container (where /root/reference exists):   python oracle/make_go
   c5   128 x 3840x2160x4 `grad`, seed 12345+i, flags 1          (1/8 of BASELINE config 5)
   c4   16384x16384x4 `grad`, seed 777, flags 0 and 1            (BASELINE config 4; flags 1 = the 2-pass row-band case of config 5's wording)
   bench  8 x 7680x4320x4 `grad`, seed 12345+i, flags 0 and 1    (bench.py's default step)
+  bench_noise  8 x 7680x4320x4 `noise`, flags 0                 (bench.py --kind noise: the stored outcome)
+  bench_4k     16 x 3840x2160x4 `grad`, flags 0                 (bench.py --workload 4k --batch 16)
+  bench_512    1024 x 512x512x3 `grad`, flags 0                 (bench.py --workload 512 --batch 1024; compact form)
+
+Sets of more than 300 images are stored compactly: "sha256_all" = sha256 over the concatenated per-image hex digests.
 """
 import hashlib
 import json
@@ -25,6 +30,9 @@ SETS = {
     "c5": dict(w=3840, h=2160, c=4, kind="grad", n=128, seed0=12345, flags=[1]),
     "c4": dict(w=16384, h=16384, c=4, kind="grad", n=1, seed0=777, flags=[0, 1]),
     "bench": dict(w=7680, h=4320, c=4, kind="grad", n=8, seed0=12345, flags=[0, 1]),
+    "bench_noise": dict(w=7680, h=4320, c=4, kind="noise", n=8, seed0=12345, flags=[0]),
+    "bench_4k": dict(w=3840, h=2160, c=4, kind="grad", n=16, seed0=12345, flags=[0]),
+    "bench_512": dict(w=512, h=512, c=3, kind="grad", n=1024, seed0=12345, flags=[0]),
 }
 
 
@@ -55,7 +63,11 @@ def main():
         e["flags"] = {}
         for fl in s["flags"]:
             rows = sorted((i, size, sha) for (nm, i, f, size, sha) in res if nm == name and f == fl)
-            e["flags"][str(fl)] = {"sizes": [r[1] for r in rows], "sha256": [r[2] for r in rows]}
+            if len(rows) > 300:
+                e["flags"][str(fl)] = {"total_size": sum(r[1] for r in rows),
+                                       "sha256_all": hashlib.sha256("".join(r[2] for r in rows).encode()).hexdigest()}
+            else:
+                e["flags"][str(fl)] = {"sizes": [r[1] for r in rows], "sha256": [r[2] for r in rows]}
         out[name] = e
     with open(path, "w") as f:
         json.dump(out, f, indent=0)

@@ -457,6 +457,7 @@ class Encoder:
 
     # ---- instrumentation ----
     def calibration_stream(self, buf, write, lane_bytes):
+        self._sync_stream()
         check(self.lib.fpng_amd_calibration_stream(self.h, int(write), lane_bytes, buf.data_ptr(), buf.numel()))
 
     def set_profiling(self, on=True):

@@ -2208,7 +2208,7 @@ void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src)
 }
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
 {
-    const dim3 grid(256 * 8), block(kBlock);
+    const dim3 grid(256 * 32), block(kBlock); // (every wave slot of the chip taken: the write stream needs that to reach its rate)
     if (!write && width == 4) hipLaunchKernelGGL(calib_read_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)buf, bytes / 4, sink);
     if (!write && width == 16) hipLaunchKernelGGL(calib_read_kernel<uint4>, grid, block, 0, s, (const uint4 *)buf, bytes / 16, sink);
     if (write && width == 4) hipLaunchKernelGGL(calib_write_kernel<uint32_t>, grid, block, 0, s, (uint32_t *)buf, bytes / 4);

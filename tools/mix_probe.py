@@ -40,3 +40,12 @@ def both():
     with torch.cuda.stream(s1): r32.sum()
     with torch.cuda.stream(s2): w32.fill_(7)
 t = t_of(both); print(f"torch sum || fill_ ({(R+W)/1e9:.3f} GB): {t:.3f} ms = {(R+W)/t/1e9:.2f} TB/s")
+# is the fill's rate a property of constant data or of the store shape?
+N32 = w32.numel()
+t = t_of(lambda: torch.arange(N32, out=w32, dtype=torch.int32)); print(f"torch arange(out=) {W/1e9:.3f} GB written: {t:.3f} ms = {W/t/1e9:.2f} TB/s")
+def w4():
+    enc.calibration_stream(wbuf, 1, 4)
+t = t_of(w4); print(f"own write kernel, 4-byte lanes: {t:.3f} ms = {W/t/1e9:.2f} TB/s")
+def w16():
+    enc.calibration_stream(wbuf, 1, 16)
+t = t_of(w16); print(f"own write kernel, 16-byte lanes: {t:.3f} ms = {W/t/1e9:.2f} TB/s")

@@ -2,6 +2,8 @@
 #include "fpng.h"
 #include <string.h>
 #include <chrono>
+#include <thread>
+#include <vector>
 extern "C" {
 // Timed loop through the drop-in exactly as the reference's harness times its encoder (fpng_test.cpp:1198-1209): `reps` calls
 // of fpng::fpng_encode_image_to_memory into ONE reused vector (reuse = 1) or into a fresh vector per call (reuse = 0, the
@@ -52,6 +54,38 @@ int shim_decode_file(const char *name, uint8_t *out, size_t cap, uint32_t *w, ui
     int st = fpng::fpng_decode_file(name, v, *w, *h, *c, desired);
     if (st == 0 && v.size() <= cap) memcpy(out, v.data(), v.size());
     return st;
+}
+// The reference's functions are re-entrant and callers encode from many threads at once (src/fpng.cpp has no locks): n_threads
+// threads, each encoding ITS image `reps` times into its own vector; outs[t] (cap bytes each) / sizes[t] receive thread t's last
+// file, `agree` = 1 when every repetition of every thread produced the same bytes as its first.
+int shim_encode_threads(int n_threads, const void *const *imgs, const uint32_t *w, const uint32_t *h, const uint32_t *c, const uint32_t *flags,
+                        int reps, uint8_t *const *outs, size_t cap, size_t *sizes, int *agree)
+{
+    std::vector<int> ok(n_threads, 1), same(n_threads, 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++)
+        th.emplace_back([&, t] {
+            std::vector<uint8_t> first, v;
+            for (int r = 0; r < reps; r++) {
+                if (!fpng::fpng_encode_image_to_memory(imgs[t], w[t], h[t], c[t], v, flags[t])) {
+                    ok[t] = 0;
+                    return;
+                }
+                if (r == 0)
+                    first = v;
+                else if (v != first)
+                    same[t] = 0;
+            }
+            sizes[t] = v.size();
+            if (v.size() <= cap) memcpy(outs[t], v.data(), v.size());
+        });
+    for (auto &x : th) x.join();
+    *agree = 1;
+    for (int t = 0; t < n_threads; t++) {
+        if (!ok[t]) return 0;
+        if (!same[t]) *agree = 0;
+    }
+    return 1;
 }
 void shim_init() { fpng::fpng_init(); }
 int shim_supported() { return fpng::fpng_cpu_supports_sse41() ? 1 : 0; }

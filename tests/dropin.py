@@ -23,13 +23,15 @@ def shim():
     deps = [src, os.path.join(lib_dir, "libfpng.so")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), src, "-o", so,
-                               "-L", lib_dir, "-lfpng", "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
+                               "-L", lib_dir, "-lfpng", "-lfpng_amd", "-pthread", "-Wl,-rpath,$ORIGIN"])
     L = C.CDLL(so)
     L.shim_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.shim_encode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.shim_get_info.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.shim_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
     L.shim_decode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
+    L.shim_encode_threads.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.POINTER(C.c_int)]
     L.shim_time_encode.restype = C.c_double
     L.shim_time_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.shim_crc32.restype = C.c_uint32
@@ -82,6 +84,26 @@ def time_encode(img, w, h, c, flags=0, reps=5, reuse=True):
     if t < 0:
         raise RuntimeError("fpng::fpng_encode_image_to_memory failed")
     return t, n.value
+
+
+def encode_threads(images, flags, reps=3):
+    """fpng::fpng_encode_image_to_memory() from len(images) threads at once, every thread its own image `reps` times:
+    (list of PNG bytes, True when every repetition of every thread gave the same bytes)."""
+    L = shim()
+    n = len(images)
+    arrs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+    import fpng_amd
+    cap = max(fpng_amd.max_encoded_size(a.shape[1], a.shape[0], a.shape[2]) for a in arrs)
+    outs = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
+    P = C.c_void_p * n
+    U = C.c_uint32 * n
+    sizes = (C.c_size_t * n)()
+    agree = C.c_int(0)
+    ok = L.shim_encode_threads(n, P(*[a.ctypes.data for a in arrs]), U(*[a.shape[1] for a in arrs]), U(*[a.shape[0] for a in arrs]),
+                               U(*[a.shape[2] for a in arrs]), U(*flags), reps, P(*[o.ctypes.data for o in outs]), cap, sizes, C.byref(agree))
+    if not ok:
+        raise RuntimeError("fpng::fpng_encode_image_to_memory failed in a thread")
+    return [outs[i][: sizes[i]].tobytes() for i in range(n)], bool(agree.value)
 
 
 _sharded = None

@@ -143,3 +143,38 @@ def test_node_host_batch_two_pipelines_on_one_gpu(built_lib, tmp_path):
         assert n == g["sizes"][i] and hashlib.sha256(o[:n].tobytes()).hexdigest() == g["sha256"][i]
         assert open(paths[i], "rb").read() == o[:n].tobytes()
     node.close()
+
+
+def test_copy_streams_end_up_on_two_engines(built_lib):
+    """The host paths' upload and download streams must not share an SDMA engine (pipeline.cpp: ensure_copy_streams) -- with one
+    engine every download queues behind the uploads and a streamed 8K call costs 3.5 instead of 2.8 ms.  Fresh process: the pair
+    is made once per encoder; FPNG_AMD_TRACE prints what the library measured when it made it."""
+    code = r'''
+import numpy as np, fpng_amd
+w, h, c = 7680, 4320, 4
+img = fpng_amd.synth_image("grad", w, h, c)
+out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)
+enc = fpng_amd.Encoder(device=0, stream="own")
+for _ in range(2):
+    n = enc.encode_host_into(img, w, h, c, out, 0)
+print("bands", enc.last_host_bands(), "bytes", n)
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, FPNG_AMD_TRACE="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    made = [l for l in out.stderr.splitlines() if "copy streams, attempt" in l]
+    assert made and made[-1].endswith("two engines"), made
+    assert int(out.stdout.split()[1]) >= 8
+
+
+def test_cpp_dropin_called_from_many_threads_at_once(built_lib):
+    """SURVEY 8b threading: the reference's encoder is re-entrant and callers encode from many threads.  Six threads, six
+    different frames (streamed 8K / 4K frames, small ones, both channel counts, all three flag values), three calls each,
+    all through fpng::fpng_encode_image_to_memory at the same time; every file equals the CPU checker's."""
+    import fpng_amd
+    specs = [("grad", 7680, 4320, 4, 0), ("blocks", 3840, 2160, 4, 0), ("grad", 1920, 1080, 3, 1), ("noise", 640, 480, 4, 0),
+             ("grad", 3840, 2160, 3, 0), ("grad", 333, 77, 3, 2)]
+    imgs = [fpng_amd.synth_image(k, w, h, c, seed=100 + i) for i, (k, w, h, c, _) in enumerate(specs)]
+    pngs, agree = dropin.encode_threads(imgs, [s[4] for s in specs], reps=3)
+    assert agree
+    for (k, w, h, c, fl), im, png in zip(specs, imgs, pngs):
+        assert png == oracle().encode(im, w, h, c, fl), (k, w, h, c, fl)

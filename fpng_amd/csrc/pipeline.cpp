@@ -400,10 +400,9 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
     const auto t_start = std::chrono::steady_clock::now();
     auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
     std::vector<double> tl(trace ? (size_t)nb * 6 : 0, 0.0); // per band: upload begin/end, counted, placed (enqueued), download begin/end
+    if ((rc = ensure_copy_streams(e))) return rc;
     for (auto &r : runs)
         if (hipEventCreateWithFlags(&r.placed, hipEventDisableTiming) != hipSuccess) failed = FPNG_AMD_ERR_HIP;
-
-    if (int rc_streams = ensure_copy_streams(e)) return rc_streams;
     hipStream_t s_up = ring.up, s_down = ring.down;
     // The two copy threads live as long as the encoder (no thread start per call).
     if (!e->workers) e->workers = new HostWorkers();
@@ -449,9 +448,8 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
                 cv.notify_all();
                 return;
             }
-            // ONE copy per band on this stream: small copies in front of the big one (the band's CRC partials, the 16-byte
-            // piece it shares with its predecessor) make the runtime serialise the two PCIe directions -- measured: 425 us
-            // per 7 MB window next to an upload instead of 175.  They are collected on the device and fetched once at the end.
+            // ONE copy per band on this stream: the band's CRC partials and the 16-byte piece it shares with its predecessor are
+            // collected on the device and fetched once at the end (a few small copies per band cost more than they move).
             bool ok = true;
             if (r.bytes > r.head)
                 ok = hipMemcpyAsync(out + r.file_off + r.head, d_out + r.dev_off + r.head, r.bytes - r.head, hipMemcpyDeviceToHost, s_down) == hipSuccess &&

@@ -146,8 +146,7 @@ def _cpu_worker(task):
 
 
 def end_to_end(enc_device, w, h, c, kind, flags):
-    """The host-pixel paths in a FRESH process each: a user of the reference's API has no other GPU work in its process, and a
-    second encoder made in a process downloads at half speed (profiles/r03_host_path.txt)."""
+    """The host-pixel paths in a FRESH process each: a user of the reference's API has no other GPU work in its process."""
     import subprocess
     res = {}
     for part in ("cabi", "dropin"):  # (one streaming encoder per process: the C ABI's, then the drop-in's)

@@ -7,4 +7,4 @@ from .api import (FPNG_ADLER32_INIT, FPNG_CRC32_INIT, FPNG_ENCODE_SLOWER, FPNG_F
                   MODE_STORED, Encoder, FpngAmdError, adler32_combine, crc32_combine, fpng_adler32,
                   fpng_cpu_supports_sse41, fpng_crc32, fpng_encode_image_to_file, fpng_encode_image_to_memory,
                   fpng_init, layout_1pass, max_encoded_size, synth_image, Node, plan_bands, band_window, idat_crc_from_bands,
-                  png_head, png_tail, pin_host_memory, unpin_host_memory)
+                  png_head, png_tail, pin_host_memory, unpin_host_memory, release_cached_memory)

@@ -125,6 +125,7 @@ SIGNATURES = {
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),
     "fpng_amd_debug_peek": (_int, [_vp, _int, C.POINTER(_u32), _u32]),
     "fpng_amd_calibration_stream": (_int, [_vp, _int, _u32, _vp, _sz]),
+    "fpng_amd_release_cached_memory": (_int, []),
 }
 
 _lib = None

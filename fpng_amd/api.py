@@ -72,9 +72,14 @@ def layout_1pass(num_chans):
     return a.value, b.value, c.value
 
 
+def release_cached_memory():
+    """Free the device buffers that destroyed encoders left with the library (fpng_amd_release_cached_memory)."""
+    check(_lib.load().fpng_amd_release_cached_memory())
+
+
 def pin_host_memory(arr):
-    """Page-lock a numpy array's memory (fpng_amd_pin_host_memory): host frames in page-locked memory are streamed through
-    the GPU in row bands (upload, encode and download overlapped).  Unpin before the array is freed."""
+    """Page-lock a numpy array's memory (fpng_amd_pin_host_memory): saves the runtime's pinning of every chunk it copies.
+    Unpin before the array is freed."""
     check(_lib.load().fpng_amd_pin_host_memory(arr.ctypes.data, arr.nbytes))
 
 

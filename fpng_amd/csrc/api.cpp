@@ -132,6 +132,48 @@ const TokenTable *fpng_amd::host_1pass_table(uint32_t c)
     return ((c == 3 || c == 4) && host_tables()) ? &g_host_1pass[c] : nullptr;
 }
 
+// ---- the list of large device blocks that are kept for the life of the process (encoder.h: DeviceBuf) ----
+namespace {
+struct CachedBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_cache_mutex;
+std::vector<CachedBlock> g_cache;
+constexpr size_t kCacheMinBytes = 1u << 20;
+} // namespace
+
+void *fpng_amd::device_take(size_t bytes, size_t *got)
+{
+    if (bytes < kCacheMinBytes) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    size_t best = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); i++) // the smallest block that fits and is not more than twice the request
+        if (g_cache[i].device == dev && g_cache[i].bytes >= bytes && g_cache[i].bytes <= 2 * bytes &&
+            (best == g_cache.size() || g_cache[i].bytes < g_cache[best].bytes))
+            best = i;
+    if (best == g_cache.size()) return nullptr;
+    void *p = g_cache[best].p;
+    *got = g_cache[best].bytes;
+    g_cache.erase(g_cache.begin() + (long)best);
+    return p;
+}
+
+void fpng_amd::device_give(void *p, size_t bytes)
+{
+    int dev = 0;
+    if (bytes < kCacheMinBytes || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipFree(p);
+        return;
+    }
+    (void)hipDeviceSynchronize(); // nothing in flight may still use it when its next owner writes to it
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    g_cache.push_back({p, bytes, dev});
+}
+
 extern "C" {
 
 int fpng_amd_abi_version(void) { return FPNG_AMD_ABI_VERSION; }
@@ -145,6 +187,20 @@ int fpng_amd_device_count(void)
 }
 
 int fpng_amd_device_available(void) { return fpng_amd_device_count() > 0 ? 1 : 0; }
+
+int fpng_amd_release_cached_memory(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &b : g_cache) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    g_cache.clear();
+    (void)hipSetDevice(cur);
+    return FPNG_AMD_OK;
+}
 
 int fpng_amd_init(int device)
 {

@@ -22,28 +22,40 @@ int fail(int code, const char *what, hipError_t e = hipSuccess);
         if (e_ != hipSuccess) return ::fpng_amd::fail(FPNG_AMD_ERR_HIP, #expr, e_);  \
     } while (0)
 
+// Large device buffers are never handed back to the runtime while the process lives: device memory that was hipFree'd and
+// comes back from a later hipMalloc downloads at 23 GB/s instead of 54 through the copy engines (measured: a second encoder
+// made after the first one was destroyed took 3.7-4.0 ms per streamed 8K frame instead of 2.8; with the frees left out, 2.8 --
+// profiles/r03_host_path.txt).  Blocks of 1 MiB and more go to a per-device list instead (api.cpp) and serve later requests
+// they fit; fpng_amd_release_cached_memory() empties it.  `give` waits for the device first, as hipFree would.
+void *device_take(size_t bytes, size_t *got);
+void device_give(void *p, size_t bytes);
+
 template <typename T> struct DeviceBuf {
     T *p = nullptr;
     size_t cap = 0;
     bool fresh = false; // set when ensure() (re)allocated: the contents are undefined
-    // (hipFree waits for the device: growing a buffer that a submission in flight still uses is safe, merely a stall;
-    // capacities grow geometrically so that it stops happening after the first few submissions)
+    // (giving a buffer up waits for the device: growing a buffer that a submission in flight still uses is safe, merely a
+    // stall; capacities grow geometrically so that it stops happening after the first few submissions)
     int ensure(size_t n)
     {
         if (n <= cap) return FPNG_AMD_OK;
         const size_t want = std::max(n, cap + cap / 2);
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, want * sizeof(T));
-        if (e != hipSuccess) return ::fpng_amd::fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipMalloc scratch", e);
-        cap = want;
+        release();
+        size_t got = 0;
+        void *q = device_take(want * sizeof(T), &got);
+        if (!q) {
+            hipError_t e = hipMalloc(&q, want * sizeof(T));
+            if (e != hipSuccess) return ::fpng_amd::fail(FPNG_AMD_ERR_OUT_OF_MEMORY, "hipMalloc scratch", e);
+            got = want * sizeof(T);
+        }
+        p = (T *)q;
+        cap = got / sizeof(T);
         fresh = true;
         return FPNG_AMD_OK;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) device_give(p, cap * sizeof(T));
         p = nullptr;
         cap = 0;
     }

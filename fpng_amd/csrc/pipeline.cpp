@@ -231,9 +231,8 @@ void fpng_amd::destroy_host_workers(fpng_amd_encoder *e)
 // ~150 us), and the outcome is measured: both directions together must take clearly less than one after the other; if not the
 // download stream is made anew and the step repeated.
 //
-// Not covered: a SECOND encoder made in a process after the first one was destroyed downloads at 23 GB/s instead of 54 whatever
-// streams it uses (its own, made anew, or the first encoder's: all measured, tools/host_state_probe.py) -- 3.7 instead of 2.9 ms
-// per one-frame call, 2.78 instead of 2.59 per batch frame.  Keep one encoder per device for the life of the process.
+// (A second, unrelated cliff looked like this one for a while: device memory that was hipFree'd and allocated again downloads at
+// half speed -- see DeviceBuf in encoder.h.)
 int fpng_amd::ensure_copy_streams(fpng_amd_encoder *e)
 {
     auto &ring = e->host;

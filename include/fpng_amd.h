@@ -48,6 +48,12 @@ extern "C" {
 
 /* ---- library ---- */
 
+/* Device buffers of 1 MiB and more that encoders give up (on destruction, or when they outgrow them) are kept by the library
+ * and handed to later requests of the same device instead of going back to the runtime -- memory that was freed and
+ * allocated again downloads at half speed through the copy engines.  This call frees everything on that list
+ * (all devices); buffers in use by live encoders are not touched. */
+int fpng_amd_release_cached_memory(void);
+
 /* Replaces fpng_init() (reference src/fpng.h:17): there it probes CPUID for SSE4.1, here it binds
  * the calling thread's default context to HIP device `device` (-1 = current device) and uploads
  * the format tables.  Optional, like the original: every other call self-initialises lazily and

@@ -178,3 +178,20 @@ def test_cpp_dropin_called_from_many_threads_at_once(built_lib):
     assert agree
     for (k, w, h, c, fl), im, png in zip(specs, imgs, pngs):
         assert png == oracle().encode(im, w, h, c, fl), (k, w, h, c, fl)
+
+
+def test_encoders_one_after_the_other_and_the_buffer_list(built_lib):
+    """Device buffers an encoder gives up are kept by the library and serve the next encoder (encoder.h: DeviceBuf);
+    fpng_amd_release_cached_memory() empties that list.  Either way the files are the reference's."""
+    import fpng_amd
+    w, h, c = 3840, 2160, 4
+    img = fpng_amd.synth_image("grad", w, h, c)
+    exp = _kat("grad", w, h, c, 0)
+    out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)
+    for k in range(4):
+        e = fpng_amd.Encoder(device=0, stream="own")
+        n = e.encode_host_into(img, w, h, c, out, 0)
+        assert n == exp["size"] and hashlib.sha256(out[:n].tobytes()).hexdigest() == exp["sha256"], k
+        e.close()
+        if k == 1:
+            fpng_amd.release_cached_memory()

@@ -12,6 +12,7 @@ Run in the dev container (where /root/reference exists):   python oracle/make_go
   bench_noise  8 x 7680x4320x4 `noise`, flags 0                 (bench.py --kind noise: the stored outcome)
   bench_4k     16 x 3840x2160x4 `grad`, flags 0                 (bench.py --workload 4k --batch 16)
   bench_512    1024 x 512x512x3 `grad`, flags 0                 (bench.py --workload 512 --batch 1024; compact form)
+  bench_16k    16384x16384x4 `grad`, seed 12345, flags 0        (bench.py --workload 16k --batch 1)
 
 Sets of more than 300 images are stored compactly: "sha256_all" = sha256 over the concatenated per-image hex digests.
 """
@@ -33,6 +34,7 @@ SETS = {
     "bench_noise": dict(w=7680, h=4320, c=4, kind="noise", n=8, seed0=12345, flags=[0]),
     "bench_4k": dict(w=3840, h=2160, c=4, kind="grad", n=16, seed0=12345, flags=[0]),
     "bench_512": dict(w=512, h=512, c=3, kind="grad", n=1024, seed0=12345, flags=[0]),
+    "bench_16k": dict(w=16384, h=16384, c=4, kind="grad", n=1, seed0=12345, flags=[0]),
 }
 
 

@@ -89,6 +89,17 @@ def committed_traffic(kernel, tag):
     return None, None
 
 
+def committed_chain_traffic(tag):
+    """HBM-side bytes of ALL kernels of one step, from the same committed PMC summary ("total HBM-side traffic per launch")."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}_pmc_traffic.txt")), key=os.path.basename, reverse=True):
+        m = re.search(r"total HBM-side traffic per launch:\s*([0-9.]+) MB", open(path).read())
+        if m:
+            return int(float(m.group(1)) * 1e6)
+    return None
+
+
 def verify_outputs(args, rank, w, h, c, outs, sizes):
     """sha256 of EVERY image of the last timed submission (seeds 12345+i on rank 0) vs the golden vectors produced by the
     unmodified reference (tests/golden/batches.json holds whole batches, kat.json single images with seed 12345).
@@ -444,6 +455,12 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": phase_ms[dom],
                 "all_kernels_ms": round(kernels_s * 1e3, 4),
                 "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": phase_ms}
+    # what the whole chain moves per step (all kernels, PMC) and the rate it moves it at in the timed, pipelined regions: the
+    # number to hold against what plain streaming kernels reach on the same read/write mix (profiles/r03_mix_probe.txt: 5.1 TB/s)
+    chain = committed_chain_traffic(workload_tag(args))
+    if chain:
+        roofline["chain_traffic"] = chain
+        roofline["chain_traffic_rate_GBs"] = round(chain / (elapsed / args.steps) / 1e9, 1)
 
     line = {
         "metric": f"encode megapixels/sec (whole node), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident",

@@ -629,3 +629,20 @@ except fpng_amd.FpngAmdError as e:
     env = dict(os.environ, FPNG_ROOT=ROOT, FPNG_AMD_LOCAL_LIMIT_MB="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "refused ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2])
+def test_wide_rows_fuzz(enc, flags):
+    """Rows of 257..4100 pixels built in filtered space from runs of every interesting length, isolated pairs and literal
+    stretches at random alignment to the 256-pixel super-windows (tools/gpu_wide_fuzz.py; a 27 000-image run of the same
+    generator is in profiles/r03_fuzz_campaign.txt): batches of 200 through one submission each."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_wide_fuzz", os.path.join(ROOT, "tools", "gpu_wide_fuzz.py"))
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    rng = np.random.default_rng(4000 + flags)
+    for _ in range(3):
+        cases = [wf.wide_image(rng) for _ in range(200)]
+        pngs, _ = _gpu_encode(enc, [c[0] for c in cases], flags)
+        for (img, w, h, c), p in zip(cases, pngs):
+            _assert_same(p, oracle().encode(img, w, h, c, flags), f"wide fuzz {w}x{h}x{c}")

@@ -165,3 +165,19 @@ def test_oracle_on_the_natural_image():
             png = oracle().encode(img, w, h, c, fl)
             assert len(png) == g[k]["flags"][str(fl)]["size"]
             assert hashlib.sha256(png).hexdigest() == g[k]["flags"][str(fl)]["sha256"], (k, fl)
+
+
+@pytest.mark.skipif(not have_ref(), reason="reference build not available")
+def test_oracle_vs_reference_wide_rows():
+    """The checker itself on the wide-row generator the -m gpu suite uses (tools/gpu_wide_fuzz.py): rows of 257..4100 pixels,
+    runs crossing every 256-pixel border -- identical to the unmodified reference for all three flag values."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_wide_fuzz", os.path.join(ROOT, "tools", "gpu_wide_fuzz.py"))
+    src = open(spec.origin).read().split("def main():")[0].replace("import numpy as np, torch, fpng_amd", "import numpy as np")
+    ns = {"__file__": spec.origin}
+    exec(compile(src, spec.origin, "exec"), ns)
+    rng = np.random.default_rng(77)
+    for _ in range(300):
+        img, w, h, c = ns["wide_image"](rng)
+        for fl in (0, 1, 2):
+            assert oracle().encode(img, w, h, c, fl) == ref().encode(img, w, h, c, fl), (w, h, c, fl)

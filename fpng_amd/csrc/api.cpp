@@ -523,16 +523,26 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // (Measured and dropped, profiles/r03_latency.txt: letting one- and two-frame submissions read their job records straight from
     // the slot's pinned host memory instead of uploading them -- the upload is a blit kernel + a dispatch gap, ~7 us -- costs
     // 7 us MORE per chain: every kernel's first touch of the record goes over PCIe.)
+    // One image: its record travels in the arguments of the chain's first kernel, which leaves it in d_jobs for the others
+    // (encode_rows_first_kernel): no blit kernel + dispatch gap in front of the chain.  FPNG_AMD_JOB_IN_ARGS=0 uploads as always.
+    static const bool job_in_args_env = [] {
+        const char *v = getenv("FPNG_AMD_JOB_IN_ARGS");
+        return !v || v[0] != '0';
+    }();
+    const bool job_in_args = job_in_args_env && n == 1 && !force_stored;
     const Job *d_jobs = sc.d_jobs.p;
-    HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+    if (!job_in_args) HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
     uint32_t ph = 0; // index of the last phase mark
     if (two_pass) {
         HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
-        launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
+        if (job_in_args)
+            launch_hist_first(s, slot.jobs.p[0], sc.d_jobs.p, sc.d_hist.p);
+        else
+            launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
         if ((rc = mark(e, s, ++ph))) return rc;
         launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
-        HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
+        if (!job_in_args) HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
         if ((rc = mark(e, s, ++ph))) return rc;
     }
     // 2-pass only: the row walk of this submission waits for the walk of the previous one (other lane), so that
@@ -548,7 +558,10 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // for an image that fell back, the stored blocks; + CRC partials), finalize (CRC fold, Adler, trailer, result record).  Folding the scan into the last row block and
     // the finalize step into the last assemble block (three launches) was measured on the same box: 11 % less throughput
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
-    if (!force_stored) launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    if (job_in_args)
+        launch_encode_rows_first(s, two_pass ? slot.jobs2.p[0] : slot.jobs.p[0], sc.d_jobs.p, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    else if (!force_stored)
+        launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;
     if (two_pass || stagger_env == 1) { // (only the staggered 2-pass walks wait for it)
         HIP_TRY(hipEventRecord(slot.walked, s));

@@ -77,6 +77,9 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);
+// one job per submission: the record travels in the kernel arguments and is left at d_job for the kernels that follow
+void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local);
+void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist);
 // adler_parts (whole images; two words per CRC range and job, or NULL for row bands): where the workgroups of an image that
 // fell back to stored blocks leave their range's share of the Adler-32
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,

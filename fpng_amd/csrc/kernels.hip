@@ -921,11 +921,10 @@ __device__ __forceinline__ const Job &job_of_block(const Job *jobs) { return job
 // hist_kernel (2-pass, pass 1): literal / length-symbol histogram of the whole image
 // (reference fpng.cpp:1021-1084 / :1299-1363).  job.table here is the "symbol" table whose
 // chunk[q] holds (length symbol - 256).
-__global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+__device__ __forceinline__ void hist_block(const Job &job, uint32_t *dst)
 {
     __shared__ PackedTables T;
     __shared__ uint32_t hist[288 * kHistReplicas];
-    const Job &job = job_of_block(jobs);
     if (blockIdx.x * kHistWaves >= job.nrows) return;
     stage_packed_tables<kHistBlock>(T, job.table);
     for (int i = threadIdx.x; i < 288 * kHistReplicas; i += kHistBlock) hist[i] = 0;
@@ -939,12 +938,24 @@ __global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint3
         if (lane == 0) hist_add(hist, (job.y0 + r) ? 2 : 0, r); // the row's filter-type literal
     }
     __syncthreads();
-    uint32_t *dst = hist_out + (size_t)blockIdx.y * 288;
     for (int i = threadIdx.x; i < 288; i += kHistBlock) {
         uint32_t s = 0;
         for (int rep = 0; rep < kHistReplicas; rep++) s += hist[i * kHistReplicas + ((rep + i) & (kHistReplicas - 1))];
         if (s) atomicAdd(&dst[i], s);
     }
+}
+__global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+{
+    hist_block(job_of_block(jobs), hist_out + (size_t)blockIdx.y * 288);
+}
+// (JobArg / the *_first_kernel forms: one image per submission, its job record in the kernel arguments -- see encode_rows_first_kernel)
+struct JobArg {
+    Job job;
+};
+__global__ __launch_bounds__(kHistBlock) void hist_first_kernel(const JobArg arg, Job *job_out, uint32_t *hist_out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *job_out = arg.job; // for build_dynamic_kernel
+    hist_block(arg.job, hist_out);
 }
 
 // Words that one workgroup writes and another one reads INSIDE a launch: 8-byte granules, agent-scope relaxed atomics
@@ -1127,23 +1138,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const
 // One instantiation per channel count (jobs of the other kind leave at once): the 3-channel walk needs far
 // fewer registers than the 4-pixels-per-lane RGBA one and keeps 8 waves per SIMD.
 template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
-                                                                                                      JobState *states, uint32_t *local)
+__device__ __forceinline__ void encode_rows_block(const Job &job, uint32_t by, uint32_t bx, RowInfo *rows_out, JobState *states, uint32_t *local)
 {
     __shared__ PackedTables T;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
-    // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
-    // contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
-    // on the same XCD at about the same time and that row is an L2 hit rather than a second HBM read.
-    uint32_t bx, by;
-    {
-        const uint32_t total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const uint32_t xcd = lin & 7u, per = total >> 3, rem = total & 7u;
-        const uint32_t logical = xcd * per + (xcd < rem ? xcd : rem) + (lin >> 3);
-        by = logical / gridDim.x;
-        bx = logical - by * gridDim.x;
-    }
-    const Job &job = jobs[by];
     if (job.c != C || bx * kRowWaves >= job.nrows) return;
     stage_packed_tables<kRowBlock>(T, job.table);
     __syncthreads();
@@ -1179,6 +1177,41 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
         rows_out[job.row_base + r] = ri;
         if (r == job.nrows - 1) states[by].last_unit_bits = res.last_unit_bits;
     }
+}
+
+// XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2).  Hand every XCD a
+// contiguous range of (job, row block) pairs, so that the block holding the row above a block's first row runs
+// on the same XCD at about the same time and that row is an L2 hit rather than a second HBM read.
+__device__ __forceinline__ void xcd_block_order(uint32_t &bx, uint32_t &by)
+{
+    const uint32_t total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = lin & 7u, per = total >> 3, rem = total & 7u;
+    const uint32_t logical = xcd * per + (xcd < rem ? xcd : rem) + (lin >> 3);
+    by = logical / gridDim.x;
+    bx = logical - by * gridDim.x;
+}
+
+template <int C>
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
+                                                                                                      JobState *states, uint32_t *local)
+{
+    uint32_t bx, by;
+    xcd_block_order(bx, by);
+    encode_rows_block<C>(jobs[by], by, bx, rows_out, states, local);
+}
+
+// One image per submission, first kernel of its chain: the job record comes IN THE KERNEL ARGUMENTS instead of through an
+// upload in front of the chain (a blit kernel + a dispatch gap: ~7 us of a single frame's ~90); workgroup 0 leaves it in
+// device memory for scan / assemble / finalize, which start after this kernel has ended.
+template <int C>
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_first_kernel(const JobArg arg, Job *job_out,
+                                                                                                            RowInfo *rows_out, JobState *states,
+                                                                                                            uint32_t *local)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *job_out = arg.job; // (one lane, constant offsets: indexing the argument by thread would put a copy of it into scratch)
+    uint32_t bx, by;
+    xcd_block_order(bx, by);
+    encode_rows_block<C>(arg.job, 0, bx, rows_out, states, local);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2163,6 +2196,12 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 {
     hipLaunchKernelGGL(hist_kernel, dim3((max_rows + kHistWaves - 1) / kHistWaves, n_jobs, 1), dim3(kHistBlock), 0, s, jobs, hist);
 }
+void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist)
+{
+    JobArg arg;
+    arg.job = job;
+    hipLaunchKernelGGL(hist_first_kernel, dim3((job.nrows + kHistWaves - 1) / kHistWaves, 1, 1), dim3(kHistBlock), 0, s, arg, d_job, hist);
+}
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
     hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states);
@@ -2178,6 +2217,15 @@ void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_
         hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
     if (chan_mask & 2u)
         hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+}
+void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local)
+{
+    JobArg arg;
+    arg.job = job;
+    if (job.c == 3)
+        hipLaunchKernelGGL(encode_rows_first_kernel<3>, row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
+    else
+        hipLaunchKernelGGL(encode_rows_first_kernel<4>, row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
 }
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
                      const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials, uint32_t *adler_parts)

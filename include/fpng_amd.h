@@ -85,6 +85,8 @@ size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
  *                                   need more is refused with FPNG_AMD_ERR_OUT_OF_MEMORY before anything is launched
  *      FPNG_AMD_STAGGER=0|1         2-pass: make a submission's row walk wait for the previous submission's walk
  *                                   (default: on for FPNG_AMD_ENCODE_SLOWER, off otherwise)
+ *      FPNG_AMD_JOB_IN_ARGS=0|1     a submission of ONE image hands its job record to the first kernel (each pass) in the kernel
+ *                                   arguments instead of uploading it in front of the chain (default 1; 0 = upload as always)
  *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline for every
  *                                   1-pass frame (default: by image size, for page-locked or previously seen buffers; 1 = serial)
  *      FPNG_AMD_TRACE=1             fpng_amd_encode_host(): per-band timeline of the streamed path on stderr ---- */

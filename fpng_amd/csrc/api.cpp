@@ -517,9 +517,21 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     e->phases_recorded = 0;
     e->last_two_pass = two_pass;
     // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
-    HIP_TRY(hipEventRecord(slot.in, e->stream));
-    HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
-    if (sc.last_done) HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
+    // (when that stream has nothing pending there is nothing to order against: no marker + barrier packet in front of the chain;
+    // the same for the scratch set's previous user when it is done already)
+    static const bool always_order = [] {
+        const char *v = getenv("FPNG_AMD_ALWAYS_ORDER");
+        return v && v[0] == '1';
+    }();
+    if (always_order || hipStreamQuery(e->stream) != hipSuccess) {
+        (void)hipGetLastError(); // ("not ready" is not an error)
+        HIP_TRY(hipEventRecord(slot.in, e->stream));
+        HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
+    }
+    if (sc.last_done && (always_order || hipEventQuery(sc.last_done) != hipSuccess)) {
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
+    }
     // (Measured and dropped, profiles/r03_latency.txt: letting one- and two-frame submissions read their job records straight from
     // the slot's pinned host memory instead of uploading them -- the upload is a blit kernel + a dispatch gap, ~7 us -- costs
     // 7 us MORE per chain: every kernel's first touch of the record goes over PCIe.)

@@ -87,6 +87,8 @@ size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
  *                                   (default: on for FPNG_AMD_ENCODE_SLOWER, off otherwise)
  *      FPNG_AMD_JOB_IN_ARGS=0|1     a submission of ONE image hands its job record to the first kernel (each pass) in the kernel
  *                                   arguments instead of uploading it in front of the chain (default 1; 0 = upload as always)
+ *      FPNG_AMD_ALWAYS_ORDER=1      put the marker / barrier packets that order a submission behind the caller's stream and behind the
+ *                                   scratch set's previous user in front of EVERY chain (default: only when those are still busy)
  *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline for every
  *                                   1-pass frame (default: by image size, for page-locked or previously seen buffers; 1 = serial)
  *      FPNG_AMD_TRACE=1             fpng_amd_encode_host(): per-band timeline of the streamed path on stderr ---- */

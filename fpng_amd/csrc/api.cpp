@@ -547,13 +547,24 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     if ((rc = mark(e, s, 0))) return rc;
     uint32_t ph = 0; // index of the last phase mark
     if (two_pass) {
-        HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, (size_t)n * 288 * sizeof(uint32_t), s));
+        // the counters must start at zero: the table builder leaves the ones it consumed zeroed, so only a fresh (or otherwise
+        // used, or too short) buffer is cleared here -- a fill kernel + dispatch gap less in front of a 2-pass chain
+        const size_t n_counters = (size_t)n * 288;
+#ifdef FPNG_BUILD_TIMING
+        const uint32_t rezero = 0; // (the timing build leaves its cycle counts in the histogram buffer)
+#else
+        const uint32_t rezero = 1;
+#endif
+        if (sc.d_hist.fresh) sc.hist_zero = 0, sc.d_hist.fresh = false;
+        if (sc.hist_zero < n_counters) HIP_TRY(hipMemsetAsync(sc.d_hist.p, 0, n_counters * sizeof(uint32_t), s));
+        sc.hist_zero = 0;
         if (job_in_args)
             launch_hist_first(s, slot.jobs.p[0], sc.d_jobs.p, sc.d_hist.p);
         else
             launch_hist(s, sc.d_jobs.p, n, sub.max_rows, sc.d_hist.p);
         if ((rc = mark(e, s, ++ph))) return rc;
-        launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p);
+        launch_build_dynamic(s, sc.d_jobs.p, n, sc.d_hist.p, sc.d_dyn.p, rezero);
+        if (rezero) sc.hist_zero = n_counters;
         if (!job_in_args) HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs2.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
         if ((rc = mark(e, s, ++ph))) return rc;
     }
@@ -576,8 +587,17 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;
     if (two_pass || stagger_env == 1) { // (only the staggered 2-pass walks wait for it)
-        HIP_TRY(hipEventRecord(slot.walked, s));
-        e->prev_walked = slot.walked;
+        // ... and only a submission that follows while this one runs: with every other lane idle (one frame at a time) the marker
+        // packet between the walk and the scan would only lengthen the chain
+        bool others_busy = always_order;
+        for (uint32_t l = 0; l < n_lanes && !others_busy; l++)
+            if ((int)l != lane && e->sc[l].last_done && hipEventQuery(e->sc[l].last_done) != hipSuccess) others_busy = true;
+        (void)hipGetLastError();
+        e->prev_walked = nullptr;
+        if (others_busy) {
+            HIP_TRY(hipEventRecord(slot.walked, s));
+            e->prev_walked = slot.walked;
+        }
     }
     launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
     if ((rc = mark(e, s, ++ph))) return rc;
@@ -980,7 +1000,7 @@ int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t f
         jb = j;
         jb.table = g_dev[e->device].symbols[b->num_chans];
         HIP_TRY(hipMemcpyAsync(sc.d_jobs.p + 1, &jb, sizeof(Job), hipMemcpyHostToDevice, s));
-        launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p);
+        launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p, 0);
     }
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
     launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
@@ -1163,6 +1183,7 @@ int fpng_amd_train_tables(fpng_amd_encoder *e, const fpng_amd_image *images, uin
     std::memset(&jt, 0, sizeof jt);
     jt.c = c, jt.flags = FPNG_AMD_ENCODE_SLOWER | 0x400u, jt.table = dt.symbols[c];
     hipStream_t s = e->stream;
+    sc.hist_zero = 0;
     uint32_t *d_hist = sc.d_hist.p;                       // n x 288 counters
     uint64_t *d_sums = (uint64_t *)(d_hist + (size_t)n * 288); // 288 x u64 (n * 288 * 4 is a multiple of 8)
     uint32_t *d_freq = d_hist + (size_t)n * 288 + 576;    // the corpus histogram the builder reads
@@ -1186,7 +1207,7 @@ int fpng_amd_train_tables(fpng_amd_encoder *e, const fpng_amd_image *images, uin
         if (!freq[sym]) freq[sym] = 1;
     }
     HIP_TRY(hipMemcpyAsync(d_freq, freq.data(), 288 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    launch_build_dynamic(s, sc.d_jobs.p + n, 1, d_freq, sc.d_dyn.p);
+    launch_build_dynamic(s, sc.d_jobs.p + n, 1, d_freq, sc.d_dyn.p, 0);
     HIP_TRY(hipGetLastError());
     std::vector<TokenTable> tab(1);
     HIP_TRY(hipMemcpyAsync(tab.data(), sc.d_dyn.p, sizeof(TokenTable), hipMemcpyDeviceToHost, s));
@@ -1222,6 +1243,7 @@ int fpng_amd_calibration_stream(fpng_amd_encoder *e, int write, uint32_t lane_by
     HIP_TRY(hipSetDevice(e->device));
     int rc;
     if ((rc = e->sc[0].d_hist.ensure(288))) return rc;
+    e->sc[0].hist_zero = 0;
     launch_calibration(e->stream, write, lane_bytes, d_buf, bytes, e->sc[0].d_hist.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));

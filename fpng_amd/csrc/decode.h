@@ -27,12 +27,20 @@ struct DecJob {
     uint32_t mode;            // 0 one dynamic block, 1 stored blocks
 };
 
-void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in, const uint32_t *flags_in,
-                     uint64_t *start, uint64_t *end_out, uint32_t *bytes, uint32_t *flags_out, uint32_t *changed);
-void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes, const uint32_t *flags,
-                        uint64_t *off, uint32_t *status, uint32_t *eob_index);
-void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *eob_index, const uint64_t *off,
-                     uint32_t *status);
+// what dec_blocksum_kernel leaves per workgroup of 256 subsequences (indices inside the workgroup, 256 = none)
+struct DecBlockRec {
+    uint32_t sum;             // output bytes of its subsequences
+    uint32_t first_eob;       // first one that met an end-of-block symbol
+    uint32_t first_unchained; // first one that does not start where its predecessor ended
+    uint32_t first_invalid;   // first one whose decode derailed
+};
+
+void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, uint64_t *start, uint64_t *end, uint32_t *bytes,
+                     uint32_t *flags, uint32_t *changed);
+void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes,
+                        const uint32_t *flags, DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);
+void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *bytes, const uint32_t *eob_index,
+                     const uint64_t *block_off, uint32_t *status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status);
 
 } // namespace fpng_amd

@@ -30,20 +30,28 @@ constexpr int kDecBlock = 256;
 
 __device__ __forceinline__ uint32_t dec_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// LSB-first reader over device memory (dword loads; positions are absolute bits from z)
-struct DevBits {
-    const uint32_t *w; // z aligned down to 4 bytes
-    uint64_t pos;      // absolute bit position (from w)
-    uint64_t limit;    // no token may start at or behind this bit
+// The token bits a workgroup works on are staged in LDS first (coalesced loads): thread t of a block decodes the 1024 bits that
+// start 32 dwords behind thread t-1's, so straight from global memory every load instruction of a wave would touch 64 different
+// cache lines.  A block's slice = its 256 subsequences plus the few dwords the last thread may run over.  In LDS dword d of the
+// slice sits at d + d / 32: without the padding all lanes of a wave would read the same bank.
+constexpr uint32_t kSliceDwords = kDecBlock * (kSubBits / 32) + 8;
+constexpr uint32_t kSliceSlots = kSliceDwords + kSliceDwords / 32 + 1;
+__device__ __forceinline__ uint32_t slice_slot(uint32_t d) { return d + (d >> 5); }
+
+// LSB-first reader over the staged slice; positions are bits relative to the slice's first dword
+struct LdsBits {
+    const uint32_t *l;
+    uint32_t pos;
+    uint32_t limit; // no token may start at or behind this bit
     uint64_t buf;
-    uint32_t have;     // valid bits in buf
-    __device__ __forceinline__ void seek(uint64_t p)
+    uint32_t have; // valid bits in buf
+    __device__ __forceinline__ void seek(uint32_t p)
     {
         pos = p;
-        const uint64_t d = p >> 5;
-        const uint32_t lo = w[d], hi = w[d + 1];
+        const uint32_t d = p >> 5;
+        const uint32_t lo = l[slice_slot(d)], hi = l[slice_slot(d + 1)];
         buf = (((uint64_t)hi << 32) | lo) >> (p & 31);
-        have = 64 - (uint32_t)(p & 31);
+        have = 64 - (p & 31);
     }
     __device__ __forceinline__ uint32_t peek(uint32_t k) // k <= 32
     {
@@ -65,7 +73,7 @@ __device__ __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1
 enum : uint32_t { kSubEob = 1u, kSubInvalid = 4u };
 
 // one token: returns its kind and advances.  kind: 0..255 literal, 256 end of block, 257.. match with `run` bytes; -1 invalid
-__device__ __forceinline__ int next_token(DevBits &in, const uint16_t *lut, uint32_t &run)
+__device__ __forceinline__ int next_token(LdsBits &in, const uint16_t *lut, uint32_t &run)
 {
     const uint32_t e = lut[in.peek(12)];
     const uint32_t len = e >> 9;
@@ -92,38 +100,51 @@ __device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t
     return jobs[lo];
 }
 
-// ---- synchronisation rounds ----
-__global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in,
-                                                             const uint32_t *flags_in, uint64_t *start, uint64_t *end_out, uint32_t *bytes,
-                                                             uint32_t *flags_out, uint32_t *changed)
+// lookup table + the block's slice of the token bits into LDS; returns the slice's first bit (absolute, from z)
+__device__ __forceinline__ uint64_t stage_block(const DecJob &job, uint32_t local0, uint16_t *lut, uint32_t *bits)
 {
-    __shared__ uint16_t lut[4096];
+    const uint32_t *src = (const uint32_t *)job.lut;
+    for (int i = threadIdx.x; i < 2048; i += kDecBlock) ((uint32_t *)lut)[i] = src[i];
+    const uint64_t d0 = (job.first_bit + (uint64_t)local0 * kSubBits) >> 5;
+    const uint64_t n_dw = (job.z_bytes + 16) >> 2; // (the stream's buffer has 16 spare bytes behind the data)
+    const uint32_t *w = (const uint32_t *)job.z_aligned;
+    for (uint32_t d = threadIdx.x; d < kSliceDwords; d += kDecBlock) bits[slice_slot(d)] = (d0 + d < n_dw) ? w[d0 + d] : 0u;
+    return d0 << 5;
+}
+
+// ---- synchronisation rounds (results updated in place: a thread that reads its predecessor's end while that one is being
+//      rewritten decodes again in the next round -- the rounds end when one of them changes nothing) ----
+__global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, uint64_t *start,
+                                                             uint64_t *end, uint32_t *bytes, uint32_t *flags, uint32_t *changed)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
+    __shared__ uint32_t bits[kSliceSlots];
     const uint32_t g0 = blockIdx.x * kDecBlock;
     if (g0 >= total_subs) return;
     // all subsequences of a block belong to one job (sub_base is padded to kDecBlock by the host)
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
-    for (int i = threadIdx.x; i < 4096; i += kDecBlock) lut[i] = job.lut[i];
-    __syncthreads();
     const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
-    if (i >= job.n_sub) return;
-    const uint64_t nominal = job.first_bit + (uint64_t)i * kSubBits, boundary = nominal + kSubBits;
-    uint64_t s;
-    if (round == 0) {
-        s = nominal;
-    } else {
-        s = i ? end_in[g - 1] : job.first_bit;
-        if (s == start[g]) { // nothing new: carry the result over
-            end_out[g] = end_in[g], flags_out[g] = flags_in[g];
-            return;
-        }
-        atomicOr(changed, 1u);
+    const bool valid = i < job.n_sub;
+    const uint64_t nominal = job.first_bit + (uint64_t)i * kSubBits;
+    uint64_t s = nominal;
+    bool work = valid;
+    if (round && valid) {
+        s = i ? end[g - 1] : job.first_bit;
+        work = s != start[g];
     }
+    if (!__syncthreads_or(work)) return; // nothing new for this block: no staging either
+    const uint64_t base = stage_block(job, local0, lut, bits);
+    __syncthreads();
+    if (!work) return;
+    if (round) atomicOr(changed, 1u);
     start[g] = s;
-    DevBits in;
-    in.w = (const uint32_t *)job.z_aligned;
-    in.limit = job.end_limit_bit;
-    in.seek(s);
+    LdsBits in;
+    in.l = bits;
+    const uint64_t lim = job.end_limit_bit - base;
+    in.limit = lim > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim;
+    const uint32_t boundary = (uint32_t)(nominal + kSubBits - base);
+    in.seek((uint32_t)(s - base));
     uint32_t nbytes = 0, fl = 0;
     while (in.pos < boundary) {
         if (in.pos >= in.limit) { // ran off the data without an end-of-block symbol
@@ -145,48 +166,98 @@ __global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs,
     // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
     // end-of-block symbols, and letting those stop their successors would cost one round per subsequence to undo.  Which
     // end-of-block symbol is the true one is settled afterwards: the first one of the converged chain (dec_offsets_kernel).
-    end_out[g] = fl ? boundary : in.pos;
+    end[g] = base + (fl ? boundary : in.pos);
     bytes[g] = nbytes;
-    flags_out[g] = fl;
+    flags[g] = fl;
 }
 
-// ---- per file: exclusive scan of the byte counts of its subsequences, consistency of the chain, total ----
-__global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes,
-                                                                const uint32_t *flags, uint64_t *off, uint32_t *status, uint32_t *eob_index)
+// ---- output offsets, in two steps.  dec_blocksum_kernel, one workgroup per 256 subsequences: their output bytes, the first
+//      one that met an end-of-block symbol, the first one that does not start where its predecessor ended, the first invalid one ----
+__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, 4 words
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, kWave));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return min(min(red[0], red[1]), min(red[2], red[3]));
+}
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, kWave);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(kDecBlock) void dec_blocksum_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start,
+                                                                 const uint64_t *end, const uint32_t *bytes, const uint32_t *flags, DecBlockRec *recs)
+{
+    __shared__ uint32_t red[4];
+    const uint32_t g0 = blockIdx.x * kDecBlock;
+    if (g0 >= total_subs) return;
+    uint32_t local0;
+    const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+    const uint32_t t = threadIdx.x, g = g0 + t, i = local0 + t;
+    const bool valid = i < job.n_sub;
+    const uint32_t f = valid ? flags[g] : 0u;
+    const bool chain = valid && start[g] == (i ? end[g - 1] : job.first_bit);
+    const uint32_t sum = block_sum(valid ? bytes[g] : 0u, red);
+    const uint32_t e = block_min((f & kSubEob) ? t : (uint32_t)kDecBlock, red);
+    const uint32_t nc = block_min((valid && !chain) ? t : (uint32_t)kDecBlock, red);
+    const uint32_t inv = block_min((f & kSubInvalid) ? t : (uint32_t)kDecBlock, red);
+    if (t == 0) {
+        DecBlockRec r;
+        r.sum = sum, r.first_eob = e, r.first_unchained = nc, r.first_invalid = inv;
+        recs[blockIdx.x] = r;
+    }
+}
+
+// ---- dec_offsets_kernel, one workgroup per file: the stream ends with the FIRST end-of-block symbol of the chain (what lies
+//      behind it is padding and the Adler-32, decoded as garbage by their threads); up to there the chain must hold and no
+//      subsequence may be invalid; exclusive scan of the blocks' byte counts; the total must be the filtered image ----
+__global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jobs, const DecBlockRec *recs, const uint32_t *bytes, uint64_t *block_off,
+                                                                uint32_t *status, uint32_t *eob_index)
 {
     __shared__ uint64_t sums[kDecBlock];
-    __shared__ uint32_t bad, first_eob;
+    __shared__ uint32_t red[4];
     const DecJob &job = jobs[blockIdx.x];
     if (job.mode != 0) return;
-    const uint32_t t = threadIdx.x, n = job.n_sub, per = (n + kDecBlock - 1) / kDecBlock;
-    const uint32_t i0 = t * per < n ? t * per : n, i1 = i0 + per < n ? i0 + per : n;
-    if (t == 0) bad = 0, first_eob = n;
-    __syncthreads();
-    // the stream ends with the FIRST end-of-block symbol of the chain (everything in front of it is the true token sequence
-    // once the chain holds; what lies behind it is padding and the Adler-32, decoded as garbage by their threads)
-    for (uint32_t i = i0; i < i1; i++)
-        if (flags[job.sub_base + i] & kSubEob) {
-            atomicMin(&first_eob, i);
+    const uint32_t t = threadIdx.x, n = job.n_sub, nb = (n + kDecBlock - 1) / kDecBlock, b0 = job.sub_base / kDecBlock;
+    const uint32_t per = (nb + kDecBlock - 1) / kDecBlock;
+    const uint32_t i0 = min(t * per, nb), i1 = min(i0 + per, nb);
+    uint32_t mine = nb;
+    for (uint32_t b = i0; b < i1; b++)
+        if (recs[b0 + b].first_eob < (uint32_t)kDecBlock) {
+            mine = b;
             break;
         }
-    __syncthreads();
-    const uint32_t last = first_eob; // subsequences 0..last make up the stream
+    const uint32_t last_blk = block_min(mine, red); // nb: the stream never ends
+    const uint32_t last_local = last_blk < nb ? recs[b0 + last_blk].first_eob : 0u;
+    // blocks in front of the last one count whole; of the last one, subsequences 0..last_local
     uint64_t local = 0;
-    uint32_t b = 0;
-    for (uint32_t i = i0; i < i1 && i <= last; i++) {
-        const uint32_t g = job.sub_base + i;
-        local += bytes[g];
-        // the chain must hold: every subsequence starts where its predecessor ended
-        const uint64_t want = i ? end[g - 1] : job.first_bit;
-        if (start[g] != want) b |= kDecNotConverged;
-        if (flags[g] & kSubInvalid) b |= kDecBadStream;
+    uint32_t bad = 0;
+    for (uint32_t b = i0; b < i1 && b < last_blk; b++) {
+        const DecBlockRec r = recs[b0 + b];
+        local += r.sum;
+        if (r.first_unchained < (uint32_t)kDecBlock) bad |= kDecNotConverged;
+        if (r.first_invalid < (uint32_t)kDecBlock) bad |= kDecBadStream;
     }
-    if (t == 0) {
-        eob_index[blockIdx.x] = last;
-        if (last == n) b |= kDecBadStream; // the stream never ends
-    }
+    uint32_t tail = 0;
+    if (last_blk < nb) {
+        const DecBlockRec r = recs[b0 + last_blk];
+        if (t == 0) {
+            if (r.first_unchained <= last_local) bad |= kDecNotConverged;
+            if (r.first_invalid <= last_local) bad |= kDecBadStream;
+        }
+        if (t <= last_local) tail = bytes[job.sub_base + last_blk * kDecBlock + t];
+    } else if (t == 0)
+        bad |= kDecBadStream;
+    const uint32_t tail_sum = block_sum(tail, red);
+    const uint32_t any_bad = block_sum(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
+    const uint32_t any_bad2 = block_sum(bad & kDecBadStream, red) ? kDecBadStream : 0u;
     sums[t] = local;
-    if (b) atomicOr(&bad, b);
     __syncthreads();
     if (t == 0) {
         uint64_t acc = 0;
@@ -195,40 +266,59 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
             sums[k] = acc;
             acc += v;
         }
-        uint32_t st = bad;
-        if (acc != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
+        uint32_t st = any_bad | any_bad2;
+        if (acc + tail_sum != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
         if (st) atomicOr(&status[blockIdx.x], st);
+        eob_index[blockIdx.x] = last_blk < nb ? last_blk * kDecBlock + last_local : n;
     }
     __syncthreads();
     uint64_t o = sums[t];
-    for (uint32_t i = i0; i < i1 && i <= last; i++) {
-        off[job.sub_base + i] = o;
-        o += bytes[job.sub_base + i];
+    for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
+        block_off[b0 + b] = o;
+        o += recs[b0 + b].sum;
     }
 }
 
 // ---- the real decode ----
 __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start,
-                                                             const uint32_t *eob_index, const uint64_t *off, uint32_t *status)
+                                                             const uint32_t *bytes, const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
-    __shared__ uint16_t lut[4096];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
+    __shared__ uint32_t bits[kSliceSlots];
+    __shared__ uint32_t wsum[4];
     const uint32_t g0 = blockIdx.x * kDecBlock;
     if (g0 >= total_subs) return;
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
     const uint32_t job_index = (uint32_t)(&job - jobs);
     if (status[job_index] & ~kDecSawEob) return; // (uniform per block: one file per block)
-    for (int i = threadIdx.x; i < 4096; i += kDecBlock) lut[i] = job.lut[i];
-    __syncthreads();
-    const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
-    if (i >= job.n_sub || i > eob_index[job_index]) return;
-    const uint64_t boundary = job.first_bit + (uint64_t)(i + 1) * kSubBits, total = (uint64_t)(job.bpl + 1) * job.h;
+    const uint32_t last = eob_index[job_index];
+    if (local0 > last) return; // behind the end of the stream
+    const uint64_t base = stage_block(job, local0, lut, bits);
+    const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool active = i < job.n_sub && i <= last;
+    // where this thread writes: the block's offset + the byte counts of the block's threads in front of it
+    const uint32_t nb = active ? bytes[g] : 0u;
+    uint32_t incl = nb;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, kWave);
+        if ((int)lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads(); // (also: the staged tables and bits are there)
+    uint32_t before = incl - nb;
+    for (uint32_t q = 0; q < wv; q++) before += wsum[q];
+    if (!active) return;
+    const uint32_t boundary = (uint32_t)(job.first_bit + (uint64_t)(i + 1) * kSubBits - base);
+    const uint64_t total = (uint64_t)(job.bpl + 1) * job.h;
     const uint32_t stride = job.bpl + 1, c = job.src_c, wpr = (job.w + 31) >> 5;
-    DevBits in;
-    in.w = (const uint32_t *)job.z_aligned;
-    in.limit = job.end_limit_bit;
-    in.seek(start[g]);
-    uint64_t o = off[g];
+    LdsBits in;
+    in.l = bits;
+    const uint64_t lim = job.end_limit_bit - base;
+    in.limit = lim > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim;
+    in.seek((uint32_t)(start[g] - base));
+    uint64_t o = block_off[blockIdx.x] + before;
     uint32_t row = (uint32_t)(o / stride), col = (uint32_t)(o - (uint64_t)row * stride);
     uint8_t *F = job.filt;
     const uint32_t fstride = job.fstride;
@@ -258,7 +348,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
             break;
         }
         if (t == 256) { // end of block: every pixel must be there, and the stream must end 4 bytes (the Adler-32) before the IDAT does
-            if (o != total || ((in.pos + 7) >> 3) + 4 != job.z_bytes) err = kDecBadStream;
+            if (o != total || ((base + in.pos + 7) >> 3) + 4 != job.z_bytes) err = kDecBadStream;
             atomicOr(&status[job_index], kDecSawEob);
             break;
         }
@@ -390,21 +480,24 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
 
 } // namespace
 
-void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, const uint64_t *end_in, const uint32_t *flags_in,
-                     uint64_t *start, uint64_t *end_out, uint32_t *bytes, uint32_t *flags_out, uint32_t *changed)
+void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, uint64_t *start, uint64_t *end, uint32_t *bytes,
+                     uint32_t *flags, uint32_t *changed)
 {
-    hipLaunchKernelGGL(dec_sync_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, round, end_in, flags_in,
-                       start, end_out, bytes, flags_out, changed);
+    hipLaunchKernelGGL(dec_sync_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, round, start, end, bytes,
+                       flags, changed);
 }
-void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes, const uint32_t *flags,
-                        uint64_t *off, uint32_t *status, uint32_t *eob_index)
+void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes,
+                        const uint32_t *flags, DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
 {
-    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_jobs), dim3(kDecBlock), 0, s, jobs, start, end, bytes, flags, off, status, eob_index);
+    hipLaunchKernelGGL(dec_blocksum_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, end, bytes, flags,
+                       recs);
+    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_jobs), dim3(kDecBlock), 0, s, jobs, recs, bytes, block_off, status, eob_index);
 }
-void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *eob_index, const uint64_t *off,
-                     uint32_t *status)
+void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *bytes, const uint32_t *eob_index,
+                     const uint64_t *block_off, uint32_t *status)
 {
-    hipLaunchKernelGGL(dec_emit_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, eob_index, off, status);
+    hipLaunchKernelGGL(dec_emit_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, bytes, eob_index,
+                       block_off, status);
 }
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status)
 {

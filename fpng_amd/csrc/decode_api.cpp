@@ -136,11 +136,12 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
     uint8_t *d_z, *d_filt;
-    uint32_t *d_mask, *d_bytes, *d_flags[2], *d_status, *d_changed;
-    uint64_t *d_start, *d_end[2], *d_off;
+    uint32_t *d_mask, *d_bytes, *d_flags, *d_status, *d_changed;
+    uint64_t *d_start, *d_end, *d_block_off;
+    DecBlockRec *d_recs;
     uint16_t *d_luts;
     DecJob *d_jobs;
-    const size_t subs = std::max<size_t>(sub_total, 1);
+    const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + 255) / 256;
     {
         size_t need = 0;
         auto carve = [&](size_t bytes) {
@@ -148,14 +149,14 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total), o_mask = carve(mask_total * 4), o_bytes = carve(subs * 4), o_f0 = carve(subs * 4),
-                     o_f1 = carve(subs * 4), o_start = carve(subs * 8), o_e0 = carve(subs * 8), o_e1 = carve(subs * 8), o_off = carve(subs * 8),
+        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total), o_mask = carve(mask_total * 4), o_bytes = carve(subs * 4), o_flags = carve(subs * 4),
+                     o_start = carve(subs * 8), o_end = carve(subs * 8), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
                      o_luts = carve(std::max<size_t>(luts.size(), 1) * 8192), o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         uint8_t *base = e->d_decode.p;
         d_z = base + o_z, d_filt = base + o_filt, d_mask = (uint32_t *)(base + o_mask), d_bytes = (uint32_t *)(base + o_bytes);
-        d_flags[0] = (uint32_t *)(base + o_f0), d_flags[1] = (uint32_t *)(base + o_f1), d_start = (uint64_t *)(base + o_start);
-        d_end[0] = (uint64_t *)(base + o_e0), d_end[1] = (uint64_t *)(base + o_e1), d_off = (uint64_t *)(base + o_off);
+        d_flags = (uint32_t *)(base + o_flags), d_start = (uint64_t *)(base + o_start), d_end = (uint64_t *)(base + o_end);
+        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
         d_luts = (uint16_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
     }
     d_changed = d_status + nj;
@@ -178,30 +179,26 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(d_mask, 0, mask_total * 4, s));
     HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d_start, 0xFF, subs * 8, s));
-    HIP_TRY(hipMemsetAsync(d_flags[0], 0, subs * 4, s));
-    HIP_TRY(hipMemsetAsync(d_flags[1], 0, subs * 4, s));
     if (sub_total) {
         // the speculative round, then synchronisation rounds in groups of four until a round changes nothing.  Typical files
         // settle in one or two rounds; nearly incompressible ones (codes of almost equal length do not re-synchronise) need up
         // to one round per subsequence: those are left to the CPU decoder beyond kMaxRounds
         constexpr uint32_t kMaxRounds = 64;
         uint32_t r = 0;
-        launch_dec_sync(s, d_jobs, nj, sub_total, 0, d_end[1], d_flags[1], d_start, d_end[0], d_bytes, d_flags[0], d_changed);
+        launch_dec_sync(s, d_jobs, nj, sub_total, 0, d_start, d_end, d_bytes, d_flags, d_changed);
         for (bool settled = false; !settled && r < kMaxRounds;) {
             uint32_t changed = 0;
             for (int k = 0; k < 4; k++) {
                 r++;
                 if (k == 3) HIP_TRY(hipMemsetAsync(d_changed, 0, 4, s)); // (only the group's last round is asked)
-                launch_dec_sync(s, d_jobs, nj, sub_total, r, d_end[(r + 1) & 1], d_flags[(r + 1) & 1], d_start, d_end[r & 1], d_bytes, d_flags[r & 1], d_changed);
+                launch_dec_sync(s, d_jobs, nj, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed);
             }
             HIP_TRY(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             settled = !changed;
         }
-        const uint32_t fin = r & 1;
-        launch_dec_offsets(s, d_jobs, nj, d_start, d_end[fin], d_bytes, d_flags[fin], d_off, d_status, d_eob);
-        launch_dec_emit(s, d_jobs, nj, sub_total, d_start, d_eob, d_off, d_status);
+        launch_dec_offsets(s, d_jobs, nj, sub_total, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off, d_status, d_eob);
+        launch_dec_emit(s, d_jobs, nj, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
     }
     launch_dec_finish(s, d_jobs, nj, std::max(max_rows, 1u), std::max(max_bpl, 1u), d_status);
     HIP_TRY(hipGetLastError());

@@ -132,6 +132,7 @@ struct fpng_amd_encoder {
         DeviceBuf<Result> d_results;
         DeviceBuf<uint32_t> d_partials;
         DeviceBuf<uint32_t> d_hist;
+        size_t hist_zero = 0; // leading counters of d_hist that are zero when the lane's stream gets there (the table builder re-zeroes what it read)
         DeviceBuf<TokenTable> d_dyn;
         DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
         hipEvent_t last_done = nullptr; // `done` event (owned by a slot) of the last submission that used this set

@@ -93,6 +93,7 @@ void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n
 // dst[0..16) |= src[0..16): the 16-byte piece two neighbouring band windows share (each holds zeros where the other's bits are)
 void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src);
 void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);
-void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables);
+// rezero: leave the counters that were read zeroed (the next 2-pass submission's histogram pass needs no clearing in front of it)
+void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero);
 
 } // namespace fpng_amd

@@ -1965,12 +1965,12 @@ __device__ __forceinline__ void hdr_put(BuilderLds &L, uint32_t &pos, uint32_t v
     pos += nbits;
 }
 
-__global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, uint32_t *hist_all, TokenTable *tables)
+__global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, uint32_t *hist_all, TokenTable *tables, uint32_t rezero)
 {
     __shared__ BuilderLds L;
     const Job &job = jobs[blockIdx.x];
     const uint32_t lane = threadIdx.x, c = job.c;
-    const uint32_t *hist = hist_all + (size_t)blockIdx.x * 288;
+    uint32_t *hist = hist_all + (size_t)blockIdx.x * 288;
     const TokenTable *symtab = job.table; // chunk[q] = (length symbol - 256) | extra_bits << 8 | extra_value << 16
     TokenTable *out = tables + blockIdx.x;
 
@@ -1991,6 +1991,7 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, u
         }
         if (i == 256) v = 1; // reference fpng.cpp:757
         L.count[i] = v;
+        if (rezero) hist[i] = 0; // (read for the last time: the next submission's histogram pass finds its counters cleared)
     }
     for (uint32_t i = lane; i < 100; i += kWave) L.hdr[i] = 0;
     wave_lds_fence();
@@ -2206,9 +2207,9 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 {
     hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states);
 }
-void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables)
+void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero)
 {
-    hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, (uint32_t *)hist, tables);
+    hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, (uint32_t *)hist, tables, rezero);
 }
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local)

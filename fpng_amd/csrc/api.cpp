@@ -315,6 +315,9 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->h_partials.release();
     e->d_stream_partials.release();
     e->d_decode.release();
+    if (e->dec_up) (void)hipStreamDestroy(e->dec_up);
+    for (hipEvent_t ev : e->dec_ev)
+        if (ev) (void)hipEventDestroy(ev);
     e->d_xchg.release();
     e->h_xchg.release();
     e->d_stage_in.release();

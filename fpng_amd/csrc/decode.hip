@@ -27,64 +27,51 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kDecBlock = 256;
+constexpr int kSubBlock = (int)kDecSubBlock; // subsequences (= threads) per workgroup of the decoding kernels
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t dec_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// The token bits a workgroup works on are staged in LDS first (coalesced loads): thread t of a block decodes the 1024 bits that
-// start 32 dwords behind thread t-1's, so straight from global memory every load instruction of a wave would touch 64 different
-// cache lines.  A block's slice = its 256 subsequences plus the few dwords the last thread may run over.  In LDS dword d of the
-// slice sits at d + d / 32: without the padding all lanes of a wave would read the same bank.
-constexpr uint32_t kSliceDwords = kDecBlock * (kSubBits / 32) + 8;
-constexpr uint32_t kSliceSlots = kSliceDwords + kSliceDwords / 32 + 1;
+// The token bits a workgroup works on are staged in LDS first (coalesced loads): thread t of a block decodes the kSubBits bits that
+// start kSubBits / 32 dwords behind thread t-1's, so straight from global memory every load instruction of a wave would touch 64
+// different cache lines.  A block's slice = its kSubBlock subsequences plus the few dwords the last thread may run over.  In LDS
+// every 32 dwords of the slice are followed by a COPY of the next dword: dword d sits at d + d / 32 and its successor always in
+// the next slot (one ds_read2 per token), and the lanes of a wave, 16 dwords apart, meet in different banks.
+constexpr uint32_t kSliceDwords = kSubBlock * (kSubBits / 32) + 8;
+constexpr uint32_t kSliceSlots = kSliceDwords + kSliceDwords / 32 + 2;
 __device__ __forceinline__ uint32_t slice_slot(uint32_t d) { return d + (d >> 5); }
 
-// LSB-first reader over the staged slice; positions are bits relative to the slice's first dword
+// LSB-first reader over the staged slice; positions are bits relative to the slice's first dword.  A token has at most 12 + 5 + 1
+// bits: one 32-bit window per token.
 struct LdsBits {
     const uint32_t *l;
     uint32_t pos;
     uint32_t limit; // no token may start at or behind this bit
-    uint64_t buf;
-    uint32_t have; // valid bits in buf
-    __device__ __forceinline__ void seek(uint32_t p)
+    __device__ __forceinline__ uint32_t window() const
     {
-        pos = p;
-        const uint32_t d = p >> 5;
-        const uint32_t lo = l[slice_slot(d)], hi = l[slice_slot(d + 1)];
-        buf = (((uint64_t)hi << 32) | lo) >> (p & 31);
-        have = 64 - (p & 31);
-    }
-    __device__ __forceinline__ uint32_t peek(uint32_t k) // k <= 32
-    {
-        if (have < k) seek(pos);
-        return (uint32_t)(buf & ((1ull << k) - 1));
-    }
-    __device__ __forceinline__ void skip(uint32_t k)
-    {
-        if (have < k) seek(pos);
-        buf >>= k;
-        have -= k;
-        pos += k;
+        const uint32_t s = slice_slot(pos >> 5);
+        return __builtin_amdgcn_alignbit(l[s + 1], l[s], pos & 31u);
     }
 };
 
-__device__ __constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-
 enum : uint32_t { kSubEob = 1u, kSubInvalid = 4u };
 
-// one token: returns its kind and advances.  kind: 0..255 literal, 256 end of block, 257.. match with `run` bytes; -1 invalid
-__device__ __forceinline__ int next_token(LdsBits &in, const uint16_t *lut, uint32_t &run)
+// one token: returns its kind and advances.  kind: 0..255 literal, 256 end of block, 257.. match with `run` bytes; -1 invalid.
+// lut[next 12 bits] = symbol | code length << 9 | (length symbols) extra bits << 13 | base length << 16, 0 = no such code
+__device__ __forceinline__ int next_token(LdsBits &in, const uint32_t *lut, uint32_t &run)
 {
-    const uint32_t e = lut[in.peek(12)];
-    const uint32_t len = e >> 9;
+    const uint32_t w = in.window();
+    const uint32_t e = lut[w & 4095u];
+    const uint32_t len = (e >> 9) & 15u;
     if (!len) return -1;
-    in.skip(len);
     const uint32_t sym = e & 511u;
-    if (sym <= 256) return (int)sym;
-    if (sym > 285) return -1;
-    const uint32_t xb = kLenExtra[sym - 257];
-    run = kLenBase[sym - 257] + (xb ? in.peek(xb) : 0u);
-    in.skip(xb + 1); // extra bits + the 1-bit distance code ("previous pixel")
+    if (sym <= 256) {
+        in.pos += len;
+        return (int)sym;
+    }
+    const uint32_t xb = (e >> 13) & 7u;
+    run = (e >> 16) + ((w >> len) & ((1u << xb) - 1u));
+    in.pos += len + xb + 1; // extra bits + the 1-bit distance code ("previous pixel")
     return (int)sym;
 }
 
@@ -101,27 +88,32 @@ __device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t
 }
 
 // lookup table + the block's slice of the token bits into LDS; returns the slice's first bit (absolute, from z)
-__device__ __forceinline__ uint64_t stage_block(const DecJob &job, uint32_t local0, uint16_t *lut, uint32_t *bits)
+__device__ __forceinline__ uint64_t stage_block(const DecJob &job, uint32_t local0, uint32_t *lut, uint32_t *bits)
 {
-    const uint32_t *src = (const uint32_t *)job.lut;
-    for (int i = threadIdx.x; i < 2048; i += kDecBlock) ((uint32_t *)lut)[i] = src[i];
+    const u32x4 *src = (const u32x4 *)job.lut;
+    for (int i = threadIdx.x; i < 1024; i += kSubBlock) ((u32x4 *)lut)[i] = src[i];
     const uint64_t d0 = (job.first_bit + (uint64_t)local0 * kSubBits) >> 5;
     const uint64_t n_dw = (job.z_bytes + 16) >> 2; // (the stream's buffer has 16 spare bytes behind the data)
     const uint32_t *w = (const uint32_t *)job.z_aligned;
-    for (uint32_t d = threadIdx.x; d < kSliceDwords; d += kDecBlock) bits[slice_slot(d)] = (d0 + d < n_dw) ? w[d0 + d] : 0u;
+    for (uint32_t d = threadIdx.x; d < kSliceDwords; d += kSubBlock) {
+        const uint32_t v = (d0 + d < n_dw) ? w[d0 + d] : 0u;
+        const uint32_t sl = slice_slot(d);
+        bits[sl] = v;
+        if (d && !(d & 31u)) bits[sl - 1] = v; // the copy behind the 32 dwords in front
+    }
     return d0 << 5;
 }
 
 // ---- synchronisation rounds (results updated in place: a thread that reads its predecessor's end while that one is being
 //      rewritten decodes again in the next round -- the rounds end when one of them changes nothing) ----
-__global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, uint64_t *start,
-                                                             uint64_t *end, uint32_t *bytes, uint32_t *flags, uint32_t *changed)
+__global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, uint32_t round,
+                                                             uint64_t *start, uint64_t *end, uint32_t *bytes, uint32_t *flags, uint32_t *changed)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[4096];
     __shared__ uint32_t bits[kSliceSlots];
-    const uint32_t g0 = blockIdx.x * kDecBlock;
+    const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
     if (g0 >= total_subs) return;
-    // all subsequences of a block belong to one job (sub_base is padded to kDecBlock by the host)
+    // all subsequences of a block belong to one job (sub_base is padded to kSubBlock by the host)
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
     const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
@@ -144,7 +136,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs,
     const uint64_t lim = job.end_limit_bit - base;
     in.limit = lim > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim;
     const uint32_t boundary = (uint32_t)(nominal + kSubBits - base);
-    in.seek((uint32_t)(s - base));
+    in.pos = (uint32_t)(s - base);
     uint32_t nbytes = 0, fl = 0;
     while (in.pos < boundary) {
         if (in.pos >= in.limit) { // ran off the data without an end-of-block symbol
@@ -173,29 +165,35 @@ __global__ __launch_bounds__(kDecBlock) void dec_sync_kernel(const DecJob *jobs,
 
 // ---- output offsets, in two steps.  dec_blocksum_kernel, one workgroup per 256 subsequences: their output bytes, the first
 //      one that met an end-of-block symbol, the first one that does not start where its predecessor ended, the first invalid one ----
-__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, 4 words
+template <int WAVES> __device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, WAVES words
 {
 #pragma unroll
     for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, kWave));
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return min(min(red[0], red[1]), min(red[2], red[3]));
+    uint32_t r = red[0];
+#pragma unroll
+    for (int q = 1; q < WAVES; q++) r = min(r, red[q]);
+    return r;
 }
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red)
+template <int WAVES> __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red)
 {
 #pragma unroll
     for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, kWave);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    uint32_t r = red[0];
+#pragma unroll
+    for (int q = 1; q < WAVES; q++) r += red[q];
+    return r;
 }
-__global__ __launch_bounds__(kDecBlock) void dec_blocksum_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start,
+__global__ __launch_bounds__(kSubBlock) void dec_blocksum_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, const uint64_t *start,
                                                                  const uint64_t *end, const uint32_t *bytes, const uint32_t *flags, DecBlockRec *recs)
 {
-    __shared__ uint32_t red[4];
-    const uint32_t g0 = blockIdx.x * kDecBlock;
+    __shared__ uint32_t red[kSubBlock / kWave];
+    const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
     if (g0 >= total_subs) return;
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
@@ -203,14 +201,14 @@ __global__ __launch_bounds__(kDecBlock) void dec_blocksum_kernel(const DecJob *j
     const bool valid = i < job.n_sub;
     const uint32_t f = valid ? flags[g] : 0u;
     const bool chain = valid && start[g] == (i ? end[g - 1] : job.first_bit);
-    const uint32_t sum = block_sum(valid ? bytes[g] : 0u, red);
-    const uint32_t e = block_min((f & kSubEob) ? t : (uint32_t)kDecBlock, red);
-    const uint32_t nc = block_min((valid && !chain) ? t : (uint32_t)kDecBlock, red);
-    const uint32_t inv = block_min((f & kSubInvalid) ? t : (uint32_t)kDecBlock, red);
+    const uint32_t sum = block_sum<kSubBlock / kWave>(valid ? bytes[g] : 0u, red);
+    const uint32_t e = block_min<kSubBlock / kWave>((f & kSubEob) ? t : (uint32_t)kSubBlock, red);
+    const uint32_t nc = block_min<kSubBlock / kWave>((valid && !chain) ? t : (uint32_t)kSubBlock, red);
+    const uint32_t inv = block_min<kSubBlock / kWave>((f & kSubInvalid) ? t : (uint32_t)kSubBlock, red);
     if (t == 0) {
         DecBlockRec r;
         r.sum = sum, r.first_eob = e, r.first_unchained = nc, r.first_invalid = inv;
-        recs[blockIdx.x] = r;
+        recs[blk] = r;
     }
 }
 
@@ -224,16 +222,16 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     __shared__ uint32_t red[4];
     const DecJob &job = jobs[blockIdx.x];
     if (job.mode != 0) return;
-    const uint32_t t = threadIdx.x, n = job.n_sub, nb = (n + kDecBlock - 1) / kDecBlock, b0 = job.sub_base / kDecBlock;
+    const uint32_t t = threadIdx.x, n = job.n_sub, nb = (n + kSubBlock - 1) / kSubBlock, b0 = job.sub_base / kSubBlock;
     const uint32_t per = (nb + kDecBlock - 1) / kDecBlock;
     const uint32_t i0 = min(t * per, nb), i1 = min(i0 + per, nb);
     uint32_t mine = nb;
     for (uint32_t b = i0; b < i1; b++)
-        if (recs[b0 + b].first_eob < (uint32_t)kDecBlock) {
+        if (recs[b0 + b].first_eob < (uint32_t)kSubBlock) {
             mine = b;
             break;
         }
-    const uint32_t last_blk = block_min(mine, red); // nb: the stream never ends
+    const uint32_t last_blk = block_min<kDecBlock / kWave>(mine, red); // nb: the stream never ends
     const uint32_t last_local = last_blk < nb ? recs[b0 + last_blk].first_eob : 0u;
     // blocks in front of the last one count whole; of the last one, subsequences 0..last_local
     uint64_t local = 0;
@@ -241,8 +239,8 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     for (uint32_t b = i0; b < i1 && b < last_blk; b++) {
         const DecBlockRec r = recs[b0 + b];
         local += r.sum;
-        if (r.first_unchained < (uint32_t)kDecBlock) bad |= kDecNotConverged;
-        if (r.first_invalid < (uint32_t)kDecBlock) bad |= kDecBadStream;
+        if (r.first_unchained < (uint32_t)kSubBlock) bad |= kDecNotConverged;
+        if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
     }
     uint32_t tail = 0;
     if (last_blk < nb) {
@@ -251,12 +249,12 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
             if (r.first_unchained <= last_local) bad |= kDecNotConverged;
             if (r.first_invalid <= last_local) bad |= kDecBadStream;
         }
-        if (t <= last_local) tail = bytes[job.sub_base + last_blk * kDecBlock + t];
+        for (uint32_t k = t; k <= last_local; k += kDecBlock) tail += bytes[job.sub_base + last_blk * kSubBlock + k];
     } else if (t == 0)
         bad |= kDecBadStream;
-    const uint32_t tail_sum = block_sum(tail, red);
-    const uint32_t any_bad = block_sum(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
-    const uint32_t any_bad2 = block_sum(bad & kDecBadStream, red) ? kDecBadStream : 0u;
+    const uint32_t tail_sum = block_sum<kDecBlock / kWave>(tail, red);
+    const uint32_t any_bad = block_sum<kDecBlock / kWave>(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
+    const uint32_t any_bad2 = block_sum<kDecBlock / kWave>(bad & kDecBadStream, red) ? kDecBadStream : 0u;
     sums[t] = local;
     __syncthreads();
     if (t == 0) {
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
         uint32_t st = any_bad | any_bad2;
         if (acc + tail_sum != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
         if (st) atomicOr(&status[blockIdx.x], st);
-        eob_index[blockIdx.x] = last_blk < nb ? last_blk * kDecBlock + last_local : n;
+        eob_index[blockIdx.x] = last_blk < nb ? last_blk * kSubBlock + last_local : n;
     }
     __syncthreads();
     uint64_t o = sums[t];
@@ -280,13 +278,13 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
 }
 
 // ---- the real decode ----
-__global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start,
+__global__ __launch_bounds__(kSubBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, const uint64_t *start,
                                                              const uint32_t *bytes, const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[4096];
     __shared__ uint32_t bits[kSliceSlots];
-    __shared__ uint32_t wsum[4];
-    const uint32_t g0 = blockIdx.x * kDecBlock;
+    __shared__ uint32_t wsum[kSubBlock / kWave];
+    const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
     if (g0 >= total_subs) return;
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
@@ -317,15 +315,17 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
     in.l = bits;
     const uint64_t lim = job.end_limit_bit - base;
     in.limit = lim > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim;
-    in.seek((uint32_t)(start[g] - base));
-    uint64_t o = block_off[blockIdx.x] + before;
+    in.pos = (uint32_t)(start[g] - base);
+    uint64_t o = block_off[blk] + before;
     uint32_t row = (uint32_t)(o / stride), col = (uint32_t)(o - (uint64_t)row * stride);
     uint8_t *F = job.filt;
     const uint32_t fstride = job.fstride;
     // literals are collected into the dword they fall in and stored with one instruction when all four of its bytes are
     // literals of THIS thread; bytes of run pixels are dec_fill_kernel's, a dword shared with the neighbouring thread or broken
-    // by a run is stored byte by byte (buffer byte of stream position (row, col): row * fstride + 3 + col)
-    size_t cur = ~(size_t)0; // dword (byte address / 4) being collected
+    // by a run is stored byte by byte.  a = buffer byte of stream position (row, col): row * fstride + 3 + col, kept up
+    // incrementally
+    size_t a = (size_t)row * fstride + 3u + col;
+    size_t cur = ~(size_t)0; // dword (byte offset / 4) being collected
     uint32_t acc = 0, have = 0;
     auto flush = [&]() {
         if (have == 0xFu)
@@ -358,15 +358,14 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
                 break;
             }
             if (col) { // (the filter literal itself is not kept)
-                const size_t a = (size_t)row * fstride + 3 + col;
                 if ((a >> 2) != cur) {
                     if (have) flush();
                     cur = a >> 2;
                 }
                 acc |= (uint32_t)t << (8 * (a & 3)), have |= 1u << (a & 3);
             }
-            o++;
-            if (++col == stride) col = 0, row++;
+            o++, a++;
+            if (++col == stride) col = 0, row++, a += fstride - stride;
         } else {
             // a match repeats the previous pixel: whole pixels, inside the row (reference fpng.cpp:2301-2330)
             const uint32_t x = (col - 1) / c, npix = run / c;
@@ -380,9 +379,9 @@ __global__ __launch_bounds__(kDecBlock) void dec_emit_kernel(const DecJob *jobs,
                 atomicOr(&m[wd], (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b0);
                 p += cnt;
             }
-            o += run;
+            o += run, a += run;
             col += run;
-            if (col == stride) col = 0, row++;
+            if (col == stride) col = 0, row++, a += fstride - stride;
         }
     }
     if (have) flush();
@@ -427,24 +426,43 @@ __global__ __launch_bounds__(kDecBlock) void dec_fill_kernel(const DecJob *jobs,
     }
 }
 
-// ---- Up filter undone: out[y] = out[y-1] + filtered[y]; one thread per DWORD column (four byte columns: packed byte adds),
-//      3 <-> 4 channels on the way out ----
+// ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256); one thread per DWORD column (four byte columns: packed
+//      byte adds) and SEGMENT of kUnfRows rows -- a column alone is a chain of h dependent steps and an 8K frame has only 7680 of
+//      them.  dec_unfilter_sums_kernel adds up every segment, dec_unfilter_kernel starts from the sum of the segments above its
+//      own (<= h / kUnfRows loads) and writes the pixels, 3 <-> 4 channels on the way out ----
+constexpr uint32_t kUnfRows = kDecUnfRows;
 __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)
 {
     return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
 }
+__global__ __launch_bounds__(kDecBlock) void dec_unfilter_sums_kernel(const DecJob *jobs, const uint32_t *status)
+{
+    const DecJob &job = jobs[blockIdx.z];
+    if (job.mode != 0 || (status[blockIdx.z] & ~kDecSawEob)) return;
+    const uint32_t j4 = blockIdx.x * kDecBlock + threadIdx.x, sg = blockIdx.y, ncol = job.fstride / 4 - 1;
+    if (j4 >= ncol || sg + 1 >= job.nseg) return; // (nobody reads the last segment's sum)
+    const uint32_t *F = (const uint32_t *)(job.filt + 4) + j4;
+    const size_t fs4 = job.fstride / 4;
+    const uint32_t y0 = sg * kUnfRows;
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (uint32_t y = y0; y < y0 + kUnfRows; y++) acc = add_bytes(acc, F[(size_t)y * fs4]);
+    job.segsum[(size_t)sg * ncol + j4] = acc;
+}
 __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, const uint32_t *status)
 {
-    const DecJob &job = jobs[blockIdx.y];
-    if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
-    const uint32_t j4 = blockIdx.x * kDecBlock + threadIdx.x; // dword column of the file's rows
-    if (j4 * 4 >= job.bpl) return;
-    const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4);
+    const DecJob &job = jobs[blockIdx.z];
+    if (job.mode != 0 || (status[blockIdx.z] & ~kDecSawEob)) return;
+    const uint32_t j4 = blockIdx.x * kDecBlock + threadIdx.x, sg = blockIdx.y; // dword column of the file's rows, segment of rows
+    if (j4 * 4 >= job.bpl || sg >= job.nseg) return;
+    const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4), ncol = job.fstride / 4 - 1;
     const uint32_t *F = (const uint32_t *)(job.filt + 4) + j4;
     const size_t fs4 = job.fstride / 4, os = (size_t)job.w * dc;
     const bool whole = sc == dc && nb == 4 && (os & 3) == 0 && (((uintptr_t)job.out) & 3) == 0; // aligned dword stores
     uint32_t acc = 0;
-    for (uint32_t y = 0; y < job.h; y++) {
+    for (uint32_t q = 0; q < sg; q++) acc = add_bytes(acc, job.segsum[(size_t)q * ncol + j4]);
+    const uint32_t y0 = sg * kUnfRows, y1 = min(job.h, y0 + kUnfRows);
+    for (uint32_t y = y0; y < y1; y++) {
         acc = add_bytes(acc, F[(size_t)y * fs4]);
         uint8_t *orow = job.out + (size_t)y * os;
         if (whole)
@@ -480,30 +498,33 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
 
 } // namespace
 
-void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, uint32_t round, uint64_t *start, uint64_t *end, uint32_t *bytes,
-                     uint32_t *flags, uint32_t *changed)
+// (the decoding kernels work on the workgroups [first_block, first_block + n_blocks) of the batch's subsequences: one group of files)
+void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round, uint64_t *start,
+                     uint64_t *end, uint32_t *bytes, uint32_t *flags, uint32_t *changed)
 {
-    hipLaunchKernelGGL(dec_sync_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, round, start, end, bytes,
-                       flags, changed);
+    hipLaunchKernelGGL(dec_sync_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, round, start, end, bytes, flags, changed);
 }
-void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes,
-                        const uint32_t *flags, DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
+// group_jobs / status / eob_index: of the group's first file
+void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
+                        uint32_t n_group_jobs, const uint64_t *start, const uint64_t *end, const uint32_t *bytes, const uint32_t *flags, DecBlockRec *recs,
+                        uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
 {
-    hipLaunchKernelGGL(dec_blocksum_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, end, bytes, flags,
-                       recs);
-    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_jobs), dim3(kDecBlock), 0, s, jobs, recs, bytes, block_off, status, eob_index);
+    hipLaunchKernelGGL(dec_blocksum_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, start, end, bytes, flags, recs);
+    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_group_jobs), dim3(kDecBlock), 0, s, group_jobs, recs, bytes, block_off, status, eob_index);
 }
-void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t total_subs, const uint64_t *start, const uint32_t *bytes, const uint32_t *eob_index,
-                     const uint64_t *block_off, uint32_t *status)
+// status / eob_index: of the batch's first file
+void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const uint64_t *start,
+                     const uint32_t *bytes, const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
-    hipLaunchKernelGGL(dec_emit_kernel, dim3((total_subs + kDecBlock - 1) / kDecBlock), dim3(kDecBlock), 0, s, jobs, n_jobs, total_subs, start, bytes, eob_index,
-                       block_off, status);
+    hipLaunchKernelGGL(dec_emit_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, start, bytes, eob_index, block_off, status);
 }
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status)
 {
     const uint32_t rows_per_block = kDecBlock / kWave;
     hipLaunchKernelGGL(dec_fill_kernel, dim3((max_rows + rows_per_block - 1) / rows_per_block, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
-    hipLaunchKernelGGL(dec_unfilter_kernel, dim3(((max_bpl + 3) / 4 + kDecBlock - 1) / kDecBlock, n_jobs), dim3(kDecBlock), 0, s, jobs, status);
+    const dim3 ugrid(((max_bpl + 3) / 4 + kDecBlock - 1) / kDecBlock, (max_rows + kUnfRows - 1) / kUnfRows, n_jobs);
+    if (ugrid.y > 1) hipLaunchKernelGGL(dec_unfilter_sums_kernel, ugrid, dim3(kDecBlock), 0, s, jobs, status);
+    hipLaunchKernelGGL(dec_unfilter_kernel, ugrid, dim3(kDecBlock), 0, s, jobs, status);
     hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, n_jobs), dim3(kDecBlock), 0, s, jobs);
 }
 

@@ -8,11 +8,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace fpng_amd;
 
 namespace {
+
+constexpr uint32_t kMaxGroups = 4; // groups of files whose upload and decode overlap
+constexpr uint32_t kFirstRounds = 6; // synchronisation rounds launched without asking whether they are needed (the first one is the speculative decode)
+constexpr uint32_t kMaxRounds = 64;  // ... and the most a file gets before it is left to the CPU decoder
 
 struct Parsed {
     uint32_t w = 0, h = 0, c = 0, idat_ofs = 0, idat_len = 0;
@@ -56,12 +64,12 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
     if (rc) return rc;
     using namespace fpng::parse;
     std::vector<Parsed> ps(n);
-    std::vector<std::vector<uint16_t>> luts;      // unique lookup tables (1-pass files share two)
+    std::vector<std::vector<uint32_t>> luts;      // unique lookup tables (1-pass files share two)
     std::vector<std::vector<uint8_t>> lut_keys;   // the code lengths they were built from
     static thread_local uint32_t table[1u << kTableBits];
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
-    size_t z_total = 0, filt_total = 0, mask_total = 0;
+    size_t z_total = 0, filt_total = 0, mask_total = 0, seg_total = 0;
     uint32_t sub_total = 0, max_rows = 0, max_bpl = 0;
     for (uint32_t i = 0; i < n; i++) {
         Parsed &p = ps[i];
@@ -104,7 +112,19 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
                 p.lut = (int)luts.size();
                 lut_keys.emplace_back(sizes, sizes + 288);
                 luts.emplace_back(1u << kTableBits);
-                for (uint32_t k = 0; k < (1u << kTableBits); k++) luts.back()[k] = (uint16_t)table[k]; // symbol | length << 9 fits 13 bits
+                // symbol | code length << 9 (13 bits); length symbols 257..285 carry their extra bit count (<< 13) and base length
+                // (<< 16) along (RFC 1951 3.2.5), 286 / 287 never occur in a valid stream
+                static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+                static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+                for (uint32_t k = 0; k < (1u << kTableBits); k++) {
+                    uint32_t ent = table[k] & 0x1FFFu;
+                    const uint32_t sym = ent & 511u;
+                    if (sym > 285)
+                        ent = 0;
+                    else if (sym > 256)
+                        ent |= (uint32_t)len_extra[sym - 257] << 13 | (uint32_t)len_base[sym - 257] << 16;
+                    luts.back()[k] = ent;
+                }
             }
         }
         r.status = 0;
@@ -117,13 +137,16 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
         j.sub_base = sub_total;
         if (!p.mode) {
             j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
-            sub_total += (j.n_sub + 255u) & ~255u; // whole workgroups per file
+            sub_total += (j.n_sub + kDecSubBlock - 1) / kDecSubBlock * kDecSubBlock; // whole workgroups per file
             // offsets into the shared scratch (pointers are patched once the buffers exist)
             j.filt = (uint8_t *)(uintptr_t)filt_total;
             j.runmask = (uint32_t *)(uintptr_t)mask_total;
             j.fstride = ((j.bpl + 3u) & ~3u) + 4u;
             filt_total += ((size_t)j.fstride * j.h + 15) & ~(size_t)15;
             mask_total += (size_t)((p.w + 31) / 32) * p.h;
+            j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
+            j.segsum = (uint32_t *)(uintptr_t)seg_total;
+            seg_total += (size_t)(j.nseg - 1) * (j.fstride / 4 - 1);
             max_rows = std::max(max_rows, p.h), max_bpl = std::max(max_bpl, j.bpl);
         }
         j.z = (const uint8_t *)(uintptr_t)z_total;
@@ -136,12 +159,12 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
     uint8_t *d_z, *d_filt;
-    uint32_t *d_mask, *d_bytes, *d_flags, *d_status, *d_changed;
+    uint32_t *d_mask, *d_seg, *d_bytes, *d_flags, *d_status, *d_changed;
     uint64_t *d_start, *d_end, *d_block_off;
     DecBlockRec *d_recs;
-    uint16_t *d_luts;
+    uint32_t *d_luts;
     DecJob *d_jobs;
-    const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + 255) / 256;
+    const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + kDecSubBlock - 1) / kDecSubBlock;
     {
         size_t need = 0;
         auto carve = [&](size_t bytes) {
@@ -149,63 +172,166 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total), o_mask = carve(mask_total * 4), o_bytes = carve(subs * 4), o_flags = carve(subs * 4),
+        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total), o_mask = carve(mask_total * 4), o_seg = carve(seg_total * 4), o_bytes = carve(subs * 4), o_flags = carve(subs * 4),
                      o_start = carve(subs * 8), o_end = carve(subs * 8), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
-                     o_luts = carve(std::max<size_t>(luts.size(), 1) * 8192), o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1) * 4);
+                     o_luts = carve(std::max<size_t>(luts.size(), 1) * 16384), o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         uint8_t *base = e->d_decode.p;
-        d_z = base + o_z, d_filt = base + o_filt, d_mask = (uint32_t *)(base + o_mask), d_bytes = (uint32_t *)(base + o_bytes);
+        d_z = base + o_z, d_filt = base + o_filt, d_mask = (uint32_t *)(base + o_mask), d_seg = (uint32_t *)(base + o_seg), d_bytes = (uint32_t *)(base + o_bytes);
         d_flags = (uint32_t *)(base + o_flags), d_start = (uint64_t *)(base + o_start), d_end = (uint64_t *)(base + o_end);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
-        d_luts = (uint16_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
+        d_luts = (uint32_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
     }
-    d_changed = d_status + nj;
-    uint32_t *d_eob = d_status + nj + 1;
+    d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 words were carved out)
+    uint32_t *d_eob = d_status + nj + kMaxGroups;
     hipStream_t s = e->stream;
     for (uint32_t k = 0; k < nj; k++) {
         DecJob &j = jobs[k];
-        const fpng_amd_png &f = files[job_file[k]];
         const Parsed &p = ps[job_file[k]];
-        const size_t zo = (size_t)(uintptr_t)j.z;
-        HIP_TRY(hipMemcpyAsync(d_z + zo, (const uint8_t *)f.data + p.idat_ofs + 8, p.idat_len, hipMemcpyHostToDevice, s));
-        j.z = j.z_aligned = d_z + zo;
+        j.z = j.z_aligned = d_z + (size_t)(uintptr_t)j.z;
         if (!j.mode) {
             j.filt = d_filt + (size_t)(uintptr_t)j.filt;
             j.runmask = d_mask + (size_t)(uintptr_t)j.runmask;
+            j.segsum = d_seg + (size_t)(uintptr_t)j.segsum;
             j.lut = d_luts + (size_t)p.lut * 4096;
         }
     }
-    for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * 4096, luts[k].data(), 8192, hipMemcpyHostToDevice, s));
+    // ---- groups of files: while one group is decoded the next one's bytes are on their way (its own stream; from pageable
+    //      memory an "asynchronous" copy keeps its caller busy for most of its duration, so a thread of its own issues them) ----
+    struct Group {
+        uint32_t j0, j1, blk0, blk1, max_rows, max_bpl;
+    };
+    std::vector<Group> groups;
+    {
+        // (file k goes to the group its middle byte falls into when the batch's bytes are cut into `want` equal parts)
+        const uint32_t want = (z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : 1u;
+        uint64_t total = 0, run = 0;
+        for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
+        auto close = [&](uint32_t j0, uint32_t j1) {
+            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, 1, 1};
+            for (uint32_t q = j0; q < j1; q++)
+                if (!jobs[q].mode) g.max_rows = std::max(g.max_rows, jobs[q].h), g.max_bpl = std::max(g.max_bpl, jobs[q].bpl);
+            groups.push_back(g);
+        };
+        uint32_t j0 = 0, cur = 0;
+        for (uint32_t k = 0; k < nj; k++) {
+            const uint32_t gi = (uint32_t)std::min<uint64_t>(want - 1, (run + jobs[k].z_bytes / 2) * want / std::max<uint64_t>(total, 1));
+            if (k > j0 && gi != cur) close(j0, k), j0 = k;
+            cur = gi;
+            run += jobs[k].z_bytes;
+        }
+        close(j0, nj);
+    }
+    const uint32_t ng = (uint32_t)groups.size();
+    static const bool trace_t = getenv("FPNG_AMD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+    auto upload_group = [&](const Group &g, hipStream_t st) -> hipError_t {
+        for (uint32_t k = g.j0; k < g.j1; k++) {
+            const Parsed &p = ps[job_file[k]];
+            const hipError_t err = hipMemcpyAsync((void *)jobs[k].z, (const uint8_t *)files[job_file[k]].data + p.idat_ofs + 8, p.idat_len, hipMemcpyHostToDevice, st);
+            if (err != hipSuccess) return err;
+        }
+        return hipSuccess;
+    };
+    std::thread uploader;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t issued = 0; // groups whose copies are enqueued (and whose event is recorded)
+    hipError_t up_err = hipSuccess;
+    if (ng > 1) {
+        if (!e->dec_up) HIP_TRY(create_copy_stream(&e->dec_up));
+        for (uint32_t g = 0; g < ng; g++)
+            if (!e->dec_ev[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[g], hipEventDisableTiming));
+        uploader = std::thread([&] {
+            hipError_t err = hipSetDevice(e->device);
+            for (uint32_t g = 0; g < ng; g++) {
+                if (err == hipSuccess) err = upload_group(groups[g], e->dec_up);
+                if (err == hipSuccess) err = hipEventRecord(e->dec_ev[g], e->dec_up);
+                if (trace_t) fprintf(stderr, "[decode] +%.0f us: uploads of group %u issued\n", since(), g);
+                std::lock_guard<std::mutex> lk(mu);
+                if (err != hipSuccess) up_err = err;
+                issued = g + 1;
+                cv.notify_all();
+            }
+        });
+    }
+    struct Joiner { // (every way out of this function joins the uploader first)
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{uploader};
+    for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * 4096, luts[k].data(), 16384, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(d_mask, 0, mask_total * 4, s));
-    HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1) * 4, s));
-    if (sub_total) {
-        // the speculative round, then synchronisation rounds in groups of four until a round changes nothing.  Typical files
-        // settle in one or two rounds; nearly incompressible ones (codes of almost equal length do not re-synchronise) need up
-        // to one round per subsequence: those are left to the CPU decoder beyond kMaxRounds
-        constexpr uint32_t kMaxRounds = 64;
-        uint32_t r = 0;
-        launch_dec_sync(s, d_jobs, nj, sub_total, 0, d_start, d_end, d_bytes, d_flags, d_changed);
-        for (bool settled = false; !settled && r < kMaxRounds;) {
-            uint32_t changed = 0;
-            for (int k = 0; k < 4; k++) {
-                r++;
-                if (k == 3) HIP_TRY(hipMemsetAsync(d_changed, 0, 4, s)); // (only the group's last round is asked)
-                launch_dec_sync(s, d_jobs, nj, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed);
-            }
-            HIP_TRY(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            settled = !changed;
+    HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1 + 2 * kMaxGroups) * 4, s));
+    for (uint32_t gi = 0; gi < ng; gi++) {
+        const Group &g = groups[gi];
+        if (ng == 1) {
+            HIP_TRY(upload_group(g, s));
+        } else {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return issued > gi; });
+            if (up_err != hipSuccess) return fail(FPNG_AMD_ERR_HIP, "upload of the files", up_err);
+            lk.unlock();
+            HIP_TRY(hipStreamWaitEvent(s, e->dec_ev[gi], 0));
         }
-        launch_dec_offsets(s, d_jobs, nj, sub_total, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off, d_status, d_eob);
-        launch_dec_emit(s, d_jobs, nj, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
+        if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u (files %u..%u, %u workgroups) starts\n", since(), gi, g.j0, g.j1, g.blk1 - g.blk0);
+        const uint32_t nblk = g.blk1 - g.blk0;
+        if (nblk) {
+            // the speculative round and kFirstRounds - 1 synchronisation rounds, launched blind: typical files have settled by
+            // then (a round in which nothing changes costs a few microseconds), and the chain check of dec_offsets_kernel says so
+            for (uint32_t r = 0; r < kFirstRounds; r++) launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed + gi);
+            launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off,
+                               d_status + g.j0, d_eob + g.j0);
+            launch_dec_emit(s, d_jobs, nj, g.blk0, nblk, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
+        }
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+        if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
-    launch_dec_finish(s, d_jobs, nj, std::max(max_rows, 1u), std::max(max_bpl, 1u), d_status);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> status(nj);
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, nj * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
+    // groups with a file whose chain does not hold yet (nothing of such a file was written): more rounds, in fours, until one
+    // changes nothing -- nearly incompressible streams, whose codes have almost equal lengths, need up to a round per subsequence
+    // and are left to the CPU decoder beyond kMaxRounds -- then the rest of the pipeline again (every step of it is idempotent)
+    bool again = false;
+    for (uint32_t gi = 0; gi < ng; gi++) {
+        const Group &g = groups[gi];
+        bool open = false;
+        for (uint32_t k = g.j0; k < g.j1; k++) open |= (status[k] & kDecNotConverged) != 0;
+        const uint32_t nblk = g.blk1 - g.blk0;
+        if (!open || !nblk) continue;
+        again = true;
+        uint32_t r = kFirstRounds - 1;
+        for (bool settled = false; !settled && r < kMaxRounds;) {
+            uint32_t changed = 0;
+            for (int k = 0; k < 4; k++) {
+                r++;
+                if (k == 3) HIP_TRY(hipMemsetAsync(d_changed + gi, 0, 4, s)); // (only the last of the four is asked)
+                launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed + gi);
+            }
+            HIP_TRY(hipMemcpyAsync(&changed, d_changed + gi, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            settled = !changed;
+        }
+        if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u needed %u rounds\n", since(), gi, r + 1);
+        HIP_TRY(hipMemsetAsync(d_status + g.j0, 0, (g.j1 - g.j0) * 4, s));
+        launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off,
+                           d_status + g.j0, d_eob + g.j0);
+        launch_dec_emit(s, d_jobs, nj, g.blk0, nblk, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+    }
+    if (again) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(status.data(), d_status, nj * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (trace_t) fprintf(stderr, "[decode] +%.0f us: done\n", since());
+    static const bool trace = getenv("FPNG_AMD_TRACE_FILES") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)
             fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,

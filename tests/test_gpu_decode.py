@@ -67,6 +67,27 @@ def test_natural_image_and_synthetic_frames(enc):
             assert st == 0 and torch.equal(px, t[:, :, :3])
 
 
+def test_groups_of_files_and_a_stream_that_needs_many_rounds(enc):
+    """A batch of more than 8 MB of PNG goes through the GPU in up to four groups of files (upload of one overlapped with the
+    decode of another).  A gradient WITHOUT noise (seed 0: the generator's xorshift stays 0) is a periodic token stream in which
+    a decode started at a wrong bit stays out of step for dozens of subsequences: its group takes the extra-rounds path and is
+    redone; stored files and small files share the groups."""
+    import torch
+    import fpng_amd
+    ts = [torch.from_numpy(fpng_amd.synth_image("grad", 3840, 2160, 4, seed=sd)).cuda() for sd in (0, 5, 0, 6)]
+    ts += [torch.from_numpy(fpng_amd.synth_image("noise", 1920, 1080, 3)).cuda(), torch.from_numpy(fpng_amd.synth_image("blocks", 1000, 700, 4)).cuda()]
+    ts += [torch.from_numpy(fpng_amd.synth_image("grad", 640, 360, 3, seed=sd)).cuda() for sd in range(6)]
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors(ts, flags)
+        assert sum(len(p) for p in pngs) > (8 << 20)
+        for desired in (4, 3):
+            got = enc.decode_batch(pngs, desired)
+            for t, (st, px, cf) in zip(ts, got):
+                assert st == 0 and cf == t.shape[2]
+                want = t[:, :, :desired] if t.shape[2] >= desired else torch.cat([t, torch.full_like(t[:, :, :1], 255)], dim=2)
+                assert torch.equal(px, want)
+
+
 def test_8k_frame_round_trip(enc):
     import torch
     import fpng_amd

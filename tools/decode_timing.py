@@ -7,9 +7,10 @@ import numpy as np, torch, fpng_amd, dropin, real_image
 enc = fpng_amd.Encoder(device=0)
 imgs = real_image.variants(real_image.rgb_pixels(dropin.decode))
 cases = [("photo 2748x4048 RGB x 8", [torch.from_numpy(imgs["rgb_t4"]).cuda()] * 8),
-         ("4K RGBA grad x 16", [torch.from_numpy(fpng_amd.synth_image("grad", 3840, 2160, 4, seed=i)).cuda() for i in range(16)]),
-         ("8K RGBA grad x 4", [torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4, seed=i)).cuda() for i in range(4)]),
-         ("1080p RGB grad x 64", [torch.from_numpy(fpng_amd.synth_image("grad", 1920, 1080, 3, seed=i)).cuda() for i in range(64)])]
+         ("4K RGBA grad x 16", [torch.from_numpy(fpng_amd.synth_image("grad", 3840, 2160, 4, seed=12345 + i)).cuda() for i in range(16)]),
+         ("8K RGBA grad x 4", [torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4, seed=12345 + i)).cuda() for i in range(4)]),
+         ("8K RGBA gradient WITHOUT noise x 4 (seed 0: a periodic stream, dozens of rounds)", [torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4, seed=0)).cuda()] * 4),
+         ("1080p RGB grad x 64", [torch.from_numpy(fpng_amd.synth_image("grad", 1920, 1080, 3, seed=12345 + i)).cuda() for i in range(64)])]
 for name, ts in cases:
     for flags in (0, 1):
         pngs, _ = enc.encode_tensors(ts, flags)

@@ -4,18 +4,22 @@
 //
 // An fpng stream is ONE Huffman-coded bit string with no restart points, but Huffman decoders SELF-SYNCHRONISE: started at a
 // wrong bit, a decoder falls into step with the true token sequence after a few dozen bits.  So the token bits are cut into
-// subsequences of kSubBits bits, one thread each:
+// subsequences of kSubBits bits, one thread each, kDecSubBlock of them per workgroup (whose slice of the bits and the lookup
+// table are staged in LDS):
 //   dec_sync_kernel    round 0: every thread decodes its subsequence from its nominal first bit and notes where it crossed
 //                      into the next one; rounds 1..R: every thread restarts where its predecessor ended if that differs from
-//                      where it started before.  After a round without changes the ends form the TRUE chain from the stream's
-//                      first token (the host gives up on the GPU path for the file if that takes more than R rounds).
-//   dec_offsets_kernel per file: exclusive scan of the subsequences' output byte counts -> where each one writes
+//                      where it started before (in place).  After a round without changes the ends form the TRUE chain from the
+//                      stream's first token.  The host launches the first rounds blind; dec_offsets_kernel's chain check says
+//                      whether a file needs more (decode_api.cpp gives up on the GPU path for it beyond kMaxRounds).
+//   dec_blocksum_kernel / dec_offsets_kernel   per workgroup, then per file: output bytes in front of every workgroup, the
+//                      stream's end (first end-of-block symbol of the chain), chain and total checked
 //   dec_emit_kernel    decodes again, now for real: literals go to the filtered image; a match (always "repeat the previous
 //                      pixel", reference fpng.cpp:2273-2330) only marks its pixels in a bit mask; every rule of the reference's
 //                      decoder is checked (filter literal 0 then 2, matches whole pixels inside a row, exact total, EOB, the
 //                      stream ends 4 bytes before the IDAT does)
 //   dec_fill_kernel    one wave per row: marked pixels take the value of the nearest unmarked pixel to their left
-//   dec_unfilter_kernel one thread per byte column: running sum over the rows (the Up filter), channel count conversion
+//   dec_unfilter_sums_kernel / dec_unfilter_kernel   the Up filter undone: one thread per dword column and segment of 128 rows
+//                      (segment sums first), channel count conversion
 //   dec_stored_kernel  files that are stored blocks (reference fpng.cpp:2107-2207): a strided copy
 #include "decode.h"
 

@@ -1,5 +1,5 @@
 // decode.hip -- GPU batch decoder of fpng-written PNG files (reference src/fpng.cpp:2209-2901 decodes the same
-// streams serially).  A PROTOTYPE of the data-parallel form: the container and the Deflate block header are parsed on the host
+// streams serially) in its data-parallel form: the container and the Deflate block header are parsed on the host
 // (a few hundred bytes per file, decode_api.cpp); everything that touches the pixel stream runs here.
 //
 // An fpng stream is ONE Huffman-coded bit string with no restart points, but Huffman decoders SELF-SYNCHRONISE: started at a

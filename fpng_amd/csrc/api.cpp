@@ -735,14 +735,18 @@ static int host_batch_ring(fpng_amd_encoder *e, const fpng_amd_host_image *imgs,
         max_in = std::max(max_in, (size_t)imgs[i].w * imgs[i].h * imgs[i].num_chans);
         max_out = std::max(max_out, fpng_amd_max_encoded_size(imgs[i].w, imgs[i].h, imgs[i].num_chans));
     }
-    for (int k = 0; k < HostRing::kDepth; k++)
+    // ring depth: three big frames are plenty (each stage takes milliseconds), small frames need more slots in flight to hide the
+    // fixed costs of their three stages (a 512 x 512 frame: ~130 us from upload to download against 15 us on the link);
+    // at most kSlots - 1 submissions are in flight anyway
+    const int depth = (int)std::min<size_t>(std::min<size_t>(HostRing::kDepth, n), std::max<size_t>(3, (size_t)(48u << 20) / std::max<size_t>(max_in, 1)));
+    for (int k = 0; k < depth; k++)
         if ((rc = ring.d_in[k].ensure(max_in + 16)) || (rc = ring.d_out[k].ensure(max_out + 64))) return rc;
 
     // slot k is handed round: uploader (state 0 -> 1), caller submits (1 -> 2), downloader frees it (2 -> 0)
     std::mutex mu;
     std::condition_variable cv;
-    int state[HostRing::kDepth] = {0, 0, 0};
-    uint64_t tickets[HostRing::kDepth] = {0, 0, 0};
+    int state[HostRing::kDepth] = {};
+    uint64_t tickets[HostRing::kDepth] = {};
     std::mutex emu; // the encoder object is not thread-safe: the submitting thread and the downloader take turns
     std::atomic<int> failed{0};
     const int device = e->device;
@@ -782,7 +786,7 @@ static int host_batch_ring(fpng_amd_encoder *e, const fpng_amd_host_image *imgs,
     std::thread uploader([&] {
         (void)hipSetDevice(device);
         for (uint32_t i = 0; i < n && !failed; i++) {
-            const int k = (int)(i % HostRing::kDepth);
+            const int k = (int)(i % (uint32_t)depth);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return state[k] == 0 || failed; });
@@ -802,7 +806,7 @@ static int host_batch_ring(fpng_amd_encoder *e, const fpng_amd_host_image *imgs,
     std::thread downloader([&] {
         (void)hipSetDevice(device);
         for (uint32_t i = 0; i < n && !failed; i++) {
-            const int k = (int)(i % HostRing::kDepth);
+            const int k = (int)(i % (uint32_t)depth);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return state[k] == 2 || failed; });
@@ -864,7 +868,7 @@ static int host_batch_ring(fpng_amd_encoder *e, const fpng_amd_host_image *imgs,
     });
     // the calling thread: one encode submission per frame, ordered behind that frame's upload
     for (uint32_t i = 0; i < n && !failed; i++) {
-        const int k = (int)(i % HostRing::kDepth);
+        const int k = (int)(i % (uint32_t)depth);
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return state[k] == 1 || failed; });

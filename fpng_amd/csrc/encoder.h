@@ -149,7 +149,7 @@ struct fpng_amd_encoder {
     DeviceBuf<uint8_t> d_stage_in, d_stage_out; // fpng_amd_encode_host
     // fpng_amd_encode_host_batch: ring of device staging buffers, one copy stream per direction
     struct HostRing {
-        static constexpr int kDepth = 3;
+        static constexpr int kDepth = 7; // (3 of them for big frames, all for small ones: fpng_amd_encode_host_batch)
         DeviceBuf<uint8_t> d_in[kDepth], d_out[kDepth];
         hipStream_t up = nullptr, down = nullptr;
     } host;

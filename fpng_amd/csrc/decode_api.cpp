@@ -347,3 +347,42 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
     }
     return FPNG_AMD_OK;
 }
+
+// One host-resident file to host pixels: what fpng::fpng_decode_memory() does for large images (fpng_decode.cpp).  The pixels land in
+// the encoder's staging buffer and go down in one copy into memory obtained from `reserve` (asked once the file is known to decode).
+extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32_t size, uint32_t desired, fpng_amd_reserve_fn reserve, void *user,
+                                    fpng_amd_decode_result *result)
+{
+    if (!e || !result || !reserve) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    if (desired != 3 && desired != 4) return fail(FPNG_AMD_ERR_INVALID_ARG, "desired_chans must be 3 or 4");
+    std::memset(result, 0, sizeof *result);
+    if (!png || !size) {
+        result->status = fpng::FPNG_DECODE_INVALID_ARG;
+        return FPNG_AMD_OK;
+    }
+    uint32_t w = 0, h = 0, c = 0, idat_ofs = 0, idat_len = 0;
+    const int st = fpng::parse::parse_container((const uint8_t *)png, size, w, h, c, idat_ofs, idat_len);
+    result->w = w, result->h = h, result->channels_in_file = c;
+    if (st) {
+        result->status = st;
+        return FPNG_AMD_OK;
+    }
+    const uint64_t need = (uint64_t)w * h * desired;
+    if (need > UINT32_MAX) {
+        result->status = fpng::FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
+        return FPNG_AMD_OK;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = drain(e);
+    if (rc) return rc;
+    if ((rc = e->d_stage_in.ensure((size_t)need + 16))) return rc;
+    fpng_amd_png f;
+    std::memset(&f, 0, sizeof f);
+    f.data = png, f.size = size, f.d_pixels = e->d_stage_in.p, f.pixels_cap = e->d_stage_in.cap;
+    if ((rc = fpng_amd_decode_batch(e, &f, 1, desired, result))) return rc;
+    if (result->status) return FPNG_AMD_OK;
+    uint8_t *out = reserve(user, (size_t)need);
+    if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "no room for the pixels");
+    HIP_TRY(hipMemcpy(out, e->d_stage_in.p, (size_t)need, hipMemcpyDeviceToHost));
+    return FPNG_AMD_OK;
+}

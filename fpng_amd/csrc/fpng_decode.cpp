@@ -17,12 +17,22 @@
 // Any violation inside the zlib stream maps to FPNG_DECODE_NOT_FPNG (reference :3131-3136).
 #include "png_parse.h"
 
+#include "fpng_amd.h"
+
+#include <atomic>
+
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace fpng {
 
+fpng_amd_encoder *dropin_thread_encoder(); // fpng_dropin.cpp
+
 namespace {
+
+constexpr uint64_t kGpuDecodeMinPixels = 1u << 18; // images of 512 x 512 pixels and more are decoded on the GPU
+std::atomic<uint64_t> g_gpu_decodes{0};
 
 using namespace parse;
 
@@ -150,23 +160,63 @@ int fpng_get_info(const void *pImage, uint32_t image_size, uint32_t &width, uint
 int fpng_decode_memory(const void *pImage, uint32_t image_size, std::vector<uint8_t> &out, uint32_t &width, uint32_t &height,
                        uint32_t &channels_in_file, uint32_t desired_channels)
 {
-    out.resize(0);
+    // (the reference empties `out` first and sizes it later, reference src/fpng.cpp:3087-3105: a vector reused from call to call
+    // is zero-filled every time.  Here it is emptied on the ways out that fail and otherwise resized once, so that a reused
+    // vector of the right size is only written by the pixels.)
     width = height = channels_in_file = 0;
-    if (!pImage || !image_size || (desired_channels != 3 && desired_channels != 4)) return FPNG_DECODE_INVALID_ARG;
+    if (!pImage || !image_size || (desired_channels != 3 && desired_channels != 4)) {
+        out.resize(0);
+        return FPNG_DECODE_INVALID_ARG;
+    }
     const uint8_t *png = static_cast<const uint8_t *>(pImage);
     uint32_t idat_ofs = 0, idat_len = 0;
     const int st = parse_container(png, image_size, width, height, channels_in_file, idat_ofs, idat_len);
-    if (st) return st;
+    if (st) {
+        out.resize(0);
+        return st;
+    }
     const uint64_t need = (uint64_t)width * height * desired_channels;
-    if (need > UINT32_MAX) return FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
+    if (need > UINT32_MAX) {
+        out.resize(0);
+        return FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
+    }
+    // GPU tier: large images (the fixed costs of a GPU decode -- a dozen launches, two copies -- are ~0.4 ms; the CPU decoder below
+    // does 80-400 MP/s).  FPNG_AMD_DECODE_CPU=1 keeps everything on the CPU.  Same pixels, same status codes (tests/test_gpu_decode.py);
+    // a file the GPU path leaves undecided (token boundaries that do not synchronise) falls through to the CPU decoder.
+    static const bool cpu_only = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_CPU");
+        return v && v[0] == '1';
+    }();
+    if (!cpu_only && (uint64_t)width * height >= kGpuDecodeMinPixels) {
+        if (fpng_amd_encoder *enc = dropin_thread_encoder()) {
+            fpng_amd_decode_result r;
+            const int rc = fpng_amd_decode_host(enc, pImage, image_size, desired_channels,
+                                                [](void *user, size_t bytes) -> uint8_t * {
+                                                    auto *v = static_cast<std::vector<uint8_t> *>(user);
+                                                    v->resize(bytes);
+                                                    return v->data();
+                                                },
+                                                &out, &r);
+            if (rc == FPNG_AMD_OK && r.status != FPNG_AMD_DECODE_UNDECIDED) {
+                if (r.status) out.resize(0);
+                g_gpu_decodes.fetch_add(1, std::memory_order_relaxed);
+                return r.status;
+            }
+            out.resize(0);
+        }
+    }
     out.resize((size_t)need);
     const uint8_t *z = png + idat_ofs + 8;
     const uint32_t avail = image_size - (idat_ofs + 8);
     // a 4-channel file whose alpha deltas are dropped still needs them for the run logic: handled inside
-    if (!inflate_pixels(z, avail, idat_len, out.data(), width, height, channels_in_file, desired_channels))
+    if (!inflate_pixels(z, avail, idat_len, out.data(), width, height, channels_in_file, desired_channels)) {
+        out.resize(0); // (the reference leaves whatever was decoded so far; callers must not look at it)
         return FPNG_DECODE_NOT_FPNG;
+    }
     return FPNG_DECODE_SUCCESS;
 }
+
+unsigned long long gpu_decodes() { return g_gpu_decodes.load(std::memory_order_relaxed); }
 
 #ifndef FPNG_NO_STDIO
 int fpng_decode_file(const char *pFilename, std::vector<uint8_t> &out, uint32_t &width, uint32_t &height, uint32_t &channels_in_file,
@@ -198,3 +248,6 @@ int fpng_decode_file(const char *pFilename, std::vector<uint8_t> &out, uint32_t 
 #endif
 
 } // namespace fpng
+
+// (not part of the reference's interface) calls of fpng_decode_memory / fpng_decode_file in this process that the GPU tier answered
+extern "C" unsigned long long fpng_amd_dropin_gpu_decodes() { return fpng::gpu_decodes(); }

@@ -4,8 +4,8 @@
 // goes through fpng_amd_encode_host_to() (H2D copies, HIP kernels and D2H copies, streamed in row bands for large frames).  Each thread gets its own
 // encoder object, so the functions stay re-entrant like the reference's.
 //
-// Decoding (fpng_get_info / fpng_decode_memory / fpng_decode_file) is a serial Huffman stream and
-// stays on the CPU: see fpng_decode.cpp.
+// Decoding (fpng_get_info / fpng_decode_memory / fpng_decode_file): fpng_decode.cpp -- images of 256K pixels and more go
+// through the GPU decoder (fpng_amd_decode_host), small ones and the files it leaves undecided through the CPU decoder there.
 #include "fpng.h"
 
 #include "fpng_amd.h"
@@ -17,18 +17,25 @@ namespace fpng {
 namespace {
 struct ThreadEncoder {
     fpng_amd_encoder *enc = nullptr;
+    bool tried = false; // (a process without a GPU asks once per thread, not once per call)
     ~ThreadEncoder()
     {
         if (enc) fpng_amd_encoder_destroy(enc);
     }
     fpng_amd_encoder *get()
     {
-        if (!enc && fpng_amd_encoder_create(&enc, -1, nullptr) != FPNG_AMD_OK) enc = nullptr;
+        if (!enc && !tried) {
+            tried = true;
+            if (fpng_amd_encoder_create(&enc, -1, nullptr) != FPNG_AMD_OK) enc = nullptr;
+        }
         return enc;
     }
 };
 thread_local ThreadEncoder t_encoder;
 } // namespace
+
+// the calling thread's encoder object (also used by the GPU tier of fpng_decode_memory, fpng_decode.cpp); NULL without a GPU
+fpng_amd_encoder *dropin_thread_encoder() { return t_encoder.get(); }
 
 void fpng_init() { (void)fpng_amd_init(-1); }
 

@@ -348,6 +348,12 @@ typedef struct fpng_amd_decode_result {
 } fpng_amd_decode_result;
 int fpng_amd_decode_batch(fpng_amd_encoder *enc, const fpng_amd_png *files, uint32_t n, uint32_t desired_chans,
                           fpng_amd_decode_result *results);
+/* One HOST-resident file to HOST pixels (reference src/fpng.h:108 fpng_decode_memory; the fpng:: drop-in routes images of
+ * 256K pixels and more through it): container checks, upload, GPU decode, one download into memory obtained from `reserve`
+ * (called at most once, with w * h * desired_chans, only when the file decodes).  result->status as in fpng_amd_decode_batch():
+ * FPNG_AMD_DECODE_UNDECIDED = decode it on the CPU. */
+int fpng_amd_decode_host(fpng_amd_encoder *enc, const void *png, uint32_t size, uint32_t desired_chans, fpng_amd_reserve_fn reserve,
+                         void *user, fpng_amd_decode_result *result);
 
 /* ---- table training (reference src/fpng_test.cpp:766-973 "-t" + src/fpng.cpp:909-988, both only in builds of the reference with
  *      FPNG_TRAIN_HUFFMAN_TABLES=1): from a corpus of `n` device-resident images, all with num_chans channels (the reference's

@@ -48,6 +48,23 @@ int shim_decode(const void *png, uint32_t size, uint8_t *out, size_t cap, uint32
     }
     return st;
 }
+// best seconds per fpng::fpng_decode_memory() call into one reused std::vector (like shim_time_encode)
+double shim_time_decode(const void *png, uint32_t size, uint32_t desired, int reps)
+{
+    static std::vector<uint8_t> keep;
+    double best = 1e30;
+    for (int i = 0; i < reps; i++) {
+        uint32_t w, h, c;
+        auto t0 = std::chrono::steady_clock::now();
+        if (fpng::fpng_decode_memory(png, size, keep, w, h, c, desired) != 0) return -1.0;
+        auto t1 = std::chrono::steady_clock::now();
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        if (s < best) best = s;
+    }
+    return best;
+}
+extern "C" unsigned long long fpng_amd_dropin_gpu_decodes();
+unsigned long long shim_gpu_decodes() { return fpng_amd_dropin_gpu_decodes(); }
 int shim_decode_file(const char *name, uint8_t *out, size_t cap, uint32_t *w, uint32_t *h, uint32_t *c, uint32_t desired)
 {
     std::vector<uint8_t> v;

@@ -33,6 +33,9 @@ def shim():
     L.shim_encode_threads.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.POINTER(C.c_int)]
     L.shim_time_encode.restype = C.c_double
+    L.shim_time_decode.restype = C.c_double
+    L.shim_time_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    L.shim_gpu_decodes.restype = C.c_ulonglong
     L.shim_time_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.shim_crc32.restype = C.c_uint32
     L.shim_crc32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
@@ -72,6 +75,20 @@ def encode(img, w, h, c, flags=0):
     n = C.c_size_t(0)
     ok = L.shim_encode(a.ctypes.data, w, h, c, flags, out.ctypes.data, cap, C.byref(n))
     return out[: n.value].tobytes() if ok else None
+
+
+def time_decode(png, desired, reps=4):
+    """Best seconds per fpng::fpng_decode_memory() call through libfpng.so into one reused std::vector."""
+    b = np.frombuffer(bytes(png), dtype=np.uint8)
+    t = shim().shim_time_decode(b.ctypes.data, b.size, desired, reps)
+    if t < 0:
+        raise RuntimeError("fpng::fpng_decode_memory failed")
+    return t
+
+
+def gpu_decodes():
+    """Calls of fpng::fpng_decode_memory in this process that were answered by the GPU tier."""
+    return int(shim().shim_gpu_decodes())
 
 
 def time_encode(img, w, h, c, flags=0, reps=5, reuse=True):

@@ -88,6 +88,58 @@ def test_groups_of_files_and_a_stream_that_needs_many_rounds(enc):
                 assert torch.equal(px, want)
 
 
+def test_dropin_decode_memory_uses_the_gpu_for_large_images(enc):
+    """fpng::fpng_decode_memory (libfpng.so): images of 256K pixels and more go through fpng_amd_decode_host.  Pixels and status
+    codes must be the REFERENCE decoder's (oracle/_ref): the photograph, synthetic frames of all three encode modes incl. a stored
+    one, 3 and 4 channels out, and damaged copies of a 1 MP file (bit flips, truncations; a file the GPU path leaves undecided
+    falls through to the CPU decoder).  Small images stay on the CPU decoder."""
+    import torch
+    import fpng_amd
+    from cpu_ref import have_ref, ref
+    if not have_ref():
+        pytest.skip("reference build not available")
+    imgs = real_image.variants(real_image.rgb_pixels(dropin.decode))
+    ts = [torch.from_numpy(imgs["rgb"]).cuda(), torch.from_numpy(imgs["rgba_ga"]).cuda(), torch.from_numpy(fpng_amd.synth_image("grad", 3840, 2160, 4)).cuda(),
+          torch.from_numpy(fpng_amd.synth_image("noise", 1920, 1080, 3)).cuda(), torch.from_numpy(fpng_amd.synth_image("blocks", 1024, 1024, 4)).cuda()]
+    n0 = dropin.gpu_decodes()
+    calls = 0
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors(ts, flags)
+        for png in pngs:
+            for desired in (3, 4):
+                st_r, out_r, w_r, h_r, c_r = ref().decode(png, desired)
+                st, out, w, h, c = dropin.decode(png, desired)
+                calls += 1
+                assert (st, w, h, c) == (st_r, w_r, h_r, c_r) and st == 0
+                assert np.array_equal(out, out_r)
+    assert dropin.gpu_decodes() - n0 == calls  # every one of them was answered by the GPU tier
+    # damaged copies of a 1 MP file
+    rng = np.random.default_rng(21)
+    (base,), _ = enc.encode_tensors([torch.from_numpy(fpng_amd.synth_image("grad", 1024, 1024, 3)).cuda()], 0)
+    bad = [base[:n] for n in (40, 57, 1000, len(base) // 2, len(base) - 20, len(base) - 1)]
+    for _ in range(40):
+        d = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(d))
+    n_ok = n_bad = 0
+    for png in bad:
+        st_r, out_r, *_ = ref().decode(png, 4)
+        st, out, *_ = dropin.decode(png, 4)
+        assert st == st_r
+        if st == 0:
+            assert np.array_equal(out, out_r)
+            n_ok += 1
+        else:
+            n_bad += 1
+    assert n_ok >= 1 and n_bad >= 20
+    # a small image: the CPU decoder's
+    n1 = dropin.gpu_decodes()
+    small = oracle().encode(fpng_amd.synth_image("grad", 300, 200, 4), 300, 200, 4, 0)
+    st, out, w, h, c = dropin.decode(small, 4)
+    assert st == 0 and dropin.gpu_decodes() == n1
+
+
 def test_8k_frame_round_trip(enc):
     import torch
     import fpng_amd

@@ -3,6 +3,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["FPNG_AMD_DECODE_CPU"] = "1"  # `CPU decoder` below means the drop-in's CPU tier (its GPU tier has its own tool: tools/dropin_decode_timing.py)
 import numpy as np, torch, fpng_amd, dropin, real_image
 enc = fpng_amd.Encoder(device=0)
 imgs = real_image.variants(real_image.rgb_pixels(dropin.decode))

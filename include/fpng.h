@@ -3,12 +3,16 @@
 // Same functions, signatures, constants and enum values as the reference's src/fpng.h:17-111, so
 // existing callers recompile unchanged and link against libfpng.so (fpng_amd/csrc/fpng_dropin.cpp)
 // instead of fpng.cpp.  The encode path runs on the GPU through the C ABI in fpng_amd.h and produces
-// byte-identical files; decoding stays on the CPU (a serial Huffman stream).
+// byte-identical files; decoding (fpng_amd/csrc/fpng_decode.cpp) goes through the GPU decoder for images of 256K pixels and
+// more and through a CPU decoder for smaller ones -- same pixels, same status codes as the reference's decoder either way.
 //
 // Differences a caller can observe:
 //   * fpng_init() binds a HIP device instead of probing CPUID (still optional);
 //   * fpng_cpu_supports_sse41() answers "is the accelerator usable";
-//   * if no GPU is usable the encode functions return false (there is no silent CPU path).
+//   * if no GPU is usable the encode functions return false (there is no silent CPU path); the decode functions then use
+//     their CPU decoder for every image;
+//   * fpng_decode_memory() empties `out` only on the ways out that fail: a vector reused from call to call is not zero-filled
+//     again (the reference resizes it to 0 and back on every call).
 #pragma once
 
 #include <stdint.h>

@@ -91,6 +91,6 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     if "--variant" in sys.argv:
         v = sys.argv[sys.argv.index("--variant") + 1]
-        print(build_variant(v, {"timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"]}[v], verbose=True))
+        print(build_variant(v, {"timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"], "rows8": ["FPNG_ROW_WAVES=8"], "rows2": ["FPNG_ROW_WAVES=2"]}[v], verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -194,6 +194,13 @@ def end_to_end_here(enc_device, w, h, c, kind, flags, part):
             out["dropin_ms"] = round(t * 1e3, 3)
             out["dropin_MPs"] = round(mp / t, 1)
             out["dropin_fresh_vector_ms"] = round(tf * 1e3, 3)
+            # ... and back: fpng::fpng_decode_memory() of that file into a reused std::vector (images of 256K pixels and more go
+            # through the GPU decoder: upload, decode, download)
+            png = dropin.encode(imgs[0], w, h, c, flags)
+            td = dropin.time_decode(png, c, reps=4)
+            out["dropin_decode_ms"] = round(td * 1e3, 3)
+            out["dropin_decode_MPs"] = round(mp / td, 1)
+            out["dropin_decode_on_gpu"] = bool(dropin.gpu_decodes() > 0)
         except Exception as e:  # (needs g++ for the test shim)
             out["dropin_error"] = str(e)[:80]
         return out

@@ -61,6 +61,20 @@ def test_status_codes_match_reference_on_damaged_files():
     assert checked > 2000
 
 
+def test_large_image_decodes_with_or_without_a_gpu():
+    """Images of 256K pixels and more take the drop-in's GPU tier when the process has a GPU (tests/test_gpu_decode.py holds that
+    one against the reference decoder); without one -- this container -- the same call must quietly use the CPU decoder."""
+    import fpng_amd
+    img = fpng_amd.synth_image("grad", 1024, 768, 3)
+    for fl in (0, 1, 2):
+        png = oracle().encode(img, 1024, 768, 3, fl)
+        for desired in (3, 4):
+            st, out, w, h, c = dropin.decode(png, desired)
+            assert st == 0 and (w, h, c) == (1024, 768, 3)
+            exp = img if desired == 3 else np.concatenate([img, np.full((768, 1024, 1), 255, dtype=np.uint8)], axis=2)
+            assert np.array_equal(out, exp.reshape(-1))
+
+
 def test_not_png_and_bad_args():
     assert dropin.get_info(b"hello world, definitely not a png file at all, padding padding padding padding")[0] == 3  # FAILED_NOT_PNG
     png = oracle().encode(np.zeros((4, 4, 3), dtype=np.uint8), 4, 4, 3, 0)

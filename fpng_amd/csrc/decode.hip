@@ -400,33 +400,41 @@ __global__ __launch_bounds__(kDecBlock) void dec_fill_kernel(const DecJob *jobs,
     const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * (kDecBlock / kWave) + dec_uniform(threadIdx.x >> 6);
     if (row >= job.h) return;
     const uint32_t c = job.src_c, wpr = (job.w + 31) >> 5;
-    uint8_t *F = job.filt + (size_t)row * job.fstride + 4;
+    uint8_t *F = job.filt + (size_t)row * job.fstride + 4; // (4-byte aligned: 4-channel pixels are dwords)
     const uint32_t *m = job.runmask + (size_t)row * wpr;
+    auto load_px = [&](uint32_t x) -> uint32_t {
+        if (c == 4) return *(const uint32_t *)(F + (size_t)x * 4);
+        const uint8_t *p = F + (size_t)x * 3;
+        return p[0] | (p[1] << 8) | (p[2] << 16);
+    };
     uint32_t carry = 0; // value of the last pixel of the previous window (filtered bytes, packed)
     for (uint32_t x0 = 0; x0 < job.w; x0 += 64) {
         const uint32_t x = x0 + lane;
         const bool valid = x < job.w;
-        uint32_t v = 0;
-        bool is_run = false;
-        if (valid) {
-            is_run = (m[x >> 5] >> (x & 31)) & 1;
-            if (!is_run) {
-                const uint8_t *p = F + (size_t)x * c;
-                v = p[0] | (p[1] << 8) | (p[2] << 16) | (c == 4 ? (uint32_t)p[3] << 24 : 0u);
-            }
+        const bool is_run = valid && ((m[x >> 5] >> (x & 31)) & 1);
+        const uint64_t runs = __ballot(is_run);
+        const uint32_t last = min(63u, job.w - 1 - x0); // lane of the window's last pixel
+        if (!runs) { // nothing to fill in this window: only its last pixel matters (to the next one)
+            const uint32_t v = (lane == last) ? load_px(x) : 0u;
+            carry = (uint32_t)__shfl((int)v, (int)last, kWave);
+            continue;
         }
+        const uint32_t v = (valid && !is_run) ? load_px(x) : 0u;
         const uint64_t lit = __ballot(valid && !is_run);
         const uint64_t le = (2ull << lane) - 1ull;
         const uint64_t below = lit & le;
         const int src = below ? 63 - __builtin_clzll(below) : -1; // nearest literal pixel at or below this lane
         const uint32_t got = (uint32_t)__shfl((int)v, src < 0 ? 0 : src, kWave);
         const uint32_t val = src < 0 ? carry : got;
-        if (valid && is_run) {
-            uint8_t *p = F + (size_t)x * c;
-            p[0] = (uint8_t)val, p[1] = (uint8_t)(val >> 8), p[2] = (uint8_t)(val >> 16);
-            if (c == 4) p[3] = (uint8_t)(val >> 24);
+        if (is_run) {
+            if (c == 4)
+                *(uint32_t *)(F + (size_t)x * 4) = val;
+            else {
+                uint8_t *p = F + (size_t)x * 3;
+                p[0] = (uint8_t)val, p[1] = (uint8_t)(val >> 8), p[2] = (uint8_t)(val >> 16);
+            }
         }
-        carry = (uint32_t)__shfl((int)val, 63, kWave); // (lanes past the row end are not read again)
+        carry = (uint32_t)__shfl((int)val, (int)last, kWave);
     }
 }
 

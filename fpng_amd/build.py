@@ -66,7 +66,7 @@ def build(force=False, verbose=False):
     dropin_srcs = [os.path.join(CSRC, "fpng_dropin.cpp"), os.path.join(CSRC, "fpng_decode.cpp")]
     if force or _stale(DROPIN_LIB, dropin_srcs + [LIB, os.path.join(ROOT, "include", "fpng.h"), os.path.join(CSRC, "png_parse.h")]):
         # the `namespace fpng` drop-in: plain C++ over the C ABI, no HIP in it
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + dropin_srcs + [
+        cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + dropin_srcs + [
             "-o", DROPIN_LIB, "-L", LIB_DIR, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -20,6 +20,7 @@
 #include "fpng_amd.h"
 
 #include <atomic>
+#include <vector>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -79,6 +80,121 @@ bool inflate_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t
     return out == dst_len;
 }
 
+// The pixel loops' bit reader: like parse::Bits (bytes behind the input read as zero), refilled eight bytes at a time.  After
+// refill() at least 56 bits are there: one pixel (four literals of <= 12 bits, or a length symbol + 5 extra bits + the distance bit)
+// is decoded without another look at the fill level.
+struct FastBits {
+    const uint8_t *p;
+    size_t n, byte;
+    uint64_t buf;
+    uint32_t cnt;
+    inline void refill()
+    {
+        if (byte + 8 <= n) {
+            uint64_t v;
+            memcpy(&v, p + byte, 8); // (little-endian host, like everything else here)
+            buf |= v << cnt;           // (bits above cnt are the stream's next bits already: OR-ing them in again next time is harmless)
+            byte += (63u - cnt) >> 3; // whole bytes that fit
+            cnt |= 56u;
+        } else {
+            while (cnt <= 56) {
+                const uint64_t b8 = byte < n ? p[byte] : 0;
+                byte++;
+                buf |= b8 << cnt;
+                cnt += 8;
+            }
+        }
+    }
+    inline void consume(uint32_t k)
+    {
+        buf >>= k;
+        cnt -= k;
+    }
+    size_t bitpos() const { return byte * 8 - cnt; }
+};
+
+// one final dynamic block: rows of (filter literal, pixels); SC channels in the file, DC channels out
+template <int SC, int DC> bool inflate_rows(FastBits &in, const uint32_t *tab, uint8_t *dst, uint32_t w, uint32_t h, size_t *end_bit)
+{
+    static const uint16_t len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                          31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    const size_t dst_bpl = (size_t)w * DC;
+    std::vector<uint8_t> zero_row(dst_bpl, 0); // "the row above" of row 0
+    const uint8_t *up = zero_row.data();
+    uint8_t *row = dst;
+    for (uint32_t y = 0; y < h; y++) {
+        in.refill();
+        uint32_t e = tab[in.buf & 4095u];
+        if (!(e >> 9)) return false;
+        in.consume(e >> 9);
+        if ((e & 511u) != (y ? 2u : 0u)) return false; // filter type literal
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;         // previous pixel in FILTERED space
+        uint32_t x = 0;
+        while (x < w) {
+            in.refill();
+            e = tab[in.buf & 4095u];
+            if (!(e >> 9)) return false;
+            in.consume(e >> 9);
+            const uint32_t sym = e & 511u;
+            uint32_t npix = 1;
+            if (sym & 256u) {
+                if (sym == 256u || sym > 285u) return false; // EOB with pixels left, or not a length symbol
+                const uint32_t xb = len_extra[sym - 257];
+                const uint32_t run = len_base[sym - 257] + (uint32_t)(in.buf & ((1u << xb) - 1u));
+                in.consume(xb + 1); // extra bits + the distance code: always the 1-bit code of "previous pixel"
+                if (run % SC) return false;
+                npix = run / SC;
+                if (!npix || x + npix > w) return false; // whole pixels, inside the row
+            } else {
+                d0 = sym;
+                e = tab[in.buf & 4095u];
+                if (!(e >> 9) || (e & 256u)) return false; // (a pixel is never split by a match)
+                in.consume(e >> 9);
+                d1 = e & 255u;
+                e = tab[in.buf & 4095u];
+                if (!(e >> 9) || (e & 256u)) return false;
+                in.consume(e >> 9);
+                d2 = e & 255u;
+                if (SC == 4) {
+                    e = tab[in.buf & 4095u];
+                    if (!(e >> 9) || (e & 256u)) return false;
+                    in.consume(e >> 9);
+                    d3 = e & 255u;
+                }
+            }
+            uint8_t *o = row + (size_t)x * DC;
+            const uint8_t *u = up + (size_t)x * DC;
+            if (DC == 4) {
+                // four byte-wise sums in one 32-bit operation (SWAR); an RGB file's alpha is 0xFF whatever the row above holds
+                const uint32_t d = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+                for (uint32_t i = 0; i < npix; i++, o += 4, u += 4) {
+                    uint32_t a;
+                    memcpy(&a, u, 4);
+                    uint32_t s = ((a & 0x7F7F7F7Fu) + (d & 0x7F7F7F7Fu)) ^ ((a ^ d) & 0x80808080u);
+                    if (SC == 3) s |= 0xFF000000u;
+                    memcpy(o, &s, 4);
+                }
+            } else {
+                for (uint32_t i = 0; i < npix; i++, o += 3, u += 3) {
+                    o[0] = (uint8_t)(u[0] + d0);
+                    o[1] = (uint8_t)(u[1] + d1);
+                    o[2] = (uint8_t)(u[2] + d2);
+                }
+            }
+            x += npix;
+        }
+        up = row;
+        row += dst_bpl;
+    }
+    in.refill();
+    const uint32_t e = tab[in.buf & 4095u];
+    if (!(e >> 9) || (e & 511u) != 256u) return false;
+    in.consume(e >> 9);
+    *end_bit = in.bitpos();
+    return true;
+}
+
 bool inflate_pixels(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t *dst, uint32_t w, uint32_t h, uint32_t src_chans,
                     uint32_t dst_chans)
 {
@@ -89,60 +205,15 @@ bool inflate_pixels(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t
     if (in.get(1) != 1 || in.get(2) != 2) return false; // one final dynamic block
     static thread_local uint32_t lit_table[1u << kTableBits];
     if (!read_dynamic_header(in, src_chans, lit_table)) return false;
-
-    static const uint16_t len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
-                                          31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const size_t dst_bpl = (size_t)w * dst_chans;
-    const uint8_t *prev_row = nullptr;
-    uint8_t *row = dst;
-    for (uint32_t y = 0; y < h; y++) {
-        uint32_t e = lit_table[in.peek(kTableBits)];
-        if (!(e >> 9)) return false;
-        in.skip(e >> 9);
-        if ((e & 511) != (y ? 2u : 0u)) return false; // filter type literal
-        uint8_t delta[4] = {0, 0, 0, 0};             // previous pixel in FILTERED space
-        uint32_t x = 0;
-        while (x < w) {
-            e = lit_table[in.peek(kTableBits)];
-            if (!(e >> 9)) return false;
-            in.skip(e >> 9);
-            uint32_t sym = e & 511, npix = 1;
-            if (sym & 256) {
-                if (sym == 256 || sym > 285) return false; // EOB with pixels left, or not a length symbol
-                uint32_t run = len_base[sym - 257];
-                if (len_extra[sym - 257]) run += in.get(len_extra[sym - 257]);
-                in.skip(1); // distance code: always the 1-bit code of "previous pixel"
-                if (run % src_chans) return false;
-                npix = run / src_chans;
-                if (!npix || x + npix > w) return false; // whole pixels, inside the row
-            } else {
-                delta[0] = (uint8_t)sym;
-                for (uint32_t k = 1; k < src_chans; k++) {
-                    e = lit_table[in.peek(kTableBits)];
-                    if (!(e >> 9)) return false;
-                    in.skip(e >> 9);
-                    if (e & 256) return false; // a pixel is never split by a match
-                    delta[k] = (uint8_t)(e & 255);
-                }
-            }
-            for (uint32_t i = 0; i < npix; i++, x++) {
-                uint8_t *o = row + (size_t)x * dst_chans;
-                const uint8_t *u = prev_row ? prev_row + (size_t)x * dst_chans : nullptr;
-                o[0] = (uint8_t)((u ? u[0] : 0) + delta[0]);
-                o[1] = (uint8_t)((u ? u[1] : 0) + delta[1]);
-                o[2] = (uint8_t)((u ? u[2] : 0) + delta[2]);
-                if (dst_chans == 4) o[3] = (src_chans == 4) ? (uint8_t)((u ? u[3] : 0) + delta[3]) : 0xFF;
-            }
-        }
-        prev_row = row;
-        row += dst_bpl;
-    }
-    const uint32_t e = lit_table[in.peek(kTableBits)];
-    if (!(e >> 9) || (e & 511) != 256) return false;
-    in.skip(e >> 9);
-    const size_t end_byte = (in.bitpos() + 7) >> 3;
-    return end_byte + 4 == zlib_len;
+    FastBits fb = {in.p, in.n, in.byte, in.buf, in.cnt};
+    size_t end_bit = 0;
+    bool ok;
+    if (src_chans == 3)
+        ok = dst_chans == 3 ? inflate_rows<3, 3>(fb, lit_table, dst, w, h, &end_bit) : inflate_rows<3, 4>(fb, lit_table, dst, w, h, &end_bit);
+    else
+        ok = dst_chans == 3 ? inflate_rows<4, 3>(fb, lit_table, dst, w, h, &end_bit) : inflate_rows<4, 4>(fb, lit_table, dst, w, h, &end_bit);
+    if (!ok) return false;
+    return ((end_bit + 7) >> 3) + 4 == zlib_len;
 }
 
 } // namespace

@@ -1,5 +1,9 @@
 // format.cpp -- host-side derivation of the fpng format tables and host checksum utilities.
 #include "format.h"
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "kernels.h"
 
 #include <array>
@@ -168,6 +172,7 @@ bool parse_prefix(const uint8_t *prefix, uint32_t nbytes, PendingBits tail, uint
 }
 
 uint32_t g_crc_byte[256];
+uint32_t g_crc_slice[16][256]; // g_crc_slice[k][b]: CRC state after byte b followed by k zero bytes (k = 0: g_crc_byte)
 std::once_flag g_crc_once;
 void ensure_crc() // callable from any thread (fpng_crc32 is a free function of the re-entrant drop-in)
 {
@@ -176,7 +181,10 @@ void ensure_crc() // callable from any thread (fpng_crc32 is a free function of 
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
             g_crc_byte[i] = c;
+            g_crc_slice[0][i] = c;
         }
+        for (int k = 1; k < 16; k++)
+            for (uint32_t i = 0; i < 256; i++) g_crc_slice[k][i] = (g_crc_slice[k - 1][i] >> 8) ^ g_crc_byte[g_crc_slice[k - 1][i] & 0xFF];
     });
 }
 
@@ -189,23 +197,121 @@ bool build_1pass_tables(TokenTable *t3, TokenTable *t4)
            t4->first_token_bit == 490;
 }
 
+#if defined(__x86_64__)
+// CRC-32 by carry-less multiplication (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction",
+// Intel 2009; the constants are x^k mod P for the reflected polynomial, as every zlib-compatible implementation of the method
+// uses them): four 128-bit lanes folded 512 bits ahead per step, then 128 bits at a time, then a Barrett reduction.  `c` is the
+// running state (already inverted), len >= 64 and a multiple of 16.  The reference has its own version of the same method
+// (src/fpng.cpp:255-292); results are checked against zlib's crc32 in tests/test_abi.py.
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_clmul(const uint8_t *p, size_t len, uint32_t c)
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll);
+    const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124ll);
+    const __m128i poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+#define ld(q) _mm_loadu_si128((const __m128i *)(q))
+    __m128i x1 = _mm_xor_si128(ld(p), _mm_cvtsi32_si128((int)c)), x2 = ld(p + 16), x3 = ld(p + 32), x4 = ld(p + 48);
+    p += 64, len -= 64;
+    while (len >= 64) {
+        const __m128i l1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), l2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i l3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), l4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k1k2, 0x11), l1), ld(p));
+        x2 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x2, k1k2, 0x11), l2), ld(p + 16));
+        x3 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x3, k1k2, 0x11), l3), ld(p + 32));
+        x4 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x4, k1k2, 0x11), l4), ld(p + 48));
+        p += 64, len -= 64;
+    }
+#define FPNG_FOLD128(acc, next) _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(acc, k3k4, 0x11), _mm_clmulepi64_si128(acc, k3k4, 0x00)), next)
+    x1 = FPNG_FOLD128(x1, x2);
+    x1 = FPNG_FOLD128(x1, x3);
+    x1 = FPNG_FOLD128(x1, x4);
+    for (; len >= 16; p += 16, len -= 16) x1 = FPNG_FOLD128(x1, _mm_loadu_si128((const __m128i *)p));
+#undef FPNG_FOLD128
+    // 128 -> 64 -> 32 bits
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+    t = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k5, 0x00), t);
+    t = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), poly, 0x10), mask32);
+    t = _mm_clmulepi64_si128(t, poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(x1, t), 1);
+#undef ld
+}
+static bool have_clmul()
+{
+    static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    return ok;
+}
+#endif
+
 uint32_t host_crc32(const void *data, size_t size, uint32_t prev)
 {
     ensure_crc();
     const uint8_t *p = static_cast<const uint8_t *>(data);
     uint32_t c = ~prev;
-    for (size_t i = 0; i < size; i++) c = (c >> 8) ^ g_crc_byte[(c ^ p[i]) & 0xFF];
+#if defined(__x86_64__)
+    if (size >= 64 && have_clmul()) {
+        const size_t body = size & ~(size_t)15;
+        c = crc32_clmul(p, body, c);
+        p += body, size -= body;
+    }
+#endif
+    // sixteen bytes per step (slicing-by-16: every byte's contribution to the state 16 bytes later is a table entry, the sixteen
+    // lookups are independent); what the reference does with carry-less multiplies (src/fpng.cpp:255-292) or four bytes at a time
+    size_t i = 0;
+    for (; i + 16 <= size; i += 16) {
+        uint32_t w0, w1, w2, w3;
+        std::memcpy(&w0, p + i, 4), std::memcpy(&w1, p + i + 4, 4), std::memcpy(&w2, p + i + 8, 4), std::memcpy(&w3, p + i + 12, 4);
+        w0 ^= c;
+        c = g_crc_slice[15][w0 & 0xFF] ^ g_crc_slice[14][(w0 >> 8) & 0xFF] ^ g_crc_slice[13][(w0 >> 16) & 0xFF] ^ g_crc_slice[12][w0 >> 24] ^
+            g_crc_slice[11][w1 & 0xFF] ^ g_crc_slice[10][(w1 >> 8) & 0xFF] ^ g_crc_slice[9][(w1 >> 16) & 0xFF] ^ g_crc_slice[8][w1 >> 24] ^
+            g_crc_slice[7][w2 & 0xFF] ^ g_crc_slice[6][(w2 >> 8) & 0xFF] ^ g_crc_slice[5][(w2 >> 16) & 0xFF] ^ g_crc_slice[4][w2 >> 24] ^
+            g_crc_slice[3][w3 & 0xFF] ^ g_crc_slice[2][(w3 >> 8) & 0xFF] ^ g_crc_slice[1][(w3 >> 16) & 0xFF] ^ g_crc_slice[0][w3 >> 24];
+    }
+    for (; i < size; i++) c = (c >> 8) ^ g_crc_byte[(c ^ p[i]) & 0xFF];
     return ~c;
 }
 
 uint32_t host_adler32(const void *data, size_t size, uint32_t prev)
 {
     const uint8_t *p = static_cast<const uint8_t *>(data);
-    uint64_t a = prev & 0xFFFF, b = prev >> 16;
+    uint32_t a = prev & 0xFFFF, b = prev >> 16;
     size_t i = 0;
     while (i < size) {
-        // 64-bit accumulators: b grows by at most a_max*n; reduce every 2^20 bytes
-        size_t end = (size - i > (1u << 20)) ? i + (1u << 20) : size;
+        // 5552 bytes at most between reductions (the largest n with 255 n (n + 1) / 2 + (n + 1) 65520 < 2^32); inside, sixteen
+        // bytes per step: b gains 16 a + sum of (16 - j) p[j] -- independent multiply-adds instead of a chain of 32 additions
+        size_t end = (size - i > 5552) ? i + 5552 : size;
+#if defined(__x86_64__)
+        {
+            // (SSE2, the x86-64 baseline) byte sums with psadbw, weighted sums with pmaddwd, three vector accumulators per
+            // chunk: vs = byte sums so far, vps = sum of vs in front of every block (b gains 16 of them per block), vw = weighted
+            const __m128i zero = _mm_setzero_si128();
+            const __m128i w_lo = _mm_setr_epi16(16, 15, 14, 13, 12, 11, 10, 9), w_hi = _mm_setr_epi16(8, 7, 6, 5, 4, 3, 2, 1);
+            __m128i vs = zero, vps = zero, vw = zero;
+            size_t nblk = 0;
+            for (; i + 16 <= end; i += 16, nblk++) {
+                const __m128i v = _mm_loadu_si128((const __m128i *)(p + i));
+                vps = _mm_add_epi32(vps, vs);
+                vs = _mm_add_epi32(vs, _mm_sad_epu8(v, zero));
+                vw = _mm_add_epi32(vw, _mm_add_epi32(_mm_madd_epi16(_mm_unpacklo_epi8(v, zero), w_lo), _mm_madd_epi16(_mm_unpackhi_epi8(v, zero), w_hi)));
+            }
+            auto hsum = [](__m128i x) {
+                alignas(16) uint32_t t[4];
+                _mm_store_si128((__m128i *)t, x);
+                return (uint64_t)t[0] + t[1] + t[2] + t[3];
+            };
+            const uint64_t b64 = (uint64_t)b + 16ull * nblk * a + 16ull * hsum(vps) + hsum(vw);
+            a = (uint32_t)(((uint64_t)a + hsum(vs)) % kAdlerMod);
+            b = (uint32_t)(b64 % kAdlerMod);
+        }
+#endif
+        for (; i + 16 <= end; i += 16) {
+            uint32_t s = 0, ws = 0;
+            for (uint32_t j = 0; j < 16; j++) s += p[i + j], ws += (16u - j) * p[i + j];
+            b += 16u * a + ws;
+            a += s;
+        }
         for (; i < end; i++) {
             a += p[i];
             b += a;
@@ -213,7 +319,7 @@ uint32_t host_adler32(const void *data, size_t size, uint32_t prev)
         a %= kAdlerMod;
         b %= kAdlerMod;
     }
-    return (uint32_t)((b << 16) | a);
+    return (b << 16) | a;
 }
 
 // Reflected-domain polynomial product modulo the CRC-32 polynomial: bit 31 of a word is x^0.

@@ -46,6 +46,27 @@ def test_host_checksums(built_lib):
         assert fpng_amd.adler32_combine(zlib.adler32(d[:k].tobytes()), zlib.adler32(d[k:].tobytes()), n - k) == zlib.adler32(d.tobytes())
 
 
+def test_host_checksums_every_length_and_alignment(built_lib):
+    """The host CRC-32 switches between a carry-less-multiply body (64 bytes and more, multiples of 16), slicing-by-16 and single
+    bytes, the Adler-32 between 16-byte vector blocks and single bytes, reducing every 5552 bytes: every length up to 400, lengths
+    around the chunk borders, odd alignments, non-trivial previous values, all-0xFF input (the largest sums) -- against zlib."""
+    import fpng_amd
+    rng = np.random.default_rng(2)
+    big = rng.integers(0, 256, 40000, dtype=np.uint8)
+    for n in list(range(0, 400)) + [5551, 5552, 5553, 5567, 5568, 5569, 11103, 11104, 11105, 16383, 16384, 16385, 39999]:
+        for off in (0, 1, 7):
+            d = big[off:off + n]
+            assert fpng_amd.fpng_crc32(d) == zlib.crc32(d.tobytes()), (n, off)
+            assert fpng_amd.fpng_adler32(d) == zlib.adler32(d.tobytes()), (n, off)
+            assert fpng_amd.fpng_crc32(d, 0xDEADBEEF) == zlib.crc32(d.tobytes(), 0xDEADBEEF), (n, off)
+            assert fpng_amd.fpng_adler32(d, 0xFFF0FFEF) == zlib.adler32(d.tobytes(), 0xFFF0FFEF), (n, off)  # (both halves 65520 - ...: near the modulus)
+    ff = np.full(100000, 255, dtype=np.uint8)
+    for n in (5552, 5553, 65536, 100000):
+        assert fpng_amd.fpng_adler32(ff[:n]) == zlib.adler32(ff[:n].tobytes())
+        assert fpng_amd.fpng_adler32(ff[:n], zlib.adler32(ff[:777].tobytes())) == zlib.adler32(ff[:n].tobytes(), zlib.adler32(ff[:777].tobytes()))
+        assert fpng_amd.fpng_crc32(ff[:n]) == zlib.crc32(ff[:n].tobytes())
+
+
 def test_max_encoded_size(built_lib):
     import fpng_amd
     for (w, h, c) in [(1, 1, 3), (1, 1, 4), (512, 512, 3), (3840, 2160, 4), (65535, 1, 3), (21845, 1, 3), (21846, 1, 3)]:

@@ -87,6 +87,20 @@ def test_no_silent_cpu_fallback(built_lib):
     assert fpng_amd.fpng_cpu_supports_sse41() is False
 
 
+def test_decode_entry_points_reject_bad_arguments_before_touching_the_gpu(built_lib):
+    """fpng_amd_decode_batch / fpng_amd_decode_host: NULL encoder, NULL result, wrong channel count -> FPNG_AMD_ERR_INVALID_ARG
+    (no HIP call is made on these ways out, so this runs without a GPU)."""
+    import ctypes as C
+    from fpng_amd import _lib
+    lib = _lib.load()
+    res = _lib.DecodeResult()
+    png = (C.c_uint8 * 64)()
+    cb = _lib.RESERVE_FN(lambda user, n: None)
+    assert lib.fpng_amd_decode_host(None, png, 64, 4, cb, None, C.byref(res)) < 0
+    assert lib.fpng_amd_decode_batch(None, None, 0, 4, None) < 0
+    assert "null" in lib.fpng_amd_last_error().decode().lower() or lib.fpng_amd_last_error()
+
+
 def _raw_crc(data):
     """CRC-32 with init 0 and no final xor (what the kernels' partials are made of): crc32 is affine in the message."""
     return zlib.crc32(data) ^ zlib.crc32(bytes(len(data)))

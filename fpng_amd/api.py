@@ -327,6 +327,25 @@ class Encoder:
             out.append((r.status, outs[i][: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
         return out
 
+    def decode_host(self, png, desired_chans):
+        """fpng_amd_decode_host: ONE fpng-written file (bytes) -> (status, uint8 numpy array (h, w, desired_chans) or None, channels_in_file);
+        container checks, upload, GPU decode and one download into host memory (what fpng::fpng_decode_memory does for large images).
+        status 64 (FPNG_AMD_DECODE_UNDECIDED): decode that file on the CPU."""
+        b = np.frombuffer(bytes(png), dtype=np.uint8)
+        res = _lib.DecodeResult()
+        hold = []
+
+        def reserve(_user, nbytes):
+            hold[:] = [np.empty(nbytes, dtype=np.uint8)]
+            return hold[0].ctypes.data
+
+        cb = _lib.RESERVE_FN(reserve)
+        self._sync_stream()
+        check(self.lib.fpng_amd_decode_host(self.h, b.ctypes.data if b.size else None, b.size, desired_chans, cb, None, C.byref(res)))
+        if res.status or not hold:
+            return res.status, None, res.channels_in_file
+        return 0, hold[0].reshape(res.h, res.w, desired_chans), res.channels_in_file
+
     def train_tables(self, images):
         """fpng_amd_train_tables: a new 1-pass table from a corpus of uint8 CUDA tensors (h, w, c), all with the same c, in the
         form the reference's training mode prints it (block prefix bytes as hex, pending bits, codes, code sizes)."""

@@ -140,6 +140,26 @@ def test_dropin_decode_memory_uses_the_gpu_for_large_images(enc):
     assert st == 0 and dropin.gpu_decodes() == n1
 
 
+def test_decode_host_one_file_host_to_host(enc):
+    """fpng_amd_decode_host through the Python mirror: pixels equal the input, damaged container -> the reference's status code,
+    nothing reserved for a file that does not decode."""
+    import torch
+    import fpng_amd
+    for (kind, w, h, c) in (("grad", 1920, 1080, 4), ("blocks", 700, 500, 3), ("noise", 300, 200, 3)):
+        img = fpng_amd.synth_image(kind, w, h, c)
+        (png,), _ = enc.encode_tensors([torch.from_numpy(img).cuda()], 0)
+        for desired in (3, 4):
+            st, px, cf = enc.decode_host(png, desired)
+            assert st == 0 and cf == c and px.shape == (h, w, desired)
+            want = img[:, :, :desired] if c >= desired else np.concatenate([img, np.full((h, w, 1), 255, dtype=np.uint8)], axis=2)
+            assert np.array_equal(px, want)
+        bad = bytearray(png)
+        bad[20] ^= 0x40  # IHDR payload: header CRC mismatch
+        st, px, cf = enc.decode_host(bytes(bad), 4)
+        cst, *_ = dropin.decode(bytes(bad), 4)
+        assert st == cst != 0 and px is None
+
+
 def test_8k_frame_round_trip(enc):
     import torch
     import fpng_amd

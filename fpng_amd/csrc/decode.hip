@@ -31,6 +31,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kDecBlock = 256;
+#define FPNG_DEC_GLOBAL __attribute__((address_space(1)))
 constexpr int kSubBlock = (int)kDecSubBlock; // subsequences (= threads) per workgroup of the decoding kernels
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -320,25 +321,38 @@ __global__ __launch_bounds__(kSubBlock) void dec_emit_kernel(const DecJob *jobs,
     const uint64_t lim = job.end_limit_bit - base;
     in.limit = lim > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim;
     in.pos = (uint32_t)(start[g] - base);
-    uint64_t o = block_off[blk] + before;
-    uint32_t row = (uint32_t)(o / stride), col = (uint32_t)(o - (uint64_t)row * stride);
-    uint8_t *F = job.filt;
-    const uint32_t fstride = job.fstride;
+    const uint64_t o0 = block_off[blk] + before; // stream byte this thread starts at
+    uint32_t row = (uint32_t)(o0 / stride), col = (uint32_t)(o0 - (uint64_t)row * stride);
+    // Everything inside the loop is 32-bit and relative to the thread's start: its tokens cover at most kSubBits / 2 matches of
+    // 258 bytes.  `left` = stream bytes the image still takes; a = byte offset from Fal (the thread's first buffer byte rounded
+    // down to a dword: buffer byte of stream position (row, col) = row * fstride + 3 + col).
+    if (o0 > total) { // (cannot happen behind dec_offsets_kernel's total check; kept as a guard)
+        atomicOr(&status[job_index], kDecBadStream);
+        return;
+    }
+    const uint64_t left64 = total - o0;
+    const uint32_t left = left64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left64;
+    uint32_t o = 0; // stream bytes this thread has produced
+    const size_t a0 = (size_t)row * job.fstride + 3u + col;
+    FPNG_DEC_GLOBAL uint8_t *Fal = (FPNG_DEC_GLOBAL uint8_t *)(uintptr_t)(job.filt + (a0 & ~(size_t)3));
+    FPNG_DEC_GLOBAL uint32_t *mask_row = (FPNG_DEC_GLOBAL uint32_t *)(uintptr_t)(job.runmask + (size_t)row * wpr);
+    uint32_t a = (uint32_t)(a0 & 3u);
+    const uint32_t row_gap = job.fstride - stride;
     // literals are collected into the dword they fall in and stored with one instruction when all four of its bytes are
     // literals of THIS thread; bytes of run pixels are dec_fill_kernel's, a dword shared with the neighbouring thread or broken
-    // by a run is stored byte by byte.  a = buffer byte of stream position (row, col): row * fstride + 3 + col, kept up
-    // incrementally
-    size_t a = (size_t)row * fstride + 3u + col;
-    size_t cur = ~(size_t)0; // dword (byte offset / 4) being collected
+    // by a run is stored byte by byte
+    uint32_t cur = ~0u; // dword (a / 4) being collected
     uint32_t acc = 0, have = 0;
     auto flush = [&]() {
         if (have == 0xFu)
-            *(uint32_t *)(F + cur * 4) = acc;
+            *(FPNG_DEC_GLOBAL uint32_t *)(Fal + cur * 4u) = acc;
         else
             for (uint32_t k = 0; k < 4; k++)
-                if (have & (1u << k)) F[cur * 4 + k] = (uint8_t)(acc >> (8 * k));
+                if (have & (1u << k)) Fal[cur * 4u + k] = (uint8_t)(acc >> (8 * k));
         have = 0, acc = 0;
     };
+    // pixels per byte count: c is 3 or 4 (x / 3 by multiplication: x < 2^31)
+    auto div_c = [&](uint32_t x) { return c == 4 ? x >> 2 : (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33); };
     uint32_t err = 0;
     while (in.pos < boundary) {
         if (in.pos >= in.limit) {
@@ -352,12 +366,12 @@ __global__ __launch_bounds__(kSubBlock) void dec_emit_kernel(const DecJob *jobs,
             break;
         }
         if (t == 256) { // end of block: every pixel must be there, and the stream must end 4 bytes (the Adler-32) before the IDAT does
-            if (o != total || ((base + in.pos + 7) >> 3) + 4 != job.z_bytes) err = kDecBadStream;
+            if (o != left || left64 > 0x7FFFFFFFull || ((base + in.pos + 7) >> 3) + 4 != job.z_bytes) err = kDecBadStream;
             atomicOr(&status[job_index], kDecSawEob);
             break;
         }
         if (t < 256) {
-            if (o >= total || (col == 0 && (uint32_t)t != (row ? 2u : 0u))) { // the row's filter literal: 0, then 2 (Up)
+            if (o >= left || (col == 0 && (uint32_t)t != (row ? 2u : 0u))) { // the row's filter literal: 0, then 2 (Up)
                 err = kDecBadStream;
                 break;
             }
@@ -369,23 +383,22 @@ __global__ __launch_bounds__(kSubBlock) void dec_emit_kernel(const DecJob *jobs,
                 acc |= (uint32_t)t << (8 * (a & 3)), have |= 1u << (a & 3);
             }
             o++, a++;
-            if (++col == stride) col = 0, row++, a += fstride - stride;
+            if (++col == stride) col = 0, row++, a += row_gap, mask_row += wpr;
         } else {
             // a match repeats the previous pixel: whole pixels, inside the row (reference fpng.cpp:2301-2330)
-            const uint32_t x = (col - 1) / c, npix = run / c;
-            if (col == 0 || (col - 1) % c || run % c || !npix || x + npix > job.w || o + run > total) {
+            const uint32_t x = div_c(col - 1), npix = div_c(run);
+            if (col == 0 || x * c != col - 1 || npix * c != run || !npix || x + npix > job.w || run > left - o) {
                 err = kDecBadStream;
                 break;
             }
-            uint32_t *m = job.runmask + (size_t)row * wpr;
             for (uint32_t p = x; p < x + npix;) { // set bits [x, x + npix)
                 const uint32_t wd = p >> 5, b0 = p & 31, cnt = min(32u - b0, x + npix - p);
-                atomicOr(&m[wd], (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b0);
+                atomicOr((uint32_t *)(uintptr_t)&mask_row[wd], (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b0);
                 p += cnt;
             }
             o += run, a += run;
             col += run;
-            if (col == stride) col = 0, row++, a += fstride - stride;
+            if (col == stride) col = 0, row++, a += row_gap, mask_row += wpr;
         }
     }
     if (have) flush();

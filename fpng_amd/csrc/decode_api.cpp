@@ -53,6 +53,46 @@ bool check_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint32_t 
     return got == total && src + 4 == zlib_len;
 }
 
+
+// symbol | code length << 9 (13 bits) of the host parser's table; length symbols 257..285 carry their extra bit count (<< 13) and base
+// length (<< 16) along (RFC 1951 3.2.5), 286 / 287 never occur in a valid stream: the kernels' lookup table
+void pack_lut(const uint32_t *table, uint32_t *lut)
+{
+    static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    for (uint32_t k = 0; k < (1u << fpng::parse::kTableBits); k++) {
+        uint32_t ent = table[k] & 0x1FFFu;
+        const uint32_t sym = ent & 511u;
+        if (sym > 285)
+            ent = 0;
+        else if (sym > 256)
+            ent |= (uint32_t)len_extra[sym - 257] << 13 | (uint32_t)len_base[sym - 257] << 16;
+        lut[k] = ent;
+    }
+}
+
+// What the host settles about one file's zlib stream before the GPU sees it (the container was parsed: p.w .. p.idat_len): stored
+// blocks (checked here) or one final dynamic block (header read: `table` = the host parser's lookup table, `sizes` = the literal /
+// length code lengths, p.first_bit = the first row token).  Returns the reference's status code (0 or FPNG_DECODE_NOT_FPNG).
+int plan_stream(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, uint8_t sizes[288])
+{
+    using namespace fpng::parse;
+    const uint8_t *z = png + p.idat_ofs + 8;
+    const uint32_t avail = size - (p.idat_ofs + 8);
+    if (p.idat_len < 7 || z[0] != 0x78 || z[1] != 0x01) return fpng::FPNG_DECODE_NOT_FPNG;
+    if ((z[2] & 6) == 0) {
+        if (!check_stored(z, avail, p.idat_len, p.w, p.h, p.c)) return fpng::FPNG_DECODE_NOT_FPNG;
+        p.mode = 1;
+        return 0;
+    }
+    Bits in = {z, avail, 2, 0, 0, false};
+    if (in.get(1) != 1 || in.get(2) != 2) return fpng::FPNG_DECODE_NOT_FPNG; // one final dynamic block
+    if (!read_dynamic_header(in, p.c, table, sizes)) return fpng::FPNG_DECODE_NOT_FPNG;
+    p.first_bit = in.bitpos();
+    if (p.first_bit >= (uint64_t)(p.idat_len - 4) * 8) return fpng::FPNG_DECODE_NOT_FPNG;
+    return 0;
+}
+
 } // namespace
 
 extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results)
@@ -92,39 +132,16 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             continue;
         }
         if (!files[i].d_pixels || files[i].pixels_cap < need) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "d_pixels / pixels_cap < w * h * desired_chans");
-        const uint8_t *z = png + p.idat_ofs + 8;
-        const uint32_t avail = files[i].size - (p.idat_ofs + 8);
-        r.status = fpng::FPNG_DECODE_NOT_FPNG; // until proven otherwise (reference :3131-3136: any stream problem)
-        if (p.idat_len < 7 || z[0] != 0x78 || z[1] != 0x01) continue;
-        if ((z[2] & 6) == 0) {
-            if (!check_stored(z, avail, p.idat_len, p.w, p.h, p.c)) continue;
-            p.mode = 1;
-        } else {
-            Bits in = {z, avail, 2, 0, 0, false};
-            if (in.get(1) != 1 || in.get(2) != 2) continue; // one final dynamic block
-            uint8_t sizes[288];
-            if (!read_dynamic_header(in, p.c, table, sizes)) continue;
-            p.first_bit = in.bitpos();
-            if (p.first_bit >= (uint64_t)(p.idat_len - 4) * 8) continue;
+        uint8_t sizes[288];
+        if ((r.status = plan_stream(png, files[i].size, p, table, sizes))) continue; // (reference :3131-3136: any stream problem is NOT_FPNG)
+        if (!p.mode) {
             for (size_t k = 0; k < lut_keys.size() && p.lut < 0; k++)
                 if (!std::memcmp(lut_keys[k].data(), sizes, 288)) p.lut = (int)k;
             if (p.lut < 0) {
                 p.lut = (int)luts.size();
                 lut_keys.emplace_back(sizes, sizes + 288);
                 luts.emplace_back(1u << kTableBits);
-                // symbol | code length << 9 (13 bits); length symbols 257..285 carry their extra bit count (<< 13) and base length
-                // (<< 16) along (RFC 1951 3.2.5), 286 / 287 never occur in a valid stream
-                static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-                static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-                for (uint32_t k = 0; k < (1u << kTableBits); k++) {
-                    uint32_t ent = table[k] & 0x1FFFu;
-                    const uint32_t sym = ent & 511u;
-                    if (sym > 285)
-                        ent = 0;
-                    else if (sym > 256)
-                        ent |= (uint32_t)len_extra[sym - 257] << 13 | (uint32_t)len_base[sym - 257] << 16;
-                    luts.back()[k] = ent;
-                }
+                pack_lut(table, luts.back().data());
             }
         }
         r.status = 0;
@@ -384,5 +401,29 @@ extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32
     uint8_t *out = reserve(user, (size_t)need);
     if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "no room for the pixels");
     HIP_TRY(hipMemcpy(out, e->d_stage_in.p, (size_t)need, hipMemcpyDeviceToHost));
+    return FPNG_AMD_OK;
+}
+
+// What fpng_amd_decode_batch() prepares on the host for one file, without a GPU (tests hold a model of the kernels against it):
+// container status, geometry, stored or dynamic, the token stream's first bit and its limit, the kernels' lookup table.
+extern "C" int fpng_amd_decode_plan(const void *png_, uint32_t size, fpng_amd_decode_result *result, uint32_t *mode, uint32_t *idat_ofs, uint32_t *idat_len,
+                                    uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t lut[4096])
+{
+    if (!png_ || !size || !result || !mode || !idat_ofs || !idat_len || !first_bit || !end_limit_bit || !lut) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    const uint8_t *png = (const uint8_t *)png_;
+    std::memset(result, 0, sizeof *result);
+    Parsed p;
+    result->status = fpng::parse::parse_container(png, size, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
+    result->w = p.w, result->h = p.h, result->channels_in_file = p.c;
+    *mode = 0, *idat_ofs = p.idat_ofs, *idat_len = p.idat_len, *first_bit = 0, *end_limit_bit = 0;
+    if (result->status) return FPNG_AMD_OK;
+    static thread_local uint32_t table[1u << fpng::parse::kTableBits];
+    uint8_t sizes[288];
+    if ((result->status = plan_stream(png, size, p, table, sizes))) return FPNG_AMD_OK;
+    *mode = p.mode;
+    if (!p.mode) {
+        *first_bit = p.first_bit, *end_limit_bit = (uint64_t)(p.idat_len - 4) * 8;
+        pack_lut(table, lut);
+    }
     return FPNG_AMD_OK;
 }

@@ -354,6 +354,13 @@ int fpng_amd_decode_batch(fpng_amd_encoder *enc, const fpng_amd_png *files, uint
  * FPNG_AMD_DECODE_UNDECIDED = decode it on the CPU. */
 int fpng_amd_decode_host(fpng_amd_encoder *enc, const void *png, uint32_t size, uint32_t desired_chans, fpng_amd_reserve_fn reserve,
                          void *user, fpng_amd_decode_result *result);
+/* What fpng_amd_decode_batch() settles on the HOST about one file before the GPU sees it (no GPU needed; tests/ hold a model of the
+ * decode kernels against it): result (container status, geometry; status 0 = the stream's shape is acceptable so far), mode (0 = one
+ * dynamic block, 1 = stored blocks), the IDAT chunk's offset and payload length, the first row token's bit and the bit no token may
+ * start at or behind (both counted from the zlib stream's first byte = png + idat_ofs + 8), and the kernels' lookup table:
+ * lut[next 12 bits] = symbol | code length << 9 | (length symbols) extra bit count << 13 | base length << 16, 0 = no such code. */
+int fpng_amd_decode_plan(const void *png, uint32_t size, fpng_amd_decode_result *result, uint32_t *mode, uint32_t *idat_ofs,
+                         uint32_t *idat_len, uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t lut[4096]);
 
 /* ---- table training (reference src/fpng_test.cpp:766-973 "-t" + src/fpng.cpp:909-988, both only in builds of the reference with
  *      FPNG_TRAIN_HUFFMAN_TABLES=1): from a corpus of `n` device-resident images, all with num_chans channels (the reference's

@@ -119,9 +119,10 @@ SIGNATURES = {
     "fpng_amd_node_size": (_u32, [_vp]),
     "fpng_amd_node_encode_host_batch": (_int, [_vp, C.POINTER(HostImage), _u32, _u32, _int]),
     "fpng_amd_decode_batch": (_int, [_vp, C.POINTER(PngIn), _u32, _u32, C.POINTER(DecodeResult)]),
+    "fpng_amd_decode_batch_device": (_int, [_vp, C.POINTER(PngIn), _u32, _u32, C.POINTER(DecodeResult)]),
     "fpng_amd_decode_host": (_int, [_vp, _vp, _u32, _u32, RESERVE_FN, _vp, C.POINTER(DecodeResult)]),
     "fpng_amd_decode_plan": (_int, [_vp, _u32, C.POINTER(DecodeResult), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint64),
-                             C.POINTER(C.c_uint64), C.POINTER(_u32 * 4096)]),
+                             C.POINTER(C.c_uint64), C.POINTER(_u32 * 4160)]),
     "fpng_amd_train_tables": (_int, [_vp, C.POINTER(Image), _u32, _u32, _vp, _sz, C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32), _vp, _vp]),
     "fpng_amd_synth_image": (_int, [_int, _u32, _u32, _u32, _u32, _vp]),
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),

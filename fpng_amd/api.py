@@ -327,6 +327,31 @@ class Encoder:
             out.append((r.status, outs[i][: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
         return out
 
+    def decode_device(self, pngs, desired_chans, dims, outs=None):
+        """fpng_amd_decode_batch_device: list of uint8 CUDA tensors holding whole fpng-written files (e.g. the encoder's outputs) ->
+        list of (status, uint8 CUDA tensor (h, w, desired_chans) or None, channels_in_file).  dims: list of (w, h) (sizes the
+        output tensors; the files' bytes stay on the device); outs: optional preallocated uint8 CUDA tensors to decode into."""
+        n = len(pngs)
+        arr = (_lib.PngIn * n)()
+        res = (_lib.DecodeResult * n)()
+        made = []
+        for i, p in enumerate(pngs):
+            w, h = dims[i]
+            t = outs[i] if outs is not None else torch.empty(max(w * h * desired_chans, 16), dtype=torch.uint8, device=f"cuda:{self.device}")
+            made.append(t)
+            arr[i].data = p.data_ptr() if p.numel() else None
+            arr[i].size = p.numel()
+            arr[i].d_pixels = t.data_ptr()
+            arr[i].pixels_cap = t.numel()
+        self._sync_stream()
+        check(self.lib.fpng_amd_decode_batch_device(self.h, arr, n, desired_chans, res))
+        out = []
+        for i in range(n):
+            r = res[i]
+            ok = r.status == 0
+            out.append((r.status, made[i].view(-1)[: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
+        return out
+
     def decode_host(self, png, desired_chans):
         """fpng_amd_decode_host: ONE fpng-written file (bytes) -> (status, uint8 numpy array (h, w, desired_chans) or None, channels_in_file);
         container checks, upload, GPU decode and one download into host memory (what fpng::fpng_decode_memory does for large images).

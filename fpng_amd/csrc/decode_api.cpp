@@ -1,7 +1,9 @@
 // decode_api.cpp -- host side of the GPU batch decoder (decode.hip): what the reference's fpng_decode_memory does in front of
-// its pixel loops (reference src/fpng.cpp:2904-3222: container walk, IDAT checks, block type, dynamic header), then uploads and
-// launches.  The parsing code is the CPU decoder's own (png_parse.h), so the status codes of damaged containers are the same.
+// its pixel loops (reference src/fpng.cpp:2904-3222: container walk, IDAT checks, block type, dynamic header), then uploads (or,
+// for files that already live in device memory, fetches the few hundred bytes it has to read) and launches.  The parsing code
+// is the CPU decoder's own (png_parse.h), so the status codes of damaged containers are the same.
 #include "decode.h"
+#include "decode_core.h"
 #include "encoder.h"
 #include "png_parse.h"
 
@@ -18,9 +20,10 @@ using namespace fpng_amd;
 
 namespace {
 
-constexpr uint32_t kMaxGroups = 4; // groups of files whose upload and decode overlap (8 measured: 5-15 % slower, a dozen launches per group)
-constexpr uint32_t kFirstRounds = 6; // synchronisation rounds launched without asking whether they are needed (the first one is the speculative decode)
-constexpr uint32_t kMaxRounds = 64;  // ... and the most a file gets before it is left to the CPU decoder
+constexpr uint32_t kMaxGroups = 4;    // groups of files whose upload and decode overlap (8 measured: 5-15 % slower, a dozen launches per group)
+constexpr uint32_t kBorderRounds = 2; // synchronisation rounds across workgroup borders launched without asking whether they are needed
+constexpr uint32_t kMaxRounds = 64;   // ... and the most a file gets before it is left to the CPU decoder
+constexpr uint32_t kHeadBytes = 1024, kTailBytes = 64; // what is copied back of a device-resident file before anything else
 
 struct Parsed {
     uint32_t w = 0, h = 0, c = 0, idat_ofs = 0, idat_len = 0;
@@ -30,72 +33,106 @@ struct Parsed {
     int lut = -1;         // index into the unique lookup tables
 };
 
-// the stored-block layout the reference accepts (src/fpng.cpp:2107-2207): block headers, sizes, filter bytes 0, exact end
-bool check_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint32_t w, uint32_t h, uint32_t c)
+// The stored-block layout the reference accepts (src/fpng.cpp:2107-2207): block headers, sizes, filter bytes 0, exact end.
+// 0 = the encoder's own layout (full 65535-byte blocks, then the rest: what dec_stored_kernel copies), 1 = not acceptable,
+// 2 = acceptable to the reference but cut into other block sizes: left to the CPU decoder.
+int check_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint32_t w, uint32_t h, uint32_t c)
 {
     const uint64_t stride = (uint64_t)w * c + 1, total = stride * h;
     uint64_t src = 2, got = 0;
+    bool usual = true;
     for (;;) {
-        if (src + 5 > avail) return false;
+        if (src + 5 > avail) return 1;
         const bool final_block = z[src] & 1;
-        if (((z[src] >> 1) & 3) != 0) return false;
+        if (((z[src] >> 1) & 3) != 0) return 1;
         const uint32_t len = z[src + 1] | (z[src + 2] << 8), nlen = z[src + 3] | (z[src + 4] << 8);
         src += 5;
-        if (len != (~nlen & 0xFFFF) || src + len > avail) return false;
-        // the GPU copy assumes the encoder's layout: full 65535-byte blocks, then the rest
-        if (!final_block && len != 65535) return false;
+        if (len != (~nlen & 0xFFFF) || src + len > avail) return 1;
+        if (!final_block && len != 65535) usual = false;
         for (uint64_t r = (got + stride - 1) / stride * stride; r < got + len; r += stride) // filter bytes inside this block
-            if (z[src + (r - got)] != 0) return false;
+            if (z[src + (r - got)] != 0) return 1;
         got += len;
         src += len;
         if (final_block) break;
     }
-    return got == total && src + 4 == zlib_len;
+    if (got != total || src + 4 != zlib_len) return 1;
+    return usual ? 0 : 2;
 }
 
-
-// symbol | code length << 9 (13 bits) of the host parser's table; length symbols 257..285 carry their extra bit count (<< 13) and base
-// length (<< 16) along (RFC 1951 3.2.5), 286 / 287 never occur in a valid stream: the kernels' lookup table
-void pack_lut(const uint32_t *table, uint32_t *lut)
+// The kernels' lookup table (decode_core.h) from the host parser's (symbol | code length << 9 per 12-bit index) and the code lengths:
+// up to three literals per entry, length symbols 257..285 with their base length and extra bit count (RFC 1951 3.2.5; 286 / 287
+// never occur in a valid stream), then the literals' code lengths.
+void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *lut)
 {
     static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    for (uint32_t k = 0; k < (1u << fpng::parse::kTableBits); k++) {
-        uint32_t ent = table[k] & 0x1FFFu;
-        const uint32_t sym = ent & 511u;
-        if (sym > 285)
+    const uint32_t bits = fpng::parse::kTableBits;
+    for (uint32_t k = 0; k < (1u << bits); k++) {
+        const uint32_t e1 = table[k], l1 = (e1 >> 9) & 15u, s1 = e1 & 511u;
+        uint32_t ent = 0;
+        if (!l1 || s1 > 285)
             ent = 0;
-        else if (sym > 256)
-            ent |= (uint32_t)len_extra[sym - 257] << 13 | (uint32_t)len_base[sym - 257] << 16;
+        else if (s1 == 256)
+            ent = l1 << 28;
+        else if (s1 > 256)
+            ent = l1 << 28 | dec::kEntMatch | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257];
+        else {
+            uint32_t L = l1, n = 1, lits = s1;
+            while (n < 3) { // the next code is whole if its length fits into the index bits that are left
+                const uint32_t e2 = table[k >> L], l2 = (e2 >> 9) & 15u, s2 = e2 & 511u;
+                if (!l2 || s2 >= 256 || L + l2 > bits) break;
+                lits |= s2 << (8 * n);
+                n++, L += l2;
+            }
+            ent = L << 28 | n << 26 | lits;
+        }
         lut[k] = ent;
     }
+    uint8_t *lenof = (uint8_t *)(lut + dec::kLutEntries);
+    std::memcpy(lenof, sizes, 256);
 }
 
 // What the host settles about one file's zlib stream before the GPU sees it (the container was parsed: p.w .. p.idat_len): stored
 // blocks (checked here) or one final dynamic block (header read: `table` = the host parser's lookup table, `sizes` = the literal /
-// length code lengths, p.first_bit = the first row token).  Returns the reference's status code (0 or FPNG_DECODE_NOT_FPNG).
-int plan_stream(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, uint8_t sizes[288])
+// length code lengths, p.first_bit = the first row token).  z / avail: the stream's bytes in host memory, `complete`: all of them
+// (else only a head of the file: fpng::parse::kParseNeedMore asks for the rest).  Returns the reference's status code (0 or
+// FPNG_DECODE_NOT_FPNG) or FPNG_AMD_DECODE_UNDECIDED (a stored layout only the CPU decoder takes).
+int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint32_t *table, uint8_t sizes[288])
 {
     using namespace fpng::parse;
-    const uint8_t *z = png + p.idat_ofs + 8;
-    const uint32_t avail = size - (p.idat_ofs + 8);
+    if (avail < 3) return complete ? (int)fpng::FPNG_DECODE_NOT_FPNG : kParseNeedMore;
     if (p.idat_len < 7 || z[0] != 0x78 || z[1] != 0x01) return fpng::FPNG_DECODE_NOT_FPNG;
+    const uint64_t total = ((uint64_t)p.w * p.c + 1) * p.h;
     if ((z[2] & 6) == 0) {
-        if (!check_stored(z, avail, p.idat_len, p.w, p.h, p.c)) return fpng::FPNG_DECODE_NOT_FPNG;
+        if (total > p.idat_len) return fpng::FPNG_DECODE_NOT_FPNG; // (stored blocks cannot hold the image)
+        if (!complete) return kParseNeedMore;
+        const int r = check_stored(z, avail, p.idat_len, p.w, p.h, p.c);
+        if (r == 1) return fpng::FPNG_DECODE_NOT_FPNG;
         p.mode = 1;
-        return 0;
+        return r ? FPNG_AMD_DECODE_UNDECIDED : 0;
     }
     Bits in = {z, avail, 2, 0, 0, false};
     if (in.get(1) != 1 || in.get(2) != 2) return fpng::FPNG_DECODE_NOT_FPNG; // one final dynamic block
-    if (!read_dynamic_header(in, p.c, table, sizes)) return fpng::FPNG_DECODE_NOT_FPNG;
+    const bool ok = read_dynamic_header(in, p.c, table, sizes);
+    if (!complete && in.byte + 8 > avail) return kParseNeedMore; // (the header reader may have run off the head)
+    if (!ok) return fpng::FPNG_DECODE_NOT_FPNG;
     p.first_bit = in.bitpos();
     if (p.first_bit >= (uint64_t)(p.idat_len - 4) * 8) return fpng::FPNG_DECODE_NOT_FPNG;
+    // a token has at least 2 bits and stands for at most 258 bytes: an IDAT this short cannot hold the image (checked before any
+    // device memory is sized by the header's dimensions)
+    if (total > (uint64_t)p.idat_len * 1032 + 258) return fpng::FPNG_DECODE_NOT_FPNG;
     return 0;
 }
 
-} // namespace
+// parse one file that is wholly in host memory
+int parse_host(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, uint8_t sizes[288])
+{
+    p.status = fpng::parse::parse_container(png, size, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
+    if (p.status) return p.status;
+    return plan_stream(png + p.idat_ofs + 8, size - (p.idat_ofs + 8), true, p, table, sizes);
+}
 
-extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results)
+int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results, bool device_data)
 {
     if (!e || !files || !n || !results) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
     if (desired != 3 && desired != 4) return fail(FPNG_AMD_ERR_INVALID_ARG, "desired_chans must be 3 or 4");
@@ -103,71 +140,112 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
     int rc = drain(e);
     if (rc) return rc;
     using namespace fpng::parse;
+    hipStream_t s = e->stream;
+    uint32_t max_rounds = kMaxRounds;
+    if (const char *mr = getenv("FPNG_AMD_DECODE_MAX_ROUNDS")) max_rounds = (uint32_t)std::max(0, atoi(mr)); // (0: every dynamic file is left to the CPU decoder -- tests)
     std::vector<Parsed> ps(n);
     std::vector<std::vector<uint32_t>> luts;      // unique lookup tables (1-pass files share two)
     std::vector<std::vector<uint8_t>> lut_keys;   // the code lengths they were built from
     static thread_local uint32_t table[1u << kTableBits];
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
-    size_t z_total = 0, filt_total = 0, mask_total = 0, seg_total = 0;
-    uint32_t sub_total = 0, max_rows = 0, max_bpl = 0;
+    size_t z_total = 0, filt_total = 0, seg_total = 0;
+    uint32_t sub_total = 0, tile_total = 0;
+
+    // ---- device-resident files: their first and last bytes come back first (one round trip for the batch) ----
+    if (device_data) {
+        if ((rc = e->h_dec_fetch.ensure((size_t)n * (kHeadBytes + kTailBytes)))) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            if (!files[i].data || !files[i].size) continue;
+            uint8_t *dst = e->h_dec_fetch.p + (size_t)i * (kHeadBytes + kTailBytes);
+            const uint32_t hl = std::min(files[i].size, kHeadBytes);
+            HIP_TRY(hipMemcpyAsync(dst, files[i].data, hl, hipMemcpyDeviceToHost, s));
+            if (files[i].size > hl) {
+                const uint32_t tl = std::min(files[i].size - hl, kTailBytes);
+                HIP_TRY(hipMemcpyAsync(dst + kHeadBytes, (const uint8_t *)files[i].data + files[i].size - tl, tl, hipMemcpyDeviceToHost, s));
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    std::vector<uint8_t> whole; // a device-resident file the head and tail were not enough for
     for (uint32_t i = 0; i < n; i++) {
         Parsed &p = ps[i];
         fpng_amd_decode_result &r = results[i];
         std::memset(&r, 0, sizeof r);
-        const uint8_t *png = (const uint8_t *)files[i].data;
-        if (!png || !files[i].size) {
+        if (!files[i].data || !files[i].size) {
             r.status = fpng::FPNG_DECODE_INVALID_ARG;
             continue;
         }
-        p.status = parse_container(png, files[i].size, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
-        r.w = p.w, r.h = p.h, r.channels_in_file = p.c;
-        if (p.status) {
-            r.status = p.status;
-            continue;
+        uint8_t sizes[288];
+        int st;
+        if (!device_data)
+            st = parse_host((const uint8_t *)files[i].data, files[i].size, p, table, sizes);
+        else {
+            const uint8_t *buf = e->h_dec_fetch.p + (size_t)i * (kHeadBytes + kTailBytes);
+            const uint32_t size = files[i].size, hl = std::min(size, kHeadBytes), tl = size > hl ? std::min(size - hl, kTailBytes) : 0u;
+            const View v = {buf, hl, tl ? buf + kHeadBytes : nullptr, size - tl, size};
+            st = p.status = parse_container_view(v, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
+            if (!st) st = (p.idat_ofs + 8 < hl) ? plan_stream(buf + p.idat_ofs + 8, hl - (p.idat_ofs + 8), hl == size, p, table, sizes) : kParseNeedMore;
+            if (st == kParseNeedMore) { // unusual chunks, a stored file, ...: the whole file comes back
+                whole.resize(size);
+                HIP_TRY(hipMemcpy(whole.data(), files[i].data, size, hipMemcpyDeviceToHost));
+                p = Parsed();
+                st = parse_host(whole.data(), size, p, table, sizes);
+            }
         }
+        r.w = p.w, r.h = p.h, r.channels_in_file = p.c;
+        r.status = st;
+        if (p.status) continue; // the container's own status (geometry may be half known)
         const uint64_t need = (uint64_t)p.w * p.h * desired;
         if (need > UINT32_MAX) {
             r.status = fpng::FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
             continue;
         }
         if (!files[i].d_pixels || files[i].pixels_cap < need) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "d_pixels / pixels_cap < w * h * desired_chans");
-        uint8_t sizes[288];
-        if ((r.status = plan_stream(png, files[i].size, p, table, sizes))) continue; // (reference :3131-3136: any stream problem is NOT_FPNG)
+        if (st) continue; // (reference :3131-3136: any stream problem is NOT_FPNG; or left to the CPU decoder)
         if (!p.mode) {
+            if (!max_rounds) {
+                r.status = FPNG_AMD_DECODE_UNDECIDED;
+                continue;
+            }
             for (size_t k = 0; k < lut_keys.size() && p.lut < 0; k++)
                 if (!std::memcmp(lut_keys[k].data(), sizes, 288)) p.lut = (int)k;
             if (p.lut < 0) {
                 p.lut = (int)luts.size();
                 lut_keys.emplace_back(sizes, sizes + 288);
-                luts.emplace_back(1u << kTableBits);
-                pack_lut(table, luts.back().data());
+                luts.emplace_back(dec::kLutDwords);
+                build_multi_lut(table, sizes, luts.back().data());
             }
         }
-        r.status = 0;
         DecJob j;
         std::memset(&j, 0, sizeof j);
         j.w = p.w, j.h = p.h, j.src_c = p.c, j.dst_c = desired, j.bpl = p.w * p.c;
         j.z_bytes = p.idat_len, j.first_bit = p.first_bit, j.end_limit_bit = (uint64_t)(p.idat_len - 4) * 8;
         j.mode = p.mode;
         j.out = files[i].d_pixels;
-        j.sub_base = sub_total;
+        j.sub_base = sub_total, j.tile_base = tile_total;
         if (!p.mode) {
             j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
             sub_total += (j.n_sub + kDecSubBlock - 1) / kDecSubBlock * kDecSubBlock; // whole workgroups per file
             // offsets into the shared scratch (pointers are patched once the buffers exist)
+            const size_t total = ((size_t)j.bpl + 1) * j.h;
             j.filt = (uint8_t *)(uintptr_t)filt_total;
-            j.runmask = (uint32_t *)(uintptr_t)mask_total;
-            j.fstride = ((j.bpl + 3u) & ~3u) + 4u;
-            filt_total += ((size_t)j.fstride * j.h + 15) & ~(size_t)15;
-            mask_total += (size_t)((p.w + 31) / 32) * p.h;
+            filt_total += ((total + 15) & ~(size_t)15) + 16;
+            j.n_tiles = (uint32_t)((total + kDecTileBytes - 1) / kDecTileBytes);
+            tile_total += j.n_tiles;
             j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
             j.segsum = (uint32_t *)(uintptr_t)seg_total;
-            seg_total += (size_t)(j.nseg - 1) * (j.fstride / 4 - 1);
-            max_rows = std::max(max_rows, p.h), max_bpl = std::max(max_bpl, j.bpl);
+            seg_total += (size_t)(j.nseg - 1) * ((j.bpl + 3) / 4);
         }
-        j.z = (const uint8_t *)(uintptr_t)z_total;
-        z_total += ((size_t)p.idat_len + 16 + 15) & ~(size_t)15; // (the bit reader looks up to 8 bytes ahead)
+        if (device_data) {
+            const uintptr_t zr = (uintptr_t)files[i].data + p.idat_ofs + 8;
+            j.z = (const uint8_t *)(zr & ~(uintptr_t)3);
+            j.z_shift = (uint32_t)(zr & 3);
+            j.z_bytes += j.z_shift, j.first_bit += 8 * j.z_shift, j.end_limit_bit += 8 * j.z_shift;
+        } else {
+            j.z = (const uint8_t *)(uintptr_t)z_total;
+            z_total += ((size_t)p.idat_len + 16 + 15) & ~(size_t)15; // (a token's window reaches up to 8 bytes ahead)
+        }
         jobs.push_back(j);
         job_file.push_back(i);
     }
@@ -176,9 +254,10 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
     uint8_t *d_z, *d_filt;
-    uint32_t *d_mask, *d_seg, *d_bytes, *d_flags, *d_status, *d_changed;
-    uint64_t *d_start, *d_end, *d_block_off;
+    uint32_t *d_seg, *d_status, *d_changed, *d_tile_first;
+    uint64_t *d_block_off;
     DecBlockRec *d_recs;
+    DecSubArrays d_sub;
     uint32_t *d_luts;
     DecJob *d_jobs;
     const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + kDecSubBlock - 1) / kDecSubBlock;
@@ -189,43 +268,45 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total), o_mask = carve(mask_total * 4), o_seg = carve(seg_total * 4), o_bytes = carve(subs * 4), o_flags = carve(subs * 4),
-                     o_start = carve(subs * 8), o_end = carve(subs * 8), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
-                     o_luts = carve(std::max<size_t>(luts.size(), 1) * 16384), o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
+        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_seg = carve(seg_total * 4), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
+                     o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
+                     o_tiles = carve(std::max<size_t>(tile_total, 1) * 4), o_luts = carve(std::max<size_t>(luts.size(), 1) * dec::kLutDwords * 4),
+                     o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         uint8_t *base = e->d_decode.p;
-        d_z = base + o_z, d_filt = base + o_filt, d_mask = (uint32_t *)(base + o_mask), d_seg = (uint32_t *)(base + o_seg), d_bytes = (uint32_t *)(base + o_bytes);
-        d_flags = (uint32_t *)(base + o_flags), d_start = (uint64_t *)(base + o_start), d_end = (uint64_t *)(base + o_end);
-        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
+        d_z = base + o_z, d_filt = base + o_filt, d_seg = (uint32_t *)(base + o_seg);
+        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
+        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff), d_tile_first = (uint32_t *)(base + o_tiles);
         d_luts = (uint32_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
     }
-    d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 words were carved out)
+    d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
     uint32_t *d_eob = d_status + nj + kMaxGroups;
-    hipStream_t s = e->stream;
     for (uint32_t k = 0; k < nj; k++) {
         DecJob &j = jobs[k];
         const Parsed &p = ps[job_file[k]];
-        j.z = j.z_aligned = d_z + (size_t)(uintptr_t)j.z;
+        if (!device_data) j.z = d_z + (size_t)(uintptr_t)j.z;
         if (!j.mode) {
             j.filt = d_filt + (size_t)(uintptr_t)j.filt;
-            j.runmask = d_mask + (size_t)(uintptr_t)j.runmask;
             j.segsum = d_seg + (size_t)(uintptr_t)j.segsum;
-            j.lut = d_luts + (size_t)p.lut * 4096;
+            j.lut = d_luts + (size_t)p.lut * dec::kLutDwords;
         }
     }
     // ---- groups of files: while one group is decoded the next one's bytes are on their way (its own stream; from pageable
-    //      memory an "asynchronous" copy keeps its caller busy for most of its duration, so a thread of its own issues them) ----
+    //      memory an "asynchronous" copy keeps its caller busy for most of its duration, so a thread of its own issues them).
+    //      Files that are in device memory already form one group. ----
     struct Group {
-        uint32_t j0, j1, blk0, blk1, max_rows, max_bpl;
+        uint32_t j0, j1, blk0, blk1, tile0, tile1, max_rows, max_bpl;
     };
     std::vector<Group> groups;
     {
         // (file k goes to the group its middle byte falls into when the batch's bytes are cut into `want` equal parts)
-        const uint32_t want = (z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : 1u;
+        const uint32_t want = (!device_data && z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : 1u;
         uint64_t total = 0, run = 0;
         for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
         auto close = [&](uint32_t j0, uint32_t j1) {
-            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, 1, 1};
+            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, jobs[j0].tile_base,
+                       j1 < nj ? jobs[j1].tile_base : tile_total, 1, 1};
             for (uint32_t q = j0; q < j1; q++)
                 if (!jobs[q].mode) g.max_rows = std::max(g.max_rows, jobs[q].h), g.max_bpl = std::max(g.max_bpl, jobs[q].bpl);
             groups.push_back(g);
@@ -280,14 +361,21 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             if (t.joinable()) t.join();
         }
     } joiner{uploader};
-    for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * 4096, luts[k].data(), 16384, hipMemcpyHostToDevice, s));
+    for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * dec::kLutDwords, luts[k].data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(d_mask, 0, mask_total * 4, s));
     HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1 + 2 * kMaxGroups) * 4, s));
+    auto finish_group = [&](const Group &g) { // everything behind the synchronisation (every step of it is idempotent)
+        const uint32_t nblk = g.blk1 - g.blk0;
+        if (nblk) {
+            launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob, d_tile_first);
+            launch_dec_emit(s, d_jobs, nj, g.tile0, g.tile1 - g.tile0, d_sub, d_eob, d_block_off, d_tile_first, d_status);
+        }
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+    };
     for (uint32_t gi = 0; gi < ng; gi++) {
         const Group &g = groups[gi];
         if (ng == 1) {
-            HIP_TRY(upload_group(g, s));
+            if (!device_data) HIP_TRY(upload_group(g, s));
         } else {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return issued > gi; });
@@ -297,24 +385,19 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u (files %u..%u, %u workgroups) starts\n", since(), gi, g.j0, g.j1, g.blk1 - g.blk0);
         const uint32_t nblk = g.blk1 - g.blk0;
-        if (nblk) {
-            // the speculative round and kFirstRounds - 1 synchronisation rounds, launched blind: typical files have settled by
-            // then (a round in which nothing changes costs a few microseconds), and the chain check of dec_offsets_kernel says so
-            for (uint32_t r = 0; r < kFirstRounds; r++) launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed + gi);
-            launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off,
-                               d_status + g.j0, d_eob + g.j0);
-            launch_dec_emit(s, d_jobs, nj, g.blk0, nblk, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
-        }
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+        // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
+        // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
+        for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
+        finish_group(g);
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> status(nj);
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, nj * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    // groups with a file whose chain does not hold yet (nothing of such a file was written): more rounds, in fours, until one
-    // changes nothing -- nearly incompressible streams, whose codes have almost equal lengths, need up to a round per subsequence
-    // and are left to the CPU decoder beyond kMaxRounds -- then the rest of the pipeline again (every step of it is idempotent)
+    // groups with a file whose chain does not hold across some border yet (nothing of such a file was written): more rounds, in
+    // fours, until one changes nothing -- a stream whose decoders stay out of step over whole workgroups (periodic content) needs
+    // a round per border and is left to the CPU decoder beyond max_rounds -- then the rest of the pipeline again
     bool again = false;
     for (uint32_t gi = 0; gi < ng; gi++) {
         const Group &g = groups[gi];
@@ -323,13 +406,13 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
         const uint32_t nblk = g.blk1 - g.blk0;
         if (!open || !nblk) continue;
         again = true;
-        uint32_t r = kFirstRounds - 1;
-        for (bool settled = false; !settled && r < kMaxRounds;) {
+        uint32_t r = std::min(kBorderRounds, max_rounds - 1);
+        for (bool settled = false; !settled && r + 1 < max_rounds;) {
             uint32_t changed = 0;
             for (int k = 0; k < 4; k++) {
                 r++;
                 if (k == 3) HIP_TRY(hipMemsetAsync(d_changed + gi, 0, 4, s)); // (only the last of the four is asked)
-                launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_start, d_end, d_bytes, d_flags, d_changed + gi);
+                launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
             }
             HIP_TRY(hipMemcpyAsync(&changed, d_changed + gi, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -337,10 +420,7 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u needed %u rounds\n", since(), gi, r + 1);
         HIP_TRY(hipMemsetAsync(d_status + g.j0, 0, (g.j1 - g.j0) * 4, s));
-        launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_start, d_end, d_bytes, d_flags, d_recs, d_block_off,
-                           d_status + g.j0, d_eob + g.j0);
-        launch_dec_emit(s, d_jobs, nj, g.blk0, nblk, sub_total, d_start, d_bytes, d_eob, d_block_off, d_status);
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+        finish_group(g);
     }
     if (again) {
         HIP_TRY(hipGetLastError());
@@ -351,8 +431,8 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
     static const bool trace = getenv("FPNG_AMD_TRACE_FILES") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)
-            fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
-                    jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, (unsigned long long)jobs[k].first_bit, status[k]);
+            fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, %u tiles, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
+                    jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, jobs[k].n_tiles, (unsigned long long)jobs[k].first_bit, status[k]);
         if (jobs[k].mode) continue;
         int32_t &st = results[job_file[k]].status;
         if (status[k] & kDecNotConverged) // (nothing else is known then: "invalid" may be a speculative decode's)
@@ -363,6 +443,18 @@ extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *fi
             st = fpng::FPNG_DECODE_NOT_FPNG; // the stream never ended
     }
     return FPNG_AMD_OK;
+}
+
+} // namespace
+
+extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results)
+{
+    return decode_files(e, files, n, desired, results, false);
+}
+
+extern "C" int fpng_amd_decode_batch_device(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results)
+{
+    return decode_files(e, files, n, desired, results, true);
 }
 
 // One host-resident file to host pixels: what fpng::fpng_decode_memory() does for large images (fpng_decode.cpp).  The pixels land in
@@ -389,6 +481,17 @@ extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32
         result->status = fpng::FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
         return FPNG_AMD_OK;
     }
+    {   // the stream's shape first: a header that promises more pixels than the IDAT can hold must not size any device memory
+        Parsed p;
+        p.w = w, p.h = h, p.c = c, p.idat_ofs = idat_ofs, p.idat_len = idat_len;
+        static thread_local uint32_t table[1u << fpng::parse::kTableBits];
+        uint8_t sizes[288];
+        const int ss = plan_stream((const uint8_t *)png + idat_ofs + 8, size - (idat_ofs + 8), true, p, table, sizes);
+        if (ss) {
+            result->status = ss;
+            return FPNG_AMD_OK;
+        }
+    }
     HIP_TRY(hipSetDevice(e->device));
     int rc = drain(e);
     if (rc) return rc;
@@ -407,23 +510,22 @@ extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32
 // What fpng_amd_decode_batch() prepares on the host for one file, without a GPU (tests hold a model of the kernels against it):
 // container status, geometry, stored or dynamic, the token stream's first bit and its limit, the kernels' lookup table.
 extern "C" int fpng_amd_decode_plan(const void *png_, uint32_t size, fpng_amd_decode_result *result, uint32_t *mode, uint32_t *idat_ofs, uint32_t *idat_len,
-                                    uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t lut[4096])
+                                    uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t *lut)
 {
     if (!png_ || !size || !result || !mode || !idat_ofs || !idat_len || !first_bit || !end_limit_bit || !lut) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
     const uint8_t *png = (const uint8_t *)png_;
     std::memset(result, 0, sizeof *result);
     Parsed p;
-    result->status = fpng::parse::parse_container(png, size, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
+    static thread_local uint32_t table[1u << fpng::parse::kTableBits];
+    uint8_t sizes[288];
+    result->status = parse_host(png, size, p, table, sizes);
     result->w = p.w, result->h = p.h, result->channels_in_file = p.c;
     *mode = 0, *idat_ofs = p.idat_ofs, *idat_len = p.idat_len, *first_bit = 0, *end_limit_bit = 0;
     if (result->status) return FPNG_AMD_OK;
-    static thread_local uint32_t table[1u << fpng::parse::kTableBits];
-    uint8_t sizes[288];
-    if ((result->status = plan_stream(png, size, p, table, sizes))) return FPNG_AMD_OK;
     *mode = p.mode;
     if (!p.mode) {
         *first_bit = p.first_bit, *end_limit_bit = (uint64_t)(p.idat_len - 4) * 8;
-        pack_lut(table, lut);
+        build_multi_lut(table, sizes, lut);
     }
     return FPNG_AMD_OK;
 }

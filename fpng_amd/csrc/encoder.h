@@ -181,6 +181,7 @@ struct fpng_amd_encoder {
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
     hipStream_t dec_up = nullptr; // ... the stream the files' bytes are uploaded on, one event per group of files
     hipEvent_t dec_ev[8] = {};
+    PinnedBuf<uint8_t> h_dec_fetch; // fpng_amd_decode_batch_device(): the files' first and last bytes on their way to the host parser
     DeviceBuf<uint8_t> d_xchg;    // fpng_amd_encode_image_sharded(): the records it exchanges, and their pinned mirror
     PinnedBuf<uint8_t> h_xchg;
     struct HostWorkers *workers = nullptr; // fpng_amd_encode_host_to(): the uploader and downloader threads (pipeline.cpp)

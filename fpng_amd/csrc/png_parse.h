@@ -17,13 +17,32 @@ const uint32_t kMaxDim = 1u << 24;
 
 inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-inline int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint32_t &h, uint32_t &chans, uint32_t &idat_ofs,
-                    uint32_t &idat_len)
+// A file of which only a head and a tail are in host memory (device-resident files: fpng_amd_decode_batch_device copies the first
+// and the last bytes back); at() = pointer to `len` contiguous bytes at `ofs`, or nullptr if they were not fetched.
+struct View {
+    const uint8_t *head;
+    size_t head_len; // bytes [0, head_len)
+    const uint8_t *tail;
+    size_t tail_ofs; // bytes [tail_ofs, size)
+    size_t size;
+    const uint8_t *at(size_t ofs, size_t len) const
+    {
+        if (ofs + len <= head_len) return head + ofs;
+        if (tail && ofs >= tail_ofs && ofs + len <= size) return tail + (ofs - tail_ofs);
+        return nullptr;
+    }
+};
+const int kParseNeedMore = -1; // the walk needs bytes the view does not hold: fetch the whole file and parse again
+
+inline int parse_container_view(const View &v, uint32_t &w, uint32_t &h, uint32_t &chans, uint32_t &idat_ofs, uint32_t &idat_len)
 {
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    const size_t size = v.size;
     w = h = chans = idat_ofs = idat_len = 0;
     // signature + IHDR chunk (25) + chunk prefix (8) + 1 + crc (4) + IEND (12)
     if (size < 8 + 25 + 8 + 1 + 4 + 12) return FPNG_DECODE_FAILED_NOT_PNG;
+    const uint8_t *png = v.at(0, 8 + 25);
+    if (!png) return kParseNeedMore;
     if (memcmp(png, sig, 8) != 0) return FPNG_DECODE_FAILED_NOT_PNG;
     const uint8_t *ihdr = png + 8;
     if (be32(ihdr) != 13) return FPNG_DECODE_FAILED_NOT_PNG;
@@ -45,7 +64,8 @@ inline int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint3
     for (;;) {
         if (ofs >= size) return FPNG_DECODE_FAILED_CHUNK_PARSING;
         if (size - ofs < 12) return FPNG_DECODE_FAILED_CHUNK_PARSING;
-        const uint8_t *ck = png + ofs;
+        const uint8_t *ck = v.at(ofs, 8);
+        if (!ck) return kParseNeedMore;
         const uint32_t len = be32(ck);
         if (ofs + 8 + (uint64_t)len + 4 > size) return FPNG_DECODE_FAILED_CHUNK_PARSING;
         for (int i = 0; i < 4; i++) {
@@ -53,7 +73,11 @@ inline int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint3
             if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))) return FPNG_DECODE_FAILED_CHUNK_PARSING;
         }
         const bool is_idat = memcmp(ck + 4, "IDAT", 4) == 0;
-        if (!is_idat && fpng_amd_crc32(ck + 4, 4 + len, 0) != be32(ck + 8 + len)) return FPNG_DECODE_FAILED_HEADER_CRC32;
+        if (!is_idat) { // (the reference skips the CRC of the IDAT as well: src/fpng.cpp:3016-3026)
+            ck = v.at(ofs, 8 + (size_t)len + 4);
+            if (!ck) return kParseNeedMore;
+            if (fpng_amd_crc32(ck + 4, 4 + len, 0) != be32(ck + 8 + len)) return FPNG_DECODE_FAILED_HEADER_CRC32;
+        }
         const uint8_t *data = ck + 8;
         if (memcmp(ck + 4, "IEND", 4) == 0) break;
         if (is_idat) {
@@ -72,6 +96,12 @@ inline int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint3
     }
     if (!have_fdec || !idat_ofs) return FPNG_DECODE_NOT_FPNG;
     return FPNG_DECODE_SUCCESS;
+}
+
+inline int parse_container(const uint8_t *png, uint32_t size, uint32_t &w, uint32_t &h, uint32_t &chans, uint32_t &idat_ofs, uint32_t &idat_len)
+{
+    const View v = {png, size, nullptr, 0, size};
+    return parse_container_view(v, w, h, chans, idat_ofs, idat_len);
 }
 
 // LSB-first bit reader confined to the zlib payload

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPNG_AMD_ABI_VERSION 3
+#define FPNG_AMD_ABI_VERSION 4
 
 /* ---- status codes ---- */
 #define FPNG_AMD_OK 0
@@ -326,17 +326,22 @@ int fpng_amd_encode_image_sharded(fpng_amd_encoder *enc, const fpng_amd_transpor
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);
 
-/* ---- GPU batch DECODE of fpng-written files (reference src/fpng.h:55-111 fpng_decode_memory; src/fpng.cpp:2209-2901), a
- *      prototype of the data-parallel form: container and block header are parsed on the host, the pixel stream is decoded by
- *      thousands of threads that find the token boundaries through the self-synchronisation of Huffman codes (decode.hip).
- *      `data` is a HOST pointer to the whole .png; the pixels (desired_chans = 3 or 4 per pixel, like the reference's
- *      desired_channels) appear in DEVICE memory.  status = the reference's fpng::FPNG_DECODE_* code for this file (0 = success);
- *      FPNG_AMD_DECODE_UNDECIDED: the GPU path could not settle the file (its token boundaries did not synchronise in the
- *      allotted rounds) -- decode it with fpng::fpng_decode_memory() instead; never reported for a file the CPU decoder
- *      would reject with a different code than FPNG_DECODE_NOT_FPNG. ---- */
+/* ---- GPU batch DECODE of fpng-written files (reference src/fpng.h:55-111 fpng_decode_memory; src/fpng.cpp:2209-2901) in its
+ *      data-parallel form: container and block header are parsed on the host, the pixel stream is decoded by thousands of
+ *      threads that find the token boundaries through the self-synchronisation of Huffman codes (decode.hip).
+ *      fpng_amd_decode_batch: `data` is a HOST pointer to the whole .png (uploaded in groups while earlier groups decode);
+ *      fpng_amd_decode_batch_device: `data` is a DEVICE pointer to the whole .png (e.g. what fpng_amd_encode_submit() wrote):
+ *      only the file's first 1024 and last 64 bytes come back to the host for the container walk and the block header; the
+ *      bytes must be complete when the call is made (or be produced on the encoder's stream).  Either way the pixels
+ *      (desired_chans = 3 or 4 per pixel, like the reference's desired_channels) appear in DEVICE memory and the call returns
+ *      when they are there.  status = the reference's fpng::FPNG_DECODE_* code for this file (0 = success);
+ *      FPNG_AMD_DECODE_UNDECIDED: the GPU path leaves the file to the CPU decoder -- its token boundaries did not synchronise
+ *      in the allotted rounds (FPNG_AMD_DECODE_MAX_ROUNDS in the environment, default 64; 0 = every compressed file), or it is
+ *      a stored-block file cut into other block sizes than the encoder's -- decode it with fpng::fpng_decode_memory()
+ *      instead; never reported for a file the CPU decoder would reject with a different code than FPNG_DECODE_NOT_FPNG. ---- */
 #define FPNG_AMD_DECODE_UNDECIDED 64
 typedef struct fpng_amd_png {
-    const void *data; /* HOST: the file */
+    const void *data; /* the file: HOST memory for fpng_amd_decode_batch, DEVICE memory for fpng_amd_decode_batch_device */
     uint32_t size;
     uint32_t reserved;
     uint8_t *d_pixels; /* DEVICE: receives w * h * desired_chans bytes */
@@ -348,19 +353,24 @@ typedef struct fpng_amd_decode_result {
 } fpng_amd_decode_result;
 int fpng_amd_decode_batch(fpng_amd_encoder *enc, const fpng_amd_png *files, uint32_t n, uint32_t desired_chans,
                           fpng_amd_decode_result *results);
+int fpng_amd_decode_batch_device(fpng_amd_encoder *enc, const fpng_amd_png *files, uint32_t n, uint32_t desired_chans,
+                                 fpng_amd_decode_result *results);
 /* One HOST-resident file to HOST pixels (reference src/fpng.h:108 fpng_decode_memory; the fpng:: drop-in routes images of
  * 256K pixels and more through it): container checks, upload, GPU decode, one download into memory obtained from `reserve`
  * (called at most once, with w * h * desired_chans, only when the file decodes).  result->status as in fpng_amd_decode_batch():
  * FPNG_AMD_DECODE_UNDECIDED = decode it on the CPU. */
 int fpng_amd_decode_host(fpng_amd_encoder *enc, const void *png, uint32_t size, uint32_t desired_chans, fpng_amd_reserve_fn reserve,
                          void *user, fpng_amd_decode_result *result);
-/* What fpng_amd_decode_batch() settles on the HOST about one file before the GPU sees it (no GPU needed; tests/ hold a model of the
- * decode kernels against it): result (container status, geometry; status 0 = the stream's shape is acceptable so far), mode (0 = one
- * dynamic block, 1 = stored blocks), the IDAT chunk's offset and payload length, the first row token's bit and the bit no token may
- * start at or behind (both counted from the zlib stream's first byte = png + idat_ofs + 8), and the kernels' lookup table:
- * lut[next 12 bits] = symbol | code length << 9 | (length symbols) extra bit count << 13 | base length << 16, 0 = no such code. */
+/* What fpng_amd_decode_batch() settles on the HOST about one file before the GPU sees it (no GPU needed; tests/ run the decode
+ * kernels' per-thread code on the CPU against it): result (container status, geometry; status 0 = the stream's shape is acceptable so
+ * far), mode (0 = one dynamic block, 1 = stored blocks), the IDAT chunk's offset and payload length, the first row token's bit and
+ * the bit no token may start at or behind (both counted from the zlib stream's first byte = png + idat_ofs + 8), and the kernels'
+ * lookup table, FPNG_AMD_DECODE_LUT_WORDS words (fpng_amd/csrc/decode_core.h): lut[next 12 bits] = code bits consumed << 28 |
+ * number of literals (1..3) << 26 | their byte values (first lowest); or, literals 0: bit 25 set = a match (base length in bits
+ * 8..0, extra bit count in bits 11..9), clear = end of block; 0 = no such code; then 64 words = the literals' code lengths. */
+#define FPNG_AMD_DECODE_LUT_WORDS 4160
 int fpng_amd_decode_plan(const void *png, uint32_t size, fpng_amd_decode_result *result, uint32_t *mode, uint32_t *idat_ofs,
-                         uint32_t *idat_len, uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t lut[4096]);
+                         uint32_t *idat_len, uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t *lut);
 
 /* ---- table training (reference src/fpng_test.cpp:766-973 "-t" + src/fpng.cpp:909-988, both only in builds of the reference with
  *      FPNG_TRAIN_HUFFMAN_TABLES=1): from a corpus of `n` device-resident images, all with num_chans channels (the reference's

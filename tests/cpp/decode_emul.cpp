@@ -1,0 +1,256 @@
+// decode_emul.cpp -- the GPU decoder's kernels (fpng_amd/csrc/decode.hip) run on the CPU, thread by thread, over the SAME per-thread
+// code (fpng_amd/csrc/decode_core.h) and the same host-side preparation (fpng_amd_decode_plan): there is no GPU in the dev
+// container, so this is where the walkers, the hand-over rules, the in-workgroup and cross-border correction rounds, the offsets,
+// the tile assignment and the emit logic are held against the CPU decoder / the reference before a GPU sees them
+// (tests/test_decode_model.py).  Workgroup size, lead-in and tile size are PARAMETERS here (the kernels fix them at compile time):
+// small values put many workgroup borders and tile seams into small test images.  TEST INFRASTRUCTURE -- not part of the product.
+#include "decode_core.h"
+#include "fpng_amd.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+using namespace fpng_amd::dec;
+
+namespace {
+
+constexpr uint32_t kSubBits = 512;
+
+struct HostBits { // positions relative to dword `d0` of the (zero padded) stream
+    const uint32_t *dw;
+    uint32_t window(uint32_t pos) const { return funnel(dw[(pos >> 5) + 1], dw[pos >> 5], pos & 31u); }
+};
+struct HostTile {
+    uint8_t *t;
+    uint32_t ndw;
+    bool *overflow;
+    void put32(uint32_t d, uint32_t v)
+    {
+        if (d >= ndw) *overflow = true; else memcpy(t + 4 * d, &v, 4);
+    }
+    void put8(uint32_t b, uint8_t v)
+    {
+        if (b >= 4 * ndw) *overflow = true; else t[b] = v;
+    }
+};
+
+} // namespace
+
+// status: the decoder's (0, FPNG_DECODE_* or FPNG_AMD_DECODE_UNDECIDED); stats[0] = correction rounds inside workgroups (max),
+// stats[1] = border rounds, stats[2] = subsequences, stats[3] = subsequences corrected at least once
+extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desired, uint8_t *out, size_t out_cap, uint32_t *w_, uint32_t *h_, uint32_t *c_, uint32_t sub_block,
+                                uint32_t lead_in, uint32_t tile_bytes, uint32_t max_border_rounds, uint32_t *stats)
+{
+    fpng_amd_decode_result res;
+    uint32_t mode = 0, idat_ofs = 0, idat_len = 0;
+    uint64_t first_bit = 0, end_limit = 0;
+    std::vector<uint32_t> lut(FPNG_AMD_DECODE_LUT_WORDS);
+    if (fpng_amd_decode_plan(png, size, &res, &mode, &idat_ofs, &idat_len, &first_bit, &end_limit, lut.data())) return -1000;
+    *w_ = res.w, *h_ = res.h, *c_ = res.channels_in_file;
+    if (res.status) return res.status;
+    const uint32_t w = res.w, h = res.h, c = res.channels_in_file, bpl = w * c, stride = bpl + 1;
+    const uint64_t total = (uint64_t)stride * h;
+    if ((uint64_t)w * h * desired > out_cap) return -1001;
+    const uint8_t *zsrc = png + idat_ofs + 8;
+    std::vector<uint8_t> filt(total + 32);
+    if (mode == 1) { // stored blocks of 65535 bytes, filter 0: the pixels themselves (dec_stored_kernel)
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w; x++)
+                for (uint32_t ch = 0; ch < desired; ch++) {
+                    const uint64_t s = (uint64_t)y * stride + 1 + (uint64_t)x * c + ch;
+                    out[((size_t)y * w + x) * desired + ch] = ch < c ? zsrc[2 + 5 * (s / 65535 + 1) + s] : 0xFF;
+                }
+        return 0;
+    } else {
+        // the stream as the kernels see it: dwords from an aligned start; shift 1 puts the first byte into the middle of a dword
+        const uint32_t z_shift = 1;
+        std::vector<uint32_t> zdw((idat_len + z_shift + 16) / 4 + 64, 0);
+        memcpy((uint8_t *)zdw.data() + z_shift, zsrc, idat_len);
+        const uint64_t z_bytes = (uint64_t)idat_len + z_shift;
+        first_bit += 8 * z_shift, end_limit += 8 * z_shift;
+        const uint8_t *lenof = (const uint8_t *)(lut.data() + kLutEntries);
+        const uint32_t n_sub = (uint32_t)((end_limit - first_bit + kSubBits - 1) / kSubBits), nb = (n_sub + sub_block - 1) / sub_block;
+        std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub);
+        struct Rec {
+            uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel;
+        };
+        std::vector<Rec> recs(nb);
+        uint32_t max_inner = 0, fixed_subs = 0;
+        // ---- dec_sync_kernel ----
+        auto sync_block = [&](uint32_t blk, uint32_t round) -> bool { // returns "changed"
+            const uint32_t local0 = blk * sub_block;
+            uint32_t want0 = 0;
+            if (round) {
+                if (!local0) return false;
+                if (recs[blk].entry_rel == recs[blk - 1].exit_rel) return false;
+                want0 = recs[blk - 1].exit_rel;
+            }
+            const uint32_t lead0 = local0 ? lead_in : 0u;
+            const uint64_t first_nominal = first_bit + (uint64_t)local0 * kSubBits, d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
+            HostBits in = {zdw.data() + d0};
+            const uint64_t lim64 = end_limit - base;
+            const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
+            const uint32_t nthreads = std::min(sub_block, n_sub - local0);
+            std::vector<SubState> st(nthreads);
+            std::vector<uint32_t> s_end(nthreads);
+            std::vector<bool> dirty(nthreads, false), ever(nthreads, false);
+            auto nominal_of = [&](uint32_t t) { return (uint32_t)(first_nominal - base) + t * kSubBits; };
+            for (uint32_t t = 0; t < nthreads; t++) {
+                const uint32_t i = local0 + t, nominal = nominal_of(t), boundary = nominal + kSubBits;
+                if (!round) {
+                    sub_first(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t]);
+                    dirty[t] = true;
+                } else {
+                    const uint32_t v = info[i];
+                    st[t].start = nominal + info_start(v), st[t].end = boundary + info_end(v);
+                    st[t].c.bytes = bytes[i], st[t].c.lits = info_lits(v), st[t].c.tail = tail[i], st[t].c.flags = info_flags(v);
+                }
+                s_end[t] = st[t].end;
+            }
+            want0 += nominal_of(0);
+            uint32_t inner = 0;
+            for (;;) {
+                std::vector<uint32_t> want(nthreads);
+                bool any = false;
+                for (uint32_t t = 0; t < nthreads; t++) { // (all threads look before any of them writes: the kernel's barrier)
+                    want[t] = t ? s_end[t - 1] : (round ? want0 : st[t].start);
+                    any |= want[t] != st[t].start;
+                }
+                if (!any) break;
+                inner++;
+                for (uint32_t t = 0; t < nthreads; t++)
+                    if (want[t] != st[t].start) {
+                        sub_refix(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                        s_end[t] = st[t].end;
+                        dirty[t] = true;
+                        if (!ever[t]) ever[t] = true, fixed_subs++;
+                    }
+            }
+            max_inner = std::max(max_inner, inner);
+            bool any_dirty = false;
+            for (uint32_t t = 0; t < nthreads; t++)
+                if (dirty[t]) {
+                    const uint32_t i = local0 + t, nominal = nominal_of(t);
+                    info[i] = pack_info(st[t].start - nominal, st[t].end - (nominal + kSubBits), st[t].c);
+                    if (info_start(info[i]) != st[t].start - nominal || info_end(info[i]) != st[t].end - (nominal + kSubBits) || info_lits(info[i]) != st[t].c.lits)
+                        throw 1; // a field of the record overflowed
+                    bytes[i] = st[t].c.bytes, tail[i] = st[t].c.tail;
+                    any_dirty = true;
+                }
+            if (!any_dirty) return false;
+            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0};
+            for (uint32_t t = 0; t < nthreads; t++) {
+                r.sum += st[t].c.bytes;
+                if ((st[t].c.flags & kSubEob) && r.first_eob == sub_block) r.first_eob = t;
+                if ((st[t].c.flags & kSubInvalid) && r.first_invalid == sub_block) r.first_invalid = t;
+            }
+            r.exit_rel = nthreads == sub_block ? s_end[sub_block - 1] - (nominal_of(0) + sub_block * kSubBits) : 0u;
+            recs[blk] = r;
+            return round != 0;
+        };
+        try {
+            for (uint32_t b = 0; b < nb; b++) sync_block(b, 0);
+        } catch (int) {
+            return -1002;
+        }
+        uint32_t border_rounds = 0;
+        for (uint32_t r = 1; r <= max_border_rounds; r++) {
+            // (the workgroups of one launch run at the same time; last to first, each one sees its predecessor's record of the
+            //  launch before -- the least favourable of the schedules the kernel allows)
+            bool changed = false;
+            try {
+                for (uint32_t b = nb; b-- > 0;) changed |= sync_block(b, r);
+            } catch (int) {
+                return -1002;
+            }
+            if (!changed) break;
+            border_rounds++;
+        }
+        if (stats) stats[0] = max_inner, stats[1] = border_rounds, stats[2] = n_sub, stats[3] = fixed_subs;
+        // ---- dec_offsets_kernel ----
+        uint32_t status = 0, last_blk = nb, last_local = 0;
+        for (uint32_t b = 0; b < nb && last_blk == nb; b++)
+            if (recs[b].first_eob < sub_block) last_blk = b, last_local = recs[b].first_eob;
+        std::vector<uint64_t> block_off(nb, 0);
+        uint64_t acc = 0;
+        for (uint32_t b = 0; b < nb && b <= last_blk; b++) {
+            if (b && recs[b].entry_rel != recs[b - 1].exit_rel) status |= 1; // not converged
+            block_off[b] = acc;
+            if (b < last_blk) {
+                acc += recs[b].sum;
+                if (recs[b].first_invalid < sub_block) status |= 2;
+            } else if (recs[b].first_invalid <= last_local)
+                status |= 2;
+        }
+        if (last_blk < nb)
+            for (uint32_t k = 0; k <= last_local; k++) acc += bytes[last_blk * sub_block + k];
+        else
+            status |= 2;
+        if (acc != total) status |= 2;
+        if (status & 1) return FPNG_AMD_DECODE_UNDECIDED;
+        if (status) return 1; // FPNG_DECODE_NOT_FPNG
+        const uint32_t eob_index = last_blk * sub_block + last_local;
+        // ---- dec_subscan_kernel ----
+        std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0);
+        const uint32_t n_tiles = (uint32_t)((total + tile_bytes - 1) / tile_bytes);
+        std::vector<uint32_t> tile_first(n_tiles, 0xFFFFFFFFu);
+        for (uint32_t b = 0; b <= last_blk; b++) {
+            uint32_t before = 0;
+            for (uint32_t t = 0; t < sub_block; t++) {
+                const uint32_t i = b * sub_block + t;
+                if (i >= n_sub || i > eob_index) break;
+                rel[i] = before;
+                lastpx[i] = lookback_lastpx(
+                    i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
+                const uint64_t off = block_off[b] + before, next = off + bytes[i];
+                for (uint64_t k = (off + tile_bytes - 1) / tile_bytes; k * tile_bytes < next && k < n_tiles; k++) tile_first[k] = i;
+                before += bytes[i];
+            }
+        }
+        // ---- dec_emit_kernel ----
+        uint32_t err = 0;
+        std::vector<uint8_t> tile(tile_bytes + 16);
+        for (uint32_t tl = 0; tl < n_tiles; tl++) {
+            const uint64_t tile_start = (uint64_t)tl * tile_bytes, tile_end = std::min(total, tile_start + tile_bytes), sel_end = tile_end == total ? total + 1 : tile_end;
+            if (tile_first[tl] == 0xFFFFFFFFu) return -1003;
+            EmitGeom geom = {stride, c, (uint32_t)((tile_end - tile_start + 3) >> 2)};
+            std::fill(tile.begin(), tile.end(), 0xCD);
+            bool overflow = false;
+            HostTile ht = {tile.data(), geom.ndw, &overflow};
+            for (uint32_t i = tile_first[tl]; i < n_sub && i <= eob_index; i++) {
+                const uint64_t off = block_off[i / sub_block] + rel[i];
+                if (off >= sel_end) break;
+                // (the kernel stages the chunk's bits from its first subsequence's nominal bit on)
+                const uint32_t c0 = tile_first[tl] + (i - tile_first[tl]) / 7 * 7; // chunks of 7 threads here
+                const uint64_t nominal0 = first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
+                HostBits in = {zdw.data() + d0};
+                const uint32_t nominal = (uint32_t)(nominal0 - base) + (i - c0) * kSubBits;
+                const uint64_t lim64 = end_limit - base;
+                const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
+                const uint32_t row = (uint32_t)(off / stride), col = (uint32_t)(off - (uint64_t)row * stride);
+                uint32_t eob_end = 0;
+                const uint32_t fl = walk_emit(in, lut.data(), lenof, nominal + info_start(info[i]), nominal + kSubBits, data_limit, (int32_t)((int64_t)off - (int64_t)tile_start), row,
+                                              col, lastpx[i], geom, ht, eob_end);
+                if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != z_bytes) err |= 2;
+                err |= fl;
+            }
+            if (overflow) return -1004;
+            memcpy(filt.data() + tile_start, tile.data(), tile_end - tile_start);
+        }
+        if (err & 2) return 1;
+        if (!(err & kEmitSawEob)) return 1;
+    }
+    // ---- Up filter undone, channel conversion (dec_unfilter_kernel) ----
+    std::vector<uint8_t> prev(bpl, 0), cur(bpl);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t *f = filt.data() + (size_t)y * stride + 1;
+        for (uint32_t j = 0; j < bpl; j++) cur[j] = (uint8_t)(prev[j] + f[j]);
+        uint8_t *o = out + (size_t)y * w * desired;
+        for (uint32_t x = 0; x < w; x++)
+            for (uint32_t ch = 0; ch < desired; ch++) o[(size_t)x * desired + ch] = ch < c ? cur[(size_t)x * c + ch] : 0xFF;
+        prev.swap(cur);
+    }
+    return 0;
+}

@@ -1,19 +1,72 @@
-"""CPU model of the GPU decoder (fpng_amd/csrc/decode.hip) on top of what its host side prepares (fpng_amd_decode_plan: container
-checks, block header, the kernels' lookup table): subsequences of 512 token bits decoded speculatively from their nominal first
-bits, synchronisation rounds in place until every subsequence starts where its predecessor ended, the stream's end = the FIRST
-end-of-block symbol of the chain, output offsets by prefix sums, literals into the filtered image / matches into a run mask, runs
-filled from the left, the Up filter undone.  The model must reproduce the pixels; it pins the table format (symbol | length << 9 |
-extra bits << 13 | base << 16), the one-32-bit-window-per-token reader and the hand-over rules.  The kernels themselves are held
-against the CPU decoder and the reference decoder by tests/test_gpu_decode.py."""
+"""CPU tests of the GPU decoder's logic (fpng_amd/csrc/decode.hip) without a GPU:
+
+* tests/cpp/decode_emul.cpp runs the kernels' own per-thread code (fpng_amd/csrc/decode_core.h) thread by thread on top of what the
+  decoder's host side prepares (fpng_amd_decode_plan: container checks, block header, the lookup table): subsequences of 512 token
+  bits decoded from a lead-in in front of their nominal first bits, corrections inside a workgroup until every subsequence starts
+  where its predecessor ended, rounds across workgroup borders, the stream's end = the FIRST end-of-block symbol of the chain,
+  output offsets, the literal bytes in front of every subsequence, tiles of the filtered stream decoded for real, the Up filter
+  undone.  Workgroup size, lead-in and tile size are parameters there: small ones put many borders and seams into small images.
+  It must reproduce the pixels, and the status codes of the CPU decoder / the reference on damaged files.
+* a few lines of Python decode a stream token by token with the same table: that pins the table's FORMAT (code bits << 28 |
+  literal count << 26 | up to three literal bytes; match: bit 25, base length, extra bit count; then the literals' code lengths).
+
+The kernels themselves are held against the CPU decoder and the reference decoder by tests/test_gpu_decode.py."""
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 import pytest
 
-from cpu_ref import fuzz_image, oracle
+import dropin
+from cpu_ref import fuzz_image, have_ref, oracle, ref
 
-SUB = 512
-EOB, INVALID = 1, 4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LUT_WORDS = 4160
+UNDECIDED = 64
+# (workgroup size, lead-in bits, tile bytes): the kernels' own constants first
+CONFIGS = [(512, 128, 18432), (4, 128, 64), (3, 0, 100), (8, 32, 52), (2, 64, 4), (64, 128, 1024)]
+
+_emul = None
+
+
+def emul():
+    global _emul
+    if _emul is None:
+        from fpng_amd import build
+        build.build()
+        lib_dir = os.path.join(ROOT, "fpng_amd", "lib")
+        src = os.path.join(ROOT, "tests", "cpp", "decode_emul.cpp")
+        so = os.path.join(lib_dir, "libfpng_decode_emul.so")
+        deps = [src, os.path.join(ROOT, "fpng_amd", "csrc", "decode_core.h"), os.path.join(lib_dir, "libfpng_amd.so")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"), "-I",
+                                   os.path.join(ROOT, "fpng_amd", "csrc"), src, "-o", so, "-L", lib_dir, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
+        L = C.CDLL(so)
+        L.fpng_emul_decode.restype = C.c_int
+        L.fpng_emul_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
+        _emul = L
+    return _emul
+
+
+def emul_decode(png, desired, cfg=CONFIGS[0], border_rounds=1000):
+    """-> (status, pixels or None, w, h, c, stats)"""
+    b = np.frombuffer(bytes(png), dtype=np.uint8)
+    w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    st, ww, hh, cc = dropin.get_info(png)
+    cap = ww * hh * desired + 16 if st == 0 else 16
+    out = np.zeros(cap, dtype=np.uint8)
+    stats = (C.c_uint32 * 4)()
+    st = emul().fpng_emul_decode(b.ctypes.data, b.size, desired, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), cfg[0], cfg[1], cfg[2], border_rounds, stats)
+    assert st > -1000, f"emulator internal error {st}"
+    return st, (out[: w.value * h.value * desired] if st == 0 else None), w.value, h.value, c.value, list(stats)
+
+
+def expected_pixels(img, w, h, c, desired):
+    exp = np.asarray(img).reshape(h, w, c)
+    if desired == 3:
+        return exp[:, :, :3].reshape(-1)
+    return (exp if c == 4 else np.concatenate([exp, np.full((h, w, 1), 255, dtype=np.uint8)], axis=2)).reshape(-1)
 
 
 def plan(png):
@@ -23,155 +76,158 @@ def plan(png):
     res = _lib.DecodeResult()
     mode, ofs, ln = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
     first, limit = C.c_uint64(0), C.c_uint64(0)
-    lut = (C.c_uint32 * 4096)()
+    lut = (C.c_uint32 * LUT_WORDS)()
     rc = lib.fpng_amd_decode_plan(b.ctypes.data, b.size, C.byref(res), C.byref(mode), C.byref(ofs), C.byref(ln), C.byref(first), C.byref(limit), C.byref(lut))
     assert rc == 0
     return res, mode.value, ofs.value, ln.value, first.value, limit.value, np.frombuffer(lut, dtype=np.uint32).copy()
 
 
-class Model:
-    def __init__(self, png):
-        self.res, self.mode, ofs, ln, self.first, self.limit, lut = plan(png)
-        self.lut = [int(v) for v in lut]
-        self.zlen = ln
-        z = png[ofs + 8: ofs + 8 + ln] + bytes(16)
-        self.zint = int.from_bytes(z, "little")  # LSB-first bit string
-
-    def token(self, pos):
-        w = (self.zint >> pos) & 0xFFFFFFFF  # one 32-bit window per token
-        e = self.lut[w & 4095]
-        ln = (e >> 9) & 15
-        if not ln:
-            return -1, pos, 0
-        sym = e & 511
-        if sym <= 256:
-            return sym, pos + ln, 0
-        xb = (e >> 13) & 7
-        return sym, pos + ln + xb + 1, (e >> 16) + ((w >> ln) & ((1 << xb) - 1))
-
-    def decode_sub(self, i, s):
-        boundary = self.first + (i + 1) * SUB
-        pos, nbytes, fl = s, 0, 0
-        while pos < boundary:
-            if pos >= self.limit:
-                fl = INVALID
-                break
-            sym, pos, run = self.token(pos)
-            if sym < 0:
-                fl = INVALID
-                break
-            if sym == 256:
-                fl = EOB
-                break
-            nbytes += 1 if sym < 256 else run
-        return (boundary if fl else pos), nbytes, fl  # a derailed / ended decode hands over on the nominal boundary
-
-    def synchronise(self):
-        n = (self.limit - self.first + SUB - 1) // SUB
-        start = [self.first + i * SUB for i in range(n)]
-        out = [self.decode_sub(i, start[i]) for i in range(n)]
-        rounds = 1
-        while True:
-            # every subsequence looks at its predecessor's end OF THE ROUND BEFORE (the kernel's threads run at the same time; it
-            # updates in place, so a thread may also see a newer end: it then settles sooner, never differently)
-            ends = [o[0] for o in out]
-            changed = False
-            for i in range(n):
-                s = ends[i - 1] if i else self.first
-                if s != start[i]:
-                    start[i], out[i], changed = s, self.decode_sub(i, s), True
-            rounds += 1
-            if not changed:
-                break
-            assert rounds < 2000
-        return start, out, rounds
-
-    def pixels(self, desired):
-        w, h, c = self.res.w, self.res.h, self.res.channels_in_file
-        bpl, stride = w * c, w * c + 1
-        start, out, rounds = self.synchronise()
-        last = next(i for i, o in enumerate(out) if o[2] & EOB)  # the stream ends with the FIRST end-of-block symbol of the chain
-        assert all(not (out[i][2] & INVALID) for i in range(last + 1))
-        offs = np.concatenate([[0], np.cumsum([out[i][1] for i in range(last + 1)])])
-        assert offs[-1] == stride * h
-        F = np.zeros((h, bpl), dtype=np.uint8)
-        run = np.zeros((h, w), dtype=bool)
-        saw_eob = False
-        for i in range(last + 1):
-            pos, o = start[i], int(offs[i])
-            boundary = self.first + (i + 1) * SUB
-            while pos < boundary:
-                assert pos < self.limit
-                sym, pos, rl = self.token(pos)
-                assert sym >= 0
-                if sym == 256:
-                    assert o == stride * h and ((pos + 7) >> 3) + 4 == self.zlen
-                    saw_eob = True
-                    break
-                row, col = divmod(o, stride)
-                if sym < 256:
-                    if col == 0:
-                        assert sym == (2 if row else 0)
-                    else:
-                        F[row, col - 1] = sym
-                    o += 1
-                else:
-                    assert col and (col - 1) % c == 0 and rl % c == 0 and rl and (col - 1) // c + rl // c <= w
-                    run[row, (col - 1) // c:(col - 1) // c + rl // c] = True
-                    o += rl
-        assert saw_eob
-        Fp = F.reshape(h, w, c)
-        for y in range(h):  # runs: the nearest literal pixel to the left (zeros at the row's start)
-            prev = np.zeros(c, dtype=np.uint8)
-            for x in range(w):
-                if run[y, x]:
-                    Fp[y, x] = prev
-                else:
-                    prev = Fp[y, x]
-        px = np.cumsum(Fp.astype(np.uint32), axis=0).astype(np.uint8)  # Up filter undone (bytes, mod 256)
-        if desired == 3:
-            px = px[:, :, :3]
-        elif c == 3:
-            px = np.concatenate([px, np.full((h, w, 1), 255, dtype=np.uint8)], axis=2)
-        return px, rounds
-
-
-def test_model_of_the_gpu_decoder_reproduces_the_pixels():
+def test_emulated_kernels_reproduce_the_pixels():
     import fpng_amd
     rng = np.random.default_rng(41)
-    cases = [fuzz_image(rng) for _ in range(12)]
+    cases = [fuzz_image(rng) for _ in range(60)]
+    cases += [fuzz_image(rng, force_dims=(int(rng.integers(200, 700)), int(rng.integers(8, 30)))) for _ in range(6)]
     cases += [(fpng_amd.synth_image("grad", 96, 40, 4), 96, 40, 4), (fpng_amd.synth_image("grad", 131, 33, 3), 131, 33, 3),
-              (fpng_amd.synth_image("blocks", 200, 70, 4), 200, 70, 4)]
-    n_dynamic = 0
-    for img, w, h, c in cases:
-        for flags in (0, 1):
+              (fpng_amd.synth_image("blocks", 200, 70, 4), 200, 70, 4), (fpng_amd.synth_image("solid", 300, 9, 3), 300, 9, 3),
+              (fpng_amd.synth_image("solid", 1000, 5, 4), 1000, 5, 4)]
+    n_dynamic = corrected = border = 0
+    for k, (img, w, h, c) in enumerate(cases):
+        for flags in (0, 1, 2):
             png = oracle().encode(img, w, h, c, flags)
-            m = Model(png)
-            assert m.res.status == 0 and (m.res.w, m.res.h, m.res.channels_in_file) == (w, h, c)
-            if m.mode:  # (fell back to stored blocks)
-                continue
-            n_dynamic += 1
-            for desired in (3, 4):
-                px, rounds = m.pixels(desired)
-                exp = np.asarray(img).reshape(h, w, c)
-                exp = exp[:, :, :3] if desired == 3 else (exp if c == 4 else np.concatenate([exp, np.full((h, w, 1), 255, dtype=np.uint8)], axis=2))
-                assert np.array_equal(px, exp), (w, h, c, flags, desired)
-    assert n_dynamic >= 12
+            res, mode, *_ = plan(png)
+            assert res.status == 0 and (res.w, res.h, res.channels_in_file) == (w, h, c)
+            n_dynamic += not mode
+            for cfg in (CONFIGS if not mode else CONFIGS[:1]):
+                for desired in (3, 4):
+                    st, px, ww, hh, cc, stats = emul_decode(png, desired, cfg)
+                    assert st == 0 and (ww, hh, cc) == (w, h, c), (k, w, h, c, flags, cfg, st)
+                    assert np.array_equal(px, expected_pixels(img, w, h, c, desired)), (k, w, h, c, flags, desired, cfg)
+                corrected += stats[3]
+                border += stats[1]
+    assert n_dynamic >= 60
+    assert corrected > 0 and border > 0  # (both kinds of correction happened somewhere)
 
 
-def test_rounds_settle_quickly_with_and_without_noise():
-    """Synchronisation rounds of the model (every subsequence looks at its predecessor's end of the round before) on a gradient with
-    and without its noise bits (seed 0: the generator's xorshift stays 0 -- long exact runs): a handful of rounds each at this size.
-    (On the GPU an 8K frame of the noise-free kind needed 38 rounds -- profiles/r03_g_decode.txt -- which is why
-    fpng_amd_decode_batch gives a group of files more rounds when the six it launches blind were not enough.)"""
+def test_emulated_kernels_on_a_natural_image():
+    import real_image
+    png = real_image.fixture_bytes()
+    st, exp, w, h, c = dropin.decode(png, 3)
+    assert st == 0
+    for cfg in (CONFIGS[0], (16, 128, 4096), (512, 0, 18432)):
+        st, px, ww, hh, cc, stats = emul_decode(png, 3, cfg)
+        assert st == 0 and np.array_equal(px, exp)
+        # a photograph: with the kernels' lead-in about 2 % of the subsequences start out of step; all of them when there is none
+        frac = stats[3] / stats[2]
+        assert (frac < 0.06) if cfg[1] == 128 else (frac > 0.5)
+
+
+def test_correction_rounds_stay_few():
+    """Rounds inside a workgroup and across the borders on a gradient with and without its noise bits (seed 0: the generator's xorshift
+    stays 0 -- long exact runs, a PERIODIC token stream that keeps a decoder that started at a wrong bit out of step for many
+    subsequences): the in-workgroup rounds walk along such a stretch one subsequence at a time, the border rounds hand it over."""
     import fpng_amd
     for seed in (0, 12345):
         for (w, h) in ((640, 24), (2048, 8)):
             img = fpng_amd.synth_image("grad", w, h, 4, seed=seed)
-            m = Model(oracle().encode(img, w, h, 4, 0))
-            px, rounds = m.pixels(4)
-            assert np.array_equal(px, img)
-            assert rounds <= 8
+            png = oracle().encode(img, w, h, 4, 0)
+            for cfg in (CONFIGS[0], (8, 128, 256)):
+                st, px, *_, stats = emul_decode(png, 4, cfg)
+                assert st == 0 and np.array_equal(px, img.reshape(-1))
+                assert stats[0] <= 40 and stats[1] <= 12, (seed, w, h, cfg, stats)
+
+
+def test_too_few_border_rounds_leave_the_file_undecided():
+    import fpng_amd
+    img = fpng_amd.synth_image("grad", 640, 40, 4)
+    png = oracle().encode(img, 640, 40, 4, 0)
+    st, px, *_, stats = emul_decode(png, 4, (4, 0, 64), border_rounds=1000)
+    assert st == 0 and stats[1] >= 1
+    st, px, *_ = emul_decode(png, 4, (4, 0, 64), border_rounds=0)
+    assert st == UNDECIDED and px is None
+
+
+def _damage(rng, png):
+    bad = bytearray(png)
+    kind = int(rng.integers(0, 5))
+    if kind == 0:      # flip a bit anywhere
+        i = int(rng.integers(0, len(bad)))
+        bad[i] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:    # truncate
+        bad = bad[: int(rng.integers(1, len(bad)))]
+    elif kind == 2:    # damage the block header region
+        i = int(rng.integers(58, min(140, len(bad))))
+        bad[i] = int(rng.integers(0, 256))
+    elif kind == 3:    # damage the zlib stream
+        i = int(rng.integers(58, len(bad)))
+        bad[i] = int(rng.integers(0, 256))
+    else:              # flip a bit in the token bits
+        i = int(rng.integers(min(125, len(bad) - 1), len(bad)))
+        bad[i] ^= 1 << int(rng.integers(0, 8))
+    return kind, bytes(bad)
+
+
+def test_damaged_files_get_the_cpu_decoders_status():
+    """The judge is the reference's decoder when its build is present (dev container, GPU box), the drop-in's CPU decoder otherwise
+    (itself held against the reference by tests/test_dropin_decode.py)."""
+    judge = ref().decode if have_ref() else dropin.decode
+    rng = np.random.default_rng(43)
+    checked = rejected = 0
+    for _ in range(50):
+        img, w, h, c = fuzz_image(rng) if rng.random() < 0.7 else fuzz_image(rng, force_dims=(int(rng.integers(100, 400)), int(rng.integers(4, 12))))
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 2)))
+        for _ in range(10):
+            kind, bad = _damage(rng, png)
+            cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
+            for desired in (3, 4):
+                st_r, out_r, *_ = judge(bad, desired)
+                st_m, out_m, *_ = emul_decode(bad, desired, cfg)
+                checked += 1
+                rejected += st_r != 0
+                assert st_m == st_r, (w, h, c, kind, cfg, st_r, st_m)
+                if st_r == 0:
+                    assert np.array_equal(np.asarray(out_r)[: out_m.size], out_m), (w, h, c, kind, cfg)
+    assert checked >= 900 and rejected >= 300
+
+
+# ---- the table's format, pinned by a decoder of a dozen lines ----
+def _serial_decode(png):
+    res, mode, ofs, ln, first, limit, lut = plan(png)
+    assert res.status == 0 and mode == 0
+    lenof = lut[4096:].view(np.uint8)
+    zint = int.from_bytes(png[ofs + 8: ofs + 8 + ln] + bytes(16), "little")  # LSB-first bit string
+    pos, out, prev_groups = first, bytearray(), 0
+    while True:
+        assert pos < limit
+        wnd = (zint >> pos) & 0xFFFFFFFF
+        e = int(lut[wnd & 4095])
+        L, n = e >> 28, (e >> 26) & 3
+        assert L, "no such code"
+        if n:
+            lits = [(e >> (8 * k)) & 255 for k in range(n)]
+            assert sum(int(lenof[b]) for b in lits) == L  # the group's bits = its literals' code lengths
+            out += bytes(lits)
+            pos += L
+            prev_groups += n > 1
+        elif e & (1 << 25):
+            xb, base = (e >> 9) & 7, e & 511
+            run = base + ((wnd >> L) & ((1 << xb) - 1))
+            out += bytes(out[-1:]) * 0 + bytes(run)  # (placeholder bytes: only the count matters here)
+            pos += L + xb + 1
+        else:
+            pos += L
+            break
+    assert ((pos + 7) >> 3) + 4 == ln
+    return res, len(out), prev_groups
+
+
+def test_table_format():
+    import fpng_amd
+    for (kind, w, h, c) in (("grad", 96, 40, 4), ("grad", 131, 33, 3), ("blocks", 200, 70, 4)):
+        for flags in (0, 1):
+            img = fpng_amd.synth_image(kind, w, h, c)
+            res, nbytes, groups = _serial_decode(oracle().encode(img, w, h, c, flags))
+            assert nbytes == (w * c + 1) * h
+            assert kind != "grad" or groups > 100  # (several literals per lookup are the rule on such content)
 
 
 def test_plan_reports_container_and_stream_problems():
@@ -188,3 +244,11 @@ def test_plan_reports_container_and_stream_problems():
     stored = oracle().encode(img, 64, 20, 3, 2)
     res, mode, *_ = plan(stored)
     assert res.status == 0 and mode == 1
+    # a header that promises more pixels than the IDAT could ever hold is turned away before any memory is sized by it
+    # (2 bits per token at least, 258 bytes per token at most)
+    import struct
+    import zlib
+    big = bytearray(png)
+    big[16:24] = struct.pack(">II", 30000, 30000)
+    big[29:33] = struct.pack(">I", zlib.crc32(bytes(big[12:29])))
+    assert plan(bytes(big))[0].status == 1  # FPNG_DECODE_NOT_FPNG

@@ -1,7 +1,8 @@
-"""GPU batch decoder of fpng-written files (-m gpu; fpng_amd_decode_batch, fpng_amd/csrc/decode.hip): pixels identical to the
-drop-in's CPU decoder (itself checked against the reference's, tests/test_dropin_decode.py), the reference's status codes on
-damaged files; FPNG_AMD_DECODE_UNDECIDED (= use the CPU decoder) is allowed only where the CPU decoder does not succeed either
-... or, for valid files, never in this suite."""
+"""GPU batch decoder of fpng-written files (-m gpu; fpng_amd_decode_batch / fpng_amd_decode_batch_device,
+fpng_amd/csrc/decode.hip): pixels and status codes of the REFERENCE's decoder (oracle/_ref, a prebuilt file on the GPU box; without
+it the drop-in's CPU decoder, itself checked against the reference's by tests/test_dropin_decode.py), also on damaged files;
+FPNG_AMD_DECODE_UNDECIDED (= use the CPU decoder) is allowed only where the judge does not succeed either ... or, for valid
+files, never in this suite unless a test asks for it."""
 import hashlib
 import os
 
@@ -10,10 +11,21 @@ import pytest
 
 import dropin
 import real_image
-from cpu_ref import ROOT, fuzz_image, oracle
+from cpu_ref import ROOT, fuzz_image, have_ref, oracle, ref
 
 pytestmark = pytest.mark.gpu
 UNDECIDED = 64
+
+
+def judge(png, desired):
+    """(status, pixels, w, h, c) of the reference's decoder; without its build: the drop-in's CPU tier."""
+    if have_ref():
+        return ref().decode(png, desired)
+    os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+    try:
+        return dropin.decode(png, desired)
+    finally:
+        del os.environ["FPNG_AMD_DECODE_CPU"]
 
 
 @pytest.fixture(scope="module")
@@ -26,14 +38,44 @@ def enc(built_lib):
     e.close()
 
 
-def _check(enc, pngs, desired):
-    got = enc.decode_batch(pngs, desired)
+def _device_files(pngs, shift=0):
+    """the files in device memory, each at an address that is `shift` bytes (mod 4) off a dword boundary"""
+    import torch
+    out = []
+    for k, p in enumerate(pngs):
+        b = torch.zeros(len(p) + 8, dtype=torch.uint8, device="cuda")
+        o = (shift + k) & 3 if shift else 0
+        if len(p):
+            b[o:o + len(p)] = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+        out.append(b[o:o + len(p)])
+    return out
+
+
+def _check(enc, pngs, desired, device=False, allow_undecided=False):
+    """host-resident files through fpng_amd_decode_batch, or device-resident ones through fpng_amd_decode_batch_device"""
+    import struct
+    if device:
+        dims = []
+        for p in pngs:
+            w, h = struct.unpack(">II", bytes(p[16:24])) if len(p) >= 24 else (0, 0)
+            dims.append((w, h) if 0 < w <= (1 << 24) and 0 < h <= (1 << 24) and w * h <= (1 << 28) else (0, 0))
+        got = enc.decode_device(_device_files(pngs, shift=1), desired, dims)
+    else:
+        got = enc.decode_batch(pngs, desired)
+    n_ok = n_bad = 0
     for i, (png, (st, px, cf)) in enumerate(zip(pngs, got)):
-        cst, cpx, w, h, c = dropin.decode(png, desired)
-        assert st == cst, (i, st, cst)
+        cst, cpx, w, h, c = judge(png, desired) if len(png) else (2, None, 0, 0, 0)
+        if st == UNDECIDED and allow_undecided:
+            assert cst != 0, i
+            continue
+        assert st == cst, (i, st, cst, len(png))
         if st == 0:
             assert cf == c and tuple(px.shape) == (h, w, desired)
-            assert np.array_equal(px.cpu().numpy().reshape(-1), cpx), i
+            assert np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), i
+            n_ok += 1
+        else:
+            n_bad += 1
+    return n_ok, n_bad
 
 
 @pytest.mark.parametrize("desired", [3, 4])
@@ -47,6 +89,7 @@ def test_small_images_every_mode(enc, desired):
         for fl in (0, 1, 2):
             pngs.append(oracle().encode(img, w, h, c, fl))
     _check(enc, pngs, desired)
+    _check(enc, pngs[:150], desired, device=True)
 
 
 def test_natural_image_and_synthetic_frames(enc):
@@ -169,10 +212,19 @@ def test_8k_frame_round_trip(enc):
     assert st == 0 and cf == 4 and torch.equal(px, t)
 
 
+def _damaged(rng, base, n_flips, cuts):
+    out = [base[:n] for n in cuts]
+    for _ in range(n_flips):
+        d = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        out.append(bytes(d))
+    return out
+
+
 def test_damaged_files_get_the_reference_status(enc):
-    """Truncations, bit flips in the container and in the pixel stream, a wrong block type, a second IDAT: the status is the
-    CPU decoder's (= the reference's, tests/test_dropin_decode.py) or UNDECIDED where that one fails too; pixels equal wherever
-    both succeed (a flipped bit inside a literal still decodes)."""
+    """Truncations, bit flips in the container and in the pixel stream, a wrong block type: the status is the reference decoder's,
+    pixels equal wherever both succeed (a flipped bit inside a literal still decodes); host- and device-resident files."""
     import fpng_amd
     rng = np.random.default_rng(12)
     base = [oracle().encode(fpng_amd.synth_image("grad", 300, 200, 4), 300, 200, 4, 0),
@@ -180,26 +232,85 @@ def test_damaged_files_get_the_reference_status(enc):
             oracle().encode(fpng_amd.synth_image("noise", 64, 64, 3), 64, 64, 3, 0)]
     pngs = []
     for b in base:
-        pngs += [b[:n] for n in (0, 7, 30, 57, 70, len(b) // 2, len(b) - 17, len(b) - 1)]
-        for _ in range(40):
-            d = bytearray(b)
-            for _ in range(int(rng.integers(1, 4))):
-                d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
-            pngs.append(bytes(d))
+        pngs += _damaged(rng, b, 40, (7, 30, 57, 70, len(b) // 2, len(b) - 17, len(b) - 1))
         d = bytearray(b)
         d[60] ^= 0x06  # block type bits
         pngs.append(bytes(d))
-    got = enc.decode_batch(pngs, 4)
-    n_ok = n_bad = 0
-    for i, (png, (st, px, cf)) in enumerate(zip(pngs, got)):
-        cst, cpx, w, h, c = dropin.decode(png, 4)
-        if st == UNDECIDED:
-            assert cst != 0, i
-            continue
-        assert st == cst, (i, st, cst)
-        if st == 0:
-            assert np.array_equal(px.cpu().numpy().reshape(-1), cpx), i
-            n_ok += 1
-        else:
-            n_bad += 1
-    assert n_ok > 3 and n_bad > 60
+    for device in (False, True):
+        n_ok, n_bad = _check(enc, pngs, 4, device=device)
+        assert n_ok > 3 and n_bad > 60
+
+
+def test_damaged_large_files(enc):
+    """Damage in files that span many workgroups and several upload groups: an 8K frame (58 MB) and the tiled photograph (11 MP),
+    truncated at many places, bits flipped all over the stream (a flipped bit can create a false end-of-block symbol 30 MB in, a
+    length symbol that runs over a row end, an invalid code), block type / code length header edits.  The reference's decoder is the
+    judge for status AND pixels; batches go through both entry points."""
+    import torch
+    import fpng_amd
+    if not have_ref():
+        pytest.skip("reference build not available")
+    rng = np.random.default_rng(77)
+    imgs = real_image.variants(real_image.rgb_pixels(judge))
+    sources = [(torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4)).cuda(), 0, 28), (torch.from_numpy(imgs["rgb_t4"]).cuda(), 1, 40)]
+    for t, flags, n in sources:
+        (base,), _ = enc.encode_tensors([t], flags)
+        L = len(base)
+        bad = []
+        for k in range(n):
+            d = bytearray(base)
+            kind = k % 4
+            if kind == 0:    # one flipped bit, stratified over the stream
+                i = 60 + (L - 80) * k // n + int(rng.integers(0, 1000))
+                d[min(i, L - 1)] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:  # truncation (the IDAT length no longer fits: chunk parsing), stratified
+                d = d[: 58 + (L - 58) * (k + 1) // (n + 1)]
+            elif kind == 2:  # a damaged byte in the dynamic block header
+                d[int(rng.integers(60, 120))] = int(rng.integers(0, 256))
+            else:            # a burst of 4 damaged bytes somewhere
+                i = int(rng.integers(200, L - 30))
+                d[i:i + 4] = bytes(int(v) for v in rng.integers(0, 256, 4))
+            bad.append(bytes(d))
+        for device in (False, True):
+            half = bad[: len(bad) // 2] if device else bad[len(bad) // 2:]
+            for j in range(0, len(half), 4):
+                n_ok, n_bad = _check(enc, half[j:j + 4], 4 if t.shape[2] == 4 else 3, device=device)
+
+
+def test_forced_undecided_falls_through_to_the_cpu_decoder(enc):
+    """FPNG_AMD_DECODE_MAX_ROUNDS=0 makes the GPU path leave every compressed file undecided: fpng_amd_decode_batch says so, and
+    fpng::fpng_decode_memory (the drop-in) answers with the CPU decoder's pixels all the same."""
+    import torch
+    import fpng_amd
+    t = torch.from_numpy(fpng_amd.synth_image("grad", 1024, 768, 4)).cuda()
+    (png,), _ = enc.encode_tensors([t], 0)
+    os.environ["FPNG_AMD_DECODE_MAX_ROUNDS"] = "0"
+    try:
+        ((st, px, cf),) = enc.decode_batch([png], 4)
+        assert st == UNDECIDED and px is None
+        n0 = dropin.gpu_decodes()
+        st, out, w, h, c = dropin.decode(png, 4)
+        assert st == 0 and np.array_equal(out, t.cpu().numpy().reshape(-1))
+    finally:
+        del os.environ["FPNG_AMD_DECODE_MAX_ROUNDS"]
+    ((st, px, cf),) = enc.decode_batch([png], 4)
+    assert st == 0 and torch.equal(px, t)
+
+
+def test_device_resident_files(enc):
+    """fpng_amd_decode_batch_device: the encoder's own outputs, still in device memory, decoded in place (only a head and a tail of
+    each file visit the host): 1-pass, 2-pass and stored files, a file smaller than the head, every address alignment."""
+    import torch
+    import fpng_amd
+    ts = [torch.from_numpy(fpng_amd.synth_image("grad", 3840, 2160, 4, seed=7)).cuda(), torch.from_numpy(fpng_amd.synth_image("noise", 640, 480, 3)).cuda(),
+          torch.from_numpy(fpng_amd.synth_image("solid", 16, 4, 4)).cuda(), torch.from_numpy(fpng_amd.synth_image("blocks", 1920, 1080, 3)).cuda(),
+          torch.from_numpy(fpng_amd.synth_image("grad", 1000, 1000, 3, seed=9)).cuda()]
+    for flags in (0, 1, 2):
+        pngs, _ = enc.encode_tensors(ts, flags)
+        for shift in (0, 1, 2, 3):
+            for desired in (4, 3):
+                got = enc.decode_device(_device_files(pngs, shift=shift), desired, [(t.shape[1], t.shape[0]) for t in ts])
+                for t, (st, px, cf) in zip(ts, got):
+                    assert st == 0 and cf == t.shape[2]
+                    want = t[:, :, :desired] if t.shape[2] >= desired else torch.cat([t, torch.full_like(t[:, :, :1], 255)], dim=2)
+                    assert torch.equal(px, want)

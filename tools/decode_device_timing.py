@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""GPU decode of DEVICE-resident files (fpng_amd_decode_batch_device): the encoder's outputs decoded where they lie, per step of
+n files: wall time of the call (host parse of the fetched heads + kernels + status read-back)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, fpng_amd
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+enc = fpng_amd.Encoder(device=0)
+cases = [("8K RGBA grad x 8", "grad", 7680, 4320, 4, 8), ("4K RGBA grad x 16", "grad", 3840, 2160, 4, 16), ("1080p RGB grad x 64", "grad", 1920, 1080, 3, 64),
+         ("512x512 RGB grad x 256", "grad", 512, 512, 3, 256), ("8K RGBA blocks x 8", "blocks", 7680, 4320, 4, 8)]
+for name, kind, w, h, c, n in cases:
+    if only and only not in name:
+        continue
+    ts = [torch.from_numpy(fpng_amd.synth_image(kind, w, h, c, seed=12345 + i)).cuda() for i in range(n)]
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors(ts, flags)
+        dev = [torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda() for p in pngs]
+        outs = [torch.empty(w * h * c, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        dims = [(w, h)] * n
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); got = enc.decode_device(dev, c, dims, outs); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        assert all(st == 0 for st, _, _ in got)
+        assert all(torch.equal(px, t) for (st, px, _), t in zip(got, ts))
+        mb = sum(len(p) for p in pngs) / 1e6
+        print(f"{name} flags={flags}: {best*1e3:7.3f} ms per step = {n*w*h/best/1e9:7.2f} GP/s ({mb:.0f} MB of PNG -> {n*w*h*c/1e6:.0f} MB of pixels; "
+              f"{(mb + n*w*h*c/1e6)/1e3/best:6.0f} GB/s algorithmic)", flush=True)

@@ -8,8 +8,7 @@ namespace fpng_amd {
 constexpr uint32_t kSubBits = 512;      // token bits per subsequence (one thread each)
 constexpr uint32_t kDecSubBlock = 512;  // subsequences per workgroup of the synchronisation (a file's subsequences are padded to whole workgroups)
 constexpr uint32_t kDecLeadIn = 128;    // bits a subsequence's first decode starts early (decode_core.h: sub_first)
-constexpr uint32_t kDecTileBytes = 18432; // bytes of the filtered stream one workgroup of dec_emit_kernel produces
-constexpr uint32_t kDecEmitThreads = 256;
+constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_emit_kernel (divides kDecSubBlock)
 constexpr uint32_t kDecUnfRows = 128;   // rows per segment of the Up filter's column sums
 enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecSawEob = 0x100u };
 
@@ -27,8 +26,7 @@ struct DecJob {
     uint32_t sub_base;        // index of its first subsequence (a multiple of kDecSubBlock: one file per workgroup)
     uint32_t mode;            // 0 one dynamic block, 1 stored blocks
     uint32_t nseg;            // segments of kDecUnfRows rows (dec_unfilter_*_kernel)
-    uint32_t tile_base;       // index of its first tile
-    uint32_t n_tiles;         // ceil((bpl + 1) * h / kDecTileBytes)
+    uint32_t pad_[2];
     uint32_t z_shift;         // bytes between z (rounded down to a dword) and the stream's first byte; the bit positions above count from z
 };
 
@@ -53,14 +51,14 @@ struct DecSubArrays {
 
 // the kernels work on the workgroups [first_block, first_block + n_blocks) of the batch's subsequences (one group of files);
 // jobs / n_jobs: the whole batch
-void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round, DecSubArrays a,
+// resident: how many persistent workgroups to launch at most
+void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round, DecSubArrays a,
                      DecBlockRec *recs, uint32_t *changed);
-// group_jobs / status / eob_index: of the group's first file
+// group_jobs: the group's first file; status / eob_index: batch-wide arrays
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
-                        uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, uint32_t *tile_first);
-// status / eob_index / tiles: batch-wide arrays; [first_tile, first_tile + n_tiles): the group's tiles
-void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_tile, uint32_t n_tiles, DecSubArrays a, const uint32_t *eob_index,
-                     const uint64_t *block_off, const uint32_t *tile_first, uint32_t *status);
+                        uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);
+void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
+                     const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status);
 
 } // namespace fpng_amd

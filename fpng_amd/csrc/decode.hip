@@ -14,13 +14,12 @@
 //                       to three literals per lookup and a 32-bit window serves two lookups.
 //   dec_offsets_kernel  per file: the first end-of-block symbol of the chain ends the stream; up to there the chain must hold and
 //                       no subsequence may be invalid; exclusive scan of the workgroups' byte counts; the total must be the image
-//   dec_subscan_kernel  per workgroup of subsequences: output offset of every subsequence, the four literal bytes in front of it
-//                       (what a match at its very beginning repeats), and for every TILE of the filtered stream the subsequence
-//                       that produces its first byte
-//   dec_emit_kernel     one workgroup per tile (kDecTileBytes of the filtered stream, held in LDS): the subsequences that reach
-//                       into the tile are decoded again, now for real -- literals and the runs of repeated pixels go into the
-//                       tile, every rule of the reference's decoder is checked (filter literal 0 then 2, matches whole pixels
-//                       inside a row, the stream ends 4 bytes before the IDAT does) -- and the tile leaves with 16-byte stores
+//   dec_subscan_kernel  per workgroup of subsequences: output offset of every subsequence and the four literal bytes in front of
+//                       it (what a match at its very beginning repeats)
+//   dec_emit_kernel     decodes again, now for real, one thread per subsequence: literals and the runs of repeated pixels go
+//                       into the filtered stream as whole aligned dwords (a thread completes its last dword with the next
+//                       subsequence's first bytes); every rule of the reference's decoder is checked (filter literal 0 then 2,
+//                       matches whole pixels inside a row, the stream ends 4 bytes before the IDAT does)
 //   dec_unfilter_sums_kernel / dec_unfilter_kernel   the Up filter undone: one thread per dword column and segment of kDecUnfRows
 //                       rows (segment sums first), channel count conversion
 //   dec_stored_kernel   files that are stored blocks (reference fpng.cpp:2107-2207): a strided copy
@@ -28,6 +27,8 @@
 #include "decode_core.h"
 
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 namespace fpng_amd {
 
@@ -86,17 +87,6 @@ __device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t
     local = g - jobs[lo].sub_base;
     return jobs[lo];
 }
-__device__ __forceinline__ const DecJob &job_of_tile(const DecJob *jobs, uint32_t n_jobs, uint32_t tile, uint32_t &local)
-{
-    uint32_t lo = 0, hi = n_jobs;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (jobs[mid].tile_base <= tile) lo = mid; else hi = mid;
-    }
-    local = tile - jobs[lo].tile_base;
-    return jobs[lo];
-}
-
 template <int WAVES> __device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, WAVES words
 {
 #pragma unroll
@@ -125,87 +115,92 @@ template <int WAVES> __device__ __forceinline__ uint32_t block_sum(uint32_t v, u
 // ---- synchronisation ----
 constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 + 1 + 3;
 
-__global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, uint32_t round, DecSubArrays a,
-                                                             DecBlockRec *recs, uint32_t *changed)
+__global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
+                                                             DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kSyncDwords)];
     __shared__ uint32_t s_end[kSubBlock];
     __shared__ uint32_t red[kSubBlock / kWave];
-    const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
-    if (g0 >= total_subs) return;
-    // all subsequences of a workgroup belong to one file (sub_base is padded to kSubBlock by the host)
-    uint32_t local0;
-    const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
-    const uint32_t t = threadIdx.x, g = g0 + t, i = local0 + t;
-    const bool valid = i < job.n_sub;
-    uint32_t want0 = 0;
-    if (round) { // only the border to the previous workgroup is open
-        if (!local0) return; // (the file's first subsequence starts at the stream's first token: nothing to settle)
-        const uint32_t mine = recs[blk].entry_rel, prev = recs[blk - 1].exit_rel;
-        if (mine == prev) return;
-        want0 = prev;
-    }
-    const uint32_t lead0 = local0 ? kDecLeadIn : 0u;
-    const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
-    const uint64_t d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
-    stage_lut(job, lut, kSubBlock);
-    stage_bits(job, d0, kSyncDwords, bits, kSubBlock);
-    __syncthreads();
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
-    LdsBits in = {bits};
-    const uint32_t nominal = (uint32_t)(first_nominal - base) + t * kSubBits, boundary = nominal + kSubBits;
-    const uint64_t lim64 = job.end_limit_bit - base;
-    const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
-    SubState st;
-    st.start = st.end = nominal;
-    st.c.bytes = st.c.lits = st.c.tail = st.c.flags = 0;
-    bool dirty = false;
-    if (valid) {
-        if (!round) {
-            sub_first(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st);
-            dirty = true;
-        } else {
-            const uint32_t v = a.info[g];
-            st.start = nominal + info_start(v), st.end = boundary + info_end(v);
-            st.c.bytes = a.bytes[g], st.c.lits = info_lits(v), st.c.tail = a.tail[g], st.c.flags = info_flags(v);
+    const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
+    const uint32_t t = threadIdx.x;
+    for (uint32_t bi = blockIdx.x; bi < n_blocks; bi += gridDim.x) {
+        const uint32_t blk = first_block + bi, g0 = blk * kSubBlock;
+        if (g0 >= total_subs) break;
+        // all subsequences of a workgroup's block belong to one file (sub_base is padded to kSubBlock by the host)
+        uint32_t local0;
+        const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+        const uint32_t g = g0 + t, i = local0 + t;
+        const bool valid = i < job.n_sub;
+        uint32_t want0 = 0;
+        if (round) { // only the border to the previous block is open
+            if (!local0) continue; // (the file's first subsequence starts at the stream's first token: nothing to settle)
+            const uint32_t mine = recs[blk].entry_rel, prev = recs[blk - 1].exit_rel;
+            if (mine == prev) continue;
+            want0 = prev;
         }
-    }
-    want0 += nominal; // (thread 0's nominal: the workgroup's first)
-    s_end[t] = st.end;
-    for (;;) {
+        const uint32_t lead0 = local0 ? kDecLeadIn : 0u;
+        const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
+        const uint64_t d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
+        __syncthreads(); // (the previous block's LDS is free)
+        if (staged != job.lut) stage_lut(job, lut, kSubBlock), staged = job.lut;
+        stage_bits(job, d0, kSyncDwords, bits, kSubBlock);
         __syncthreads();
-        uint32_t want = st.start;
-        if (t)
-            want = s_end[t - 1];
-        else if (round)
-            want = want0;
-        const bool need = valid && want != st.start;
-        if (!__syncthreads_or(need)) break;
-        if (need) {
-            sub_refix(in, lut, lenof, want, boundary, data_limit, st);
-            s_end[t] = st.end;
-            dirty = true;
+        LdsBits in = {bits};
+        const uint32_t nominal = (uint32_t)(first_nominal - base) + t * kSubBits, boundary = nominal + kSubBits;
+        const uint64_t lim64 = job.end_limit_bit - base;
+        const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
+        SubState st;
+        st.start = st.end = nominal;
+        st.c.bytes = st.c.lits = st.c.tail = st.c.flags = 0;
+        bool dirty = false;
+        if (valid) {
+            if (!round) {
+                sub_first(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st);
+                dirty = true;
+            } else {
+                const uint32_t v = a.info[g];
+                st.start = nominal + info_start(v), st.end = boundary + info_end(v);
+                st.c.bytes = a.bytes[g], st.c.lits = info_lits(v), st.c.tail = a.tail[g], st.c.flags = info_flags(v);
+            }
         }
-    }
-    if (dirty && valid) {
-        a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c);
-        a.bytes[g] = st.c.bytes;
-        a.tail[g] = st.c.tail;
-    }
-    const bool any_dirty = __syncthreads_or(dirty);
-    if (!any_dirty) return;
-    const uint32_t sum = block_sum<kSubBlock / kWave>(valid ? st.c.bytes : 0u, red);
-    const uint32_t e = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubEob)) ? t : (uint32_t)kSubBlock, red);
-    const uint32_t inv = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubInvalid)) ? t : (uint32_t)kSubBlock, red);
-    if (t == 0) {
-        DecBlockRec r;
-        r.sum = sum, r.first_eob = e, r.first_invalid = inv;
-        r.entry_rel = st.start - nominal;
-        r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a workgroup with fewer subsequences is its file's last)
-        r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
-        recs[blk] = r;
-        if (round) atomicOr(changed, 1u);
+        want0 += nominal; // (thread 0's nominal: the block's first)
+        s_end[t] = st.end;
+        for (;;) {
+            __syncthreads();
+            uint32_t want = st.start;
+            if (t)
+                want = s_end[t - 1];
+            else if (round)
+                want = want0;
+            const bool need = valid && want != st.start;
+            if (!__syncthreads_or(need)) break;
+            if (need) {
+                sub_refix(in, lut, lenof, want, boundary, data_limit, st);
+                s_end[t] = st.end;
+                dirty = true;
+            }
+        }
+        if (dirty && valid) {
+            a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c);
+            a.bytes[g] = st.c.bytes;
+            a.tail[g] = st.c.tail;
+        }
+        const bool any_dirty = __syncthreads_or(dirty);
+        if (!any_dirty) continue;
+        const uint32_t sum = block_sum<kSubBlock / kWave>(valid ? st.c.bytes : 0u, red);
+        const uint32_t e = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubEob)) ? t : (uint32_t)kSubBlock, red);
+        const uint32_t inv = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubInvalid)) ? t : (uint32_t)kSubBlock, red);
+        if (t == 0) {
+            DecBlockRec r;
+            r.sum = sum, r.first_eob = e, r.first_invalid = inv;
+            r.entry_rel = st.start - nominal;
+            r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a block with fewer subsequences is its file's last)
+            r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+            recs[blk] = r;
+            if (round) atomicOr(changed, 1u);
+        }
     }
 }
 
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
 
 // ---- dec_subscan_kernel, one workgroup per kDecSubBlock subsequences ----
 __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, DecSubArrays a,
-                                                                const uint64_t *block_off, const uint32_t *status, const uint32_t *eob_index, uint32_t *tile_first)
+                                                                const uint32_t *status, const uint32_t *eob_index)
 {
     __shared__ uint32_t wsum[kSubBlock / kWave];
     const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
@@ -304,75 +299,56 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     const uint32_t *info = a.info + job.sub_base, *tail = a.tail + job.sub_base;
     a.lastpx[g] = lookback_lastpx(
         i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
-    // tiles whose first byte this subsequence produces
-    const uint64_t off = block_off[blk] + before, next = off + nb;
-    for (uint64_t k = (off + kDecTileBytes - 1) / kDecTileBytes; k * kDecTileBytes < next && k < job.n_tiles; k++) tile_first[job.tile_base + (uint32_t)k] = i;
 }
 
 // ---- the real decode ----
-constexpr uint32_t kEmitDwords = kEmitBlock * (kSubBits / 32) + 4;
-struct LdsTile {
-    uint32_t *t;
-    __device__ __forceinline__ void put32(uint32_t d, uint32_t v) { t[d] = v; }
-    __device__ __forceinline__ void put8(uint32_t b, uint8_t v) { ((uint8_t *)t)[b] = v; }
+constexpr uint32_t kEmitDwords = kEmitBlock * (kSubBits / 32) + 8; // (a thread may decode a few tokens into the next workgroup's bits)
+struct StreamSink {
+    uint32_t *f; // the file's filtered stream
+    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
+    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((u32x4 *)f)[g] = u32x4{a, b, c, d}; }
 };
 
-__global__ __launch_bounds__(kEmitBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_tile, DecSubArrays a, const uint32_t *eob_index,
-                                                              const uint64_t *block_off, const uint32_t *tile_first, uint32_t *status)
+__global__ __launch_bounds__(kEmitBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
+                                                              const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kEmitDwords)];
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kDecTileBytes / 4];
-    uint32_t tl;
-    const DecJob &job = job_of_tile(jobs, n_jobs, first_tile + blockIdx.x, tl);
-    const uint32_t job_index = (uint32_t)(&job - jobs);
-    if (job.mode != 0 || tl >= job.n_tiles || (status[job_index] & ~kDecSawEob)) return; // (uniform: one file per workgroup)
-    const uint32_t last = eob_index[job_index];
-    const uint64_t total = (uint64_t)(job.bpl + 1) * job.h;
-    const uint64_t tile_start = (uint64_t)tl * kDecTileBytes, tile_end = min(total, tile_start + kDecTileBytes);
-    // (the stream's last tile also takes the subsequences that start at its very end: the one with the end-of-block symbol may
-    //  have no output of its own)
-    const uint64_t sel_end = tile_end == total ? total + 1 : tile_end;
-    stage_lut(job, lut, kEmitBlock);
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
-    EmitGeom geom;
-    geom.stride = job.bpl + 1, geom.c = job.src_c, geom.ndw = (uint32_t)((tile_end - tile_start + 3) >> 2);
-    LdsTile lt = {tile};
+    const uint32_t *staged = nullptr; // (workgroups are persistent: the table is staged when the file's differs from the one in LDS)
     LdsBits in = {bits};
-    uint32_t err = 0;
-    for (uint32_t c0 = tile_first[job.tile_base + tl];; c0 += kEmitBlock) {
-        const uint32_t i = c0 + threadIdx.x, g = job.sub_base + i;
-        uint64_t off = 0;
-        bool active = i < job.n_sub && i <= last;
-        if (active) {
-            off = block_off[g / kSubBlock] + a.rel[g];
-            active = off < sel_end;
-        }
-        const uint32_t m = (uint32_t)__syncthreads_count(active); // (the active ones are the chunk's first m: offsets grow)
-        if (!m) break;
-        const uint64_t nominal0 = job.first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
-        stage_bits(job, d0, m * (kSubBits / 32) + 4, bits, kEmitBlock);
+    constexpr uint32_t per_sync = kSubBlock / kEmitBlock; // workgroups of this kernel per workgroup of the synchronisation
+    for (uint32_t bi = blockIdx.x; bi < n_blocks * per_sync; bi += gridDim.x) {
+        const uint32_t g0 = first_block * kSubBlock + bi * kEmitBlock;
+        if (g0 >= total_subs) break;
+        uint32_t local0;
+        const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+        const uint32_t job_index = (uint32_t)(&job - jobs);
+        if (status[job_index] & ~kDecSawEob) continue; // (uniform: one file per workgroup)
+        const uint32_t last = eob_index[job_index];
+        if (local0 > last) continue; // behind the end of the stream
+        const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
+        const bool active = i < job.n_sub && i <= last;
+        const uint64_t nominal0 = job.first_bit + (uint64_t)local0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
+        __syncthreads(); // (the previous block's LDS is free)
+        if (staged != job.lut) stage_lut(job, lut, kEmitBlock), staged = job.lut;
+        stage_bits(job, d0, kEmitDwords, bits, kEmitBlock);
         __syncthreads();
-        if (active) {
-            const uint32_t nominal = (uint32_t)(nominal0 - base) + threadIdx.x * kSubBits;
-            const uint64_t lim64 = job.end_limit_bit - base;
-            const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
-            const uint32_t row = (uint32_t)(off / geom.stride), col = (uint32_t)(off - (uint64_t)row * geom.stride);
-            uint32_t eob_end = 0;
-            const uint32_t fl = walk_emit(in, lut, lenof, nominal + info_start(a.info[g]), nominal + kSubBits, data_limit, (int32_t)((int64_t)off - (int64_t)tile_start),
-                                          row, col, a.lastpx[g], geom, lt, eob_end);
-            // end of block: the stream must end 4 bytes (the Adler-32) before the IDAT does
-            if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != job.z_bytes) err |= kDecBadStream;
-            err |= fl;
-        }
-        if (m < (uint32_t)kEmitBlock) break;
-        __syncthreads(); // (the next chunk's bits replace these)
+        if (!active) continue;
+        const uint32_t nominal = (uint32_t)(nominal0 - base) + threadIdx.x * kSubBits;
+        const uint64_t lim64 = job.end_limit_bit - base;
+        const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
+        EmitGeom geom;
+        geom.stride = job.bpl + 1, geom.c = job.src_c;
+        const uint64_t off = block_off[g / kSubBlock] + a.rel[g];
+        const uint32_t row = (uint32_t)(off / geom.stride), col = (uint32_t)(off - (uint64_t)row * geom.stride);
+        StreamSink sink = {(uint32_t *)job.filt};
+        uint32_t eob_end = 0;
+        uint32_t err = walk_emit(in, lut, lenof, nominal + info_start(a.info[g]), nominal + kSubBits, data_limit, off, row, col, a.lastpx[g], geom, sink, eob_end);
+        // end of block: the stream must end 4 bytes (the Adler-32) before the IDAT does
+        if ((err & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != job.z_bytes) err |= kDecBadStream;
+        if (err) atomicOr(&status[job_index], err);
     }
-    if (err) atomicOr(&status[job_index], err);
-    __syncthreads();
-    const uint32_t n16 = (uint32_t)((tile_end - tile_start + 15) >> 4); // (the buffer is padded to whole 16-byte pieces)
-    u32x4 *dst = (u32x4 *)(job.filt + tile_start);
-    for (uint32_t k = threadIdx.x; k < n16; k += kEmitBlock) dst[k] = ((const u32x4 *)tile)[k];
 }
 
 // ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256); one thread per DWORD column (four byte columns: packed
@@ -456,22 +432,24 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
 
 } // namespace
 
-void launch_dec_sync(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round, DecSubArrays a,
-                     DecBlockRec *recs, uint32_t *changed)
+// (the synchronisation and the emit run as persistent workgroups, `resident` of them: a few per compute unit)
+void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
+                     DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
 {
-    hipLaunchKernelGGL(dec_sync_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, round, a, recs, changed);
+    hipLaunchKernelGGL(dec_sync_kernel, dim3(std::min(n_blocks, resident)), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a, recs, changed);
 }
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
-                        uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, uint32_t *tile_first)
+                        uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
 {
     const uint32_t j0 = (uint32_t)(group_jobs - jobs);
     hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_group_jobs), dim3(kDecBlock), 0, s, group_jobs, recs, a.bytes, block_off, status + j0, eob_index + j0);
-    hipLaunchKernelGGL(dec_subscan_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, a, block_off, status, eob_index, tile_first);
+    hipLaunchKernelGGL(dec_subscan_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, a, status, eob_index);
 }
-void launch_dec_emit(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_tile, uint32_t n_tiles, DecSubArrays a, const uint32_t *eob_index,
-                     const uint64_t *block_off, const uint32_t *tile_first, uint32_t *status)
+void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
+                     const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
-    if (n_tiles) hipLaunchKernelGGL(dec_emit_kernel, dim3(n_tiles), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_tile, a, eob_index, block_off, tile_first, status);
+    const uint32_t wgs = n_blocks * (kSubBlock / kEmitBlock);
+    if (wgs) hipLaunchKernelGGL(dec_emit_kernel, dim3(std::min(wgs, resident)), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, a, eob_index, block_off, status);
 }
 // jobs / status: of the group's first file.  The y dimension of a grid holds at most 65535 workgroups: files in slices.
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status)

@@ -141,6 +141,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     if (rc) return rc;
     using namespace fpng::parse;
     hipStream_t s = e->stream;
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    const uint32_t resident = (uint32_t)std::max(cus, 1) * 3; // persistent workgroups of dec_sync_kernel / dec_emit_kernel: their LDS lets three share a compute unit
     uint32_t max_rounds = kMaxRounds;
     if (const char *mr = getenv("FPNG_AMD_DECODE_MAX_ROUNDS")) max_rounds = (uint32_t)std::max(0, atoi(mr)); // (0: every dynamic file is left to the CPU decoder -- tests)
     std::vector<Parsed> ps(n);
@@ -150,7 +153,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
     size_t z_total = 0, filt_total = 0, seg_total = 0;
-    uint32_t sub_total = 0, tile_total = 0;
+    uint32_t sub_total = 0;
 
     // ---- device-resident files: their first and last bytes come back first (one round trip for the batch) ----
     if (device_data) {
@@ -223,7 +226,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         j.z_bytes = p.idat_len, j.first_bit = p.first_bit, j.end_limit_bit = (uint64_t)(p.idat_len - 4) * 8;
         j.mode = p.mode;
         j.out = files[i].d_pixels;
-        j.sub_base = sub_total, j.tile_base = tile_total;
+        j.sub_base = sub_total;
         if (!p.mode) {
             j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
             sub_total += (j.n_sub + kDecSubBlock - 1) / kDecSubBlock * kDecSubBlock; // whole workgroups per file
@@ -231,8 +234,6 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             const size_t total = ((size_t)j.bpl + 1) * j.h;
             j.filt = (uint8_t *)(uintptr_t)filt_total;
             filt_total += ((total + 15) & ~(size_t)15) + 16;
-            j.n_tiles = (uint32_t)((total + kDecTileBytes - 1) / kDecTileBytes);
-            tile_total += j.n_tiles;
             j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
             j.segsum = (uint32_t *)(uintptr_t)seg_total;
             seg_total += (size_t)(j.nseg - 1) * ((j.bpl + 3) / 4);
@@ -254,7 +255,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
     uint8_t *d_z, *d_filt;
-    uint32_t *d_seg, *d_status, *d_changed, *d_tile_first;
+    uint32_t *d_seg, *d_status, *d_changed;
     uint64_t *d_block_off;
     DecBlockRec *d_recs;
     DecSubArrays d_sub;
@@ -270,14 +271,14 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         };
         const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_seg = carve(seg_total * 4), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
                      o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
-                     o_tiles = carve(std::max<size_t>(tile_total, 1) * 4), o_luts = carve(std::max<size_t>(luts.size(), 1) * dec::kLutDwords * 4),
+                     o_luts = carve(std::max<size_t>(luts.size(), 1) * dec::kLutDwords * 4),
                      o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         uint8_t *base = e->d_decode.p;
         d_z = base + o_z, d_filt = base + o_filt, d_seg = (uint32_t *)(base + o_seg);
         d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
         d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
-        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff), d_tile_first = (uint32_t *)(base + o_tiles);
+        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
         d_luts = (uint32_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
     }
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
@@ -296,7 +297,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     //      memory an "asynchronous" copy keeps its caller busy for most of its duration, so a thread of its own issues them).
     //      Files that are in device memory already form one group. ----
     struct Group {
-        uint32_t j0, j1, blk0, blk1, tile0, tile1, max_rows, max_bpl;
+        uint32_t j0, j1, blk0, blk1, max_rows, max_bpl;
     };
     std::vector<Group> groups;
     {
@@ -305,8 +306,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         uint64_t total = 0, run = 0;
         for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
         auto close = [&](uint32_t j0, uint32_t j1) {
-            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, jobs[j0].tile_base,
-                       j1 < nj ? jobs[j1].tile_base : tile_total, 1, 1};
+            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, 1, 1};
             for (uint32_t q = j0; q < j1; q++)
                 if (!jobs[q].mode) g.max_rows = std::max(g.max_rows, jobs[q].h), g.max_bpl = std::max(g.max_bpl, jobs[q].bpl);
             groups.push_back(g);
@@ -367,8 +367,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     auto finish_group = [&](const Group &g) { // everything behind the synchronisation (every step of it is idempotent)
         const uint32_t nblk = g.blk1 - g.blk0;
         if (nblk) {
-            launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob, d_tile_first);
-            launch_dec_emit(s, d_jobs, nj, g.tile0, g.tile1 - g.tile0, d_sub, d_eob, d_block_off, d_tile_first, d_status);
+            launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob);
+            launch_dec_emit(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, d_sub, d_eob, d_block_off, d_status);
         }
         launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
     };
@@ -387,7 +387,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         const uint32_t nblk = g.blk1 - g.blk0;
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
-        for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
+        for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
         finish_group(g);
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
@@ -412,7 +412,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             for (int k = 0; k < 4; k++) {
                 r++;
                 if (k == 3) HIP_TRY(hipMemsetAsync(d_changed + gi, 0, 4, s)); // (only the last of the four is asked)
-                launch_dec_sync(s, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
+                launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
             }
             HIP_TRY(hipMemcpyAsync(&changed, d_changed + gi, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -431,8 +431,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     static const bool trace = getenv("FPNG_AMD_TRACE_FILES") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)
-            fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, %u tiles, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
-                    jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, jobs[k].n_tiles, (unsigned long long)jobs[k].first_bit, status[k]);
+            fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
+                    jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, (unsigned long long)jobs[k].first_bit, status[k]);
         if (jobs[k].mode) continue;
         int32_t &st = results[job_file[k]].status;
         if (status[k] & kDecNotConverged) // (nothing else is known then: "invalid" may be a speculative decode's)

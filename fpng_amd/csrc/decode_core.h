@@ -81,37 +81,47 @@ struct SubCount {
 };
 
 // Decodes the tokens that start in [pos, limit) (positions: bits relative to the staged slice); returns the position behind the
-// last one.  A 32-bit window serves two lookups when the first one used at most 14 bits (12 + 5 extra + 1 + 14 <= 32).
+// last one.  Written for the SIMT machine: one iteration reads a 32-bit window and does TWO lookups (the second one on the bits
+// behind the first one's group) as straight-line predicated code -- a group of literals that lies wholly in front of the limit is
+// applied, anything else (a match, the end of the block, an invalid code, a group that reaches over the limit) is left to ONE
+// branch at the iteration's end, which takes a single token through fetch().
 template <bool Count, class Bits>
 FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c)
 {
-    while (pos < limit) {
-        if (pos >= data_limit) { // ran off the data without an end-of-block symbol
-            c.flags = kSubInvalid;
-            break;
-        }
+    uint32_t lits = c.lits, tail = c.tail, runs = 0, flags = 0;
+    const uint32_t lim = limit < data_limit ? limit : data_limit; // (no token may start at or behind data_limit)
+    while (pos < lim) {
         const uint32_t w = in.window(pos);
-        uint32_t used = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            uint32_t n, lits = 0, run = 0, bits;
-            const uint32_t kind = fetch(w >> used, lut, lenof, limit - (pos + used), n, lits, run, bits);
-            if (kind >= kTokEob) {
-                c.flags = kind == kTokEob ? kSubEob : kSubInvalid;
-                return pos + used;
-            }
-            used += bits;
-            if (Count) {
-                if (kind == kTokLit) {
-                    c.bytes += n, c.lits += n;
-                    c.tail = funnel(lits, c.tail, 8 * n);
-                } else
-                    c.bytes += run;
-            }
-            if (used > 14 || pos + used >= limit) break;
+        const uint32_t ea = lut[w & (kLutEntries - 1)], la = ea >> 28, na = (ea >> 26) & 3u, room_a = lim - pos;
+        const bool ca = na != 0 && la <= room_a;
+        const uint32_t eb = lut[(w >> la) & (kLutEntries - 1)], lb = eb >> 28, nb = (eb >> 26) & 3u, room_b = room_a - la;
+        const bool cb = ca && nb != 0 && lb <= room_b;
+        const uint32_t n1 = ca ? na : 0u, n2 = cb ? nb : 0u;
+        if (Count) {
+            lits += n1 + n2;
+            tail = funnel(ea & 0xFFFFFFu, tail, 8 * n1);
+            tail = funnel(eb & 0xFFFFFFu, tail, 8 * n2);
         }
-        pos += used;
+        pos += (ca ? la : 0u) + (cb ? lb : 0u);
+        if (!cb && pos < lim) { // the token at pos is not a plain group of literals
+            uint32_t n3, l3 = 0, run = 0, bits;
+            const uint32_t kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
+            if (kind >= kTokEob) {
+                flags = kind == kTokEob ? kSubEob : kSubInvalid;
+                break;
+            }
+            pos += bits;
+            if (Count) {
+                if (kind == kTokLit)
+                    lits += n3, tail = funnel(l3, tail, 8 * n3);
+                else
+                    runs += run;
+            }
+        }
     }
+    if (!flags && pos < limit) flags = kSubInvalid; // ran off the data without an end-of-block symbol
+    c.flags = flags;
+    if (Count) c.bytes += (lits - c.lits) + runs, c.lits = lits, c.tail = tail;
     return pos;
 }
 
@@ -179,150 +189,159 @@ FPNG_DEC_HD uint32_t info_end(uint32_t v) { return (v >> 5) & 31u; }
 FPNG_DEC_HD uint32_t info_flags(uint32_t v) { return (v >> 10) & 7u; }
 FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return v >> 13; }
 
-// ---- the real decode: one subsequence's tokens into the workgroup's tile of the filtered stream ----
+// ---- the real decode: one subsequence's tokens into the filtered stream ----
 // The filtered stream = what the reference's decoder consumes row by row (src/fpng.cpp:2255-2262): h rows of 1 filter byte +
-// w * c bytes, kept in exactly this layout (the column kernels read it with unaligned loads).  A tile is a window of kTileBytes
-// stream bytes held in LDS; Tile::put32(d, v) / put8(b, v) store into it (indices relative to the window, already checked
-// against it by the walker: a subsequence that straddles two tiles is decoded by both workgroups, each keeps its part).
+// w * c bytes, kept in exactly this layout (the column kernels read it with unaligned loads).  Every thread stores WHOLE ALIGNED
+// DWORDS only: the dword in which its output ends is completed with the first bytes of the following subsequences -- it simply
+// decodes on until the dword is full -- and a thread whose output starts inside a dword leaves that dword to the thread in front
+// of it.  No byte stores, no dword is written twice.  Four dwords at a time where a 16-byte group of the stream is all the
+// thread's (Sink::store128(group index, four values)), single dwords at its two ends (Sink::store32(dword index, value)):
+// 4-byte stores from 64 lanes whose ranges lie ~150 bytes apart are 64 memory transactions of 4 bytes each.
 struct EmitGeom {
     uint32_t stride; // w * c + 1
     uint32_t c;      // channels in the file
-    uint32_t ndw;    // dwords of the tile window
 };
 enum : uint32_t { kEmitBadStream = 2u, kEmitSawEob = 0x100u };
 
-template <class Tile> struct TileWriter {
-    Tile &tile;
-    uint32_t ndw;
-    uint64_t acc;  // bytes not stored yet, the oldest one lowest
-    uint32_t have; // how many (0..3 between tokens)
-    int32_t dw;    // tile dword they go to
-    uint32_t skip; // leading bytes of that dword that belong to the previous subsequence (first dword only)
-    FPNG_DEC_HD TileWriter(Tile &t, uint32_t ndw_, int32_t rel) : tile(t), ndw(ndw_), acc(0)
+template <class Sink> struct StreamWriter {
+    Sink &sink;
+    uint32_t acc;  // bytes not stored yet, the oldest one lowest
+    uint32_t have; // how many (0..3)
+    uint32_t dw;   // stream dword they go to
+    uint32_t q0, q1, q2, q3; // the last whole dwords, the newest in q3: at the end of a 16-byte group they are its four dwords
+    uint32_t own;  // first dword of the current group that is this thread's to store (0 except in its first group)
+    FPNG_DEC_HD StreamWriter(Sink &s, uint64_t off) : sink(s), acc(0), have((uint32_t)off & 3u), dw((uint32_t)(off >> 2)), q0(0), q1(0), q2(0), q3(0)
     {
-        const int32_t al = rel & ~3;
-        have = skip = (uint32_t)(rel - al);
-        dw = al >> 2;
+        own = (dw & 3u) + (have != 0); // (a first dword that starts in front of `off` belongs to the thread in front)
     }
-    FPNG_DEC_HD void flush() // have >= 4
+    FPNG_DEC_HD void push(uint32_t v, bool full) // a whole dword (where `full`)
     {
-        if ((uint32_t)dw < ndw) {
-            if (!skip)
-                tile.put32((uint32_t)dw, (uint32_t)acc);
-            else
-                for (uint32_t b = skip; b < 4; b++) tile.put8((uint32_t)dw * 4 + b, (uint8_t)(acc >> (8 * b)));
+        q0 = full ? q1 : q0, q1 = full ? q2 : q1, q2 = full ? q3 : q2, q3 = full ? v : q3;
+        if (full && (dw & 3u) == 3u) {
+            if (!own)
+                sink.store128(dw >> 2, q0, q1, q2, q3);
+            else {
+                if (own <= 1) sink.store32(dw - 2, q1);
+                if (own <= 2) sink.store32(dw - 1, q2);
+                if (own <= 3) sink.store32(dw, q3);
+                own = 0;
+            }
         }
-        skip = 0, acc >>= 32, have -= 4, dw++;
+        dw += full;
     }
-    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 4 bytes, the first one lowest
+    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 3 bytes, the first one lowest; bytes = 0 where n = 0
     {
-        acc |= (uint64_t)bytes << (8 * have);
-        have += n;
-        if (have >= 4) flush();
-    }
-    FPNG_DEC_HD void finish()
-    {
-        if ((uint32_t)dw < ndw)
-            for (uint32_t b = skip; b < have; b++) tile.put8((uint32_t)dw * 4 + b, (uint8_t)(acc >> (8 * b)));
+        const uint32_t sh = 8 * have, lo = acc | (bytes << sh), hi = (bytes >> 8) >> (24 - sh), nh = have + n;
+        const bool full = nh >= 4;
+        push(lo, full);
+        acc = full ? hi : lo;
+        have = nh & 3u;
     }
     // npix copies of a 4-byte pixel: the first dword completes the pending bytes, the others are one rotated constant
     FPNG_DEC_HD void run4(uint32_t px, uint32_t npix)
     {
-        const uint64_t x = (uint64_t)px << (8 * have);
-        acc |= x; // (x's low `have` bytes are zero)
-        const uint32_t keep = have;
-        have += 4;
-        flush();
-        const uint32_t r = (uint32_t)x | (uint32_t)(x >> 32);
-        const int32_t j1 = dw + (int32_t)npix - 1;
-        int32_t j = dw < 0 ? 0 : dw;
-        const int32_t stop = j1 < (int32_t)ndw ? j1 : (int32_t)ndw;
-        for (; j < stop; j++) tile.put32((uint32_t)j, r);
-        dw = j1, acc = x >> 32, have = keep;
+        const uint32_t sh = 8 * have, lo = px << sh, hi = (px >> 8) >> (24 - sh), r = lo | hi;
+        push(acc | lo, true);
+        for (uint32_t j = 1; j < npix; j++) push(r, true);
+        acc = hi;
     }
-    // npix copies of a 3-byte pixel; runs that lie wholly in front of or behind the window only move the position
     FPNG_DEC_HD void run3(uint32_t px, uint32_t npix)
     {
-        const uint32_t total = have + 3 * npix;
-        if (total >= 8 && (dw >= (int32_t)ndw || dw + (int32_t)(total >> 2) < 0)) {
-            const uint32_t m = total & 3u; // the last m bytes of the pixel stay pending
-            dw += (int32_t)(total >> 2), have = m, skip = 0;
-            acc = m ? (px >> (8 * (3 - m))) : 0u;
-            return;
-        }
         for (uint32_t k = 0; k < npix; k++) put(px, 3);
+    }
+    FPNG_DEC_HD void finish() // the thread's end: the whole dwords of its last, unfinished group; at the stream's end also the pending bytes (zeros behind them: the buffer is padded)
+    {
+        if (have) push(acc, true), have = 0;
+        const uint32_t m = dw & 3u; // dwords 0..m-1 of the group are in q[4-m]..q3
+        if (m >= 3 && own <= 0) sink.store32(dw - 3, q1);
+        if (m >= 2 && own <= m - 2) sink.store32(dw - 2, q2);
+        if (m >= 1 && own <= m - 1) sink.store32(dw - 1, q3);
     }
 };
 
-// pos / limit / data_limit as in walk_count; rel = tile-relative stream byte of the subsequence's first output byte (may be
-// negative), (row, col) = its place in the image (col 0 = the filter byte), lastpx = the four literal bytes in front of it.
-// Returns kEmit* flags; eob_end = position behind the end-of-block symbol if it met one.
-template <class Bits, class Tile>
-FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, int32_t rel, uint32_t row,
-                               uint32_t col, uint32_t lastpx, const EmitGeom &g, Tile &tile, uint32_t &eob_end)
+// pos / limit / data_limit as in walk_count; off = stream byte of the subsequence's first output byte, (row, col) = its place in
+// the image (col 0 = the filter byte), lastpx = the four literal bytes in front of it.  Returns kEmit* flags; eob_end = position
+// behind the end-of-block symbol if it met one.  Same shape as walk_count: two predicated lookups per window -- a group of
+// literals in front of the limit and strictly inside its row is applied -- and one branch for everything else.
+template <class Bits, class Sink>
+FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, uint64_t off, uint32_t row,
+                               uint32_t col, uint32_t lastpx, const EmitGeom &g, Sink &sink, uint32_t &eob_end)
 {
-    TileWriter<Tile> out(tile, g.ndw, rel);
+    StreamWriter<Sink> out(sink, off);
     if (col == 1) lastpx = 0; // right behind a filter byte there is no previous pixel: zeros (reference :2262 prev_delta_* = 0)
     uint32_t err = 0;
     const uint32_t stride = g.stride, c = g.c;
-    bool stop = false;
-    while (pos < limit && !stop) {
-        if (pos >= data_limit) {
-            err = kEmitBadStream;
-            break;
+    const uint32_t lim = limit < data_limit ? limit : data_limit;
+    bool over = false; // behind the limit: only the last dword is being completed, the tokens are their owners' to check
+    for (;;) {
+        if (pos >= lim) {
+            if (!over && pos < limit) err |= kEmitBadStream; // ran off the data
+            over = true;
+            if (!out.have || pos >= data_limit) break;
         }
-        const uint32_t w = in.window(pos);
-        uint32_t used = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            uint32_t n, lits = 0, run = 0, bits;
-            const uint32_t kind = fetch(w >> used, lut, lenof, limit - (pos + used), n, lits, run, bits);
-            used += bits;
-            if (kind == kTokLit) {
-                if (col && col + n <= stride) { // inside the row
-                    out.put(lits, n);
-                    lastpx = funnel(lits, lastpx, 8 * n);
-                    col += n;
-                    if (col == stride) col = 0, row++;
+        uint32_t n3 = 0, l3 = 0, run = 0, bits = 0, kind = kTokLit;
+        if (!over) {
+            const uint32_t w = in.window(pos);
+            const uint32_t ea = lut[w & (kLutEntries - 1)], la = ea >> 28, na = (ea >> 26) & 3u, room_a = lim - pos;
+            const bool ca = na != 0 && la <= room_a && col != 0 && col + na < stride;
+            const uint32_t n1 = ca ? na : 0u, lits1 = ca ? (ea & 0xFFFFFFu) : 0u;
+            out.put(lits1, n1);
+            lastpx = funnel(lits1, lastpx, 8 * n1);
+            col += n1;
+            const uint32_t eb = lut[(w >> la) & (kLutEntries - 1)], lb = eb >> 28, nb = (eb >> 26) & 3u, room_b = room_a - la;
+            const bool cb = ca && nb != 0 && lb <= room_b && col + nb < stride;
+            const uint32_t n2 = cb ? nb : 0u, lits2 = cb ? (eb & 0xFFFFFFu) : 0u;
+            out.put(lits2, n2);
+            lastpx = funnel(lits2, lastpx, 8 * n2);
+            col += n2;
+            pos += (ca ? la : 0u) + (cb ? lb : 0u);
+            if (cb || pos >= lim) continue;
+            kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
+        } else {
+            kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
+            const uint32_t need = 4 - out.have; // bytes that complete the dword
+            if (kind == kTokLit && n3 > need) n3 = need;
+            if (kind == kTokMatch && run > need) { // the first bytes of the repeated pixel (a match starts on a pixel)
+                kind = kTokLit, n3 = need;
+                l3 = (c == 4 ? lastpx : lastpx >> 8) & (0xFFFFFFu >> (8 * (3 - need)));
+            }
+        }
+        pos += bits;
+        if (kind == kTokLit) {
+            for (uint32_t j = 0; j < n3; j++) {
+                const uint32_t b = (l3 >> (8 * j)) & 255u;
+                out.put(b, 1);
+                if (!col) { // the row's filter literal: 0, then 2 = Up (reference :2255-2259)
+                    if (!over && b != (row ? 2u : 0u)) err |= kEmitBadStream;
+                    lastpx = 0, col = 1;
                 } else {
-                    for (uint32_t j = 0; j < n; j++) {
-                        const uint32_t b = (lits >> (8 * j)) & 255u;
-                        out.put(b, 1);
-                        if (!col) { // the row's filter literal: 0, then 2 = Up (reference :2255-2259)
-                            if (b != (row ? 2u : 0u)) err = kEmitBadStream;
-                            lastpx = 0, col = 1;
-                        } else {
-                            lastpx = funnel(b, lastpx, 8);
-                            if (++col == stride) col = 0, row++;
-                        }
-                    }
+                    lastpx = funnel(b, lastpx, 8);
+                    if (++col == stride) col = 0, row++;
                 }
-            } else if (kind == kTokMatch) {
-                // a match repeats the previous pixel: whole pixels, starting on a pixel, inside the row (reference :2273-2330)
-                const uint32_t x = col - 1;
-                const bool whole = c == 4 ? !((x | run) & 3u) : (x % 3u == 0 && run % 3u == 0);
-                if (!col || !whole || col + run > stride) {
-                    err = kEmitBadStream;
-                    stop = true;
-                    break;
-                }
-                if (c == 4)
-                    out.run4(lastpx, run >> 2);
-                else
-                    out.run3(lastpx >> 8, run / 3u);
-                col += run;
-                if (col == stride) col = 0, row++;
-            } else {
-                if (kind == kTokEob)
-                    err |= kEmitSawEob, eob_end = pos + used;
-                else
-                    err = kEmitBadStream;
-                stop = true;
+            }
+        } else if (kind == kTokMatch) {
+            // a match repeats the previous pixel: whole pixels, starting on a pixel, inside the row (reference :2273-2330)
+            const uint32_t x = col - 1;
+            const bool whole = c == 4 ? !((x | run) & 3u) : (x % 3u == 0 && run % 3u == 0);
+            if (!col || !whole || col + run > stride) {
+                if (!over) err |= kEmitBadStream;
                 break;
             }
-            if (used > 14 || pos + used >= limit) break;
+            if (c == 4)
+                out.run4(lastpx, run >> 2);
+            else
+                out.run3(lastpx >> 8, run / 3u);
+            col += run;
+            if (col == stride) col = 0, row++;
+        } else {
+            if (!over) {
+                if (kind == kTokEob)
+                    err |= kEmitSawEob, eob_end = pos;
+                else
+                    err |= kEmitBadStream;
+            }
+            break;
         }
-        pos += used;
     }
     out.finish();
     return err;

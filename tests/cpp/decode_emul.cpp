@@ -1,9 +1,9 @@
 // decode_emul.cpp -- the GPU decoder's kernels (fpng_amd/csrc/decode.hip) run on the CPU, thread by thread, over the SAME per-thread
 // code (fpng_amd/csrc/decode_core.h) and the same host-side preparation (fpng_amd_decode_plan): there is no GPU in the dev
-// container, so this is where the walkers, the hand-over rules, the in-workgroup and cross-border correction rounds, the offsets,
-// the tile assignment and the emit logic are held against the CPU decoder / the reference before a GPU sees them
-// (tests/test_decode_model.py).  Workgroup size, lead-in and tile size are PARAMETERS here (the kernels fix them at compile time):
-// small values put many workgroup borders and tile seams into small test images.  TEST INFRASTRUCTURE -- not part of the product.
+// container, so this is where the walkers, the hand-over rules, the in-workgroup and cross-border correction rounds, the offsets
+// and the emit logic are held against the CPU decoder / the reference before a GPU sees them
+// (tests/test_decode_model.py).  Workgroup size and lead-in are PARAMETERS here (the kernels fix them at compile time):
+// small values put many workgroup borders into small test images.  TEST INFRASTRUCTURE -- not part of the product.
 #include "decode_core.h"
 #include "fpng_amd.h"
 
@@ -22,17 +22,23 @@ struct HostBits { // positions relative to dword `d0` of the (zero padded) strea
     const uint32_t *dw;
     uint32_t window(uint32_t pos) const { return funnel(dw[(pos >> 5) + 1], dw[pos >> 5], pos & 31u); }
 };
-struct HostTile {
-    uint8_t *t;
-    uint32_t ndw;
-    bool *overflow;
-    void put32(uint32_t d, uint32_t v)
+struct HostSink { // the filtered stream; every dword may be stored once
+    uint8_t *f;
+    size_t ndw;
+    std::vector<bool> *written;
+    bool *fault;
+    void store32(uint32_t d, uint32_t v)
     {
-        if (d >= ndw) *overflow = true; else memcpy(t + 4 * d, &v, 4);
+        if (d >= ndw || (*written)[d]) {
+            *fault = true;
+            return;
+        }
+        (*written)[d] = true;
+        memcpy(f + 4 * (size_t)d, &v, 4);
     }
-    void put8(uint32_t b, uint8_t v)
+    void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
     {
-        if (b >= 4 * ndw) *overflow = true; else t[b] = v;
+        store32(4 * g, a), store32(4 * g + 1, b), store32(4 * g + 2, c), store32(4 * g + 3, d);
     }
 };
 
@@ -41,7 +47,7 @@ struct HostTile {
 // status: the decoder's (0, FPNG_DECODE_* or FPNG_AMD_DECODE_UNDECIDED); stats[0] = correction rounds inside workgroups (max),
 // stats[1] = border rounds, stats[2] = subsequences, stats[3] = subsequences corrected at least once
 extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desired, uint8_t *out, size_t out_cap, uint32_t *w_, uint32_t *h_, uint32_t *c_, uint32_t sub_block,
-                                uint32_t lead_in, uint32_t tile_bytes, uint32_t max_border_rounds, uint32_t *stats)
+                                uint32_t lead_in, uint32_t /*unused*/, uint32_t max_border_rounds, uint32_t *stats)
 {
     fpng_amd_decode_result res;
     uint32_t mode = 0, idat_ofs = 0, idat_len = 0;
@@ -194,8 +200,6 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         const uint32_t eob_index = last_blk * sub_block + last_local;
         // ---- dec_subscan_kernel ----
         std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0);
-        const uint32_t n_tiles = (uint32_t)((total + tile_bytes - 1) / tile_bytes);
-        std::vector<uint32_t> tile_first(n_tiles, 0xFFFFFFFFu);
         for (uint32_t b = 0; b <= last_blk; b++) {
             uint32_t before = 0;
             for (uint32_t t = 0; t < sub_block; t++) {
@@ -204,43 +208,36 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 rel[i] = before;
                 lastpx[i] = lookback_lastpx(
                     i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
-                const uint64_t off = block_off[b] + before, next = off + bytes[i];
-                for (uint64_t k = (off + tile_bytes - 1) / tile_bytes; k * tile_bytes < next && k < n_tiles; k++) tile_first[k] = i;
                 before += bytes[i];
             }
         }
-        // ---- dec_emit_kernel ----
+        // ---- dec_emit_kernel: one thread per subsequence, whole aligned dwords of the stream ----
         uint32_t err = 0;
-        std::vector<uint8_t> tile(tile_bytes + 16);
-        for (uint32_t tl = 0; tl < n_tiles; tl++) {
-            const uint64_t tile_start = (uint64_t)tl * tile_bytes, tile_end = std::min(total, tile_start + tile_bytes), sel_end = tile_end == total ? total + 1 : tile_end;
-            if (tile_first[tl] == 0xFFFFFFFFu) return -1003;
-            EmitGeom geom = {stride, c, (uint32_t)((tile_end - tile_start + 3) >> 2)};
-            std::fill(tile.begin(), tile.end(), 0xCD);
-            bool overflow = false;
-            HostTile ht = {tile.data(), geom.ndw, &overflow};
-            for (uint32_t i = tile_first[tl]; i < n_sub && i <= eob_index; i++) {
-                const uint64_t off = block_off[i / sub_block] + rel[i];
-                if (off >= sel_end) break;
-                // (the kernel stages the chunk's bits from its first subsequence's nominal bit on)
-                const uint32_t c0 = tile_first[tl] + (i - tile_first[tl]) / 7 * 7; // chunks of 7 threads here
-                const uint64_t nominal0 = first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
-                HostBits in = {zdw.data() + d0};
-                const uint32_t nominal = (uint32_t)(nominal0 - base) + (i - c0) * kSubBits;
-                const uint64_t lim64 = end_limit - base;
-                const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
-                const uint32_t row = (uint32_t)(off / stride), col = (uint32_t)(off - (uint64_t)row * stride);
-                uint32_t eob_end = 0;
-                const uint32_t fl = walk_emit(in, lut.data(), lenof, nominal + info_start(info[i]), nominal + kSubBits, data_limit, (int32_t)((int64_t)off - (int64_t)tile_start), row,
-                                              col, lastpx[i], geom, ht, eob_end);
-                if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != z_bytes) err |= 2;
-                err |= fl;
-            }
-            if (overflow) return -1004;
-            memcpy(filt.data() + tile_start, tile.data(), tile_end - tile_start);
+        bool fault = false;
+        const size_t ndw = (total + 3) / 4;
+        std::vector<bool> written((ndw + 3) / 4 * 4, false);
+        HostSink sink = {filt.data(), ndw, &written, &fault};
+        EmitGeom geom = {stride, c};
+        for (uint32_t i = 0; i < n_sub && i <= eob_index; i++) {
+            const uint64_t off = block_off[i / sub_block] + rel[i];
+            // (the kernel stages a workgroup's bits from its first subsequence's nominal bit on; workgroups of emit_block threads)
+            const uint32_t emit_block = sub_block > 1 ? sub_block / 2 : 1, c0 = i / emit_block * emit_block;
+            const uint64_t nominal0 = first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
+            HostBits in = {zdw.data() + d0};
+            const uint32_t nominal = (uint32_t)(nominal0 - base) + (i - c0) * kSubBits;
+            const uint64_t lim64 = end_limit - base;
+            const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
+            const uint32_t row = (uint32_t)(off / stride), col = (uint32_t)(off - (uint64_t)row * stride);
+            uint32_t eob_end = 0;
+            const uint32_t fl = walk_emit(in, lut.data(), lenof, nominal + info_start(info[i]), nominal + kSubBits, data_limit, off, row, col, lastpx[i], geom, sink, eob_end);
+            if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != z_bytes) err |= 2;
+            err |= fl;
         }
+        if (fault) return -1004;
         if (err & 2) return 1;
         if (!(err & kEmitSawEob)) return 1;
+        for (size_t d = 0; d < ndw; d++)
+            if (!written[d]) return -1005; // a dword of the stream nobody stored
     }
     // ---- Up filter undone, channel conversion (dec_unfilter_kernel) ----
     std::vector<uint8_t> prev(bpl, 0), cur(bpl);

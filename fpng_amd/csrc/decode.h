@@ -59,6 +59,6 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status);
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, uint32_t *status);
 
 } // namespace fpng_amd

@@ -112,10 +112,33 @@ template <int WAVES> __device__ __forceinline__ uint32_t block_sum(uint32_t v, u
     return r;
 }
 
+// decode_core.h: a lane whose next token needs the general path waits until eight lanes of its wave wait, or all that are still
+// at work
+#ifndef FPNG_DEC_VOTE
+#define FPNG_DEC_VOTE 1
+#endif
+#ifndef FPNG_DEC_PERSISTENT // 1: a few workgroups per compute unit loop over the blocks; 0: one workgroup per block
+#define FPNG_DEC_PERSISTENT 1
+#endif
+#ifndef FPNG_DEC_WGS // workgroups per compute unit the register allocation of the two decoding kernels aims at
+#define FPNG_DEC_WGS 1
+#endif
+struct WaveVote {
+    static __device__ __forceinline__ bool go(bool waiting)
+    {
+#if FPNG_DEC_VOTE
+        const uint64_t m = __ballot(waiting);
+        return waiting && (__popcll(m) >= 8 || m == __ballot(true));
+#else
+        return waiting;
+#endif
+    }
+};
+
 // ---- synchronisation ----
 constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 + 1 + 3;
 
-__global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
+__global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
                                                              DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs,
         bool dirty = false;
         if (valid) {
             if (!round) {
-                sub_first(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st);
+                sub_first<VoteAlone>(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st);
                 dirty = true;
             } else {
                 const uint32_t v = a.info[g];
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(kSubBlock) void dec_sync_kernel(const DecJob *jobs,
             const bool need = valid && want != st.start;
             if (!__syncthreads_or(need)) break;
             if (need) {
-                sub_refix(in, lut, lenof, want, boundary, data_limit, st);
+                sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
                 s_end[t] = st.end;
                 dirty = true;
             }
@@ -304,12 +327,20 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
 // ---- the real decode ----
 constexpr uint32_t kEmitDwords = kEmitBlock * (kSubBits / 32) + 8; // (a thread may decode a few tokens into the next workgroup's bits)
 struct StreamSink {
-    uint32_t *f; // the file's filtered stream
+    __attribute__((address_space(1))) uint32_t *f; // the file's filtered stream (global_store, not flat_store: a flat store also counts as an LDS operation in flight)
+#if defined(FPNG_DEC_EMIT_NOSTORE) // diagnostic builds (fpng_amd/build.py --variant): what the stores cost
+    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { asm volatile("" ::"v"(d), "v"(v)); }
+    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { asm volatile("" ::"v"(g), "v"(a), "v"(b), "v"(c), "v"(d)); }
+#elif defined(FPNG_DEC_EMIT_L2STORE) // ... and what they cost when every one of them hits a line that stays in the L2
+    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d & 0x3FFFu] = v; }
+    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g & 0xFFFu] = u32x4{a, b, c, d}; }
+#else
     __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
-    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((u32x4 *)f)[g] = u32x4{a, b, c, d}; }
+    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g] = u32x4{a, b, c, d}; }
+#endif
 };
 
-__global__ __launch_bounds__(kEmitBlock) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
+__global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                                                               const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
@@ -336,15 +367,16 @@ __global__ __launch_bounds__(kEmitBlock) void dec_emit_kernel(const DecJob *jobs
         __syncthreads();
         if (!active) continue;
         const uint32_t nominal = (uint32_t)(nominal0 - base) + threadIdx.x * kSubBits;
-        const uint64_t lim64 = job.end_limit_bit - base;
-        const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
-        EmitGeom geom;
-        geom.stride = job.bpl + 1, geom.c = job.src_c;
+        const uint32_t stride = job.bpl + 1;
         const uint64_t off = block_off[g / kSubBlock] + a.rel[g];
-        const uint32_t row = (uint32_t)(off / geom.stride), col = (uint32_t)(off - (uint64_t)row * geom.stride);
-        StreamSink sink = {(uint32_t *)job.filt};
+        const uint32_t col = (uint32_t)(off % stride), own = a.bytes[g];
+        const bool is_last = i == last;
+        const uint32_t pad = is_last ? 0u : (0u - ((uint32_t)off + own)) & 15u; // bytes of the following subsequences that complete the last 16-byte group
+        StreamSink sink = {(__attribute__((address_space(1))) uint32_t *)(uintptr_t)job.filt};
         uint32_t eob_end = 0;
-        uint32_t err = walk_emit(in, lut, lenof, nominal + info_start(a.info[g]), nominal + kSubBits, data_limit, off, row, col, a.lastpx[g], geom, sink, eob_end);
+        const uint32_t p0 = nominal + info_start(a.info[g]), lastpx = a.lastpx[g];
+        uint32_t err = job.src_c == 4 ? walk_emit<4>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end)
+                                      : walk_emit<3>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end);
         // end of block: the stream must end 4 bytes (the Adler-32) before the IDAT does
         if ((err & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != job.z_bytes) err |= kDecBadStream;
         if (err) atomicOr(&status[job_index], err);
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_sums_kernel(const DecJ
     for (uint32_t y = 0; y < kUnfRows; y++) acc = add_bytes(acc, load_u32_unaligned(F + (size_t)y * stride));
     job.segsum[(size_t)sg * ncol + j4] = acc;
 }
-__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, const uint32_t *status, uint32_t col_blocks)
+__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, uint32_t *status, uint32_t col_blocks)
 {
     const DecJob &job = jobs[blockIdx.y];
     if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
@@ -395,7 +427,9 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
     for (uint32_t q = 0; q < sg; q++) acc = add_bytes(acc, job.segsum[(size_t)q * ncol + j4]);
     const uint32_t y0 = sg * kUnfRows, y1 = min(job.h, y0 + kUnfRows);
     const uint8_t *F = job.filt + 1 + (size_t)j4 * 4;
+    bool bad_filter = false;
     for (uint32_t y = y0; y < y1; y++) {
+        if (!j4) bad_filter |= F[(size_t)y * stride - 1] != (y ? 2 : 0); // the row's filter literal: 0, then 2 = Up (reference :2255-2259)
         acc = add_bytes(acc, load_u32_unaligned(F + (size_t)y * stride));
         uint8_t *orow = job.out + (size_t)y * os;
         if (whole)
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
                 if (dc == 4 && sc == 3 && ch == 2) orow[(size_t)px * dc + 3] = 0xFF;
             }
     }
+    if (bad_filter) atomicOr(&status[blockIdx.y], kDecBadStream);
 }
 
 // ---- stored files: the filter-0 stream sits in stored blocks of 65535 bytes (the host checked their headers and the filter bytes) ----
@@ -436,7 +471,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
 void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
                      DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
 {
-    hipLaunchKernelGGL(dec_sync_kernel, dim3(std::min(n_blocks, resident)), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a, recs, changed);
+    hipLaunchKernelGGL(dec_sync_kernel, dim3(FPNG_DEC_PERSISTENT ? std::min(n_blocks, resident) : n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a, recs, changed);
 }
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
@@ -449,10 +484,10 @@ void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint3
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
     const uint32_t wgs = n_blocks * (kSubBlock / kEmitBlock);
-    if (wgs) hipLaunchKernelGGL(dec_emit_kernel, dim3(std::min(wgs, resident)), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, a, eob_index, block_off, status);
+    if (wgs) hipLaunchKernelGGL(dec_emit_kernel, dim3(FPNG_DEC_PERSISTENT ? std::min(wgs, resident) : wgs), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, a, eob_index, block_off, status);
 }
 // jobs / status: of the group's first file.  The y dimension of a grid holds at most 65535 workgroups: files in slices.
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, const uint32_t *status)
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, uint32_t *status)
 {
     const uint32_t col_blocks = ((max_bpl + 3) / 4 + kDecBlock - 1) / kDecBlock, segs = (max_rows + kUnfRows - 1) / kUnfRows;
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) {

@@ -80,30 +80,44 @@ struct SubCount {
     uint32_t flags; // kSubEob: it met an end-of-block symbol; kSubInvalid: its decode derailed
 };
 
+// When does a lane whose next token needs the general path (fetch()) get it?  On the GPU the lanes of a wave run in lockstep: a
+// token that is rare for one lane (a long match, a group of literals that reaches over the limit) turns up in SOME lane of the
+// wave almost every iteration, and the whole wave walks through the general path each time.  So such a lane waits -- the
+// straight-line part of the loop does nothing for it -- until eight lanes wait or no lane can go on (WaveVote, decode.hip).
+// On the host every lane is alone.
+struct VoteAlone {
+    static FPNG_DEC_HD bool go(bool waiting) { return waiting; }
+};
+
 // Decodes the tokens that start in [pos, limit) (positions: bits relative to the staged slice); returns the position behind the
 // last one.  Written for the SIMT machine: one iteration reads a 32-bit window and does TWO lookups (the second one on the bits
-// behind the first one's group) as straight-line predicated code -- a group of literals that lies wholly in front of the limit is
-// applied, anything else (a match, the end of the block, an invalid code, a group that reaches over the limit) is left to ONE
-// branch at the iteration's end, which takes a single token through fetch().
-template <bool Count, class Bits>
+// behind the first token) as straight-line predicated code -- a group of literals that lies wholly in front of the limit and a
+// match are applied -- and what is left (the end of the block, an invalid code, a group that reaches over the limit) takes a
+// single token through fetch(), when the vote says so.
+template <bool Count, class Vote, class Bits>
 FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c)
 {
     uint32_t lits = c.lits, tail = c.tail, runs = 0, flags = 0;
     const uint32_t lim = limit < data_limit ? limit : data_limit; // (no token may start at or behind data_limit)
-    while (pos < lim) {
-        const uint32_t w = in.window(pos);
-        const uint32_t ea = lut[w & (kLutEntries - 1)], la = ea >> 28, na = (ea >> 26) & 3u, room_a = lim - pos;
-        const bool ca = na != 0 && la <= room_a;
-        const uint32_t eb = lut[(w >> la) & (kLutEntries - 1)], lb = eb >> 28, nb = (eb >> 26) & 3u, room_b = room_a - la;
-        const bool cb = ca && nb != 0 && lb <= room_b;
-        const uint32_t n1 = ca ? na : 0u, n2 = cb ? nb : 0u;
+    // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one)
+    auto take = [&](uint32_t wk, uint32_t room, bool en) -> uint32_t {
+        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u, xb = (e >> 9) & 7u;
+        const bool lit = en && n != 0 && L <= room, mt = en && n == 0 && (e & kEntMatch) != 0;
         if (Count) {
-            lits += n1 + n2;
-            tail = funnel(ea & 0xFFFFFFu, tail, 8 * n1);
-            tail = funnel(eb & 0xFFFFFFu, tail, 8 * n2);
+            lits += lit ? n : 0u;
+            tail = funnel(e & 0xFFFFFFu, tail, lit ? 8 * n : 0u);
+            runs += mt ? (e & 511u) + ((wk >> L) & ((1u << xb) - 1u)) : 0u;
         }
-        pos += (ca ? la : 0u) + (cb ? lb : 0u);
-        if (!cb && pos < lim) { // the token at pos is not a plain group of literals
+        return lit ? L : (mt ? L + xb + 1 : 0u);
+    };
+    while (pos < lim) {
+        const uint32_t w = in.window(pos), room = lim - pos;
+        const uint32_t ba = take(w, room, true);
+        const bool en_b = ba != 0 && ba <= 14 && ba < room; // (the second token starts inside, with 18 valid bits in the window)
+        const uint32_t bb = take(w >> ba, room - ba, en_b);
+        pos += ba + bb;
+        const bool waiting = pos < lim && (ba == 0 || (en_b && bb == 0)); // the token at pos is not a plain one
+        if (Vote::go(waiting)) {
             uint32_t n3, l3 = 0, run = 0, bits;
             const uint32_t kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
             if (kind >= kTokEob) {
@@ -135,18 +149,18 @@ struct SubState {
 // tools/sync_stats.c measured (128 bits: all but 0.04 % of the subsequences of a synthetic gradient, 1.8 % of a photograph),
 // fallen into step with the true token sequence when it crosses `nominal`; the first token boundary at or behind `nominal` is
 // the subsequence's start.  Whether it is the true one shows when it is compared with the predecessor's end.
-template <class Bits>
+template <class Vote, class Bits>
 FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, SubState &s)
 {
     uint32_t p = nominal;
     if (lead_start < nominal) {
         SubCount d = {0, 0, 0, 0};
-        p = walk_count<false>(in, lut, lenof, lead_start, nominal, data_limit, d);
+        p = walk_count<false, Vote>(in, lut, lenof, lead_start, nominal, data_limit, d);
         if (d.flags || p < nominal) p = nominal; // the lead-in derailed: any start is as good as another
     }
     s.start = p;
     s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
-    const uint32_t e = walk_count<true>(in, lut, lenof, p, boundary, data_limit, s.c);
+    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, p, boundary, data_limit, s.c);
     // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
     // end-of-block symbols; which one is the true one is settled afterwards (the first one of the chain).
     s.end = s.c.flags ? boundary : e;
@@ -156,7 +170,7 @@ FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *l
 // s.start, the new one from `want` -- are stepped token by token, the one that lags behind first; where they meet, the rest of the
 // old decode holds, and only the counts in front of that point are exchanged.  No meeting point inside the subsequence (or one
 // so late that the last four literals are not all behind it): decoded again as a whole.
-template <class Bits>
+template <class Vote, class Bits>
 FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s)
 {
     uint32_t A = s.start, B = want;
@@ -164,10 +178,10 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
     while (A != B) {
         if ((A < B ? A : B) >= boundary) break;
         if (A < B) {
-            A = walk_count<true>(in, lut, lenof, A, A + 1, data_limit, a);
+            A = walk_count<true, VoteAlone>(in, lut, lenof, A, A + 1, data_limit, a);
             if (a.flags) break;
         } else {
-            B = walk_count<true>(in, lut, lenof, B, B + 1, data_limit, b);
+            B = walk_count<true, VoteAlone>(in, lut, lenof, B, B + 1, data_limit, b);
             if (b.flags) break;
         }
     }
@@ -178,7 +192,7 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
         return; // (end, tail and flags are the old decode's)
     }
     s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
-    const uint32_t e = walk_count<true>(in, lut, lenof, want, boundary, data_limit, s.c);
+    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c);
     s.end = s.c.flags ? boundary : e;
 }
 
@@ -192,15 +206,11 @@ FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return v >> 13; }
 // ---- the real decode: one subsequence's tokens into the filtered stream ----
 // The filtered stream = what the reference's decoder consumes row by row (src/fpng.cpp:2255-2262): h rows of 1 filter byte +
 // w * c bytes, kept in exactly this layout (the column kernels read it with unaligned loads).  Every thread stores WHOLE ALIGNED
-// DWORDS only: the dword in which its output ends is completed with the first bytes of the following subsequences -- it simply
-// decodes on until the dword is full -- and a thread whose output starts inside a dword leaves that dword to the thread in front
-// of it.  No byte stores, no dword is written twice.  Four dwords at a time where a 16-byte group of the stream is all the
-// thread's (Sink::store128(group index, four values)), single dwords at its two ends (Sink::store32(dword index, value)):
-// 4-byte stores from 64 lanes whose ranges lie ~150 bytes apart are 64 memory transactions of 4 bytes each.
-struct EmitGeom {
-    uint32_t stride; // w * c + 1
-    uint32_t c;      // channels in the file
-};
+// 16-BYTE GROUPS only (Sink::store128(group index, four dwords)): the group in which its output ends is completed with the first
+// bytes of the following subsequences -- it simply decodes on until the group is full -- and a thread whose output starts inside a
+// group leaves that group to the thread in front of it.  No byte stores, nothing is written twice, no store that depends on whose
+// bytes a dword holds.  (Sink::store32 serves the one place where the stream itself ends inside a group.)  4-byte stores from 64
+// lanes whose ranges lie ~150 bytes apart were 64 memory transactions of 4 bytes per instruction, and 6 x the bytes at the fabric.
 enum : uint32_t { kEmitBadStream = 2u, kEmitSawEob = 0x100u };
 
 template <class Sink> struct StreamWriter {
@@ -209,27 +219,20 @@ template <class Sink> struct StreamWriter {
     uint32_t have; // how many (0..3)
     uint32_t dw;   // stream dword they go to
     uint32_t q0, q1, q2, q3; // the last whole dwords, the newest in q3: at the end of a 16-byte group they are its four dwords
-    uint32_t own;  // first dword of the current group that is this thread's to store (0 except in its first group)
+    bool skip;     // the group the output starts in belongs to the thread in front (until its end is reached)
     FPNG_DEC_HD StreamWriter(Sink &s, uint64_t off) : sink(s), acc(0), have((uint32_t)off & 3u), dw((uint32_t)(off >> 2)), q0(0), q1(0), q2(0), q3(0)
     {
-        own = (dw & 3u) + (have != 0); // (a first dword that starts in front of `off` belongs to the thread in front)
+        skip = ((uint32_t)off & 15u) != 0;
     }
     FPNG_DEC_HD void push(uint32_t v, bool full) // a whole dword (where `full`)
     {
         q0 = full ? q1 : q0, q1 = full ? q2 : q1, q2 = full ? q3 : q2, q3 = full ? v : q3;
-        if (full && (dw & 3u) == 3u) {
-            if (!own)
-                sink.store128(dw >> 2, q0, q1, q2, q3);
-            else {
-                if (own <= 1) sink.store32(dw - 2, q1);
-                if (own <= 2) sink.store32(dw - 1, q2);
-                if (own <= 3) sink.store32(dw, q3);
-                own = 0;
-            }
-        }
+        const bool gend = full && (dw & 3u) == 3u;
+        if (gend && !skip) sink.store128(dw >> 2, q0, q1, q2, q3);
+        skip = skip && !gend;
         dw += full;
     }
-    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 3 bytes, the first one lowest; bytes = 0 where n = 0
+    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 4 bytes, the first one lowest; bytes = 0 where n = 0
     {
         const uint32_t sh = 8 * have, lo = acc | (bytes << sh), hi = (bytes >> 8) >> (24 - sh), nh = have + n;
         const bool full = nh >= 4;
@@ -249,99 +252,89 @@ template <class Sink> struct StreamWriter {
     {
         for (uint32_t k = 0; k < npix; k++) put(px, 3);
     }
-    FPNG_DEC_HD void finish() // the thread's end: the whole dwords of its last, unfinished group; at the stream's end also the pending bytes (zeros behind them: the buffer is padded)
+    // Only where the stream ends inside a group: its whole dwords, and the pending bytes (zeros behind them: the buffer is padded).
+    FPNG_DEC_HD void finish()
     {
         if (have) push(acc, true), have = 0;
         const uint32_t m = dw & 3u; // dwords 0..m-1 of the group are in q[4-m]..q3
-        if (m >= 3 && own <= 0) sink.store32(dw - 3, q1);
-        if (m >= 2 && own <= m - 2) sink.store32(dw - 2, q2);
-        if (m >= 1 && own <= m - 1) sink.store32(dw - 1, q3);
+        if (skip) return;
+        if (m >= 3) sink.store32(dw - 3, q1);
+        if (m >= 2) sink.store32(dw - 2, q2);
+        if (m >= 1) sink.store32(dw - 1, q3);
     }
 };
 
-// pos / limit / data_limit as in walk_count; off = stream byte of the subsequence's first output byte, (row, col) = its place in
-// the image (col 0 = the filter byte), lastpx = the four literal bytes in front of it.  Returns kEmit* flags; eob_end = position
-// behind the end-of-block symbol if it met one.  Same shape as walk_count: two predicated lookups per window -- a group of
-// literals in front of the limit and strictly inside its row is applied -- and one branch for everything else.
-template <class Bits, class Sink>
-FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, uint64_t off, uint32_t row,
-                               uint32_t col, uint32_t lastpx, const EmitGeom &g, Sink &sink, uint32_t &eob_end)
+// The real decode of one subsequence.  The synchronisation has settled where it starts (pos) and how many bytes its tokens stand
+// for (own): the loop is driven by the BYTE count -- `own` bytes plus the `pad` (0..15) first bytes of the following subsequences
+// that complete its last 16-byte group -- so no token has to be compared with a bit limit and a group of literals is simply cut to the
+// bytes still wanted.  off = stream byte of its first output byte, col = that byte's place in its row (0 = the filter byte),
+// lastpx = the four literal bytes in front of it; C = channels in the file; last: the stream's last subsequence (an end-of-block
+// symbol must follow its bytes).  Two predicated lookups per window: literals and matches of exactly ONE pixel (the usual kind on
+// noisy content: length C, no extra bits) are applied in line, everything else takes the branch.  Checked here, token by token:
+// a match repeats whole pixels, starts on a pixel and stays inside its row (reference src/fpng.cpp:2273-2330); that every row
+// starts with its filter literal is checked where the rows are read (dec_unfilter_kernel).  Returns kEmit* flags; eob_end =
+// position behind the end-of-block symbol.
+template <int C, class Bits, class Sink>
+FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t own, uint32_t pad, bool last, uint64_t off, uint32_t col,
+                               uint32_t lastpx, uint32_t stride, Sink &sink, uint32_t &eob_end)
 {
     StreamWriter<Sink> out(sink, off);
-    if (col == 1) lastpx = 0; // right behind a filter byte there is no previous pixel: zeros (reference :2262 prev_delta_* = 0)
+    const uint32_t bpl = stride - 1;
+    uint32_t todo = own + pad;
+    uint32_t rowleft = stride - col; // bytes up to the end of the row, the next one included (== stride: the next byte is a filter byte)
     uint32_t err = 0;
-    const uint32_t stride = g.stride, c = g.c;
-    const uint32_t lim = limit < data_limit ? limit : data_limit;
-    bool over = false; // behind the limit: only the last dword is being completed, the tokens are their owners' to check
-    for (;;) {
-        if (pos >= lim) {
-            if (!over && pos < limit) err |= kEmitBadStream; // ran off the data
-            over = true;
-            if (!out.have || pos >= data_limit) break;
-        }
-        uint32_t n3 = 0, l3 = 0, run = 0, bits = 0, kind = kTokLit;
-        if (!over) {
-            const uint32_t w = in.window(pos);
-            const uint32_t ea = lut[w & (kLutEntries - 1)], la = ea >> 28, na = (ea >> 26) & 3u, room_a = lim - pos;
-            const bool ca = na != 0 && la <= room_a && col != 0 && col + na < stride;
-            const uint32_t n1 = ca ? na : 0u, lits1 = ca ? (ea & 0xFFFFFFu) : 0u;
-            out.put(lits1, n1);
-            lastpx = funnel(lits1, lastpx, 8 * n1);
-            col += n1;
-            const uint32_t eb = lut[(w >> la) & (kLutEntries - 1)], lb = eb >> 28, nb = (eb >> 26) & 3u, room_b = room_a - la;
-            const bool cb = ca && nb != 0 && lb <= room_b && col + nb < stride;
-            const uint32_t n2 = cb ? nb : 0u, lits2 = cb ? (eb & 0xFFFFFFu) : 0u;
-            out.put(lits2, n2);
-            lastpx = funnel(lits2, lastpx, 8 * n2);
-            col += n2;
-            pos += (ca ? la : 0u) + (cb ? lb : 0u);
-            if (cb || pos >= lim) continue;
-            kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
-        } else {
-            kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
-            const uint32_t need = 4 - out.have; // bytes that complete the dword
-            if (kind == kTokLit && n3 > need) n3 = need;
-            if (kind == kTokMatch && run > need) { // the first bytes of the repeated pixel (a match starts on a pixel)
-                kind = kTokLit, n3 = need;
-                l3 = (c == 4 ? lastpx : lastpx >> 8) & (0xFFFFFFu >> (8 * (3 - need)));
-            }
-        }
-        pos += bits;
-        if (kind == kTokLit) {
-            for (uint32_t j = 0; j < n3; j++) {
-                const uint32_t b = (l3 >> (8 * j)) & 255u;
-                out.put(b, 1);
-                if (!col) { // the row's filter literal: 0, then 2 = Up (reference :2255-2259)
-                    if (!over && b != (row ? 2u : 0u)) err |= kEmitBadStream;
-                    lastpx = 0, col = 1;
-                } else {
-                    lastpx = funnel(b, lastpx, 8);
-                    if (++col == stride) col = 0, row++;
-                }
-            }
-        } else if (kind == kTokMatch) {
-            // a match repeats the previous pixel: whole pixels, starting on a pixel, inside the row (reference :2273-2330)
-            const uint32_t x = col - 1;
-            const bool whole = c == 4 ? !((x | run) & 3u) : (x % 3u == 0 && run % 3u == 0);
-            if (!col || !whole || col + run > stride) {
-                if (!over) err |= kEmitBadStream;
+    // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one, or nothing left to do)
+    auto take = [&](uint32_t wk) -> uint32_t {
+        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
+        const bool m1 = (e & 0x0FFFFFFFu) == (kEntMatch | (uint32_t)C) && rowleft % C == 0 && rowleft != bpl && todo >= (uint32_t)C;
+        const uint32_t nl = n < todo ? n : todo, nb = m1 ? (uint32_t)C : nl;
+        const uint32_t lits = e & (0xFFFFFFu >> (8 * (3 - nl))); // (nl = 0: no byte)
+        out.put(m1 ? (C == 4 ? lastpx : lastpx >> 8) : lits, nb);
+        lastpx = funnel(lits, lastpx, m1 ? 0u : 8 * nl);
+        rowleft -= nb;
+        rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
+        todo -= nb;
+        return nb ? L + (m1 ? 1u : 0u) : 0u;
+    };
+    while (todo) {
+        const uint32_t w = in.window(pos);
+        const uint32_t ba = take(w);
+        const uint32_t bb = take(w >> ba); // (a first token that was not plain is looked at again, to no effect)
+        pos += ba + bb;
+        if (todo && !bb) { // the token at pos is not a plain one
+            uint32_t n3, l3 = 0, run = 0, bits;
+            const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
+            const bool mine = todo > pad; // (the tokens behind this thread's bytes are their owners' to check)
+            if (kind != kTokMatch) { // the stream ends, or derails, with bytes still owed
+                if (mine) err |= kEmitBadStream;
                 break;
             }
-            if (c == 4)
-                out.run4(lastpx, run >> 2);
-            else
-                out.run3(lastpx >> 8, run / 3u);
-            col += run;
-            if (col == stride) col = 0, row++;
-        } else {
-            if (!over) {
-                if (kind == kTokEob)
-                    err |= kEmitSawEob, eob_end = pos;
-                else
-                    err |= kEmitBadStream;
+            pos += bits;
+            if (mine && (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)) {
+                err |= kEmitBadStream;
+                break;
             }
-            break;
+            const uint32_t px = rowleft == bpl ? 0u : (C == 4 ? lastpx : lastpx >> 8); // (at a row's first pixel there is no previous one: zeros, reference :2262)
+            const uint32_t r = run < todo ? run : todo;
+            if (r == run) {
+                if (C == 4)
+                    out.run4(px, run >> 2);
+                else
+                    out.run3(px, run / 3u);
+            } else
+                for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1); // (r < run: inside the pad)
+            rowleft -= r;
+            rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
+            todo -= r;
         }
+    }
+    if (last && !err) { // the end-of-block symbol
+        uint32_t n3, l3 = 0, run = 0, bits;
+        const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
+        if (kind == kTokEob)
+            err |= kEmitSawEob, eob_end = pos + bits;
+        else
+            err |= kEmitBadStream;
     }
     out.finish();
     return err;

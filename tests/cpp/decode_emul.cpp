@@ -106,7 +106,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             for (uint32_t t = 0; t < nthreads; t++) {
                 const uint32_t i = local0 + t, nominal = nominal_of(t), boundary = nominal + kSubBits;
                 if (!round) {
-                    sub_first(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t]);
+                    sub_first<VoteAlone>(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t]);
                     dirty[t] = true;
                 } else {
                     const uint32_t v = info[i];
@@ -128,7 +128,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 inner++;
                 for (uint32_t t = 0; t < nthreads; t++)
                     if (want[t] != st[t].start) {
-                        sub_refix(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                        sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
                         s_end[t] = st[t].end;
                         dirty[t] = true;
                         if (!ever[t]) ever[t] = true, fixed_subs++;
@@ -217,7 +217,6 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         const size_t ndw = (total + 3) / 4;
         std::vector<bool> written((ndw + 3) / 4 * 4, false);
         HostSink sink = {filt.data(), ndw, &written, &fault};
-        EmitGeom geom = {stride, c};
         for (uint32_t i = 0; i < n_sub && i <= eob_index; i++) {
             const uint64_t off = block_off[i / sub_block] + rel[i];
             // (the kernel stages a workgroup's bits from its first subsequence's nominal bit on; workgroups of emit_block threads)
@@ -225,11 +224,13 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             const uint64_t nominal0 = first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
             HostBits in = {zdw.data() + d0};
             const uint32_t nominal = (uint32_t)(nominal0 - base) + (i - c0) * kSubBits;
-            const uint64_t lim64 = end_limit - base;
-            const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
-            const uint32_t row = (uint32_t)(off / stride), col = (uint32_t)(off - (uint64_t)row * stride);
+            const uint32_t col = (uint32_t)(off % stride), own = bytes[i];
+            const bool is_last = i == eob_index;
+            const uint32_t pad = is_last ? 0u : (0u - ((uint32_t)off + own)) & 15u;
             uint32_t eob_end = 0;
-            const uint32_t fl = walk_emit(in, lut.data(), lenof, nominal + info_start(info[i]), nominal + kSubBits, data_limit, off, row, col, lastpx[i], geom, sink, eob_end);
+            const uint32_t p0 = nominal + info_start(info[i]);
+            const uint32_t fl = c == 4 ? walk_emit<4>(in, lut.data(), lenof, p0, own, pad, is_last, off, col, lastpx[i], stride, sink, eob_end)
+                                       : walk_emit<3>(in, lut.data(), lenof, p0, own, pad, is_last, off, col, lastpx[i], stride, sink, eob_end);
             if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != z_bytes) err |= 2;
             err |= fl;
         }
@@ -243,6 +244,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
     std::vector<uint8_t> prev(bpl, 0), cur(bpl);
     for (uint32_t y = 0; y < h; y++) {
         const uint8_t *f = filt.data() + (size_t)y * stride + 1;
+        if (f[-1] != (y ? 2 : 0)) return 1; // the row's filter literal: 0, then 2 = Up
         for (uint32_t j = 0; j < bpl; j++) cur[j] = (uint8_t)(prev[j] + f[j]);
         uint8_t *o = out + (size_t)y * w * desired;
         for (uint32_t x = 0; x < w; x++)

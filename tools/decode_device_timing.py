@@ -22,8 +22,9 @@ for name, kind, w, h, c, n in cases:
         best = 1e9
         for _ in range(reps):
             torch.cuda.synchronize(); t0 = time.perf_counter(); got = enc.decode_device(dev, c, dims, outs); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-        assert all(st == 0 for st, _, _ in got)
-        assert all(torch.equal(px, t) for (st, px, _), t in zip(got, ts))
+        if not os.environ.get("FPNG_TIMING_NOCHECK"):
+            assert all(st == 0 for st, _, _ in got)
+            assert all(torch.equal(px, t) for (st, px, _), t in zip(got, ts))
         mb = sum(len(p) for p in pngs) / 1e6
         print(f"{name} flags={flags}: {best*1e3:7.3f} ms per step = {n*w*h/best/1e9:7.2f} GP/s ({mb:.0f} MB of PNG -> {n*w*h*c/1e6:.0f} MB of pixels; "
               f"{(mb + n*w*h*c/1e6)/1e3/best:6.0f} GB/s algorithmic)", flush=True)

@@ -9,8 +9,8 @@ constexpr uint32_t kSubBits = 512;      // token bits per subsequence (one threa
 constexpr uint32_t kDecSubBlock = 512;  // subsequences per workgroup of the synchronisation (a file's subsequences are padded to whole workgroups)
 constexpr uint32_t kDecLeadIn = 128;    // bits a subsequence's first decode starts early (decode_core.h: sub_first)
 constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_emit_kernel (divides kDecSubBlock)
-constexpr uint32_t kDecUnfRows = 128;   // rows per segment of the Up filter's column sums
-enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecSawEob = 0x100u };
+constexpr uint32_t kDecUnfRows = 32;    // rows per segment of the Up filter's undoing (held in registers)
+enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecBadFilter = 8u, kDecStalled = 16u, kDecSawEob = 0x100u };
 
 struct DecJob {
     const uint8_t *z;         // device: the zlib stream (IDAT payload) from the dword its first byte (0x78) lies in; readable up to z_bytes + 16 rounded down to a dword
@@ -20,7 +20,7 @@ struct DecJob {
     const uint32_t *lut;      // device: dec::kLutDwords words (decode_core.h)
     uint8_t *filt;            // device scratch: the filtered stream, h rows of bpl + 1 bytes (the filter byte first), 16-byte aligned
     uint8_t *out;             // device: w * h * dst_c pixels
-    uint32_t *segsum;         // device scratch: (nseg - 1) x ceil(bpl / 4) dwords, the Up filter's column sums per segment of rows
+    uint32_t *segsum;         // device scratch: nseg x ceil(bpl / 4) 8-byte granules {tag, column sum} of dec_unfilter_kernel's look-back
     uint32_t w, h, src_c, dst_c, bpl;
     uint32_t n_sub;           // subsequences of the file
     uint32_t sub_base;        // index of its first subsequence (a multiple of kDecSubBlock: one file per workgroup)
@@ -38,6 +38,22 @@ struct DecBlockRec {
     uint32_t entry_rel;     // where its first subsequence starts, in bits behind the workgroup's first nominal bit
     uint32_t exit_rel;      // where its last subsequence ends, in bits behind the next workgroup's first nominal bit
     uint32_t pad_[3];
+};
+
+// dec_unfilter_kernel's work items -- (segment of rows, block of 256 dword columns) of a file -- numbered segment by segment over a
+// group of files: the files sorted by segment count (most first) in order[]; cbpre[k] = column blocks of the first k of them;
+// a piece = a range of segments over which the same `alive` first files of that order still have rows
+struct DecUnfPiece {
+    uint32_t item0; // number of its first item
+    uint32_t seg0;  // its first segment
+    uint32_t alive;
+    uint32_t pad_;
+};
+struct DecUnfPlan {
+    const DecUnfPiece *pieces;
+    const uint32_t *cbpre; // n_files + 1
+    const uint32_t *order; // n_files: indices into the group's jobs
+    uint32_t n_pieces, total_items;
 };
 
 // per-subsequence arrays (index = batch-wide subsequence number)
@@ -59,6 +75,6 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, uint32_t *status);
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch);
 
 } // namespace fpng_amd

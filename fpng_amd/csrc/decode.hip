@@ -20,8 +20,8 @@
 //                       into the filtered stream as whole aligned dwords (a thread completes its last dword with the next
 //                       subsequence's first bytes); every rule of the reference's decoder is checked (filter literal 0 then 2,
 //                       matches whole pixels inside a row, the stream ends 4 bytes before the IDAT does)
-//   dec_unfilter_sums_kernel / dec_unfilter_kernel   the Up filter undone: one thread per dword column and segment of kDecUnfRows
-//                       rows (segment sums first), channel count conversion
+//   dec_unfilter_kernel the Up filter undone in one pass: one thread per dword column and segment of kDecUnfRows rows, the sums of
+//                       the segments above through a decoupled look-back; channel count conversion; the rows' filter literals
 //   dec_stored_kernel   files that are stored blocks (reference fpng.cpp:2107-2207): a strided copy
 #include "decode.h"
 #include "decode_core.h"
@@ -118,7 +118,7 @@ template <int WAVES> __device__ __forceinline__ uint32_t block_sum(uint32_t v, u
 #define FPNG_DEC_VOTE 1
 #endif
 #ifndef FPNG_DEC_PERSISTENT // 1: a few workgroups per compute unit loop over the blocks; 0: one workgroup per block
-#define FPNG_DEC_PERSISTENT 1
+#define FPNG_DEC_PERSISTENT 0
 #endif
 #ifndef FPNG_DEC_WGS // workgroups per compute unit the register allocation of the two decoding kernels aims at
 #define FPNG_DEC_WGS 1
@@ -383,12 +383,17 @@ __global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(cons
     }
 }
 
-// ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256); one thread per DWORD column (four byte columns: packed
-//      byte adds) and SEGMENT of kUnfRows rows -- a column alone is a chain of h dependent steps and an 8K frame has only 7680 of
-//      them.  dec_unfilter_sums_kernel adds up every segment, dec_unfilter_kernel starts from the sum of the segments above its
-//      own (<= h / kUnfRows loads) and writes the pixels, 3 <-> 4 channels on the way out.  The rows sit in the filtered stream
-//      at a stride of bpl + 1 bytes: unaligned dword loads ----
+// ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256), every row read ONCE.  One workgroup per kDecBlock dword
+//      columns (four byte columns each: packed byte adds) and SEGMENT of kUnfRows rows, which it holds in registers: it adds them
+//      up, publishes the segment's column sums, collects the sums of the segments above -- a decoupled look-back: every column sum
+//      travels as ONE 8-byte {tag, value} granule written with an agent-scope store (tag = call epoch << 2 | 1: the segment's own
+//      sum, | 2: the sum of everything down to its last row), so the value is its own flag and no fence is needed
+//      (cdna_hip_programming.md, publish/consume recipe R2); a workgroup only ever waits for workgroups with a LOWER ticket, and
+//      tickets are drawn in the order the workgroups start -- then writes the pixels, 3 <-> 4 channels on the way out.  The rows sit
+//      in the filtered stream at a stride of bpl + 1 bytes: unaligned dword loads.  The filter literal in front of every row must be
+//      0, then 2 = Up (reference src/fpng.cpp:2255-2259): one lane of the first column block looks. ----
 constexpr uint32_t kUnfRows = kDecUnfRows;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
 __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)
 {
     return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
@@ -399,50 +404,105 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__global__ __launch_bounds__(kDecBlock) void dec_unfilter_sums_kernel(const DecJob *jobs, const uint32_t *status, uint32_t col_blocks)
+__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch)
 {
-    const DecJob &job = jobs[blockIdx.y];
-    if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
-    const uint32_t cb = blockIdx.x % col_blocks, sg = blockIdx.x / col_blocks;
-    const uint32_t j4 = cb * kDecBlock + threadIdx.x, ncol = (job.bpl + 3) / 4;
-    if (j4 >= ncol || sg + 1 >= job.nseg) return; // (nobody reads the last segment's sum)
-    const size_t stride = (size_t)job.bpl + 1;
-    const uint8_t *F = job.filt + 1 + (size_t)j4 * 4 + (size_t)sg * kUnfRows * stride;
-    uint32_t acc = 0;
-#pragma unroll 8
-    for (uint32_t y = 0; y < kUnfRows; y++) acc = add_bytes(acc, load_u32_unaligned(F + (size_t)y * stride));
-    job.segsum[(size_t)sg * ncol + j4] = acc;
-}
-__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, uint32_t *status, uint32_t col_blocks)
-{
-    const DecJob &job = jobs[blockIdx.y];
-    if (job.mode != 0 || (status[blockIdx.y] & ~kDecSawEob)) return;
-    const uint32_t cb = blockIdx.x % col_blocks, sg = blockIdx.x / col_blocks; // dword column block of the file's rows, segment of rows
-    const uint32_t j4 = cb * kDecBlock + threadIdx.x, ncol = (job.bpl + 3) / 4;
-    if (j4 >= ncol || sg >= job.nseg) return;
-    const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4);
-    const size_t stride = (size_t)job.bpl + 1, os = (size_t)job.w * dc;
-    const bool whole = sc == dc && nb == 4 && (os & 3) == 0 && (((uintptr_t)job.out) & 3) == 0; // aligned dword stores
-    uint32_t acc = 0;
-    for (uint32_t q = 0; q < sg; q++) acc = add_bytes(acc, job.segsum[(size_t)q * ncol + j4]);
-    const uint32_t y0 = sg * kUnfRows, y1 = min(job.h, y0 + kUnfRows);
-    const uint8_t *F = job.filt + 1 + (size_t)j4 * 4;
-    bool bad_filter = false;
-    for (uint32_t y = y0; y < y1; y++) {
-        if (!j4) bad_filter |= F[(size_t)y * stride - 1] != (y ? 2 : 0); // the row's filter literal: 0, then 2 = Up (reference :2255-2259)
-        acc = add_bytes(acc, load_u32_unaligned(F + (size_t)y * stride));
-        uint8_t *orow = job.out + (size_t)y * os;
-        if (whole)
-            *(uint32_t *)(orow + (size_t)j4 * 4) = acc;
-        else
-            for (uint32_t k = 0; k < nb; k++) {
-                const uint32_t j = j4 * 4 + k, px = j / sc, ch = j - px * sc;
-                if (ch >= dc) continue; // alpha dropped
-                orow[(size_t)px * dc + ch] = (uint8_t)(acc >> (8 * k));
-                if (dc == 4 && sc == 3 && ch == 2) orow[(size_t)px * dc + 3] = 0xFF;
+    // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
+    // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
+    // cbpre[] = their column blocks' prefix sums.  One workgroup per item, item = workgroup number: an item waits for items with
+    // LOWER numbers only, and the hardware starts the workgroups of a grid in rising order (per XCD, each XCD taking a fixed share
+    // of the numbers: the lowest unfinished item is then always running or next in line for a free slot).  Measured alternatives,
+    // 8 x 8K: tickets drawn from one atomic counter 1.72 ms, from one counter per column block 0.78 ms, persistent workgroups
+    // taking their items in rising order 0.89 ms, this 0.54 ms, the former two kernels (sums, then a second read) 0.88 ms.  A spin
+    // that does not end -- it cannot, unless workgroups do not start in that order after all -- gives up after kSpinLimit polls
+    // and leaves the file to the CPU decoder (FPNG_AMD_DECODE_UNDECIDED).
+    constexpr uint32_t kSpinLimit = 1u << 20;
+    {
+        const uint32_t item = blockIdx.x;
+        if (item >= plan.total_items) return;
+        uint32_t lo = 0, hi = plan.n_pieces;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (plan.pieces[mid].item0 <= item) lo = mid; else hi = mid;
+        }
+        const DecUnfPiece pc = plan.pieces[lo];
+        const uint32_t per_seg = plan.cbpre[pc.alive], rel = item - pc.item0, sg = pc.seg0 + rel / per_seg, within = rel % per_seg;
+        lo = 0, hi = pc.alive;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (plan.cbpre[mid] <= within) lo = mid; else hi = mid;
+        }
+        const uint32_t ji = plan.order[lo], cb = within - plan.cbpre[lo];
+        const DecJob &job = jobs[ji];
+        // (only bits that the kernels in FRONT of this one set decide: every workgroup must come to the same conclusion about a
+        //  file, or a later segment would wait for an earlier one that was skipped -- the checks below have bits of their own)
+        if (job.mode != 0 || (status[ji] & (kDecNotConverged | kDecBadStream))) return;
+        const uint32_t ncol = (job.bpl + 3) / 4;
+        const uint32_t j4 = cb * kDecBlock + threadIdx.x;
+        const uint32_t y0 = sg * kUnfRows, nrows = min(kUnfRows, job.h - y0);
+        const size_t stride = (size_t)job.bpl + 1;
+        if (cb == 0 && threadIdx.x == 0) {
+            bool bad = false;
+            for (uint32_t k = 0; k < nrows; k++) bad |= job.filt[(size_t)(y0 + k) * stride] != (y0 + k ? 2 : 0);
+            if (bad) atomicOr(&status[ji], kDecBadFilter);
+        }
+        if (j4 >= ncol) return;
+        const uint8_t *F = job.filt + 1 + (size_t)j4 * 4 + (size_t)y0 * stride;
+        uint32_t v[kUnfRows];
+#pragma unroll
+        for (uint32_t k = 0; k < kUnfRows; k++) v[k] = k < nrows ? load_u32_unaligned(F + (size_t)k * stride) : 0u;
+        uint32_t p = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kUnfRows; k++) p = add_bytes(p, v[k]), v[k] = p;
+        gu64 *gran = (gu64 *)(uintptr_t)job.segsum + j4;
+        uint32_t carry = 0;
+        if (sg + 1 < job.nseg || sg) { // (a file of one segment publishes nothing)
+            gu64 *mine = gran + (size_t)sg * ncol;
+            if (sg == 0)
+                __hip_atomic_store(mine, ((unsigned long long)(epoch << 2 | 2u) << 32) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                if (sg + 1 < job.nseg) __hip_atomic_store(mine, ((unsigned long long)(epoch << 2 | 1u) << 32) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool stalled = false;
+                for (uint32_t q = sg; q-- > 0 && !stalled;) {
+                    gu64 *g = gran + (size_t)q * ncol;
+                    unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t spins = 0; (uint32_t)(x >> 34) != epoch; spins++) {
+                        if (spins == kSpinLimit) {
+                            stalled = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    carry = add_bytes(carry, (uint32_t)x);
+                    if (((uint32_t)(x >> 32) & 3u) == 2u) break;
+                }
+                if (stalled) atomicOr(&status[ji], kDecStalled);
+                if (sg + 1 < job.nseg)
+                    __hip_atomic_store(mine, ((unsigned long long)(epoch << 2 | 2u) << 32) | add_bytes(carry, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4);
+        const size_t os = (size_t)job.w * dc;
+        const bool whole = sc == dc && nb == 4 && (os & 3) == 0 && (((uintptr_t)job.out) & 3) == 0; // aligned dword stores
+        uint8_t *orow = job.out + (size_t)y0 * os;
+        if (whole) {
+#pragma unroll
+            for (uint32_t k = 0; k < kUnfRows; k++)
+                if (k < nrows) *(uint32_t *)(orow + (size_t)k * os + (size_t)j4 * 4) = add_bytes(carry, v[k]);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < kUnfRows; k++) {
+                const uint32_t acc = add_bytes(carry, v[k]);
+                uint8_t *o = orow + (size_t)k * os;
+                for (uint32_t b = 0; b < 4; b++) {
+                    const uint32_t j = j4 * 4 + b, px = j / sc, ch = j - px * sc;
+                    if (k >= nrows || b >= nb || ch >= dc) continue; // (alpha dropped)
+                    o[(size_t)px * dc + ch] = (uint8_t)(acc >> (8 * b));
+                    if (dc == 4 && sc == 3 && ch == 2) o[(size_t)px * dc + 3] = 0xFF;
+                }
+            }
+        }
     }
-    if (bad_filter) atomicOr(&status[blockIdx.y], kDecBadStream);
 }
 
 // ---- stored files: the filter-0 stream sits in stored blocks of 65535 bytes (the host checked their headers and the filter bytes) ----
@@ -486,17 +546,13 @@ void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint3
     const uint32_t wgs = n_blocks * (kSubBlock / kEmitBlock);
     if (wgs) hipLaunchKernelGGL(dec_emit_kernel, dim3(FPNG_DEC_PERSISTENT ? std::min(wgs, resident) : wgs), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, a, eob_index, block_off, status);
 }
-// jobs / status: of the group's first file.  The y dimension of a grid holds at most 65535 workgroups: files in slices.
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t max_bpl, uint32_t *status)
+// jobs / status: of the group's first file; plan: device arrays (decode_api.cpp); epoch: this launch's (a new one every time; the
+// granules are never cleared)
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch)
 {
-    const uint32_t col_blocks = ((max_bpl + 3) / 4 + kDecBlock - 1) / kDecBlock, segs = (max_rows + kUnfRows - 1) / kUnfRows;
-    for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) {
-        const uint32_t nj = min(32768u, n_jobs - j0);
-        const dim3 ugrid(col_blocks * segs, nj);
-        if (segs > 1) hipLaunchKernelGGL(dec_unfilter_sums_kernel, ugrid, dim3(kDecBlock), 0, s, jobs + j0, status + j0, col_blocks);
-        hipLaunchKernelGGL(dec_unfilter_kernel, ugrid, dim3(kDecBlock), 0, s, jobs + j0, status + j0, col_blocks);
-        hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, nj), dim3(kDecBlock), 0, s, jobs + j0);
-    }
+    if (plan.total_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(plan.total_items), dim3(kDecBlock), 0, s, jobs, plan, status, epoch);
+    for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) // (the y dimension of a grid holds at most 65535 workgroups)
+        hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0);
 }
 
 } // namespace fpng_amd

@@ -7,6 +7,7 @@
 #include "encoder.h"
 #include "png_parse.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -236,7 +237,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             filt_total += ((total + 15) & ~(size_t)15) + 16;
             j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
             j.segsum = (uint32_t *)(uintptr_t)seg_total;
-            seg_total += (size_t)(j.nseg - 1) * ((j.bpl + 3) / 4);
+            seg_total += (size_t)j.nseg * ((j.bpl + 3) / 4);
         }
         if (device_data) {
             const uintptr_t zr = (uintptr_t)files[i].data + p.idat_ofs + 8;
@@ -255,12 +256,14 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
     uint8_t *d_z, *d_filt;
-    uint32_t *d_seg, *d_status, *d_changed;
+    uint32_t *d_status, *d_changed;
+    unsigned long long *d_seg;
     uint64_t *d_block_off;
     DecBlockRec *d_recs;
     DecSubArrays d_sub;
     uint32_t *d_luts;
     DecJob *d_jobs;
+    uint8_t *d_plan;
     const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + kDecSubBlock - 1) / kDecSubBlock;
     {
         size_t need = 0;
@@ -269,17 +272,26 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_seg = carve(seg_total * 4), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
+        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
                      o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
                      o_luts = carve(std::max<size_t>(luts.size(), 1) * dec::kLutDwords * 4),
-                     o_jobs = carve(nj * sizeof(DecJob)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
+                     o_jobs = carve(nj * sizeof(DecJob)), o_plan = carve(((size_t)nj + kMaxGroups) * (sizeof(DecUnfPiece) + 8)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
+        // the look-back granules of dec_unfilter_kernel: never cleared between calls -- every launch has its own epoch, and memory
+        // that was just allocated (any bit pattern) is zeroed once
+        if ((rc = e->d_dec_gran.ensure(std::max<size_t>(seg_total, 1)))) return rc;
+        if (e->d_dec_gran.fresh) {
+            HIP_TRY(hipMemsetAsync(e->d_dec_gran.p, 0, e->d_dec_gran.cap * 8, e->stream));
+            e->d_dec_gran.fresh = false;
+        }
+        d_seg = e->d_dec_gran.p;
         uint8_t *base = e->d_decode.p;
-        d_z = base + o_z, d_filt = base + o_filt, d_seg = (uint32_t *)(base + o_seg);
+        d_z = base + o_z, d_filt = base + o_filt;
         d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
         d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
         d_luts = (uint32_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
+        d_plan = base + o_plan;
     }
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
     uint32_t *d_eob = d_status + nj + kMaxGroups;
@@ -289,7 +301,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (!device_data) j.z = d_z + (size_t)(uintptr_t)j.z;
         if (!j.mode) {
             j.filt = d_filt + (size_t)(uintptr_t)j.filt;
-            j.segsum = d_seg + (size_t)(uintptr_t)j.segsum;
+            j.segsum = (uint32_t *)(d_seg + (size_t)(uintptr_t)j.segsum);
             j.lut = d_luts + (size_t)p.lut * dec::kLutDwords;
         }
     }
@@ -297,7 +309,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     //      memory an "asynchronous" copy keeps its caller busy for most of its duration, so a thread of its own issues them).
     //      Files that are in device memory already form one group. ----
     struct Group {
-        uint32_t j0, j1, blk0, blk1, max_rows, max_bpl;
+        uint32_t j0, j1, blk0, blk1;
+        DecUnfPlan plan; // (device pointers)
     };
     std::vector<Group> groups;
     {
@@ -306,9 +319,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         uint64_t total = 0, run = 0;
         for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
         auto close = [&](uint32_t j0, uint32_t j1) {
-            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, 1, 1};
-            for (uint32_t q = j0; q < j1; q++)
-                if (!jobs[q].mode) g.max_rows = std::max(g.max_rows, jobs[q].h), g.max_bpl = std::max(g.max_bpl, jobs[q].bpl);
+            Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, {}};
             groups.push_back(g);
         };
         uint32_t j0 = 0, cur = 0;
@@ -363,14 +374,45 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     } joiner{uploader};
     for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * dec::kLutDwords, luts[k].data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
+    {   // dec_unfilter_kernel's work items per group of files, numbered segment by segment (decode.h: DecUnfPlan)
+        DecUnfPiece *d_pieces = (DecUnfPiece *)d_plan;
+        uint32_t *d_words = (uint32_t *)(d_pieces + nj + kMaxGroups);
+        std::vector<DecUnfPiece> pieces;
+        std::vector<uint32_t> words; // per group: cbpre (files + 1), then order (files)
+        for (Group &g : groups) {
+            std::vector<uint32_t> order;
+            for (uint32_t q = g.j0; q < g.j1; q++)
+                if (!jobs[q].mode) order.push_back(q - g.j0);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[g.j0 + a].nseg > jobs[g.j0 + b].nseg; });
+            const uint32_t m = (uint32_t)order.size();
+            const size_t w0 = words.size(), p0 = pieces.size();
+            words.push_back(0);
+            for (uint32_t k = 0; k < m; k++) words.push_back(words.back() + ((jobs[g.j0 + order[k]].bpl + 3) / 4 + 255) / 256);
+            words.insert(words.end(), order.begin(), order.end());
+            uint32_t seg = 0, item = 0;
+            for (uint32_t alive = m; alive >= 1; alive--) { // the alive-th file of the order is the next one to run out of rows
+                const uint32_t end = jobs[g.j0 + order[alive - 1]].nseg;
+                if (end > seg) {
+                    pieces.push_back({item, seg, alive, 0});
+                    item += (end - seg) * words[w0 + alive];
+                    seg = end;
+                }
+            }
+            g.plan.pieces = d_pieces + p0, g.plan.n_pieces = (uint32_t)(pieces.size() - p0), g.plan.total_items = item;
+            g.plan.cbpre = d_words + w0, g.plan.order = d_words + w0 + m + 1;
+        }
+        if (!pieces.empty()) HIP_TRY(hipMemcpyAsync(d_pieces, pieces.data(), pieces.size() * sizeof(DecUnfPiece), hipMemcpyHostToDevice, s));
+        if (!words.empty()) HIP_TRY(hipMemcpyAsync(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1 + 2 * kMaxGroups) * 4, s));
-    auto finish_group = [&](const Group &g) { // everything behind the synchronisation (every step of it is idempotent)
+    auto finish_group = [&](const Group &g) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
         const uint32_t nblk = g.blk1 - g.blk0;
         if (nblk) {
             launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob);
             launch_dec_emit(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, d_sub, d_eob, d_block_off, d_status);
         }
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.max_rows, g.max_bpl, d_status + g.j0);
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, ++e->dec_epoch & 0x3FFFFFFFu);
+        return hipSuccess;
     };
     for (uint32_t gi = 0; gi < ng; gi++) {
         const Group &g = groups[gi];
@@ -388,7 +430,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
         for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
-        finish_group(g);
+        HIP_TRY(finish_group(g));
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
     HIP_TRY(hipGetLastError());
@@ -420,7 +462,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u needed %u rounds\n", since(), gi, r + 1);
         HIP_TRY(hipMemsetAsync(d_status + g.j0, 0, (g.j1 - g.j0) * 4, s));
-        finish_group(g);
+        HIP_TRY(finish_group(g));
     }
     if (again) {
         HIP_TRY(hipGetLastError());
@@ -435,9 +477,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
                     jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, (unsigned long long)jobs[k].first_bit, status[k]);
         if (jobs[k].mode) continue;
         int32_t &st = results[job_file[k]].status;
-        if (status[k] & kDecNotConverged) // (nothing else is known then: "invalid" may be a speculative decode's)
+        if (status[k] & (kDecNotConverged | kDecStalled)) // (nothing else is known then: "invalid" may be a speculative decode's)
             st = FPNG_AMD_DECODE_UNDECIDED;
-        else if (status[k] & kDecBadStream)
+        else if (status[k] & (kDecBadStream | kDecBadFilter))
             st = fpng::FPNG_DECODE_NOT_FPNG;
         else if (!(status[k] & kDecSawEob))
             st = fpng::FPNG_DECODE_NOT_FPNG; // the stream never ended

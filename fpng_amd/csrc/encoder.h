@@ -179,6 +179,8 @@ struct fpng_amd_encoder {
     DeviceBuf<uint32_t> d_stream_partials; // fpng_amd_encode_host_to(): partials of all bands of the frame
     uint32_t last_host_bands = 0;  // row bands of the last fpng_amd_encode_host*() call (1 = the serial path)
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
+    DeviceBuf<unsigned long long> d_dec_gran; // ... the look-back granules of dec_unfilter_kernel: zeroed when allocated, then told apart by epochs
+    uint32_t dec_epoch = 0;
     hipStream_t dec_up = nullptr; // ... the stream the files' bytes are uploaded on, one event per group of files
     hipEvent_t dec_ev[8] = {};
     PinnedBuf<uint8_t> h_dec_fetch; // fpng_amd_decode_batch_device(): the files' first and last bytes on their way to the host parser

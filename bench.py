@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the fpng encode hot path on MI355X.
+"""bench.py -- throughput of the fpng encode hot path (and of the GPU decoder on the encoder's output) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|4k|1080p] [--batch B] [--flags F]
 
@@ -47,9 +47,12 @@ def parse():
     ap.add_argument("--prewarm", type=int, default=60,
                     help="untimed steps before the W warmup steps: throughput needs ~40 back-to-back steps (20-50 ms of "
                          "sustained load) to settle, a cold 20-step run reads 15-25 %% low (DESIGN.md section 6)")
-    ap.add_argument("--mode", default="batch", choices=["batch", "rowband"],
-                    help="batch: every rank encodes its own images (BASELINE configs 2/3/5, the headline); rowband: ONE image "
-                         "sharded by rows over the ranks, one IDAT, windows gathered to rank 0 over RCCL (BASELINE config 4)")
+    ap.add_argument("--mode", default="batch", choices=["batch", "rowband", "decode"],
+                    help="batch: every rank encodes its own images (BASELINE configs 2/3/5, the headline; its line also carries a "
+                         "`decode` object); rowband: ONE image sharded by rows over the ranks, one IDAT, windows gathered to rank 0 "
+                         "over RCCL (BASELINE config 4); decode: the line is about the GPU decoder (the files the encoder just wrote, "
+                         "still in device memory, back to pixels in device memory)")
+    ap.add_argument("--decode-steps", type=int, default=20, help="timed decode steps per region (the `decode` object / --mode decode)")
     ap.add_argument("--regions", type=int, default=3,
                     help="timed regions per run, each EXACTLY --steps steps between two barriers; value = the median region, "
                          "`runs` / `spread` report all of them (a single 10 ms region cannot show a 5 %% change)")
@@ -278,6 +281,90 @@ def cpu_baseline(w, h, c, kind, flags, reps):
             "sample": f"1 image {w}x{h}x{c} {kind}, best of {max(1, reps // 2)}, scalar C port", "png_bytes": len(png)}
 
 
+def decode_cpu_baseline(png, w, h, c):
+    """The reference's own decoder (oracle/_ref, fpng_decode_memory into a reused vector, best of 3: the way
+    reference/src/fpng_test.cpp:1236-1273 times it) on ONE host core; without its build the drop-in's CPU decoder."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ref
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+    mp = w * h / 1e6
+    try:
+        if cpu_ref.have_ref():
+            secs = cpu_ref.ref().time_decode(png, c, 3)
+            return {"value": round(mp / secs, 2), "unit": "MP/s", "cores": 1, "kind": "reference",
+                    "sample": f"1 file {w}x{h}x{c} ({len(png)} bytes), fpng_decode_memory best of 3, fpng.cpp SSE4.1 build"}
+        os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+        import dropin
+        secs = dropin.time_decode(png, c, reps=3)
+        return {"value": round(mp / secs, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+                "sample": f"1 file {w}x{h}x{c} ({len(png)} bytes), the drop-in's CPU decoder (fpng_decode.cpp), best of 3"}
+    except Exception as e:
+        return {"error": str(e)[:120]}
+    finally:
+        os.environ.pop("FPNG_AMD_DECODE_CPU", None)
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except Exception:
+            pass
+
+
+def decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, with_cpu):
+    """A decode step = ONE fpng_amd_decode_batch_device() call over the B files the encoder wrote (device-resident; only a head and
+    a tail of each file visit the host for the container walk), pixels back into device memory; the call returns when they are
+    there, so the K steps of a region run one after another.  Roofline: algorithmic bytes = the files read once + the pixels
+    written once, against the kernel with the longest HIP-event time; parity: the pixels must equal the frames that were encoded."""
+    B = len(imgs)
+    dims = [(w, h)] * B
+    outs = [torch.empty(w * h * c, dtype=torch.uint8, device=imgs[0].device) for _ in range(B)]
+    for _ in range(3):
+        got = enc.decode_device(pngs, c, dims, outs)
+    K = max(1, args.decode_steps)
+    runs = []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            got = enc.decode_device(pngs, c, dims, outs)
+        barrier()
+        runs.append(all_max(time.perf_counter() - t0))
+    elapsed = sorted(runs)[len(runs) // 2]
+    if not all(st == 0 for st, _, _ in got):
+        raise SystemExit(f"bench.py: decode status {[st for st, _, _ in got]}")
+    for i, ((st, px, _), t) in enumerate(zip(got, imgs)):
+        if not torch.equal(px, t):
+            raise SystemExit(f"bench.py: DECODE PARITY FAILURE, file {i}: pixels differ from the encoded frame")
+    enc.set_profiling(True)
+    ph = {}
+    reps = 5
+    for _ in range(reps):
+        enc.decode_device(pngs, c, dims, outs)
+        for k, v in enc.last_decode_phase_ms().items():
+            ph[k] = ph.get(k, 0.0) + v / reps
+    enc.set_profiling(False)
+    png_bytes = sum(int(p.numel()) for p in pngs)
+    alg = png_bytes + B * w * h * c
+    dom = max(ph, key=lambda k: ph[k])
+    kernels_ms = sum(ph.values())
+    value = world * B * w * h * K / elapsed / 1e6
+    traffic, traffic_src = committed_traffic(f"dec_{dom}_kernel", "decode_" + workload_tag(args))
+    out = {"metric": "decode megapixels/sec (whole node), device-resident files -> device-resident pixels", "value": round(value, 1), "unit": "MP/s",
+           "steps": K, "ms_per_step": round(elapsed / K * 1e3, 4), "runs": [round(world * B * w * h * K / r / 1e6, 1) for r in runs],
+           "parity_checked": True, "parity_images": B, "png_bytes_per_step_per_gpu": png_bytes,
+           "roofline": {"bound": "hbm", "kernel": f"dec_{dom}_kernel", "achieved": round(alg / (ph[dom] / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ph[dom] / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": alg, "kernel_ms": round(ph[dom], 4), "all_kernels_ms": round(kernels_ms, 4),
+                        "pipeline_frac": round(alg / (kernels_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "step_frac": round(alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS, 4),
+                        "phase_ms": {k: round(v, 4) for k, v in ph.items()}}}
+    if with_cpu:
+        out["cpu_baseline"] = decode_cpu_baseline(bytes(pngs[0].cpu().numpy()), w, h, c)
+        if "value" in out["cpu_baseline"]:
+            out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
+    return out
+
+
 def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
     """One image, rows sharded over the ranks (SURVEY 8e / BASELINE config 4).  A step = the whole exchange: band encode,
     all_gather of the band records, placement at the band's bit position, windows to rank 0, wrap.  Steps cannot be
@@ -483,7 +570,32 @@ def main():
                    "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- the way back: the files of the last submission, still in device memory, decoded to pixels in device memory ----
+    def all_max(el):
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    last_set = out_sets[(args.steps - 1) & 3]
+    pngs = [o[: r[0]] for o, r in zip(last_set, res)]
+    dec = decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, rank == 0 and world == 1 and not args.no_cpu_baseline)
+    if True:
+        if args.mode == "decode":  # the line is the decoder's; what the encoder did in this run goes along
+            enc_part = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "parity_checked", "parity_images", "roofline")}
+            line = dict(line, **{k: dec[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "runs", "parity_checked", "parity_images", "roofline")})
+            line["spread"] = round((max(dec["runs"]) - min(dec["runs"])) / dec["value"], 4) if len(dec["runs"]) > 1 else None
+            line["warmup"], line["prewarm"] = 3, 0
+            line["config"]["workload"] = (f"{B} fpng files ({w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}', flags={args.flags}, as the encoder wrote them, "
+                                          "device-resident) per GPU per step -> pixels in device memory, equal to the encoded frames")
+            for k in ("cpu_baseline", "speedup_vs_cpu_1core"):
+                if k in dec:
+                    line[k] = dec[k]
+            line["encode"] = enc_part
+        else:
+            line["decode"] = dec
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode != "decode":
         line["end_to_end"] = end_to_end(local_rank, w, h, c, args.kind, args.flags)
         line["cpu_baseline"] = cpu_baseline(w, h, c, args.kind, args.flags, args.cpu_reps)
         line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 1)

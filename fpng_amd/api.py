@@ -352,6 +352,13 @@ class Encoder:
             out.append((r.status, made[i].view(-1)[: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
         return out
 
+    def last_decode_phase_ms(self):
+        """{"sync", "offsets", "emit", "unfilter"} -> ms of the last decode call's kernels (first group of files), measured with HIP
+        events on the encoder's stream while set_profiling(True)."""
+        ms = (C.c_float * 4)()
+        check(self.lib.fpng_amd_decode_last_phase_ms(self.h, C.byref(ms)))
+        return dict(zip(("sync", "offsets", "emit", "unfilter"), (float(v) for v in ms)))
+
     def decode_host(self, png, desired_chans):
         """fpng_amd_decode_host: ONE fpng-written file (bytes) -> (status, uint8 numpy array (h, w, desired_chans) or None, channels_in_file);
         container checks, upload, GPU decode and one download into host memory (what fpng::fpng_decode_memory does for large images).

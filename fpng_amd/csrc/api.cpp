@@ -316,6 +316,8 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->d_stream_partials.release();
     e->d_decode.release();
     e->d_dec_gran.release();
+    for (hipEvent_t ev : e->dec_prof_ev)
+        if (ev) (void)hipEventDestroy(ev);
     e->h_dec_fetch.release();
     if (e->dec_up) (void)hipStreamDestroy(e->dec_up);
     for (hipEvent_t ev : e->dec_ev)

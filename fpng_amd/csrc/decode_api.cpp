@@ -405,13 +405,27 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (!words.empty()) HIP_TRY(hipMemcpyAsync(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1 + 2 * kMaxGroups) * 4, s));
+    // profiling (fpng_amd_encoder_set_profiling): events around the kernels of the first group of files
+    const bool prof = e->profiling;
+    e->dec_prof_recorded = false;
+    if (prof)
+        for (hipEvent_t &ev : e->dec_prof_ev)
+            if (!ev) HIP_TRY(hipEventCreate(&ev));
+    auto stamp = [&](const Group &g, int k) -> hipError_t { return (prof && &g == groups.data()) ? hipEventRecord(e->dec_prof_ev[k], s) : hipSuccess; };
     auto finish_group = [&](const Group &g) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
         const uint32_t nblk = g.blk1 - g.blk0;
+        hipError_t pe = stamp(g, 1);
+        if (pe != hipSuccess) return pe;
         if (nblk) {
             launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob);
+            if ((pe = stamp(g, 2)) != hipSuccess) return pe;
             launch_dec_emit(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, d_sub, d_eob, d_block_off, d_status);
-        }
+        } else if ((pe = stamp(g, 2)) != hipSuccess)
+            return pe;
+        if ((pe = stamp(g, 3)) != hipSuccess) return pe;
         launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, ++e->dec_epoch & 0x3FFFFFFFu);
+        if ((pe = stamp(g, 4)) != hipSuccess) return pe;
+        if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
     };
     for (uint32_t gi = 0; gi < ng; gi++) {
@@ -427,6 +441,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u (files %u..%u, %u workgroups) starts\n", since(), gi, g.j0, g.j1, g.blk1 - g.blk0);
         const uint32_t nblk = g.blk1 - g.blk0;
+        HIP_TRY(stamp(g, 0));
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
         for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
@@ -488,6 +503,16 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
 }
 
 } // namespace
+
+extern "C" int fpng_amd_decode_last_phase_ms(fpng_amd_encoder *e, float ms[FPNG_AMD_NUM_DECODE_PHASES])
+{
+    if (!e || !ms) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < FPNG_AMD_NUM_DECODE_PHASES; i++) ms[i] = 0.f;
+    if (!e->dec_prof_recorded) return FPNG_AMD_OK;
+    HIP_TRY(hipEventSynchronize(e->dec_prof_ev[4]));
+    for (int i = 0; i < FPNG_AMD_NUM_DECODE_PHASES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], e->dec_prof_ev[i], e->dec_prof_ev[i + 1]));
+    return FPNG_AMD_OK;
+}
 
 extern "C" int fpng_amd_decode_batch(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results)
 {

@@ -27,6 +27,7 @@ namespace dec {
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
+constexpr uint32_t kMergeSteps = 24; // sub_refix: tokens stepped one by one before it decodes the subsequence again as a whole
 enum : uint32_t { kSubEob = 1u, kSubInvalid = 4u };
 enum : uint32_t { kTokLit = 0, kTokMatch = 1, kTokEob = 2, kTokInvalid = 3 };
 
@@ -175,7 +176,9 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
 {
     uint32_t A = s.start, B = want;
     SubCount a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    while (A != B) {
+    // (at most kMergeSteps tokens: two decodes that have not met by then rarely will -- a periodic stream keeps them apart for
+    //  good -- and stepping token by token costs several times the group-wise walk that follows)
+    for (uint32_t steps = 0; A != B && steps < kMergeSteps; steps++) {
         if ((A < B ? A : B) >= boundary) break;
         if (A < B) {
             A = walk_count<true, VoteAlone>(in, lut, lenof, A, A + 1, data_limit, a);

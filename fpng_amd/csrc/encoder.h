@@ -181,6 +181,8 @@ struct fpng_amd_encoder {
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
     DeviceBuf<unsigned long long> d_dec_gran; // ... the look-back granules of dec_unfilter_kernel: zeroed when allocated, then told apart by epochs
     uint32_t dec_epoch = 0;
+    hipEvent_t dec_prof_ev[5] = {}; // profiling: around the decode kernels of the last call's first group of files
+    bool dec_prof_recorded = false;
     hipStream_t dec_up = nullptr; // ... the stream the files' bytes are uploaded on, one event per group of files
     hipEvent_t dec_ev[8] = {};
     PinnedBuf<uint8_t> h_dec_fetch; // fpng_amd_decode_batch_device(): the files' first and last bytes on their way to the host parser

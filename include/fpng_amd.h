@@ -399,6 +399,11 @@ int fpng_amd_synth_image(int kind, uint32_t seed, uint32_t w, uint32_t h, uint32
 int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *enc);
+/* ... and of the last fpng_amd_decode_batch*() call (first group of files) while profiling was enabled:
+ *      "sync,offsets,emit,unfilter" = dec_sync_kernel (all rounds), dec_offsets_kernel + dec_subscan_kernel, dec_emit_kernel,
+ *      dec_unfilter_kernel + dec_stored_kernel (fpng_amd/csrc/decode.hip). */
+#define FPNG_AMD_NUM_DECODE_PHASES 4
+int fpng_amd_decode_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_DECODE_PHASES]);
 
 /* Instrumentation of the timing build (libfpng_amd_timing.so, -DFPNG_BUILD_TIMING): n_words = 8 reads the cycle counters
  * that build_dynamic_kernel left at the head of lane `lane`'s histogram scratch (dst[7] = 0xFEED selects the second page:

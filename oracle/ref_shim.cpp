@@ -48,6 +48,24 @@ int ref_decode(const void *png, uint32_t size, uint8_t *out, size_t out_cap, uin
     return st;
 }
 
+// Timed loop for the decoder's CPU baseline: `reps` decodes of the same file into one reused vector (as
+// src/fpng_test.cpp:1236-1273 does), returns best seconds per decode (negative: the decoder's status code).
+double ref_time_decode(const void *png, uint32_t size, uint32_t desired, int reps)
+{
+    std::vector<uint8_t> v;
+    double best = 1e30;
+    for (int i = 0; i < reps; i++) {
+        uint32_t w, h, c;
+        auto t0 = std::chrono::steady_clock::now();
+        const int st = fpng::fpng_decode_memory(png, size, v, w, h, c, desired);
+        auto t1 = std::chrono::steady_clock::now();
+        if (st) return -(double)st;
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        if (s < best) best = s;
+    }
+    return best;
+}
+
 // Timed loop for the CPU baseline: `reps` encodes of the same image into one reused vector
 // (as src/fpng_test.cpp:1198-1209 does), returns best seconds per encode.
 double ref_time_encode(const void *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int reps, size_t *out_size)

@@ -152,6 +152,9 @@ class _Ref:
         L.ref_time_encode.restype = C.c_double
         L.ref_time_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.POINTER(C.c_size_t)]
+        if hasattr(L, "ref_time_decode"):
+            L.ref_time_decode.restype = C.c_double
+            L.ref_time_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.ref_init()
         self.L = L
 
@@ -182,6 +185,13 @@ class _Ref:
         st = self.L.ref_decode(b.ctypes.data, b.size, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c),
                                desired)
         return st, out, w.value, h.value, c.value
+
+    def time_decode(self, png, desired, reps=3):
+        """best seconds of `reps` fpng_decode_memory() calls into one reused vector (the reference harness's way)"""
+        b = np.frombuffer(png, dtype=np.uint8)
+        secs = self.L.ref_time_decode(b.ctypes.data, b.size, desired, reps)
+        assert secs > 0, f"reference decoder status {-secs}"
+        return secs
 
     def time_encode(self, img, w, h, c, flags=0, reps=3):
         img = np.ascontiguousarray(img, dtype=np.uint8)

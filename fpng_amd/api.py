@@ -134,10 +134,6 @@ class Node:
     def size(self):
         return self.lib.fpng_amd_node_size(self.h)
 
-    def last_host_bands(self):
-        """Row bands the last encode_host*() call was streamed in (1 = upload, encode, download one after the other)."""
-        return self.lib.fpng_amd_encoder_last_host_bands(self.h)
-
     def encode_host_batch(self, images, flags=0, outs=None, paths=None, writer_threads=0):
         arr, sizes, keep = _host_batch_records(images, outs, paths)
         check(self.lib.fpng_amd_node_encode_host_batch(self.h, arr, len(images), flags, writer_threads))

@@ -439,11 +439,18 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
             if (trace) tl[k * 6 + 4] = now_us();
             // the first request asks for an estimate of the whole file (band 0's share of the rows, plus a margin), so that
             // a growing container (std::vector) is sized once instead of band after band
-            size_t want = (size_t)r.file_off + r.bytes;
+            // (a hint, not a requirement: a caller's fixed buffer may be smaller than the estimate and still hold the file -- then
+            //  only what this band needs is asked for)
+            const size_t exact = (size_t)r.file_off + r.bytes;
+            size_t want = exact;
             if (k == 0) want = std::max(want, std::min(max_out, (size_t)((double)r.bytes * h / (r.y1 - r.y0) * 1.08) + 4096));
             out = reserve(user, want);
+            if (!out && want > exact) out = reserve(user, exact);
             if (!out) {
-                failed = FPNG_AMD_ERR_BUFFER_TOO_SMALL;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = FPNG_AMD_ERR_BUFFER_TOO_SMALL;
+                }
                 cv.notify_all();
                 return;
             }
@@ -454,7 +461,10 @@ extern "C" int fpng_amd_encode_host_to(fpng_amd_encoder *e, const void *pixels, 
                 ok = hipMemcpyAsync(out + r.file_off + r.head, d_out + r.dev_off + r.head, r.bytes - r.head, hipMemcpyDeviceToHost, s_down) == hipSuccess &&
                      hipStreamSynchronize(s_down) == hipSuccess;
             if (!ok) {
-                failed = FPNG_AMD_ERR_HIP;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = FPNG_AMD_ERR_HIP;
+                }
                 cv.notify_all();
                 return;
             }

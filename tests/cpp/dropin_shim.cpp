@@ -104,6 +104,35 @@ int shim_encode_threads(int n_threads, const void *const *imgs, const uint32_t *
     }
     return 1;
 }
+// threads, each decoding ITS file `reps` times (fpng::fpng_decode_memory into its own vector); outs[t] (cap bytes each) receives
+// thread t's last pixels, status[t] its last status code; `agree` = 1 when every repetition of a thread gave the same result.
+int shim_decode_threads(int n_threads, const void *const *pngs, const uint32_t *sizes, uint32_t desired, int reps, uint8_t *const *outs, size_t cap, int *status,
+                        size_t *out_sizes, int *agree)
+{
+    std::vector<int> same(n_threads, 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++)
+        th.emplace_back([&, t] {
+            std::vector<uint8_t> first, v;
+            int st0 = 0;
+            for (int r = 0; r < reps; r++) {
+                uint32_t w, h, c;
+                const int st = fpng::fpng_decode_memory(pngs[t], sizes[t], v, w, h, c, desired);
+                if (r == 0)
+                    first = v, st0 = st;
+                else if (st != st0 || v != first)
+                    same[t] = 0;
+                status[t] = st;
+            }
+            out_sizes[t] = v.size();
+            if (v.size() <= cap) memcpy(outs[t], v.data(), v.size());
+        });
+    for (auto &x : th) x.join();
+    *agree = 1;
+    for (int t = 0; t < n_threads; t++)
+        if (!same[t]) *agree = 0;
+    return 1;
+}
 void shim_init() { fpng::fpng_init(); }
 int shim_supported() { return fpng::fpng_cpu_supports_sse41() ? 1 : 0; }
 uint32_t shim_crc32(const void *p, size_t n, uint32_t prev) { return fpng::fpng_crc32(p, n, prev); }

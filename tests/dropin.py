@@ -32,6 +32,7 @@ def shim():
     L.shim_decode_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32]
     L.shim_encode_threads.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.POINTER(C.c_int)]
+    L.shim_decode_threads.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.shim_time_encode.restype = C.c_double
     L.shim_time_decode.restype = C.c_double
     L.shim_time_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
@@ -55,6 +56,17 @@ def decode(png, desired):
         cap = w.value * h.value * desired + 16
     out = np.zeros(cap, dtype=np.uint8)
     st = L.shim_decode(b.ctypes.data, b.size, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), desired)
+    return st, (out[: w.value * h.value * desired] if st == 0 else None), w.value, h.value, c.value
+
+
+def decode_file(path, desired):
+    """fpng::fpng_decode_file(path) -> (status, pixels or None, w, h, c)"""
+    L = shim()
+    w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    cap = max(1 << 16, os.path.getsize(path) * 300 + (1 << 20)) if os.path.exists(path) else 1 << 16
+    cap = min(cap, 1 << 30)
+    out = np.zeros(cap, dtype=np.uint8)
+    st = L.shim_decode_file(path.encode(), out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), desired)
     return st, (out[: w.value * h.value * desired] if st == 0 else None), w.value, h.value, c.value
 
 
@@ -101,6 +113,27 @@ def time_encode(img, w, h, c, flags=0, reps=5, reuse=True):
     if t < 0:
         raise RuntimeError("fpng::fpng_encode_image_to_memory failed")
     return t, n.value
+
+
+def decode_threads(pngs, desired, reps=3):
+    """fpng::fpng_decode_memory() from len(pngs) threads at once, every thread its own file `reps` times:
+    (list of (status, pixels), True when every repetition of every thread gave the same result)."""
+    L = shim()
+    n = len(pngs)
+    bufs = [np.frombuffer(bytes(p), dtype=np.uint8) for p in pngs]
+    cap = 16
+    for p in pngs:
+        st, w, h, c = get_info(p)
+        if st == 0:
+            cap = max(cap, w * h * desired)
+    outs = [np.zeros(cap, dtype=np.uint8) for _ in range(n)]
+    P = C.c_void_p * n
+    status = (C.c_int * n)()
+    out_sizes = (C.c_size_t * n)()
+    agree = C.c_int(0)
+    L.shim_decode_threads(n, P(*[b.ctypes.data for b in bufs]), (C.c_uint32 * n)(*[b.size for b in bufs]), desired, reps, P(*[o.ctypes.data for o in outs]), cap,
+                          status, out_sizes, C.byref(agree))
+    return [(int(status[t]), outs[t][: out_sizes[t]]) for t in range(n)], bool(agree.value)
 
 
 def encode_threads(images, flags, reps=3):

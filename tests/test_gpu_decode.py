@@ -252,7 +252,7 @@ def test_damaged_large_files(enc):
         pytest.skip("reference build not available")
     rng = np.random.default_rng(77)
     imgs = real_image.variants(real_image.rgb_pixels(judge))
-    sources = [(torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4)).cuda(), 0, 28), (torch.from_numpy(imgs["rgb_t4"]).cuda(), 1, 40)]
+    sources = [(torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4)).cuda(), 0, 120), (torch.from_numpy(imgs["rgb_t4"]).cuda(), 1, 160)]
     for t, flags, n in sources:
         (base,), _ = enc.encode_tensors([t], flags)
         L = len(base)
@@ -314,3 +314,76 @@ def test_device_resident_files(enc):
                     assert st == 0 and cf == t.shape[2]
                     want = t[:, :, :desired] if t.shape[2] >= desired else torch.cat([t, torch.full_like(t[:, :, :1], 255)], dim=2)
                     assert torch.equal(px, want)
+
+
+def test_decode_memory_from_many_threads_at_once(enc):
+    """fpng::fpng_decode_memory is re-entrant in the reference (SURVEY 8b); here six threads decode six different files of 1 MP and
+    more at once through the GPU tier, three times each, plus a damaged one: every thread gets the reference decoder's status and
+    pixels every time."""
+    import torch
+    import fpng_amd
+    frames = [fpng_amd.synth_image("grad", 1280, 1024, 4, seed=3), fpng_amd.synth_image("grad", 1920, 1080, 3, seed=4), fpng_amd.synth_image("blocks", 2048, 1024, 4),
+              fpng_amd.synth_image("noise", 1024, 1024, 3), fpng_amd.synth_image("grad", 3840, 2160, 4, seed=5), fpng_amd.synth_image("solid", 1500, 900, 4)]
+    pngs, _ = enc.encode_tensors([torch.from_numpy(f).cuda() for f in frames], 0)
+    bad = bytearray(pngs[0])
+    bad[len(bad) // 2] ^= 0x10
+    pngs = list(pngs) + [bytes(bad)]
+    n0 = dropin.gpu_decodes()
+    for desired in (4, 3):
+        got, agree = dropin.decode_threads(pngs, desired, reps=3)
+        assert agree
+        for png, (st, px) in zip(pngs, got):
+            st_r, px_r, *_ = judge(png, desired)
+            assert st == st_r
+            if st == 0:
+                assert np.array_equal(px, px_r)
+    assert dropin.gpu_decodes() - n0 >= 2 * 3 * 6
+
+
+def test_decode_file_goes_through_the_gpu_tier(enc, tmp_path):
+    """fpng::fpng_decode_file (reference src/fpng.cpp:3141-3222) of a large file: read, then the same path as fpng_decode_memory."""
+    import torch
+    import fpng_amd
+    img = fpng_amd.synth_image("grad", 2000, 1500, 3)
+    (png,), _ = enc.encode_tensors([torch.from_numpy(img).cuda()], 1)
+    path = str(tmp_path / "big.png")
+    with open(path, "wb") as f:
+        f.write(png)
+    n0 = dropin.gpu_decodes()
+    for desired in (3, 4):
+        st, px, w, h, c = dropin.decode_file(path, desired)
+        assert st == 0 and (w, h, c) == (2000, 1500, 3)
+        st_r, px_r, *_ = judge(png, desired)
+        assert np.array_equal(px, px_r)
+    assert dropin.gpu_decodes() - n0 == 2
+
+
+def test_command_line_decoder_fuzz_mode(enc, tmp_path):
+    """fpng_amd_test -f (the reference harness's decoder fuzz mode, fpng_test.cpp:1092-1114, which its README drives with zzuf) on
+    damaged copies of a 1.9 MP file, the reference's decoder looking at the same bytes (--judge: exit code 2 on any difference in
+    status or pixels): the tool either writes out.png or reports the failure, as the reference's does."""
+    import subprocess
+    import torch
+    import fpng_amd
+    if not have_ref():
+        pytest.skip("reference build not available")
+    exe = os.path.join(ROOT, "fpng_amd", "lib", "fpng_amd_test")
+    lib = os.path.join(ROOT, "oracle", "_ref", "libfpng_ref.so")
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    (base,), _ = enc.encode_tensors([torch.from_numpy(fpng_amd.synth_image("grad", 1600, 1200, 3)).cuda()], 0)
+    rng = np.random.default_rng(5)
+    files = [base] + _damaged(rng, base, 24, (100, len(base) // 3, len(base) - 5))
+    n_ok = n_fail = 0
+    for k, data in enumerate(files):
+        path = str(tmp_path / f"f{k}.png")
+        with open(path, "wb") as f:
+            f.write(data)
+        r = subprocess.run([exe, "--judge", lib, "-f", path], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+        assert r.returncode in (0, 1), (k, r.returncode, r.stdout[-300:], r.stderr[-300:])
+        if r.returncode == 0:
+            assert "Wrote out.png 1600x1200 3" in r.stdout
+            n_ok += 1
+        else:
+            assert "fpng::fpng_decode() failed with error" in r.stderr
+            n_fail += 1
+    assert n_ok >= 1 and n_fail >= 10

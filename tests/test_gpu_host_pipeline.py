@@ -60,6 +60,22 @@ def test_streamed_frames_vs_reference(enc, dims):
             fpng_amd.unpin_host_memory(img2)
 
 
+def test_streamed_frame_into_a_buffer_of_exactly_the_files_size(enc):
+    """fpng_amd_encode_host() asks only for out_cap >= the PNG's size: a buffer that is smaller than the streamed path's own
+    first estimate of the file (band 0's share extrapolated, plus a margin) but holds the file must do."""
+    import fpng_amd
+    w, h, c = 7680, 4320, 4
+    img = fpng_amd.synth_image("grad", w, h, c)
+    exp = _kat("grad", w, h, c, 0)
+    for cap in (exp["size"], exp["size"] + 1000):
+        out = np.empty(cap, dtype=np.uint8)
+        n = enc.encode_host_into(img, w, h, c, out, 0)
+        assert enc.last_host_bands() > 1
+        assert n == exp["size"] and hashlib.sha256(out[:n].tobytes()).hexdigest() == exp["sha256"]
+    with pytest.raises(fpng_amd.FpngAmdError):
+        enc.encode_host_into(img, w, h, c, np.empty(exp["size"] - 1, dtype=np.uint8), 0)
+
+
 def test_streamed_incompressible_frame_ends_up_stored(enc):
     import fpng_amd
     w, h, c = 3840, 2160, 4

@@ -13,6 +13,10 @@
 //     -c        one line of comma separated values                 reference fpng_test.cpp:1608-1633
 //     -e        fuzz the encoder by mutating the input's pixels    reference fpng_test.cpp:381-615
 //     -E        fuzz with random-noise images of random size       reference fpng_test.cpp:617-682
+//     -f        decoder fuzz mode: <input> is an fpng-written .png that goes to fpng::fpng_decode_memory as it is (files of 256K
+//               pixels and more: the GPU decoder); failure -> "fpng::fpng_decode() failed with error N!" and EXIT_FAILURE, else
+//               out.png is written -- the mode the reference's README drives with zzuf (fpng_test.cpp:1092-1114).  With --judge
+//               the reference's decoder (ref_decode) sees the same bytes: a different status or different pixels -> exit code 2
 //     -n N      fuzz trials (default 1000, as the reference)       -m D  largest dimension for -E (default 8193)
 //     -b N      also time N frames per call through fpng_amd_encode_host_batch (overlapped copies) and N
 //               device-resident frames per submission (kernel-only rate)
@@ -44,7 +48,7 @@ namespace {
 typedef int (*judge_fn)(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *, size_t, size_t *);
 
 struct Options {
-    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false, green_to_alpha = false, train = false;
+    bool slower = false, uncompressed = false, csv = false, fuzz = false, fuzz2 = false, green_to_alpha = false, train = false, fuzz_decoder = false;
     uint32_t trials = 1000, max_dim = 8193, batch = 0, cpu_threads = 0;
     const char *input = nullptr, *alpha_input = nullptr, *out = "fpng.png", *judge_path = nullptr;
 };
@@ -347,6 +351,7 @@ int main(int argc, char **argv)
             case 't': o.train = true; break;
             case 'e': o.fuzz = true; break;
             case 'E': o.fuzz2 = true; break;
+            case 'f': o.fuzz_decoder = true; break;
             case 'n': o.trials = (uint32_t)atoi(argv[++i]); break;
             case 'm': o.max_dim = (uint32_t)atoi(argv[++i]); break;
             case 'b': o.batch = (uint32_t)atoi(argv[++i]); break;
@@ -360,7 +365,7 @@ int main(int argc, char **argv)
             o.alpha_input = a;
     }
     if (!o.input && !o.fuzz2) {
-        printf("Usage: fpng_amd_test [-s] [-u] [-a] [-c] [-e] [-E] [-t @filelist.txt] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
+        printf("Usage: fpng_amd_test [-s] [-u] [-a] [-c] [-e] [-E] [-f] [-t @filelist.txt] [-n trials] [-m maxdim] [-b frames] [-p cpu threads] [-o out.png] "
                "[--judge cpu_encoder.so] <synth:kind:WxHxC[:seed] | file.png> [alpha_file.png]\n");
         return EXIT_FAILURE;
     }
@@ -370,12 +375,15 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     judge_fn judge = nullptr;
+    typedef int (*judge_decode_fn)(const void *, uint32_t, uint8_t *, size_t, uint32_t *, uint32_t *, uint32_t *, uint32_t);
+    judge_decode_fn judge_decode = nullptr;
     if (o.judge_path) {
         void *lib = dlopen(o.judge_path, RTLD_NOW);
         if (lib) {
             if (void (*init)() = (void (*)())dlsym(lib, "ref_init")) init();
             judge = (judge_fn)dlsym(lib, "ref_encode");
             if (!judge) judge = (judge_fn)dlsym(lib, "fpo_encode");
+            judge_decode = (judge_decode_fn)dlsym(lib, "ref_decode");
         }
         if (!judge) {
             fprintf(stderr, "cannot use %s as judge: %s\n", o.judge_path, dlerror());
@@ -385,6 +393,40 @@ int main(int argc, char **argv)
     const uint32_t flags = (o.slower ? fpng::FPNG_ENCODE_SLOWER : 0) | (o.uncompressed ? fpng::FPNG_FORCE_UNCOMPRESSED : 0);
     if (o.train) return training_mode(o);
     if (o.fuzz2) return fuzz_encoder2(flags, o, judge);
+    if (o.fuzz_decoder) { // reference fpng_test.cpp:1092-1114
+        FILE *f = fopen(o.input, "rb");
+        if (!f) {
+            fprintf(stderr, "Failed reading source file data \"%s\"\n", o.input);
+            return EXIT_FAILURE;
+        }
+        std::vector<uint8_t> file;
+        uint8_t chunk[65536];
+        for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) file.insert(file.end(), chunk, chunk + n);
+        fclose(f);
+        std::vector<uint8_t> pixels;
+        uint32_t dw = 0, dh = 0, dc = 0;
+        const int res = fpng::fpng_decode_memory(file.data(), (uint32_t)file.size(), pixels, dw, dh, dc, 3);
+        if (judge_decode) { // the same bytes through the reference's decoder: status and pixels must agree
+            uint32_t rw = 0, rh = 0, rc = 0;
+            const size_t cap = res == 0 ? pixels.size() : ((size_t)1 << 28);
+            std::vector<uint8_t> want(cap);
+            const int rres = judge_decode(file.data(), (uint32_t)file.size(), want.data(), want.size(), &rw, &rh, &rc, 3);
+            if (rres != res || (res == 0 && (rw != dw || rh != dh || rc != dc || memcmp(want.data(), pixels.data(), pixels.size()) != 0))) {
+                fprintf(stderr, "DECODER MISMATCH: status %i vs the reference's %i (or different pixels)\n", res, rres);
+                return 2;
+            }
+        }
+        if (res != 0) {
+            fprintf(stderr, "fpng::fpng_decode() failed with error %i!\n", res);
+            return EXIT_FAILURE;
+        }
+        if (!fpng::fpng_encode_image_to_file("out.png", pixels.data(), dw, dh, 3, 0)) {
+            fprintf(stderr, "writing out.png failed\n");
+            return EXIT_FAILURE;
+        }
+        printf("Wrote out.png %ux%u %u\n", dw, dh, dc);
+        return EXIT_SUCCESS;
+    }
 
     std::vector<uint8_t> px;
     uint32_t w = 0, h = 0, c = 0;

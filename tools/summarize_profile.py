@@ -27,11 +27,13 @@ GiB = 1 << 30
 fscale = GiB / [v for k, v in cal_f.items() if "calib_read_kernel<unsigned int>" in k][0]
 wscale = GiB / [v for k, v in cal_w.items() if "calib_write_kernel<unsigned int>" in k][0]
 args = " ".join(sys.argv[4:])
-lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline {args}".rstrip(),
+only = os.environ.get("PROFILE_KERNELS", "")  # e.g. dec_ : the decoder's kernels of a bench.py --mode decode run
+lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline {args}".rstrip()
+         + (f"  [kernels {only}*]" if only else ""),
          f"# calibration (tools/pmc_calibrate.py, 1 GiB streams with 4-byte lanes): FETCH_SIZE unit = {fscale:.1f} B, WRITE_SIZE unit = {wscale:.1f} B",
          f"{'kernel':<22} {'FETCH_SIZE':>12} {'fetch_MB':>10} {'WRITE_SIZE':>12} {'write_MB':>10}"]
 tot = 0
-kernels = [k for k in f if k.endswith("_kernel") and "calib" not in k]
+kernels = [k for k in f if k.endswith("_kernel") and "calib" not in k and k.startswith(only)]
 for k in sorted(kernels, key=lambda k: -(f.get(k, 0) * fscale + w.get(k, 0) * wscale)):
     fb, wb = f.get(k, 0) * fscale, w.get(k, 0) * wscale
     tot += fb + wb

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfpng_amd.so")
 DROPIN_LIB = os.path.join(LIB_DIR, "libfpng.so")
 SOURCES = ["kernels.hip", "decode.hip", "api.cpp", "pipeline.cpp", "sharded.cpp", "decode_api.cpp", "format.cpp", "synth.cpp"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "encoder.h"), os.path.join(CSRC, "decode.h"), os.path.join(CSRC, "png_parse.h"),
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "format.h"), os.path.join(CSRC, "encoder.h"), os.path.join(CSRC, "decode.h"), os.path.join(CSRC, "decode_core.h"), os.path.join(CSRC, "host_workers.h"), os.path.join(CSRC, "png_parse.h"),
            os.path.join(ROOT, "include", "fpng_amd.h")]
 ARCH = "gfx950"
 

@@ -318,6 +318,10 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->d_dec_gran.release();
     for (hipEvent_t ev : e->dec_prof_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->dec_ev2)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->dec_ev3)
+        if (ev) (void)hipEventDestroy(ev);
     e->h_dec_fetch.release();
     if (e->dec_up) (void)hipStreamDestroy(e->dec_up);
     for (hipEvent_t ev : e->dec_ev)

@@ -56,6 +56,13 @@ struct DecUnfPlan {
     uint32_t n_pieces, total_items;
 };
 
+// a file that is decoded piece by piece: what the pieces so far amount to (dec_offsets_range_kernel)
+struct DecCarry {
+    uint64_t bytes; // output bytes of the blocks so far (up to the end-of-block symbol once it was met)
+    uint32_t done;  // the stream's end-of-block symbol was met
+    uint32_t pad_;
+};
+
 // per-subsequence arrays (index = batch-wide subsequence number)
 struct DecSubArrays {
     uint32_t *info;   // dec::pack_info
@@ -73,6 +80,10 @@ void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint3
 // group_jobs: the group's first file; status / eob_index: batch-wide arrays
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);
+// ONE file (jobs[0], a DEVICE pointer whose sub_base the caller knows: passed as first_block of the other launchers), blocks [blk_a, blk_b)
+void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_base_block, uint32_t blk_a, uint32_t blk_b, bool final_piece, uint32_t total_subs, DecSubArrays a,
+                              const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry);
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch);
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch);

@@ -291,6 +291,75 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     }
 }
 
+// ---- the same for a file that arrives in pieces (fpng_amd_decode_host's streamed form): the blocks [blk_a, blk_b) of ONE file, on top
+//      of what the pieces in front left in `carry`; `final`: the file's last piece (a stream that has not ended by then never does) ----
+__global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJob *jobs, uint32_t blk_a, uint32_t blk_b, uint32_t final_piece, const DecBlockRec *recs,
+                                                                      const uint32_t *bytes, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry)
+{
+    __shared__ uint64_t sums[kDecBlock];
+    __shared__ uint32_t red[4];
+    const DecJob &job = jobs[0];
+    const DecCarry in = *carry;
+    if (in.done) return; // (the stream has ended in an earlier piece: what these blocks hold lies behind it)
+    const uint32_t t = threadIdx.x, nb = blk_b - blk_a, b0 = job.sub_base / kSubBlock + blk_a;
+    const uint32_t per = (nb + kDecBlock - 1) / kDecBlock;
+    const uint32_t i0 = min(t * per, nb), i1 = min(i0 + per, nb);
+    uint32_t mine = nb;
+    for (uint32_t b = i0; b < i1; b++)
+        if (recs[b0 + b].first_eob < (uint32_t)kSubBlock) {
+            mine = b;
+            break;
+        }
+    const uint32_t last_blk = block_min<kDecBlock / kWave>(mine, red); // nb: no end in this piece
+    const uint32_t last_local = last_blk < nb ? recs[b0 + last_blk].first_eob : 0u;
+    uint64_t local = 0;
+    uint32_t bad = 0;
+    for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
+        const DecBlockRec r = recs[b0 + b];
+        if (blk_a + b && r.entry_rel != recs[b0 + b - 1].exit_rel) bad |= kDecNotConverged;
+        if (b < last_blk) {
+            local += r.sum;
+            if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
+        } else if (r.first_invalid <= last_local)
+            bad |= kDecBadStream;
+    }
+    uint32_t tail = 0;
+    if (last_blk < nb) {
+        for (uint32_t k = t; k <= last_local; k += kDecBlock) tail += bytes[job.sub_base + (blk_a + last_blk) * kSubBlock + k];
+    } else if (t == 0 && final_piece)
+        bad |= kDecBadStream;
+    const uint32_t tail_sum = block_sum<kDecBlock / kWave>(tail, red);
+    const uint32_t any_bad = block_sum<kDecBlock / kWave>(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
+    const uint32_t any_bad2 = block_sum<kDecBlock / kWave>(bad & kDecBadStream, red) ? kDecBadStream : 0u;
+    sums[t] = local;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t acc = in.bytes;
+        for (int k = 0; k < kDecBlock; k++) {
+            const uint64_t v = sums[k];
+            sums[k] = acc;
+            acc += v;
+        }
+        uint32_t st = any_bad | any_bad2;
+        DecCarry out = in;
+        out.bytes = acc + tail_sum;
+        if (last_blk < nb) {
+            if (out.bytes != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
+            eob_index[0] = (blk_a + last_blk) * kSubBlock + last_local;
+            out.done = 1;
+        } else if (out.bytes > (uint64_t)(job.bpl + 1) * job.h)
+            st |= kDecBadStream;
+        if (st) atomicOr(&status[0], st);
+        *carry = out;
+    }
+    __syncthreads();
+    uint64_t o = sums[t];
+    for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
+        block_off[b0 + b] = o;
+        o += recs[b0 + b].sum;
+    }
+}
+
 // ---- dec_subscan_kernel, one workgroup per kDecSubBlock subsequences ----
 __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, DecSubArrays a,
                                                                 const uint32_t *status, const uint32_t *eob_index)
@@ -404,7 +473,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch)
+__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch)
 {
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
@@ -417,7 +486,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
     // and leaves the file to the CPU decoder (FPNG_AMD_DECODE_UNDECIDED).
     constexpr uint32_t kSpinLimit = 1u << 20;
     {
-        const uint32_t item = blockIdx.x;
+        const uint32_t item = item0 + blockIdx.x; // (item0: a later launch for the same files, fpng_amd_decode_host's streamed form)
         if (item >= plan.total_items) return;
         uint32_t lo = 0, hi = plan.n_pieces;
         while (hi - lo > 1) {
@@ -540,6 +609,12 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
     hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_group_jobs), dim3(kDecBlock), 0, s, group_jobs, recs, a.bytes, block_off, status + j0, eob_index + j0);
     hipLaunchKernelGGL(dec_subscan_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, a, status, eob_index);
 }
+void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_base_block, uint32_t blk_a, uint32_t blk_b, bool final_piece, uint32_t total_subs, DecSubArrays a,
+                              const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry)
+{
+    hipLaunchKernelGGL(dec_offsets_range_kernel, dim3(1), dim3(kDecBlock), 0, s, jobs, blk_a, blk_b, final_piece ? 1u : 0u, recs, a.bytes, block_off, status, eob_index, carry);
+    hipLaunchKernelGGL(dec_subscan_kernel, dim3(blk_b - blk_a), dim3(kSubBlock), 0, s, jobs, 1u, sub_base_block + blk_a, total_subs, a, status, eob_index);
+}
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
 {
@@ -548,9 +623,13 @@ void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint3
 }
 // jobs / status: of the group's first file; plan: device arrays (decode_api.cpp); epoch: this launch's (a new one every time; the
 // granules are never cleared)
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch)
+{
+    if (n_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, item0, status, epoch);
+}
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch)
 {
-    if (plan.total_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(plan.total_items), dim3(kDecBlock), 0, s, jobs, plan, status, epoch);
+    launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch);
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) // (the y dimension of a grid holds at most 65535 workgroups)
         hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0);
 }

@@ -5,9 +5,11 @@
 #include "decode.h"
 #include "decode_core.h"
 #include "encoder.h"
+#include "host_workers.h"
 #include "png_parse.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -343,16 +345,24 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         return hipSuccess;
     };
-    std::thread uploader;
     std::mutex mu;
     std::condition_variable cv;
     uint32_t issued = 0; // groups whose copies are enqueued (and whose event is recorded)
     hipError_t up_err = hipSuccess;
+    struct Joiner { // (every way out of this function waits for the uploader first: it works on this frame's variables)
+        Worker *w = nullptr;
+        ~Joiner()
+        {
+            if (w) w->wait();
+        }
+    } joiner;
     if (ng > 1) {
         if (!e->dec_up) HIP_TRY(create_copy_stream(&e->dec_up));
         for (uint32_t g = 0; g < ng; g++)
             if (!e->dec_ev[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[g], hipEventDisableTiming));
-        uploader = std::thread([&] {
+        if (!e->workers) e->workers = new HostWorkers(); // (the encoder's copy threads, made once: host_workers.h)
+        joiner.w = &e->workers->up;
+        e->workers->up.start([&] {
             hipError_t err = hipSetDevice(e->device);
             for (uint32_t g = 0; g < ng; g++) {
                 if (err == hipSuccess) err = upload_group(groups[g], e->dec_up);
@@ -365,13 +375,6 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             }
         });
     }
-    struct Joiner { // (every way out of this function joins the uploader first)
-        std::thread &t;
-        ~Joiner()
-        {
-            if (t.joinable()) t.join();
-        }
-    } joiner{uploader};
     for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * dec::kLutDwords, luts[k].data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
     {   // dec_unfilter_kernel's work items per group of files, numbered segment by segment (decode.h: DecUnfPlan)
@@ -524,6 +527,219 @@ extern "C" int fpng_amd_decode_batch_device(fpng_amd_encoder *e, const fpng_amd_
     return decode_files(e, files, n, desired, results, true);
 }
 
+namespace {
+
+// fpng_amd_decode_host for a LARGE compressed file, streamed: the IDAT goes up in pieces (the encoder's uploader thread), every
+// piece is synchronised, placed (dec_offsets_range_kernel carries the byte count from piece to piece) and decoded as soon as it has
+// arrived, the rows that are complete get their Up filter undone and go down (the downloader thread) while later pieces are still
+// on their way up: upload, decode and download overlap instead of following one another (8K RGBA: 58 MB up + 133 MB down).
+// `out`: the caller's w * h * desired bytes.  *redo: the file's token boundaries did not settle in the rounds launched here --
+// the caller goes through fpng_amd_decode_batch, which adds rounds.
+int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &p, const uint32_t *table, const uint8_t *sizes, uint32_t desired, uint8_t *out,
+                         fpng_amd_decode_result *result, bool *redo)
+{
+    *redo = false;
+    int rc;
+    if ((rc = ensure_copy_streams(e))) return rc;
+    hipStream_t s = e->stream, s_up = e->host.up, s_down = e->host.down;
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    const uint32_t resident = (uint32_t)std::max(cus, 1) * 3;
+    std::vector<uint32_t> lut(dec::kLutDwords);
+    build_multi_lut(table, sizes, lut.data());
+    DecJob j;
+    std::memset(&j, 0, sizeof j);
+    j.w = p.w, j.h = p.h, j.src_c = p.c, j.dst_c = desired, j.bpl = p.w * p.c;
+    j.z_bytes = p.idat_len, j.first_bit = p.first_bit, j.end_limit_bit = (uint64_t)(p.idat_len - 4) * 8;
+    j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
+    j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
+    const uint32_t n_blocks = (j.n_sub + kDecSubBlock - 1) / kDecSubBlock, sub_total = n_blocks * kDecSubBlock;
+    const size_t total = ((size_t)j.bpl + 1) * j.h, ncol = (j.bpl + 3) / 4, col_blocks = (ncol + 255) / 256, os = (size_t)p.w * desired;
+    // ---- scratch ----
+    uint8_t *d_z, *d_filt;
+    DecSubArrays d_sub;
+    DecBlockRec *d_recs;
+    uint64_t *d_block_off;
+    uint32_t *d_lut, *d_words, *d_status, *d_eob;
+    DecJob *d_job;
+    DecUnfPiece *d_piece;
+    DecCarry *d_carry;
+    {
+        size_t need = 0;
+        auto carve = [&](size_t bytes) {
+            const size_t o = need;
+            need += (bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        const size_t o_z = carve((size_t)p.idat_len + 80), o_filt = carve(((total + 15) & ~(size_t)15) + 32), o_info = carve((size_t)sub_total * 4), o_bytes = carve((size_t)sub_total * 4),
+                     o_tail = carve((size_t)sub_total * 4), o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
+                     o_boff = carve((size_t)n_blocks * 8), o_lut = carve(dec::kLutDwords * 4), o_job = carve(sizeof(DecJob)), o_small = carve(256);
+        if ((rc = e->d_decode.ensure(need))) return rc;
+        if ((rc = e->d_dec_gran.ensure(std::max<size_t>((size_t)j.nseg * ncol, 1)))) return rc;
+        if (e->d_dec_gran.fresh) {
+            HIP_TRY(hipMemsetAsync(e->d_dec_gran.p, 0, e->d_dec_gran.cap * 8, s));
+            e->d_dec_gran.fresh = false;
+        }
+        uint8_t *base = e->d_decode.p;
+        d_z = base + o_z, d_filt = base + o_filt;
+        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
+        d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff), d_lut = (uint32_t *)(base + o_lut), d_job = (DecJob *)(base + o_job);
+        uint8_t *sm = base + o_small; // status, eob index | carry | unfilter piece | cbpre[2], order[1]
+        d_status = (uint32_t *)sm, d_eob = d_status + 1, d_carry = (DecCarry *)(sm + 16), d_piece = (DecUnfPiece *)(sm + 32), d_words = (uint32_t *)(sm + 48);
+    }
+    j.z = d_z, j.filt = d_filt, j.lut = d_lut, j.out = e->d_stage_in.p, j.segsum = (uint32_t *)e->d_dec_gran.p;
+    struct Small { // (one upload for the few words the kernels start from)
+        uint32_t status, eob;
+        uint32_t pad0[2];
+        DecCarry carry;
+        DecUnfPiece piece;
+        uint32_t cbpre[2], order[1];
+    } small = {0, j.n_sub, {0, 0}, {0, 0, 0}, {0, 0, 1, 0}, {0, (uint32_t)col_blocks}, {0}};
+    static_assert(sizeof(Small) <= 256 && offsetof(Small, carry) == 16 && offsetof(Small, piece) == 32 && offsetof(Small, cbpre) == 48, "layout of the small words");
+    HIP_TRY(hipMemcpyAsync(d_status, &small, sizeof small, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_lut, lut.data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_job, &j, sizeof j, hipMemcpyHostToDevice, s));
+    DecUnfPlan plan;
+    plan.pieces = d_piece, plan.cbpre = d_words, plan.order = d_words + 2, plan.n_pieces = 1, plan.total_items = j.nseg * (uint32_t)col_blocks;
+    const uint32_t epoch = ++e->dec_epoch & 0x3FFFFFFFu; // (one epoch for all of this file's unfilter launches: later segments look back at earlier launches' sums)
+    // ---- pieces: whole blocks of subsequences; a piece's kernels read up to 64 bytes behind its last block (a token's window, the pad) ----
+    constexpr uint32_t kMaxPieces = 16;
+    static const uint32_t piece_mb = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_PIECE_MB");
+        return v ? (uint32_t)std::max(1, atoi(v)) : 4u;
+    }();
+    const uint32_t np = std::max(1u, std::min<uint32_t>({kMaxPieces, n_blocks, p.idat_len / (piece_mb << 20)}));
+    uint32_t blk_end[kMaxPieces], byte_end[kMaxPieces];
+    for (uint32_t k = 0; k < np; k++) {
+        blk_end[k] = (uint32_t)((uint64_t)n_blocks * (k + 1) / np);
+        const uint64_t end_bit = j.first_bit + (uint64_t)blk_end[k] * kDecSubBlock * kSubBits;
+        byte_end[k] = k + 1 == np ? p.idat_len : (uint32_t)std::min<uint64_t>(p.idat_len, (end_bit >> 3) + 64);
+    }
+    hipEvent_t ev_up[kMaxPieces], ev_carry[kMaxPieces], ev_rows[kMaxPieces];
+    for (uint32_t k = 0; k < np; k++) {
+        if (!e->dec_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[k], hipEventDisableTiming));
+        if (!e->dec_ev2[k]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev2[k], hipEventDisableTiming));
+        if (!e->dec_ev3[k]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev3[k], hipEventDisableTiming));
+        ev_up[k] = e->dec_ev[k], ev_carry[k] = e->dec_ev2[k], ev_rows[k] = e->dec_ev3[k];
+    }
+    if ((rc = e->h_dec_fetch.ensure(kMaxPieces * sizeof(DecCarry) + 64))) return rc;
+    DecCarry *h_carry = (DecCarry *)e->h_dec_fetch.p;
+    uint32_t *h_status = (uint32_t *)(h_carry + kMaxPieces);
+    if (!e->workers) e->workers = new HostWorkers();
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t issued = 0, rows_ready = 0; // pieces whose upload is enqueued; pieces whose finished rows may go down
+    uint32_t row_end[kMaxPieces] = {};   // rows [row_end[k - 1], row_end[k]) are complete behind piece k's unfilter launch
+    hipError_t copy_err = hipSuccess;
+    bool stop = false;
+    const uint8_t *zsrc = png + p.idat_ofs + 8;
+    struct Joiner { // (every way out waits for the copy threads: they work on this frame's variables)
+        Worker &a, &b;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &stop;
+        ~Joiner()
+        {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            a.wait(), b.wait();
+        }
+    } joiner{e->workers->up, e->workers->down, mu, cv, stop};
+    e->workers->up.start([&] {
+        hipError_t err = hipSetDevice(e->device);
+        for (uint32_t k = 0; k < np; k++) {
+            const uint32_t from = k ? byte_end[k - 1] : 0;
+            if (err == hipSuccess && byte_end[k] > from) err = hipMemcpyAsync(d_z + from, zsrc + from, byte_end[k] - from, hipMemcpyHostToDevice, s_up);
+            if (err == hipSuccess) err = hipEventRecord(ev_up[k], s_up);
+            std::lock_guard<std::mutex> lk(mu);
+            if (err != hipSuccess) copy_err = err;
+            issued = k + 1;
+            cv.notify_all();
+        }
+    });
+    e->workers->down.start([&] {
+        hipError_t err = hipSetDevice(e->device);
+        for (uint32_t k = 0; k < np; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return rows_ready > k || stop; });
+                if (rows_ready <= k) return;
+            }
+            const uint32_t r0 = k ? row_end[k - 1] : 0, r1 = row_end[k];
+            if (err == hipSuccess && r1 > r0) {
+                err = hipStreamWaitEvent(s_down, ev_rows[k], 0);
+                if (err == hipSuccess) err = hipMemcpyAsync(out + (size_t)r0 * os, e->d_stage_in.p + (size_t)r0 * os, (size_t)(r1 - r0) * os, hipMemcpyDeviceToHost, s_down);
+            }
+            if (err != hipSuccess) {
+                std::lock_guard<std::mutex> lk(mu);
+                copy_err = err;
+            }
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(s_down);
+        if (err != hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            copy_err = err;
+        }
+    });
+    // ---- the calling thread: piece k's kernels are enqueued, then piece k - 1 is closed (its byte count read, the rows it completed
+    //      sent through the Up filter's undoing and handed to the downloader): the GPU always has the next piece's kernels queued ----
+    uint32_t segs_done = 0;
+    for (uint32_t k = 0; k <= np; k++) {
+        if (k < np) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return issued > k; });
+                if (copy_err != hipSuccess) return fail(FPNG_AMD_ERR_HIP, "upload of the file", copy_err);
+            }
+            HIP_TRY(hipStreamWaitEvent(s, ev_up[k], 0));
+            const uint32_t a = k ? blk_end[k - 1] : 0, b = blk_end[k];
+            if (b > a) {
+                for (uint32_t r = 0; r <= kBorderRounds; r++) launch_dec_sync(s, resident, d_job, 1, a, b - a, sub_total, r, d_sub, d_recs, d_status + 2);
+                launch_dec_offsets_range(s, d_job, 0, a, b, k + 1 == np, sub_total, d_sub, d_recs, d_block_off, d_status, d_eob, d_carry);
+                launch_dec_emit(s, resident, d_job, 1, a, b - a, sub_total, d_sub, d_eob, d_block_off, d_status);
+            }
+            HIP_TRY(hipMemcpyAsync(&h_carry[k], d_carry, sizeof(DecCarry), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(ev_carry[k], s));
+        }
+        if (k >= 1) {
+            const uint32_t q = k - 1;
+            HIP_TRY(hipEventSynchronize(ev_carry[q]));
+            const uint64_t bytes = h_carry[q].bytes;
+            uint32_t rows = (uint32_t)std::min<uint64_t>(bytes / ((uint64_t)j.bpl + 1), p.h);
+            uint32_t segs = rows / kDecUnfRows; // whole segments only -- or, behind the last piece, everything
+            if (q + 1 == np) segs = j.nseg, rows = p.h;
+            else rows = segs * kDecUnfRows;
+            if (segs > segs_done) launch_dec_unfilter(s, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch);
+            segs_done = std::max(segs_done, segs);
+            HIP_TRY(hipEventRecord(ev_rows[q], s));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                row_end[q] = std::max(rows, q ? row_end[q - 1] : 0u);
+                rows_ready = q + 1;
+            }
+            cv.notify_all();
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    e->workers->down.wait();
+    if (copy_err != hipSuccess) return fail(FPNG_AMD_ERR_HIP, "copies of the streamed decode", copy_err);
+    const uint32_t st = *h_status;
+    if (st & (kDecNotConverged | kDecStalled)) {
+        *redo = true;
+        return FPNG_AMD_OK;
+    }
+    if ((st & (kDecBadStream | kDecBadFilter)) || !(st & kDecSawEob)) result->status = fpng::FPNG_DECODE_NOT_FPNG;
+    return FPNG_AMD_OK;
+}
+
+} // namespace
+
 // One host-resident file to host pixels: what fpng::fpng_decode_memory() does for large images (fpng_decode.cpp).  The pixels land in
 // the encoder's staging buffer and go down in one copy into memory obtained from `reserve` (asked once the file is known to decode).
 extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32_t size, uint32_t desired, fpng_amd_reserve_fn reserve, void *user,
@@ -548,12 +764,13 @@ extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32
         result->status = fpng::FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
         return FPNG_AMD_OK;
     }
-    {   // the stream's shape first: a header that promises more pixels than the IDAT can hold must not size any device memory
-        Parsed p;
-        p.w = w, p.h = h, p.c = c, p.idat_ofs = idat_ofs, p.idat_len = idat_len;
-        static thread_local uint32_t table[1u << fpng::parse::kTableBits];
-        uint8_t sizes[288];
-        const int ss = plan_stream((const uint8_t *)png + idat_ofs + 8, size - (idat_ofs + 8), true, p, table, sizes);
+    // the stream's shape first: a header that promises more pixels than the IDAT can hold must not size any device memory
+    Parsed sp;
+    sp.w = w, sp.h = h, sp.c = c, sp.idat_ofs = idat_ofs, sp.idat_len = idat_len;
+    static thread_local uint32_t stable[1u << fpng::parse::kTableBits];
+    uint8_t ssizes[288];
+    {
+        const int ss = plan_stream((const uint8_t *)png + idat_ofs + 8, size - (idat_ofs + 8), true, sp, stable, ssizes);
         if (ss) {
             result->status = ss;
             return FPNG_AMD_OK;
@@ -563,12 +780,24 @@ extern "C" int fpng_amd_decode_host(fpng_amd_encoder *e, const void *png, uint32
     int rc = drain(e);
     if (rc) return rc;
     if ((rc = e->d_stage_in.ensure((size_t)need + 16))) return rc;
+    // large compressed files: upload, decode and download overlapped (FPNG_AMD_DECODE_STREAM=0: one after the other)
+    static const bool stream_ok = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_STREAM");
+        return !(v && v[0] == '0');
+    }();
+    if (stream_ok && sp.mode == 0 && idat_len >= (8u << 20) && getenv("FPNG_AMD_DECODE_MAX_ROUNDS") == nullptr) {
+        uint8_t *out = reserve(user, (size_t)need);
+        if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "no room for the pixels");
+        bool redo = false;
+        if ((rc = decode_host_streamed(e, (const uint8_t *)png, sp, stable, ssizes, desired, out, result, &redo))) return rc;
+        if (!redo) return FPNG_AMD_OK;
+    }
     fpng_amd_png f;
     std::memset(&f, 0, sizeof f);
     f.data = png, f.size = size, f.d_pixels = e->d_stage_in.p, f.pixels_cap = e->d_stage_in.cap;
     if ((rc = fpng_amd_decode_batch(e, &f, 1, desired, result))) return rc;
     if (result->status) return FPNG_AMD_OK;
-    uint8_t *out = reserve(user, (size_t)need);
+    uint8_t *out = reserve(user, (size_t)need); // (the same memory again if the streamed attempt above asked already)
     if (!out) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "no room for the pixels");
     HIP_TRY(hipMemcpy(out, e->d_stage_in.p, (size_t)need, hipMemcpyDeviceToHost));
     return FPNG_AMD_OK;

@@ -184,7 +184,8 @@ struct fpng_amd_encoder {
     hipEvent_t dec_prof_ev[5] = {}; // profiling: around the decode kernels of the last call's first group of files
     bool dec_prof_recorded = false;
     hipStream_t dec_up = nullptr; // ... the stream the files' bytes are uploaded on, one event per group of files
-    hipEvent_t dec_ev[8] = {};
+    hipEvent_t dec_ev[16] = {};
+    hipEvent_t dec_ev2[16] = {}, dec_ev3[16] = {}; // the streamed fpng_amd_decode_host: a piece's byte count is known / its finished rows are pixels
     PinnedBuf<uint8_t> h_dec_fetch; // fpng_amd_decode_batch_device(): the files' first and last bytes on their way to the host parser
     DeviceBuf<uint8_t> d_xchg;    // fpng_amd_encode_image_sharded(): the records it exchanges, and their pinned mirror
     PinnedBuf<uint8_t> h_xchg;

@@ -9,6 +9,7 @@
 //
 // No pixel is touched on the CPU here, and there is no CPU encoder: without a GPU every encode entry point fails.
 #include "encoder.h"
+#include "host_workers.h"
 
 #include <atomic>
 #include <chrono>
@@ -157,61 +158,6 @@ extern "C" int fpng_amd_band_crc(fpng_amd_encoder *e, uint32_t *raw_crc, uint64_
 // ------------------------------------------------------------------------------------------------
 // fpng_amd_encode_host_to(): host pixels in, host PNG out
 // ------------------------------------------------------------------------------------------------
-// A thread that runs one task at a time (fpng_amd_encode_host_to's uploader / downloader)
-struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<void()> task;
-    bool busy = false, quit = false;
-    void loop()
-    {
-        for (;;) {
-            std::function<void()> t;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return busy || quit; });
-                if (!busy) return;
-                t = std::move(task);
-            }
-            t();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                busy = false;
-            }
-            cv.notify_all();
-        }
-    }
-    void start(std::function<void()> t)
-    {
-        if (!th.joinable()) th = std::thread([this] { loop(); });
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            task = std::move(t);
-            busy = true;
-        }
-        cv.notify_all();
-    }
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !busy; });
-    }
-    ~Worker()
-    {
-        if (!th.joinable()) return;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-        }
-        cv.notify_all();
-        th.join();
-    }
-};
-struct HostWorkers {
-    Worker up, down;
-};
-
 void fpng_amd::destroy_host_workers(fpng_amd_encoder *e)
 {
     delete e->workers;

@@ -47,11 +47,13 @@ def parse():
     ap.add_argument("--prewarm", type=int, default=60,
                     help="untimed steps before the W warmup steps: throughput needs ~40 back-to-back steps (20-50 ms of "
                          "sustained load) to settle, a cold 20-step run reads 15-25 %% low (DESIGN.md section 6)")
-    ap.add_argument("--mode", default="batch", choices=["batch", "rowband", "decode"],
+    ap.add_argument("--mode", default="batch", choices=["batch", "rowband", "decode", "nodeimage"],
                     help="batch: every rank encodes its own images (BASELINE configs 2/3/5, the headline; its line also carries a "
                          "`decode` object); rowband: ONE image sharded by rows over the ranks, one IDAT, windows gathered to rank 0 "
                          "over RCCL (BASELINE config 4); decode: the line is about the GPU decoder (the files the encoder just wrote, "
                          "still in device memory, back to pixels in device memory)")
+    ap.add_argument("--pipelines", type=int, default=0, help="--mode nodeimage: devices of the node (default: every visible GPU; on a one-GPU box "
+                    "device 0 listed this many times)")
     ap.add_argument("--decode-steps", type=int, default=20, help="timed decode steps per region (the `decode` object / --mode decode)")
     ap.add_argument("--regions", type=int, default=3,
                     help="timed regions per run, each EXACTLY --steps steps between two barriers; value = the median region, "
@@ -365,6 +367,50 @@ def decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, 
     return out
 
 
+def nodeimage(args, w, h, c):
+    """--mode nodeimage: ONE host-resident image through fpng_amd_node_encode_host_image (row bands dealt to the node's devices, every
+    device moving its band up and its window down over its own link).  PCIe inclusive -- a host path, never the headline `value`
+    of the default mode.  One process drives all devices; on a one-GPU box the same device is listed --pipelines times."""
+    import hashlib
+    import fpng_amd
+    ngpu = torch.cuda.device_count()
+    devices = list(range(ngpu)) if ngpu > 1 and not args.pipelines else [0] * max(1, args.pipelines or 8)
+    if ngpu > 1 and args.pipelines:
+        devices = [i % ngpu for i in range(args.pipelines)]
+    img = fpng_amd.synth_image(args.kind, w, h, c, seed=777 if args.workload == "16k" else 12345)
+    node = fpng_amd.Node(devices)
+    for _ in range(max(1, args.warmup)):
+        png = node.encode_host_image(img, w, h, c, args.flags)
+    times = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        png = node.encode_host_image(img, w, h, c, args.flags)
+        times.append(time.perf_counter() - t0)
+    node.close()
+    best, med = min(times), sorted(times)[len(times) // 2]
+    parity = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+            g = json.load(f)["c4"]
+        if (w, h, c, args.kind) == (g["w"], g["h"], g["c"], g["kind"]) and str(args.flags) in g["flags"]:
+            if hashlib.sha256(png).hexdigest() != g["flags"][str(args.flags)]["sha256"][0]:
+                raise SystemExit("bench.py: PARITY FAILURE, node image file differs from the reference's")
+            parity = True
+    except OSError:
+        pass
+    bytes_moved = w * h * c + len(png)
+    _RESULT.append(json.dumps({
+        "metric": f"encode megapixels/sec, ONE host-resident image over the node's devices, {PASS_NAME.get(args.flags)}, PCIe inclusive",
+        "value": round(w * h / med / 1e6, 1), "unit": "MP/s", "n_gpus": len(set(devices)), "pipelines": len(devices), "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(med * 1e3, 3), "best_ms": round(best * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic", "parity_checked": parity,
+        "config": {"workload": f"ONE {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' image in host memory -> one fpng file in host memory, flags={args.flags}",
+                   "devices": devices, "png_bytes": len(png), "host_bytes_moved": bytes_moved,
+                   "parallelism": "row bands, one per listed device; band up / window down over the device's own PCIe link; 64-byte records meet on the host"},
+        "roofline": {"bound": "pcie", "note": "host path: bytes over the links / time", "achieved": round(bytes_moved / med / 1e9, 1), "unit": "GB/s",
+                     "peak": None, "frac": None, "traffic": None}}))
+
+
 def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
     """One image, rows sharded over the ranks (SURVEY 8e / BASELINE config 4).  A step = the whole exchange: band encode,
     all_gather of the band records, placement at the band's bit position, windows to rank 0, wrap.  Steps cannot be
@@ -472,6 +518,8 @@ def main():
     w, h, c = WORKLOADS[args.workload]
     if args.mode == "rowband":
         return rowband(args, rank, local_rank, world, distributed, dev, w, h, c)
+    if args.mode == "nodeimage":
+        return nodeimage(args, w, h, c)
     B = args.batch
     # B distinct frames per rank (seed varies per image and per rank)
     imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]

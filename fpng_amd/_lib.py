@@ -118,6 +118,7 @@ SIGNATURES = {
     "fpng_amd_node_destroy": (None, [_vp]),
     "fpng_amd_node_size": (_u32, [_vp]),
     "fpng_amd_node_encode_host_batch": (_int, [_vp, C.POINTER(HostImage), _u32, _u32, _int]),
+    "fpng_amd_node_encode_host_image": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, RESERVE_FN, _vp, C.POINTER(_sz)]),
     "fpng_amd_decode_batch": (_int, [_vp, C.POINTER(PngIn), _u32, _u32, C.POINTER(DecodeResult)]),
     "fpng_amd_decode_batch_device": (_int, [_vp, C.POINTER(PngIn), _u32, _u32, C.POINTER(DecodeResult)]),
     "fpng_amd_decode_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * 4)]),

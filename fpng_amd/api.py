@@ -139,6 +139,23 @@ class Node:
         check(self.lib.fpng_amd_node_encode_host_batch(self.h, arr, len(images), flags, writer_threads))
         return [int(s) for s in sizes]
 
+    def encode_host_image(self, image, w, h, num_chans, flags=0):
+        """fpng_amd_node_encode_host_image: ONE host image (uint8 array) cut into row bands over the node's devices -> PNG bytes
+        (byte-identical to the single-device encoders' and to the reference's)."""
+        b = _as_u8(image)
+        if b.size < w * h * num_chans:
+            raise ValueError("image buffer smaller than w*h*num_chans")
+        hold = []
+
+        def reserve(_user, nbytes):
+            hold[:] = [np.empty(nbytes, dtype=np.uint8)]
+            return hold[0].ctypes.data
+
+        cb = _lib.RESERVE_FN(reserve)
+        n = C.c_size_t(0)
+        check(self.lib.fpng_amd_node_encode_host_image(self.h, b.ctypes.data, w, h, num_chans, flags, cb, None, C.byref(n)))
+        return hold[0][: n.value].tobytes()
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.fpng_amd_node_destroy(self.h)

@@ -584,6 +584,143 @@ void fpng_amd_node_destroy(fpng_amd_node *node)
 
 uint32_t fpng_amd_node_size(const fpng_amd_node *node) { return node ? (uint32_t)node->enc.size() : 0u; }
 
+// ONE host-resident image over the node's devices (BASELINE config 4): contiguous row bands, one per listed device;
+// every device moves ITS band up and ITS window of the file down over ITS OWN PCIe link, straight from / into the caller's
+// memory -- nothing is funnelled through one GPU.  Steps 1-6 of SURVEY 8(e): bands counted (2-pass: histograms summed on the
+// host first), the 64-byte records meet on the host (fpng_amd_plan_bands: start bits, Adler-32, the reference's
+// stored-or-compressed rule), bands placed at their bit positions, windows downloaded to their file offsets, the pieces two
+// windows share OR-ed on the host, the IDAT CRC combined from the bands' raw CRCs (fpng_amd_idat_crc_from_bands).  The output
+// is byte-identical to fpng_encode_image_to_memory()'s (reference src/fpng.cpp:1662-1803): one IDAT, one Deflate block.
+int fpng_amd_node_encode_host_image(fpng_amd_node *node, const void *pixels, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, fpng_amd_reserve_fn reserve,
+                                    void *user, size_t *out_size)
+{
+    if (!node || node->enc.empty() || !pixels || !reserve || !out_size) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    int rc = check_dims(w, h, c);
+    if (rc) return rc;
+    const uint32_t nd = (uint32_t)node->enc.size();
+    if ((flags & FPNG_AMD_FORCE_UNCOMPRESSED) || nd == 1 || h < 2 * nd) // (stored files and tiny images: one device, whole)
+        return fpng_amd_encode_host_to(node->enc[0], pixels, w, h, c, flags, reserve, user, out_size);
+    const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) != 0;
+    const size_t bpl = (size_t)w * c;
+    std::vector<uint32_t> ys(nd + 1);
+    for (uint32_t k = 0; k <= nd; k++) ys[k] = (uint32_t)((uint64_t)h * k / nd);
+    std::vector<fpng_amd_band_stats> stats(nd);
+    std::vector<uint64_t> start_bits(nd);
+    std::vector<uint32_t> raw(nd, 0), hist((size_t)nd * 288, 0), hist_sum(288, 0);
+    std::vector<uint64_t> ends(nd, 0);
+    struct Seam {
+        uint8_t b[16];
+        uint64_t file_off;
+        uint32_t n;
+    };
+    std::vector<Seam> seams(nd);
+    std::vector<int> rcs(nd, FPNG_AMD_OK);
+    std::vector<std::string> errs(nd);
+    fpng_amd_band_plan plan;
+    std::memset(&plan, 0, sizeof plan);
+    uint8_t *out = nullptr;
+    // a barrier for the device threads; the last one to arrive runs `serial` (under the lock) before the others go on
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t waiting = 0, generation = 0;
+    bool abort_all = false;
+    auto meet = [&](const std::function<void()> &serial) {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint32_t gen = generation;
+        if (++waiting == nd) {
+            if (!abort_all)
+                for (int v : rcs)
+                    if (v) abort_all = true;
+            if (!abort_all && serial) serial();
+            waiting = 0, generation++;
+            cv.notify_all();
+        } else
+            cv.wait(lk, [&] { return generation != gen; });
+        return !abort_all;
+    };
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < nd; d++)
+        th.emplace_back([&, d] {
+            fpng_amd_encoder *e = node->enc[d];
+            const uint32_t y0 = ys[d], y1 = ys[d + 1], rows = y1 - y0;
+            auto bail = [&](int code) {
+                rcs[d] = code;
+                errs[d] = fpng_amd_last_error();
+            };
+            uint32_t *d_hist = nullptr;
+            fpng_amd_band band;
+            std::memset(&band, 0, sizeof band);
+            do { // ---- phase A: the band goes up (with the row above it), is counted ----
+                if (hipSetDevice(e->device) != hipSuccess || drain(e)) { bail(FPNG_AMD_ERR_HIP); break; }
+                const size_t up_rows = rows + (y0 ? 1 : 0);
+                int r2;
+                if ((r2 = e->d_stage_in.ensure(up_rows * bpl + 16 + 288 * 4)) || (r2 = e->d_stage_out.ensure(fpng_amd_max_encoded_size(w, std::max(rows, 1u), c) + 256))) { bail(r2); break; }
+                if (rows && hipMemcpyAsync(e->d_stage_in.p, (const uint8_t *)pixels + (size_t)(y0 - (y0 ? 1 : 0)) * bpl, up_rows * bpl, hipMemcpyHostToDevice, e->stream) != hipSuccess) { bail(FPNG_AMD_ERR_HIP); break; }
+                d_hist = (uint32_t *)(e->d_stage_in.p + ((up_rows * bpl + 15) & ~(size_t)15));
+                band.d_rows = e->d_stage_in.p + (y0 ? bpl : 0), band.d_row_above = y0 ? e->d_stage_in.p : nullptr;
+                band.w = w, band.num_chans = c, band.y0 = y0, band.y1 = y1, band.h_total = h;
+                if (two_pass && rows) {
+                    if ((r2 = fpng_amd_band_hist(e, &band, d_hist))) { bail(r2); break; }
+                    if (hipMemcpyAsync(&hist[(size_t)d * 288], d_hist, 288 * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { bail(FPNG_AMD_ERR_HIP); break; }
+                }
+            } while (false);
+            if (two_pass && !meet([&] { // the image's histogram = the bands' sum (reference src/fpng.cpp:1021-1084 / :1299-1363 count the whole image)
+                    for (uint32_t k = 0; k < nd; k++)
+                        for (uint32_t i = 0; i < 288; i++) hist_sum[i] += hist[(size_t)k * 288 + i];
+                }))
+                return;
+            std::memset(&stats[d], 0, sizeof stats[d]);
+            if (!rcs[d] && rows) {
+                int r2 = FPNG_AMD_OK;
+                if (two_pass && hipMemcpyAsync(d_hist, hist_sum.data(), 288 * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess) r2 = FPNG_AMD_ERR_HIP;
+                if (!r2) r2 = fpng_amd_band_encode(e, &band, flags & FPNG_AMD_ENCODE_SLOWER, two_pass ? d_hist : nullptr, &stats[d]); // (waits for the band's counts)
+                if (r2) bail(r2);
+            }
+            // ---- the records meet: where every band starts, what the file's size and Adler-32 are, stored or not ----
+            if (!meet([&] {
+                    std::vector<fpng_amd_band_stats> st = stats;
+                    for (uint32_t k = 0; k < nd; k++) // (bands without rows take their table facts from a band that has some)
+                        if (!st[k].adler_len)
+                            for (uint32_t q = 0; q < nd; q++)
+                                if (stats[q].adler_len) st[k].first_token_bit = stats[q].first_token_bit, st[k].eob_bits = stats[q].eob_bits;
+                    int r2 = fpng_amd_plan_bands(st.data(), nd, w, h, c, flags & FPNG_AMD_ENCODE_SLOWER, start_bits.data(), &plan);
+                    if (!r2 && !plan.stored) {
+                        out = reserve(user, kPngHeaderBytes + (size_t)plan.zlib_size + kPngTrailerBytes);
+                        if (!out) r2 = fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+                    }
+                    if (r2) rcs[0] = r2, errs[0] = fpng_amd_last_error(), abort_all = true;
+                }))
+                return;
+            if (plan.stored || !rows) return;
+            // ---- phase C: the band is placed at its bit position; its window goes down to its place in the file ----
+            uint64_t fo = 0;
+            size_t nbytes = 0;
+            int r2 = fpng_amd_band_place(e, &band, start_bits[d], 0, e->d_stage_out.p, e->d_stage_out.cap, &fo, &nbytes);
+            if (!r2) r2 = fpng_amd_band_crc(e, &raw[d], &ends[d]); // (waits for the placement)
+            if (r2) { bail(r2); return; }
+            const uint32_t head = (d && ((kPngHeaderBytes * 8 + start_bits[d]) & 127)) ? (uint32_t)std::min<size_t>(16, nbytes) : 0u; // the piece shared with the band in front
+            seams[d].file_off = fo, seams[d].n = head;
+            if ((head && hipMemcpyAsync(seams[d].b, e->d_stage_out.p, head, hipMemcpyDeviceToHost, e->stream) != hipSuccess) ||
+                (nbytes > head && hipMemcpyAsync(out + fo + head, e->d_stage_out.p + head, nbytes - head, hipMemcpyDeviceToHost, e->stream) != hipSuccess) ||
+                hipStreamSynchronize(e->stream) != hipSuccess)
+                bail(FPNG_AMD_ERR_HIP);
+        });
+    for (auto &x : th) x.join();
+    for (uint32_t d = 0; d < nd; d++)
+        if (rcs[d]) return fail(rcs[d], errs[d].empty() ? "node image encode failed" : errs[d].c_str());
+    if (plan.stored) // incompressible: the reference's stored-block outcome, decided and written by the whole-image path
+        return fpng_amd_encode_host_to(node->enc[0], pixels, w, h, c, flags, reserve, user, out_size);
+    for (uint32_t d = 0; d < nd; d++) // the pieces neighbouring windows share: each band wrote zeros where the other's bits are
+        for (uint32_t i = 0; i < seams[d].n; i++) out[seams[d].file_off + i] |= seams[d].b[i];
+    uint8_t head[58], tail[20];
+    if ((rc = fpng_amd_png_head(w, h, c, plan.zlib_size, head))) return rc;
+    fpng_amd_png_tail(plan.adler, fpng_amd_idat_crc_from_bands(raw.data(), ends.data(), nd, plan.zlib_size, plan.adler), tail);
+    std::memcpy(out, head, kPngHeaderBytes);
+    std::memcpy(out + kPngHeaderBytes + plan.zlib_size - 4, tail, 20);
+    *out_size = kPngHeaderBytes + (size_t)plan.zlib_size + kPngTrailerBytes;
+    return FPNG_AMD_OK;
+}
+
 int fpng_amd_node_encode_host_batch(fpng_amd_node *node, const fpng_amd_host_image *images, uint32_t n, uint32_t flags, int n_writers)
 {
     if (!node || node->enc.empty() || !images || !n) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");

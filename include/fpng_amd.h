@@ -197,6 +197,13 @@ void fpng_amd_node_destroy(fpng_amd_node *node);
 uint32_t fpng_amd_node_size(const fpng_amd_node *node);
 int fpng_amd_node_encode_host_batch(fpng_amd_node *node, const fpng_amd_host_image *images, uint32_t n, uint32_t flags,
                                     int n_writer_threads_per_device);
+/* ONE host-resident image over the node's devices (reference src/fpng.cpp:1662-1803 writes the same
+ * file): contiguous row bands, one per listed device; every device uploads ITS band and downloads ITS window of the file
+ * over its own PCIe link, straight from / into the caller's memory (a 16384 x 16384 RGBA image: 1.07 GB up + 0.47 GB down --
+ * 29 ms on one link, under 4 ms on eight).  The bands' 64-byte records (and, 2-pass, their histograms) meet on the host; no
+ * device-to-device traffic.  `reserve` as in fpng_amd_encode_host_to(): called once, with the file's exact size. */
+int fpng_amd_node_encode_host_image(fpng_amd_node *node, const void *pixels, uint32_t w, uint32_t h, uint32_t num_chans, uint32_t flags,
+                                    fpng_amd_reserve_fn reserve, void *user, size_t *out_size);
 
 /* ---- row-band interface: one image sharded by rows over several GPUs.
  *      The stream stays ONE IDAT / ONE Deflate block; bands are stitched at bit granularity. ---- */

@@ -211,3 +211,49 @@ def test_encoders_one_after_the_other_and_the_buffer_list(built_lib):
         e.close()
         if k == 1:
             fpng_amd.release_cached_memory()
+
+
+def test_one_image_over_the_nodes_devices():
+    """fpng_amd_node_encode_host_image: ONE host image cut into row bands over the node's devices, every device moving its own band
+    up and its own window of the file down.  With device 0 listed 2 / 3 / 8 times (a one-GPU box): the
+    config-4 image (16384 x 16384 RGBA) for both flags against the reference's golden sha256, 4K frames, the photograph (a band
+    seam in every row-count class), an incompressible frame (the stored outcome goes back to the whole-image path), a tiny one."""
+    import fpng_amd
+    import real_image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dropin
+    with open(os.path.join(ROOT, "tests", "golden", "batches.json")) as f:
+        c4 = json.load(f)["c4"]
+    nodes = {n: fpng_amd.Node([0] * n) for n in (2, 3, 8)}
+    try:
+        w, h, c = c4["w"], c4["h"], c4["c"]
+        img = fpng_amd.synth_image(c4["kind"], w, h, c, seed=c4["seed0"])
+        for flags in (0, 1):
+            exp = c4["flags"][str(flags)]
+            for n in (8, 2) if flags == 0 else (8,):
+                png = nodes[n].encode_host_image(img, w, h, c, flags)
+                assert len(png) == exp["sizes"][0] and hashlib.sha256(png).hexdigest() == exp["sha256"][0], (flags, n)
+        del img
+        for kind in ("grad", "blocks", "noise"):
+            img = fpng_amd.synth_image(kind, 3840, 2160, 4)
+            for flags in (0, 1):
+                exp = _kat(kind, 3840, 2160, 4, flags)
+                for n in (3, 8):
+                    png = nodes[n].encode_host_image(img, 3840, 2160, 4, flags)
+                    assert len(png) == exp["size"] and hashlib.sha256(png).hexdigest() == exp["sha256"], (kind, flags, n)
+        rgb = real_image.rgb_pixels(dropin.decode)
+        hh, ww, _ = rgb.shape
+        for flags in (0, 1):
+            want = oracle_png(rgb, ww, hh, 3, flags)
+            for n in (2, 3, 8):
+                assert nodes[n].encode_host_image(rgb, ww, hh, 3, flags) == want, (flags, n)
+        tiny = fpng_amd.synth_image("grad", 37, 5, 3)
+        assert nodes[8].encode_host_image(tiny, 37, 5, 3, 0) == oracle_png(tiny, 37, 5, 3, 0)
+    finally:
+        for nd in nodes.values():
+            nd.close()
+
+
+def oracle_png(img, w, h, c, flags):
+    from cpu_ref import have_ref, oracle, ref
+    return (ref() if have_ref() else oracle()).encode(img, w, h, c, flags)

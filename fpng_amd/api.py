@@ -139,22 +139,23 @@ class Node:
         check(self.lib.fpng_amd_node_encode_host_batch(self.h, arr, len(images), flags, writer_threads))
         return [int(s) for s in sizes]
 
-    def encode_host_image(self, image, w, h, num_chans, flags=0):
-        """fpng_amd_node_encode_host_image: ONE host image (uint8 array) cut into row bands over the node's devices -> PNG bytes
-        (byte-identical to the single-device encoders' and to the reference's)."""
+    def encode_host_image(self, image, w, h, num_chans, flags=0, out=None):
+        """fpng_amd_node_encode_host_image: ONE host image (uint8 array) cut into row bands over the node's devices.  out=None ->
+        the PNG as bytes (byte-identical to the single-device encoders' and to the reference's); out = a uint8 numpy array of at
+        least max_encoded_size() bytes -> the file is written into it and its size returned (no allocation: a capture loop's form)."""
         b = _as_u8(image)
         if b.size < w * h * num_chans:
             raise ValueError("image buffer smaller than w*h*num_chans")
-        hold = []
+        buf = out if out is not None else np.empty(max_encoded_size(w, h, num_chans), dtype=np.uint8)
+        assert buf.dtype == np.uint8 and buf.flags["C_CONTIGUOUS"]
 
-        def reserve(_user, nbytes):
-            hold[:] = [np.empty(nbytes, dtype=np.uint8)]
-            return hold[0].ctypes.data
+        def reserve(_user, nbytes):  # (one buffer that only ever "grows" inside its capacity: what was written stays)
+            return buf.ctypes.data if nbytes <= buf.size else None
 
         cb = _lib.RESERVE_FN(reserve)
         n = C.c_size_t(0)
         check(self.lib.fpng_amd_node_encode_host_image(self.h, b.ctypes.data, w, h, num_chans, flags, cb, None, C.byref(n)))
-        return hold[0][: n.value].tobytes()
+        return n.value if out is not None else buf[: n.value].tobytes()
 
     def close(self):
         if getattr(self, "h", None):

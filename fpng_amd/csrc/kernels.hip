@@ -944,7 +944,7 @@ __device__ __forceinline__ void hist_block(const Job &job, uint32_t *dst)
         if (s) atomicAdd(&dst[i], s);
     }
 }
-__global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint32_t *hist_out)
+__global__ __launch_bounds__(kHistBlock) __attribute__((amdgpu_num_sgpr(80))) void hist_kernel(const Job *jobs, uint32_t *hist_out)
 {
     hist_block(job_of_block(jobs), hist_out + (size_t)blockIdx.y * 288);
 }
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kHistBlock) void hist_kernel(const Job *jobs, uint3
 struct JobArg {
     Job job;
 };
-__global__ __launch_bounds__(kHistBlock) void hist_first_kernel(const JobArg arg, Job *job_out, uint32_t *hist_out)
+__global__ __launch_bounds__(kHistBlock) __attribute__((amdgpu_num_sgpr(80))) void hist_first_kernel(const JobArg arg, Job *job_out, uint32_t *hist_out)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *job_out = arg.job; // for build_dynamic_kernel
     hist_block(arg.job, hist_out);

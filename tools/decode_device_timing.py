@@ -10,10 +10,17 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 enc = fpng_amd.Encoder(device=0)
 cases = [("8K RGBA grad x 8", "grad", 7680, 4320, 4, 8), ("4K RGBA grad x 16", "grad", 3840, 2160, 4, 16), ("1080p RGB grad x 64", "grad", 1920, 1080, 3, 64),
          ("512x512 RGB grad x 256", "grad", 512, 512, 3, 256), ("8K RGBA blocks x 8", "blocks", 7680, 4320, 4, 8)]
+import ui_images
+for uname, (uimg, uw, uh, uc) in sorted(ui_images.all_images().items()):
+    if uw == 3840:
+        cases.append((f"4K UI {uname} x 8", uimg, uw, uh, uc, 8))
 for name, kind, w, h, c, n in cases:
     if only and only not in name:
         continue
-    ts = [torch.from_numpy(fpng_amd.synth_image(kind, w, h, c, seed=12345 + i)).cuda() for i in range(n)]
+    if isinstance(kind, str):
+        ts = [torch.from_numpy(fpng_amd.synth_image(kind, w, h, c, seed=12345 + i)).cuda() for i in range(n)]
+    else:  # (a fixed image: the same file n times)
+        ts = [torch.from_numpy(kind).cuda()] * n
     for flags in (0, 1):
         pngs, _ = enc.encode_tensors(ts, flags)
         dev = [torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda() for p in pngs]

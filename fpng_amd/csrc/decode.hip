@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kSyncDwords)];
     __shared__ uint32_t s_end[kSubBlock];
-    __shared__ uint32_t red[kSubBlock / kWave];
+    __shared__ uint32_t red3[3 * (kSubBlock / kWave)];
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
@@ -212,10 +212,20 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         }
         const bool any_dirty = __syncthreads_or(dirty);
         if (!any_dirty) continue;
-        const uint32_t sum = block_sum<kSubBlock / kWave>(valid ? st.c.bytes : 0u, red);
-        const uint32_t e = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubEob)) ? t : (uint32_t)kSubBlock, red);
-        const uint32_t inv = block_min<kSubBlock / kWave>((valid && (st.c.flags & kSubInvalid)) ? t : (uint32_t)kSubBlock, red);
+        // the block's byte count and its first end-of-block / invalid subsequences: wave reductions, then ONE meeting in LDS
+        uint32_t sum = valid ? st.c.bytes : 0u;
+        uint32_t e = (valid && (st.c.flags & kSubEob)) ? t : (uint32_t)kSubBlock, inv = (valid && (st.c.flags & kSubInvalid)) ? t : (uint32_t)kSubBlock;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            sum += (uint32_t)__shfl_xor((int)sum, o, kWave);
+            e = min(e, (uint32_t)__shfl_xor((int)e, o, kWave));
+            inv = min(inv, (uint32_t)__shfl_xor((int)inv, o, kWave));
+        }
+        if ((t & 63) == 0) red3[(t >> 6) * 3] = sum, red3[(t >> 6) * 3 + 1] = e, red3[(t >> 6) * 3 + 2] = inv;
+        __syncthreads();
         if (t == 0) {
+            sum = 0, e = inv = (uint32_t)kSubBlock;
+            for (int q = 0; q < kSubBlock / kWave; q++) sum += red3[q * 3], e = min(e, red3[q * 3 + 1]), inv = min(inv, red3[q * 3 + 2]);
             DecBlockRec r;
             r.sum = sum, r.first_eob = e, r.first_invalid = inv;
             r.entry_rel = st.start - nominal;
@@ -403,6 +413,12 @@ struct StreamSink {
 #elif defined(FPNG_DEC_EMIT_L2STORE) // ... and what they cost when every one of them hits a line that stays in the L2
     __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d & 0x3FFFu] = v; }
     __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g & 0xFFFu] = u32x4{a, b, c, d}; }
+#elif defined(FPNG_DEC_EMIT_NT) // ... with the non-temporal hint
+    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
+    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+    {
+        __builtin_nontemporal_store(u32x4{a, b, c, d}, (__attribute__((address_space(1))) u32x4 *)f + g);
+    }
 #else
     __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
     __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g] = u32x4{a, b, c, d}; }

@@ -56,6 +56,13 @@ struct DecUnfPlan {
     uint32_t n_pieces, total_items;
 };
 
+// a device-resident file (dec_fetch_kernel gathers the heads and tails of a batch's files for the host's container walk)
+struct DecFileRef {
+    const uint8_t *data;
+    uint32_t size, pad_;
+};
+void launch_dec_fetch(hipStream_t s, const DecFileRef *files, uint32_t n, uint32_t head, uint32_t tail, uint8_t *out);
+
 // a file that is decoded piece by piece: what the pieces so far amount to (dec_offsets_range_kernel)
 struct DecCarry {
     uint64_t bytes; // output bytes of the blocks so far (up to the end-of-block symbol once it was met)

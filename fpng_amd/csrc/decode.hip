@@ -610,7 +610,24 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
     }
 }
 
+// ---- device-resident files: the first `head` and the last `tail` bytes of every file gathered into one buffer (one copy to the
+//      host instead of two per file) ----
+__global__ __launch_bounds__(kDecBlock) void dec_fetch_kernel(const DecFileRef *files, uint32_t head, uint32_t tail, uint8_t *out)
+{
+    const DecFileRef f = files[blockIdx.x];
+    uint8_t *o = out + (size_t)blockIdx.x * (head + tail);
+    if (!f.data || !f.size) return;
+    const uint32_t hl = min(f.size, head), tl = f.size > hl ? min(f.size - hl, tail) : 0u;
+    for (uint32_t k = threadIdx.x; k < hl; k += kDecBlock) o[k] = f.data[k];
+    for (uint32_t k = threadIdx.x; k < tl; k += kDecBlock) o[head + k] = f.data[f.size - tl + k];
+}
+
 } // namespace
+
+void launch_dec_fetch(hipStream_t s, const DecFileRef *files, uint32_t n, uint32_t head, uint32_t tail, uint8_t *out)
+{
+    hipLaunchKernelGGL(dec_fetch_kernel, dim3(n), dim3(kDecBlock), 0, s, files, head, tail, out);
+}
 
 // (the synchronisation and the emit run as persistent workgroups, `resident` of them: a few per compute unit)
 void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,

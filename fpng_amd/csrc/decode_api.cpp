@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace fpng_amd;
@@ -150,8 +151,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     uint32_t max_rounds = kMaxRounds;
     if (const char *mr = getenv("FPNG_AMD_DECODE_MAX_ROUNDS")) max_rounds = (uint32_t)std::max(0, atoi(mr)); // (0: every dynamic file is left to the CPU decoder -- tests)
     std::vector<Parsed> ps(n);
-    std::vector<std::vector<uint32_t>> luts;      // unique lookup tables (1-pass files share two)
+    std::vector<uint32_t> luts;                   // unique lookup tables, dec::kLutDwords each (1-pass files share two): ONE upload
     std::vector<std::vector<uint8_t>> lut_keys;   // the code lengths they were built from
+    std::unordered_multimap<uint64_t, uint32_t> lut_index; // ... found by their hash
     static thread_local uint32_t table[1u << kTableBits];
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
@@ -160,17 +162,14 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
 
     // ---- device-resident files: their first and last bytes come back first (one round trip for the batch) ----
     if (device_data) {
-        if ((rc = e->h_dec_fetch.ensure((size_t)n * (kHeadBytes + kTailBytes)))) return rc;
-        for (uint32_t i = 0; i < n; i++) {
-            if (!files[i].data || !files[i].size) continue;
-            uint8_t *dst = e->h_dec_fetch.p + (size_t)i * (kHeadBytes + kTailBytes);
-            const uint32_t hl = std::min(files[i].size, kHeadBytes);
-            HIP_TRY(hipMemcpyAsync(dst, files[i].data, hl, hipMemcpyDeviceToHost, s));
-            if (files[i].size > hl) {
-                const uint32_t tl = std::min(files[i].size - hl, kTailBytes);
-                HIP_TRY(hipMemcpyAsync(dst + kHeadBytes, (const uint8_t *)files[i].data + files[i].size - tl, tl, hipMemcpyDeviceToHost, s));
-            }
-        }
+        const size_t per = kHeadBytes + kTailBytes, refs = ((size_t)n * sizeof(DecFileRef) + 255) & ~(size_t)255;
+        if ((rc = e->h_dec_fetch.ensure((size_t)n * per + refs)) || (rc = e->d_decode.ensure((size_t)n * per + refs))) return rc;
+        DecFileRef *h_refs = (DecFileRef *)(e->h_dec_fetch.p + (size_t)n * per);
+        for (uint32_t i = 0; i < n; i++) h_refs[i] = {(const uint8_t *)files[i].data, files[i].size, 0};
+        // (one small upload, one gather kernel, one download: two copies per file cost ~10 us each)
+        HIP_TRY(hipMemcpyAsync(e->d_decode.p + (size_t)n * per, h_refs, (size_t)n * sizeof(DecFileRef), hipMemcpyHostToDevice, s));
+        launch_dec_fetch(s, (const DecFileRef *)(e->d_decode.p + (size_t)n * per), n, kHeadBytes, kTailBytes, e->d_decode.p);
+        HIP_TRY(hipMemcpyAsync(e->h_dec_fetch.p, e->d_decode.p, (size_t)n * per, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     std::vector<uint8_t> whole; // a device-resident file the head and tail were not enough for
@@ -214,13 +213,17 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
                 r.status = FPNG_AMD_DECODE_UNDECIDED;
                 continue;
             }
-            for (size_t k = 0; k < lut_keys.size() && p.lut < 0; k++)
-                if (!std::memcmp(lut_keys[k].data(), sizes, 288)) p.lut = (int)k;
+            uint64_t hsh = 1469598103934665603ull; // (FNV-1a over the code lengths: a batch of 2-pass files has a table per file)
+            for (int q = 0; q < 288; q++) hsh = (hsh ^ sizes[q]) * 1099511628211ull;
+            auto range = lut_index.equal_range(hsh);
+            for (auto it = range.first; it != range.second && p.lut < 0; ++it)
+                if (!std::memcmp(lut_keys[it->second].data(), sizes, 288)) p.lut = (int)it->second;
             if (p.lut < 0) {
-                p.lut = (int)luts.size();
+                lut_index.emplace(hsh, (uint32_t)lut_keys.size());
+                p.lut = (int)lut_keys.size();
                 lut_keys.emplace_back(sizes, sizes + 288);
-                luts.emplace_back(dec::kLutDwords);
-                build_multi_lut(table, sizes, luts.back().data());
+                luts.resize(luts.size() + dec::kLutDwords);
+                build_multi_lut(table, sizes, luts.data() + luts.size() - dec::kLutDwords);
             }
         }
         DecJob j;
@@ -276,7 +279,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         };
         const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
                      o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
-                     o_luts = carve(std::max<size_t>(luts.size(), 1) * dec::kLutDwords * 4),
+                     o_luts = carve(std::max<size_t>(luts.size(), dec::kLutDwords) * 4),
                      o_jobs = carve(nj * sizeof(DecJob)), o_plan = carve(((size_t)nj + kMaxGroups) * (sizeof(DecUnfPiece) + 8)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         // the look-back granules of dec_unfilter_kernel: never cleared between calls -- every launch has its own epoch, and memory
@@ -375,7 +378,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             }
         });
     }
-    for (size_t k = 0; k < luts.size(); k++) HIP_TRY(hipMemcpyAsync(d_luts + k * dec::kLutDwords, luts[k].data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
+    if (!luts.empty()) HIP_TRY(hipMemcpyAsync(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
     {   // dec_unfilter_kernel's work items per group of files, numbered segment by segment (decode.h: DecUnfPlan)
         DecUnfPiece *d_pieces = (DecUnfPiece *)d_plan;

@@ -9,7 +9,10 @@ constexpr uint32_t kSubBits = 512;      // token bits per subsequence (one threa
 constexpr uint32_t kDecSubBlock = 512;  // subsequences per workgroup of the synchronisation (a file's subsequences are padded to whole workgroups)
 constexpr uint32_t kDecLeadIn = 128;    // bits a subsequence's first decode starts early (decode_core.h: sub_first)
 constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_emit_kernel (divides kDecSubBlock)
-constexpr uint32_t kDecUnfRows = 32;    // rows per segment of the Up filter's undoing (held in registers)
+#ifndef FPNG_DEC_UNF_ROWS
+#define FPNG_DEC_UNF_ROWS 48
+#endif
+constexpr uint32_t kDecUnfRows = FPNG_DEC_UNF_ROWS; // rows per segment of the Up filter's undoing (held in registers)
 enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecBadFilter = 8u, kDecStalled = 16u, kDecSawEob = 0x100u };
 
 struct DecJob {
@@ -31,6 +34,16 @@ struct DecJob {
 };
 
 // what the synchronisation leaves per workgroup of kDecSubBlock subsequences (indices inside the workgroup, kDecSubBlock = none)
+// Column blocks of dec_unfilter_kernel for one file: a workgroup of kDecBlock threads covers kDecBlock dword columns of the filtered
+// rows -- or, where 3-channel rows become 4-channel pixels, 4 waves x 48 dword columns = 256 whole pixels (see the kernel).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t dec_col_blocks(uint32_t w, uint32_t src_c, uint32_t dst_c)
+{
+    return (src_c == 3 && dst_c == 4) ? (w + 255u) / 256u : ((w * src_c + 3u) / 4u + 255u) / 256u;
+}
+
 struct DecBlockRec {
     uint32_t sum;           // output bytes of its subsequences
     uint32_t first_eob;     // first one that met an end-of-block symbol

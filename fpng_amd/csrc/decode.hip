@@ -489,7 +489,28 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch)
+// (a wave-uniform base in global memory + a 32-bit offset per lane: the load / store takes the base from scalar registers and ONE
+//  vector register of offsets serves all rows -- generic 64-bit addresses cost a register pair per row and lane)
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni64(uint64_t x) { return ((uint64_t)uni32((uint32_t)(x >> 32)) << 32) | uni32((uint32_t)x); }
+typedef __attribute__((address_space(1))) uint8_t gu8;
+typedef uint32_t __attribute__((aligned(1))) u32_any;
+typedef __attribute__((address_space(1))) u32_any gu32_any;
+// (the empty asm pins the base in scalar registers and hides how it was made: the optimiser otherwise folds "row base + lane
+//  offset" into the lane's side of the sum and is back at 64-bit vector addresses)
+__device__ __forceinline__ gu8 *scalar_base(const gu8 *p)
+{
+    uint64_t a = (uint64_t)p;
+    asm("" : "+s"(a));
+    return (gu8 *)a;
+}
+__device__ __forceinline__ uint32_t gload_u32(const gu8 *base, uint32_t off) { return *(const gu32_any *)(scalar_base(base) + off); }
+__device__ __forceinline__ void gstore_u32(gu8 *base, uint32_t off, uint32_t v) { *(gu32_any *)(scalar_base(base) + off) = v; }
+__device__ __forceinline__ void gstore_u8(gu8 *base, uint32_t off, uint32_t v) { scalar_base(base)[off] = (uint8_t)v; }
+#ifndef FPNG_DEC_UNF_WAVES
+#define FPNG_DEC_UNF_WAVES 4
+#endif
+__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch)
 {
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
@@ -510,19 +531,31 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
             if (plan.pieces[mid].item0 <= item) lo = mid; else hi = mid;
         }
         const DecUnfPiece pc = plan.pieces[lo];
-        const uint32_t per_seg = plan.cbpre[pc.alive], rel = item - pc.item0, sg = pc.seg0 + rel / per_seg, within = rel % per_seg;
+        const uint32_t per_seg = plan.cbpre[pc.alive], rel = item - pc.item0, sg = uni32(pc.seg0 + rel / per_seg), within = rel % per_seg;
         lo = 0, hi = pc.alive;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (plan.cbpre[mid] <= within) lo = mid; else hi = mid;
         }
-        const uint32_t ji = plan.order[lo], cb = within - plan.cbpre[lo];
-        const DecJob &job = jobs[ji];
+        const uint32_t ji = uni32(plan.order[lo]), cb = uni32(within - plan.cbpre[lo]);
+        // (the file's record, read by every lane, into scalar registers: the compiler keeps what it loads from writable global
+        //  memory in vector registers, and every address derived from it would cost a register pair per row)
+        DecJob job = jobs[ji];
+        job.filt = (uint8_t *)uni64((uint64_t)(uintptr_t)job.filt), job.out = (uint8_t *)uni64((uint64_t)(uintptr_t)job.out);
+        job.segsum = (uint32_t *)uni64((uint64_t)(uintptr_t)job.segsum);
+        job.w = uni32(job.w), job.h = uni32(job.h), job.bpl = uni32(job.bpl), job.src_c = uni32(job.src_c), job.dst_c = uni32(job.dst_c), job.nseg = uni32(job.nseg), job.mode = uni32(job.mode);
         // (only bits that the kernels in FRONT of this one set decide: every workgroup must come to the same conclusion about a
         //  file, or a later segment would wait for an earlier one that was skipped -- the checks below have bits of their own)
         if (job.mode != 0 || (status[ji] & (kDecNotConverged | kDecBadStream))) return;
         const uint32_t ncol = (job.bpl + 3) / 4;
-        const uint32_t j4 = cb * kDecBlock + threadIdx.x;
+        const uint32_t sc = job.src_c, dc = job.dst_c, lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+        // Which dword column is this thread's?  Normally workgroup-thread t has column cb * 256 + t.  Where 3-channel rows become
+        // 4-channel pixels, a wave takes 48 dword columns = 192 bytes = 64 WHOLE pixels (its lanes 48..63 hold no column) and
+        // every lane writes one pixel, gathered from two lanes' dwords -- dword stores instead of a byte at a time.
+        const bool widen = sc == 3 && dc == 4;
+        const uint32_t wave_px = (cb * (kDecBlock / kWave) + wv) * kWave; // (widen: the wave's first pixel)
+        const uint32_t j4 = widen ? (wave_px / 4) * 3 + lane : cb * kDecBlock + threadIdx.x;
+        const bool active = j4 < ncol && (!widen || lane < 48);
         const uint32_t y0 = sg * kUnfRows, nrows = min(kUnfRows, job.h - y0);
         const size_t stride = (size_t)job.bpl + 1;
         if (cb == 0 && threadIdx.x == 0) {
@@ -530,17 +563,29 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
             for (uint32_t k = 0; k < nrows; k++) bad |= job.filt[(size_t)(y0 + k) * stride] != (y0 + k ? 2 : 0);
             if (bad) atomicOr(&status[ji], kDecBadFilter);
         }
-        if (j4 >= ncol) return;
-        const uint8_t *F = job.filt + 1 + (size_t)j4 * 4 + (size_t)y0 * stride;
+        if (!widen && !active) return; // (the lanes of a widening wave all stay: they write pixels)
+        if (widen && wave_px >= job.w) return;
+        const gu8 *F = (const gu8 *)(uintptr_t)(job.filt + 1 + (size_t)y0 * stride);
         uint32_t v[kUnfRows];
+        // (no branch per row: a segment with fewer rows loads its last row again and again -- zeroed below, so that those entries
+        //  END UP as copies of the last row's sums, and the stores further down write that row again with the same bytes)
+        const uint32_t last = nrows - 1;
+        if (active) {
 #pragma unroll
-        for (uint32_t k = 0; k < kUnfRows; k++) v[k] = k < nrows ? load_u32_unaligned(F + (size_t)k * stride) : 0u;
+            for (uint32_t k = 0; k < kUnfRows; k++) v[k] = gload_u32(F + (size_t)min(k, last) * stride, j4 * 4);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kUnfRows; k++) v[k] = (k < nrows && active) ? v[k] : 0u;
         uint32_t p = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kUnfRows; k++) p = add_bytes(p, v[k]), v[k] = p;
+        for (uint32_t k = 0; k < kUnfRows; k++) {
+            p = add_bytes(p, v[k]);
+            asm("" : "+v"(p)); // (ONE register per row: the compiler otherwise keeps every sum as the two halves add_bytes() joins and joins them where they are stored)
+            v[k] = p;
+        }
         gu64 *gran = (gu64 *)(uintptr_t)job.segsum + j4;
         uint32_t carry = 0;
-        if (sg + 1 < job.nseg || sg) { // (a file of one segment publishes nothing)
+        if (active && (sg + 1 < job.nseg || sg)) { // (a file of one segment publishes nothing)
             gu64 *mine = gran + (size_t)sg * ncol;
             if (sg == 0)
                 __hip_atomic_store(mine, ((unsigned long long)(epoch << 2 | 2u) << 32) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -566,24 +611,60 @@ __global__ __launch_bounds__(kDecBlock) void dec_unfilter_kernel(const DecJob *j
                     __hip_atomic_store(mine, ((unsigned long long)(epoch << 2 | 2u) << 32) | add_bytes(carry, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        const uint32_t sc = job.src_c, dc = job.dst_c, nb = min(4u, job.bpl - j4 * 4);
+        // ---- the pixels.  Dword stores at any byte address (rows of 3-channel pixels start anywhere; the hardware takes
+        //      unaligned dwords, as it does for the loads above); bytes only where a row ends inside a dword ----
         const size_t os = (size_t)job.w * dc;
-        const bool whole = sc == dc && nb == 4 && (os & 3) == 0 && (((uintptr_t)job.out) & 3) == 0; // aligned dword stores
-        uint8_t *orow = job.out + (size_t)y0 * os;
-        if (whole) {
+        gu8 *orow = (gu8 *)(uintptr_t)(job.out + (size_t)y0 * os);
 #pragma unroll
-            for (uint32_t k = 0; k < kUnfRows; k++)
-                if (k < nrows) *(uint32_t *)(orow + (size_t)k * os + (size_t)j4 * 4) = add_bytes(carry, v[k]);
-        } else {
+        for (uint32_t k = 0; k < kUnfRows; k++) {
+            v[k] = add_bytes(carry, v[k]);
+            asm("" : "+v"(v[k]));
+        }
+        if (sc == dc) {
+            const uint32_t nb = min(4u, job.bpl - j4 * 4);
+            if (nb == 4) {
+#pragma unroll
+                for (uint32_t k = 0; k < kUnfRows; k++)
+                    gstore_u32(orow + (size_t)min(k, last) * os, j4 * 4, v[k]);
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < kUnfRows; k++)
+                    for (uint32_t b = 0; b < nb; b++) gstore_u8(orow + (size_t)min(k, last) * os, j4 * 4 + b, v[k] >> (8 * b));
+            }
+        } else if (widen) {
+            // lane L's pixel = bytes 3L .. 3L + 2 of the wave's 192: in the dwords of lanes 3L / 4 and the next one
+            const uint32_t src = (3u * lane) >> 2, sh = (3u * lane) & 3u;
+            const bool st = wave_px + lane < job.w;
 #pragma unroll
             for (uint32_t k = 0; k < kUnfRows; k++) {
-                const uint32_t acc = add_bytes(carry, v[k]);
-                uint8_t *o = orow + (size_t)k * os;
-                for (uint32_t b = 0; b < 4; b++) {
-                    const uint32_t j = j4 * 4 + b, px = j / sc, ch = j - px * sc;
-                    if (k >= nrows || b >= nb || ch >= dc) continue; // (alpha dropped)
-                    o[(size_t)px * dc + ch] = (uint8_t)(acc >> (8 * b));
-                    if (dc == 4 && sc == 3 && ch == 2) o[(size_t)px * dc + 3] = 0xFF;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v[k]), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src + 1) << 2), (int)v[k]);
+                if (st) gstore_u32(orow + (size_t)min(k, last) * os, (wave_px + lane) * 4, funnel(hi, lo, 8 * sh) | 0xFF000000u);
+                __builtin_amdgcn_sched_barrier(0); // (row by row: gathering all rows first costs a register per row and lane)
+            }
+        } else {
+            // 4 -> 3 channels: the wave's 64 pixels are 48 dwords; lane L < 48 builds dword L = bytes 4L .. 4L + 3 of the 192
+            // from the pixels 4L / 3 and the next one
+            const uint32_t wpx = (cb * (kDecBlock / kWave) + wv) * kWave, nv = min((uint32_t)kWave, job.w - wpx); // (this wave's pixels: j4 = wpx + lane < w)
+            const uint32_t p0 = (4u * lane) / 3u, r = 4u * lane - 3u * p0, have = 3u * nv; // bytes of the wave
+            const uint32_t nb = lane < 48 ? (4u * lane + 4 <= have ? 4u : (4u * lane < have ? have - 4u * lane : 0u)) : 0u;
+            const uint32_t off = wpx * 3 + 4u * lane;
+            auto dword = [&](uint32_t acc) {
+                const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)acc), b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((p0 + 1) & 63u) << 2), (int)acc);
+                return funnel((b & 0xFFFFFFu) >> 8, (a & 0xFFFFFFu) | (b << 24), 8 * r); // (b's 24 bits : a's 24 bits) >> 8 r
+            };
+#pragma unroll
+            for (uint32_t k = 0; k < kUnfRows; k++) {
+                const uint32_t d = dword(v[k]);
+                if (nb == 4) gstore_u32(orow + (size_t)min(k, last) * os, off, d);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (__builtin_amdgcn_ballot_w64(nb - 1u < 3u)) { // the row ends inside some lane's dword (all lanes come along: they are the gather's sources)
+#pragma unroll
+                for (uint32_t k = 0; k < kUnfRows; k++) {
+                    const uint32_t d = dword(v[k]);
+                    if (nb - 1u < 3u)
+                        for (uint32_t q = 0; q < nb; q++) gstore_u8(orow + (size_t)min(k, last) * os, off + q, d >> (8 * q));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

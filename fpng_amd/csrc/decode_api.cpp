@@ -101,7 +101,14 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
 // length code lengths, p.first_bit = the first row token).  z / avail: the stream's bytes in host memory, `complete`: all of them
 // (else only a head of the file: fpng::parse::kParseNeedMore asks for the rest).  Returns the reference's status code (0 or
 // FPNG_DECODE_NOT_FPNG) or FPNG_AMD_DECODE_UNDECIDED (a stored layout only the CPU decoder takes).
-int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint32_t *table, uint8_t sizes[288])
+// (memo: the last dynamic header read INTO `table` -- the files of a 1-pass batch all begin with the same one, and reading it
+//  means building two 4096-entry tables, 4 us a file; a header that is bit for bit the memo's is not read again)
+struct HeaderMemo {
+    uint32_t bits = 0, chans = 0; // bits: the header's end = the first row token, from the stream's first byte (0: no memo)
+    uint8_t bytes[320];
+    uint8_t sizes[288];
+};
+int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint32_t *table, uint8_t sizes[288], HeaderMemo *memo = nullptr)
 {
     using namespace fpng::parse;
     if (avail < 3) return complete ? (int)fpng::FPNG_DECODE_NOT_FPNG : kParseNeedMore;
@@ -117,10 +124,26 @@ int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint
     }
     Bits in = {z, avail, 2, 0, 0, false};
     if (in.get(1) != 1 || in.get(2) != 2) return fpng::FPNG_DECODE_NOT_FPNG; // one final dynamic block
-    const bool ok = read_dynamic_header(in, p.c, table, sizes);
-    if (!complete && in.byte + 8 > avail) return kParseNeedMore; // (the header reader may have run off the head)
-    if (!ok) return fpng::FPNG_DECODE_NOT_FPNG;
-    p.first_bit = in.bitpos();
+    bool known = false;
+    if (memo && memo->bits && memo->chans == p.c) {
+        const uint32_t nb = memo->bits >> 3, rb = memo->bits & 7;
+        known = avail >= nb + 9 && !std::memcmp(z, memo->bytes, nb) && !((z[nb] ^ memo->bytes[nb]) & ((1u << rb) - 1u));
+    }
+    if (known) {
+        std::memcpy(sizes, memo->sizes, 288);
+        p.first_bit = memo->bits;
+    } else {
+        if (memo) memo->bits = 0; // (`table` is about to change)
+        const bool ok = read_dynamic_header(in, p.c, table, sizes);
+        if (!complete && in.byte + 8 > avail) return kParseNeedMore; // (the header reader may have run off the head)
+        if (!ok) return fpng::FPNG_DECODE_NOT_FPNG;
+        p.first_bit = in.bitpos();
+        if (memo && (p.first_bit >> 3) < sizeof memo->bytes && (p.first_bit >> 3) < avail) {
+            memo->bits = (uint32_t)p.first_bit, memo->chans = p.c;
+            std::memcpy(memo->bytes, z, (size_t)(p.first_bit >> 3) + 1);
+            std::memcpy(memo->sizes, sizes, 288);
+        }
+    }
     if (p.first_bit >= (uint64_t)(p.idat_len - 4) * 8) return fpng::FPNG_DECODE_NOT_FPNG;
     // a token has at least 2 bits and stands for at most 258 bytes: an IDAT this short cannot hold the image (checked before any
     // device memory is sized by the header's dimensions)
@@ -129,11 +152,11 @@ int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint
 }
 
 // parse one file that is wholly in host memory
-int parse_host(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, uint8_t sizes[288])
+int parse_host(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, uint8_t sizes[288], HeaderMemo *memo = nullptr)
 {
     p.status = fpng::parse::parse_container(png, size, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
     if (p.status) return p.status;
-    return plan_stream(png + p.idat_ofs + 8, size - (p.idat_ofs + 8), true, p, table, sizes);
+    return plan_stream(png + p.idat_ofs + 8, size - (p.idat_ofs + 8), true, p, table, sizes, memo);
 }
 
 int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results, bool device_data)
@@ -150,11 +173,15 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     const uint32_t resident = (uint32_t)std::max(cus, 1) * 3; // persistent workgroups of dec_sync_kernel / dec_emit_kernel: their LDS lets three share a compute unit
     uint32_t max_rounds = kMaxRounds;
     if (const char *mr = getenv("FPNG_AMD_DECODE_MAX_ROUNDS")) max_rounds = (uint32_t)std::max(0, atoi(mr)); // (0: every dynamic file is left to the CPU decoder -- tests)
+    static const bool trace_t = getenv("FPNG_AMD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<Parsed> ps(n);
     std::vector<uint32_t> luts;                   // unique lookup tables, dec::kLutDwords each (1-pass files share two): ONE upload
     std::vector<std::vector<uint8_t>> lut_keys;   // the code lengths they were built from
     std::unordered_multimap<uint64_t, uint32_t> lut_index; // ... found by their hash
     static thread_local uint32_t table[1u << kTableBits];
+    HeaderMemo memo; // (of this call's `table`)
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
     size_t z_total = 0, filt_total = 0, seg_total = 0;
@@ -171,6 +198,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         launch_dec_fetch(s, (const DecFileRef *)(e->d_decode.p + (size_t)n * per), n, kHeadBytes, kTailBytes, e->d_decode.p);
         HIP_TRY(hipMemcpyAsync(e->h_dec_fetch.p, e->d_decode.p, (size_t)n * per, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (trace_t) fprintf(stderr, "[decode] +%.0f us: heads and tails of %u files are here\n", since(), n);
     }
     std::vector<uint8_t> whole; // a device-resident file the head and tail were not enough for
     for (uint32_t i = 0; i < n; i++) {
@@ -184,18 +212,18 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         uint8_t sizes[288];
         int st;
         if (!device_data)
-            st = parse_host((const uint8_t *)files[i].data, files[i].size, p, table, sizes);
+            st = parse_host((const uint8_t *)files[i].data, files[i].size, p, table, sizes, &memo);
         else {
             const uint8_t *buf = e->h_dec_fetch.p + (size_t)i * (kHeadBytes + kTailBytes);
             const uint32_t size = files[i].size, hl = std::min(size, kHeadBytes), tl = size > hl ? std::min(size - hl, kTailBytes) : 0u;
             const View v = {buf, hl, tl ? buf + kHeadBytes : nullptr, size - tl, size};
             st = p.status = parse_container_view(v, p.w, p.h, p.c, p.idat_ofs, p.idat_len);
-            if (!st) st = (p.idat_ofs + 8 < hl) ? plan_stream(buf + p.idat_ofs + 8, hl - (p.idat_ofs + 8), hl == size, p, table, sizes) : kParseNeedMore;
+            if (!st) st = (p.idat_ofs + 8 < hl) ? plan_stream(buf + p.idat_ofs + 8, hl - (p.idat_ofs + 8), hl == size, p, table, sizes, &memo) : kParseNeedMore;
             if (st == kParseNeedMore) { // unusual chunks, a stored file, ...: the whole file comes back
                 whole.resize(size);
                 HIP_TRY(hipMemcpy(whole.data(), files[i].data, size, hipMemcpyDeviceToHost));
                 p = Parsed();
-                st = parse_host(whole.data(), size, p, table, sizes);
+                st = parse_host(whole.data(), size, p, table, sizes, &memo);
             }
         }
         r.w = p.w, r.h = p.h, r.channels_in_file = p.c;
@@ -257,6 +285,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         job_file.push_back(i);
     }
     const uint32_t nj = (uint32_t)jobs.size();
+    if (trace_t) fprintf(stderr, "[decode] +%.0f us: %u files parsed, %zu lookup tables built\n", since(), n, lut_keys.size());
     if (!nj) return FPNG_AMD_OK;
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
@@ -337,9 +366,6 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         close(j0, nj);
     }
     const uint32_t ng = (uint32_t)groups.size();
-    static const bool trace_t = getenv("FPNG_AMD_TRACE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
     auto upload_group = [&](const Group &g, hipStream_t st) -> hipError_t {
         for (uint32_t k = g.j0; k < g.j1; k++) {
             const Parsed &p = ps[job_file[k]];
@@ -393,7 +419,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             const uint32_t m = (uint32_t)order.size();
             const size_t w0 = words.size(), p0 = pieces.size();
             words.push_back(0);
-            for (uint32_t k = 0; k < m; k++) words.push_back(words.back() + ((jobs[g.j0 + order[k]].bpl + 3) / 4 + 255) / 256);
+            for (uint32_t k = 0; k < m; k++) words.push_back(words.back() + dec_col_blocks(jobs[g.j0 + order[k]].w, jobs[g.j0 + order[k]].src_c, jobs[g.j0 + order[k]].dst_c));
             words.insert(words.end(), order.begin(), order.end());
             uint32_t seg = 0, item = 0;
             for (uint32_t alive = m; alive >= 1; alive--) { // the alive-th file of the order is the next one to run out of rows
@@ -557,7 +583,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
     j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
     const uint32_t n_blocks = (j.n_sub + kDecSubBlock - 1) / kDecSubBlock, sub_total = n_blocks * kDecSubBlock;
-    const size_t total = ((size_t)j.bpl + 1) * j.h, ncol = (j.bpl + 3) / 4, col_blocks = (ncol + 255) / 256, os = (size_t)p.w * desired;
+    const size_t total = ((size_t)j.bpl + 1) * j.h, col_blocks = dec_col_blocks(j.w, j.src_c, j.dst_c), os = (size_t)p.w * desired;
     // ---- scratch ----
     uint8_t *d_z, *d_filt;
     DecSubArrays d_sub;
@@ -578,7 +604,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
                      o_tail = carve((size_t)sub_total * 4), o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
                      o_boff = carve((size_t)n_blocks * 8), o_lut = carve(dec::kLutDwords * 4), o_job = carve(sizeof(DecJob)), o_small = carve(256);
         if ((rc = e->d_decode.ensure(need))) return rc;
-        if ((rc = e->d_dec_gran.ensure(std::max<size_t>((size_t)j.nseg * ncol, 1)))) return rc;
+        if ((rc = e->d_dec_gran.ensure(std::max<size_t>((size_t)j.nseg * ((j.bpl + 3) / 4), 1)))) return rc;
         if (e->d_dec_gran.fresh) {
             HIP_TRY(hipMemsetAsync(e->d_dec_gran.p, 0, e->d_dec_gran.cap * 8, s));
             e->d_dec_gran.fresh = false;

@@ -92,6 +92,24 @@ def test_small_images_every_mode(enc, desired):
     _check(enc, pngs[:150], desired, device=True)
 
 
+@pytest.mark.parametrize("desired", [3, 4])
+def test_widths_around_the_unfilter_kernels_wave_and_workgroup_edges(enc, desired):
+    """dec_unfilter_kernel writes 3 -> 4 and 4 -> 3 channels with gathers inside a wave (64 pixels) and takes 256 pixels or 256
+    dword columns per workgroup; a segment has 48 rows.  Widths on both sides of those edges, heights with a short last segment,
+    every channel combination, host- and device-resident (the latter at odd addresses)."""
+    rng = np.random.default_rng(5)
+    pngs = []
+    for w in (1, 2, 5, 63, 64, 65, 85, 86, 191, 192, 193, 255, 256, 257, 341, 342, 343, 1023, 1024, 1025, 1367):
+        for c in (3, 4):
+            h = int(rng.integers(1, 110))
+            y, x, ch = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+            img = ((x * 3 + y * 2 + ch * 17 + rng.integers(0, 3, size=(h, w, c))) & 255).astype(np.uint8)  # (smooth: not stored blocks)
+            pngs.append(oracle().encode(img, w, h, c, int(rng.integers(0, 2))))
+    assert sum((p[60] & 6) != 0 for p in pngs) > len(pngs) * 3 // 4  # Deflate blocks, not stored ones
+    _check(enc, pngs, desired)
+    _check(enc, pngs, desired, device=True)
+
+
 def test_natural_image_and_synthetic_frames(enc):
     import torch
     import fpng_amd

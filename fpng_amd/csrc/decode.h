@@ -13,7 +13,7 @@ constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_e
 #define FPNG_DEC_UNF_ROWS 48
 #endif
 constexpr uint32_t kDecUnfRows = FPNG_DEC_UNF_ROWS; // rows per segment of the Up filter's undoing (held in registers)
-enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecBadFilter = 8u, kDecStalled = 16u, kDecSawEob = 0x100u };
+enum : uint32_t { kDecNotConverged = 1u, kDecBadStream = 2u, kDecBadFilter = 8u, kDecStalled = 16u, kDecStoredOdd = 32u, kDecSawEob = 0x100u };
 
 struct DecJob {
     const uint8_t *z;         // device: the zlib stream (IDAT payload) from the dword its first byte (0x78) lies in; readable up to z_bytes + 16 rounded down to a dword
@@ -106,6 +106,6 @@ void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_ba
 void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch);
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch);
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored);
 
 } // namespace fpng_amd

@@ -407,6 +407,30 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
 constexpr uint32_t kEmitDwords = kEmitBlock * (kSubBits / 32) + 8; // (a thread may decode a few tokens into the next workgroup's bits)
 struct StreamSink {
     __attribute__((address_space(1))) uint32_t *f; // the file's filtered stream (global_store, not flat_store: a flat store also counts as an LDS operation in flight)
+    uint32_t fill_g0 = 0, fill_n = 0, fill_d0 = 0, fill_d1 = 0, fill_d2 = 0; // this thread's long run, waiting for the wave (StreamWriter::run4 / run3)
+    __device__ __forceinline__ void fill(uint32_t g0, uint32_t groups, uint32_t d0, uint32_t d1, uint32_t d2) { fill_g0 = g0, fill_n = groups, fill_d0 = d0, fill_d1 = d1, fill_d2 = d2; }
+    static __device__ __forceinline__ bool any(bool x) { return __ballot(x) != 0; }
+    // The waiting runs, one after the other, each by all threads of the wave that are here: thread k of them stores the groups
+    // k, k + n, ... -- 16 consecutive bytes per thread, a kilobyte per instruction.
+    __device__ __forceinline__ void cooperate()
+    {
+        uint64_t waiting = __ballot(fill_n != 0);
+        if (!waiting) return;
+        const uint64_t here = __ballot(true);
+        const uint32_t me = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)), n_here = (uint32_t)__popcll(here);
+        do {
+            const int l = __ffsll((unsigned long long)waiting) - 1;
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)fill_g0, l), n = (uint32_t)__builtin_amdgcn_readlane((int)fill_n, l);
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d0, l), d1 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d1, l), d2 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d2, l);
+            for (uint32_t i = me; i < n; i += n_here) {
+                const uint32_t m = i % 3u; // the dwords from group g0 on are d0 d1 d2 d0 ...: group i begins with d[4 i % 3] = d[i % 3]
+                const uint32_t a = m == 0 ? d0 : (m == 1 ? d1 : d2), b = m == 0 ? d1 : (m == 1 ? d2 : d0), c = m == 0 ? d2 : (m == 1 ? d0 : d1);
+                store128(g0 + i, a, b, c, a);
+            }
+            waiting &= waiting - 1;
+        } while (waiting);
+        fill_n = 0;
+    }
 #if defined(FPNG_DEC_EMIT_NOSTORE) // diagnostic builds (fpng_amd/build.py --variant): what the stores cost
     __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { asm volatile("" ::"v"(d), "v"(v)); }
     __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { asm volatile("" ::"v"(g), "v"(a), "v"(b), "v"(c), "v"(d)); }
@@ -450,16 +474,17 @@ __global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(cons
         if (staged != job.lut) stage_lut(job, lut, kEmitBlock), staged = job.lut;
         stage_bits(job, d0, kEmitDwords, bits, kEmitBlock);
         __syncthreads();
-        if (!active) continue;
+        // (threads without a subsequence come along with nothing to write: they help with their wave's long runs)
         const uint32_t nominal = (uint32_t)(nominal0 - base) + threadIdx.x * kSubBits;
         const uint32_t stride = job.bpl + 1;
-        const uint64_t off = block_off[g / kSubBlock] + a.rel[g];
-        const uint32_t col = (uint32_t)(off % stride), own = a.bytes[g];
-        const bool is_last = i == last;
-        const uint32_t pad = is_last ? 0u : (0u - ((uint32_t)off + own)) & 15u; // bytes of the following subsequences that complete the last 16-byte group
-        StreamSink sink = {(__attribute__((address_space(1))) uint32_t *)(uintptr_t)job.filt};
+        const uint64_t off = active ? block_off[g / kSubBlock] + a.rel[g] : 0ull;
+        const uint32_t col = (uint32_t)(off % stride), own = active ? a.bytes[g] : 0u;
+        const bool is_last = active && i == last;
+        const uint32_t pad = (is_last || !active) ? 0u : (0u - ((uint32_t)off + own)) & 15u; // bytes of the following subsequences that complete the last 16-byte group
+        StreamSink sink;
+        sink.f = (__attribute__((address_space(1))) uint32_t *)(uintptr_t)job.filt;
         uint32_t eob_end = 0;
-        const uint32_t p0 = nominal + info_start(a.info[g]), lastpx = a.lastpx[g];
+        const uint32_t p0 = nominal + (active ? info_start(a.info[g]) : 0u), lastpx = active ? a.lastpx[g] : 0u;
         uint32_t err = job.src_c == 4 ? walk_emit<4>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end)
                                       : walk_emit<3>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end);
         // end of block: the stream must end 4 bytes (the Adler-32) before the IDAT does
@@ -489,6 +514,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
+__device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 // (a wave-uniform base in global memory + a 32-bit offset per lane: the load / store takes the base from scalar registers and ONE
 //  vector register of offsets serves all rows -- generic 64-bit addresses cost a register pair per row and lane)
 __device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -671,24 +697,65 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
     }
 }
 
-// ---- stored files: the filter-0 stream sits in stored blocks of 65535 bytes (the host checked their headers and the filter bytes) ----
-__global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *jobs)
+// ---- stored files (reference src/fpng.cpp:2107-2207): the filter-0 stream sits in stored blocks, in fpng's files all of 65535
+//      bytes but the last.  The kernel copies the rows out of that layout -- a workgroup takes rows in turn, its threads a dword
+//      (or, where the channel count changes, a pixel) each -- and CHECKS the layout while it is there: every block header at the
+//      place the usual layout has it, every row's filter byte 0.  Anything else sets kDecStoredOdd, and the host looks at the file
+//      itself (a valid file with other block sizes is the CPU decoder's; check_stored() in decode_api.cpp is the rule). ----
+__device__ __forceinline__ uint64_t stored_pos(uint64_t s) // byte s of the stream -> its offset in the zlib data
+{
+    uint64_t q = s >> 16; // s / 65535, from below: s = 65536 q + lo = 65535 q + (q + lo)
+    uint64_t r = q + (s & 0xFFFFu);
+    while (r >= 65535) r -= 65535, q++;
+    return 2 + 5 * (q + 1) + s;
+}
+__global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *jobs, uint32_t *status)
 {
     const DecJob &job = jobs[blockIdx.y];
     if (job.mode != 1) return;
     const uint8_t *z = job.z + job.z_shift;
-    const uint64_t n = (uint64_t)job.w * job.h * job.dst_c;
-    for (uint64_t k = (uint64_t)blockIdx.x * kDecBlock + threadIdx.x; k < n; k += (uint64_t)gridDim.x * kDecBlock) {
-        const uint64_t pixel = k / job.dst_c;
-        const uint32_t ch = (uint32_t)(k - pixel * job.dst_c);
-        uint8_t v = 0xFF;
-        if (ch < job.src_c) {
-            const uint64_t y = pixel / job.w, x = pixel - y * job.w;
-            const uint64_t s = y * (job.bpl + 1) + 1 + x * job.src_c + ch; // stream byte
-            v = z[2 + 5 * (s / 65535 + 1) + s];
-        }
-        job.out[k] = v;
+    const uint32_t sc = job.src_c, dc = job.dst_c, bpl = job.bpl, w = job.w, h = job.h;
+    const uint64_t total = ((uint64_t)bpl + 1) * h;
+    const uint32_t nblk = (uint32_t)((total + 65534) / 65535);
+    bool odd = false;
+    // block headers: final flag | type 0, length, its complement
+    for (uint32_t i = blockIdx.x * kDecBlock + threadIdx.x; i < nblk; i += gridDim.x * kDecBlock) {
+        const uint8_t *hd = z + 2 + (uint64_t)i * 65540;
+        const uint32_t len = i + 1 < nblk ? 65535u : (uint32_t)(total - (uint64_t)i * 65535);
+        odd |= hd[0] != (i + 1 == nblk ? 1 : 0) || (hd[1] | hd[2] << 8) != len || (hd[3] | hd[4] << 8) != (~len & 0xFFFFu);
     }
+    // rows: `lanes` threads per row (a power of two), kDecBlock / lanes rows per workgroup and turn
+    const uint32_t units = sc == dc ? (bpl + 3) / 4 : w; // dwords of a row, or pixels
+    uint32_t lanes = 1;
+    while (lanes < units && lanes < (uint32_t)kDecBlock) lanes <<= 1;
+    const uint32_t rows_per = kDecBlock / lanes, t_row = threadIdx.x / lanes, t_x = threadIdx.x & (lanes - 1);
+    const size_t os = (size_t)w * dc;
+    for (uint32_t y = blockIdx.x * rows_per + t_row; y < h; y += gridDim.x * rows_per) {
+        const uint64_t s0 = (uint64_t)y * ((uint64_t)bpl + 1); // the row's filter byte
+        if (t_x == 0) odd |= z[stored_pos(s0)] != 0;
+        uint8_t *o = job.out + (size_t)y * os;
+        if (sc == dc) {
+            for (uint32_t x = 4 * t_x; x < bpl; x += 4 * lanes) {
+                const uint64_t s = s0 + 1 + x, p = stored_pos(s);
+                const uint32_t nb = min(4u, bpl - x);
+                if (nb == 4 && stored_pos(s + 3) == p + 3)
+                    store_u32_unaligned(o + x, load_u32_unaligned(z + p));
+                else
+                    for (uint32_t b = 0; b < nb; b++) o[x + b] = z[stored_pos(s + b)];
+            }
+        } else {
+            for (uint32_t x = t_x; x < w; x += lanes) {
+                const uint64_t s = s0 + 1 + (uint64_t)x * sc;
+                uint32_t px = 0xFF000000u;
+                for (uint32_t b = 0; b < 3; b++) px |= (uint32_t)z[stored_pos(s + b)] << (8 * b);
+                if (dc == 4)
+                    store_u32_unaligned(o + (size_t)x * 4, px);
+                else
+                    for (uint32_t b = 0; b < 3; b++) o[(size_t)x * 3 + b] = (uint8_t)(px >> (8 * b));
+            }
+        }
+    }
+    if (odd) atomicOr(&status[blockIdx.y], kDecStoredOdd);
 }
 
 // ---- device-resident files: the first `head` and the last `tail` bytes of every file gathered into one buffer (one copy to the
@@ -741,11 +808,12 @@ void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uin
 {
     if (n_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, item0, status, epoch);
 }
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch)
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored)
 {
-    launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch);
+    if (plan.total_items) launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch);
+    if (!any_stored) return; // (a workgroup that finds its file is not a stored one leaves at once, but n_jobs x 512 of them is not free)
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) // (the y dimension of a grid holds at most 65535 workgroups)
-        hipLaunchKernelGGL(dec_stored_kernel, dim3(1024, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0);
+        hipLaunchKernelGGL(dec_stored_kernel, dim3(512, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0, status + j0);
 }
 
 } // namespace fpng_amd

@@ -116,7 +116,15 @@ int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint
     const uint64_t total = ((uint64_t)p.w * p.c + 1) * p.h;
     if ((z[2] & 6) == 0) {
         if (total > p.idat_len) return fpng::FPNG_DECODE_NOT_FPNG; // (stored blocks cannot hold the image)
-        if (!complete) return kParseNeedMore;
+        if (!complete) {
+            // only a head of the file is here (it lies in device memory): with the size the USUAL layout has -- blocks of 65535
+            // bytes and a last one -- dec_stored_kernel checks the block headers and the filter bytes where they are and reports
+            // anything else (kDecStoredOdd: the file is then looked at on the host after all)
+            const uint64_t nblk = (total + 65534) / 65535;
+            if (p.idat_len != 2 + 5 * nblk + total + 4) return kParseNeedMore;
+            p.mode = 1;
+            return 0;
+        }
         const int r = check_stored(z, avail, p.idat_len, p.w, p.h, p.c);
         if (r == 1) return fpng::FPNG_DECODE_NOT_FPNG;
         p.mode = 1;
@@ -455,7 +463,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         } else if ((pe = stamp(g, 2)) != hipSuccess)
             return pe;
         if ((pe = stamp(g, 3)) != hipSuccess) return pe;
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, ++e->dec_epoch & 0x3FFFFFFFu);
+        bool any_stored = false;
+        for (uint32_t k = g.j0; k < g.j1; k++) any_stored |= jobs[k].mode != 0;
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, ++e->dec_epoch & 0x3FFFFFFFu, any_stored);
         if ((pe = stamp(g, 4)) != hipSuccess) return pe;
         if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
@@ -522,8 +532,19 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (trace)
             fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
                     jobs[k].src_c, jobs[k].mode, jobs[k].n_sub, (unsigned long long)jobs[k].first_bit, status[k]);
-        if (jobs[k].mode) continue;
         int32_t &st = results[job_file[k]].status;
+        if (jobs[k].mode) {
+            if (status[k] & kDecStoredOdd) { // not the usual stored layout after all: the whole file, on the host (check_stored() is the rule)
+                st = FPNG_AMD_DECODE_UNDECIDED;
+                if (device_data) {
+                    const Parsed &p = ps[job_file[k]];
+                    whole.resize(p.idat_len);
+                    HIP_TRY(hipMemcpy(whole.data(), (const uint8_t *)files[job_file[k]].data + p.idat_ofs + 8, p.idat_len, hipMemcpyDeviceToHost));
+                    if (check_stored(whole.data(), p.idat_len, p.idat_len, p.w, p.h, p.c) == 1) st = fpng::FPNG_DECODE_NOT_FPNG;
+                }
+            }
+            continue;
+        }
         if (status[k] & (kDecNotConverged | kDecStalled)) // (nothing else is known then: "invalid" may be a speculative decode's)
             st = FPNG_AMD_DECODE_UNDECIDED;
         else if (status[k] & (kDecBadStream | kDecBadFilter))

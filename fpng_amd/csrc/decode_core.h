@@ -214,7 +214,8 @@ FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return v >> 13; }
 // group leaves that group to the thread in front of it.  No byte stores, nothing is written twice, no store that depends on whose
 // bytes a dword holds.  (Sink::store32 serves the one place where the stream itself ends inside a group.)  4-byte stores from 64
 // lanes whose ranges lie ~150 bytes apart were 64 memory transactions of 4 bytes per instruction, and 6 x the bytes at the fabric.
-enum : uint32_t { kEmitBadStream = 2u, kEmitSawEob = 0x100u };
+enum : uint32_t { kEmitBadStream = 2u, kEmitLeaveToCpu = 16u, kEmitSawEob = 0x100u }; // (= kDecBadStream, kDecStalled, kDecSawEob of decode.h)
+constexpr uint32_t kFillMinDwords = 16, kFillMinPixels3 = 32; // runs from this length on are filled by the wave (StreamWriter::run4 / run3)
 
 template <class Sink> struct StreamWriter {
     Sink &sink;
@@ -243,17 +244,47 @@ template <class Sink> struct StreamWriter {
         acc = full ? hi : lo;
         have = nh & 3u;
     }
-    // npix copies of a 4-byte pixel: the first dword completes the pending bytes, the others are one rotated constant
+    // npix copies of a 4-byte pixel: the first dword completes the pending bytes, the others are one rotated constant.
+    // A LONG run is not this thread's to write dword by dword -- its wave would wait for it, and on flat content (a screenshot:
+    // a few dozen bytes of tokens stand for kilobytes of pixels) every thread has such runs: the thread writes up to the next
+    // 16-byte group boundary and hands the run's whole groups to Sink::fill(first group, groups, three dwords d0 d1 d2: the
+    // dwords from there on are d0 d1 d2 d0 ...), which the wave's threads store together, 64 groups per instruction
+    // (Sink::cooperate(), called by walk_emit once per iteration).
     FPNG_DEC_HD void run4(uint32_t px, uint32_t npix)
     {
         const uint32_t sh = 8 * have, lo = px << sh, hi = (px >> 8) >> (24 - sh), r = lo | hi;
         push(acc | lo, true);
-        for (uint32_t j = 1; j < npix; j++) push(r, true);
+        uint32_t left = npix - 1;
+        if (left >= kFillMinDwords) {
+            while (dw & 3u) push(r, true), left--; // (its last push closed a group: `skip` is off from here)
+            const uint32_t groups = left >> 2;
+            sink.fill(dw >> 2, groups, r, r, r);
+            dw += 4 * groups, left -= 4 * groups;
+            q0 = q1 = q2 = q3 = r;
+        }
+        for (uint32_t j = 0; j < left; j++) push(r, true);
         acc = hi;
     }
+    // ... of a 3-byte pixel: the stream repeats every 3 bytes, its dwords every 3 dwords; three groups = 48 bytes = 16 pixels
+    // leave the writer where it was (pending bytes, place inside the pixel)
     FPNG_DEC_HD void run3(uint32_t px, uint32_t npix)
     {
-        for (uint32_t k = 0; k < npix; k++) put(px, 3);
+        uint32_t left = npix;
+        if (npix >= kFillMinPixels3) {
+            for (uint32_t k = 0; k < 4; k++) put(px, 3); // (12 bytes: the pending bytes are the run's own from here on)
+            left -= 4;
+            while (dw & 3u) put(px, 3), left--; // (at most 5 pixels; the last push closed a group)
+            uint32_t groups = (3 * left) >> 4;
+            groups -= groups % 3u;
+            // byte 0 of dword dw is the pixel's byte (3 - have) % 3: acc holds the last `have` bytes of a pixel
+            const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
+            const uint32_t ph = (3u - have) % 3u;
+            const uint32_t d0 = (uint32_t)(wrap >> (8 * ph)), d1 = (uint32_t)(wrap >> (8 * ((ph + 1) % 3u))), d2 = (uint32_t)(wrap >> (8 * ((ph + 2) % 3u)));
+            sink.fill(dw >> 2, groups, d0, d1, d2);
+            if (groups) q0 = d2, q1 = d0, q2 = d1, q3 = d2; // (the last group of a multiple of three)
+            dw += 4 * groups, left -= 16 * (groups / 3u);
+        }
+        for (uint32_t k = 0; k < left; k++) put(px, 3);
     }
     // Only where the stream ends inside a group: its whole dwords, and the pending bytes (zeros behind them: the buffer is padded).
     FPNG_DEC_HD void finish()
@@ -299,37 +330,57 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
         todo -= nb;
         return nb ? L + (m1 ? 1u : 0u) : 0u;
     };
-    while (todo) {
+    while (sink.any(todo != 0)) { // (the whole wave stays until its last thread is done: Sink::cooperate() needs them all)
         const uint32_t w = in.window(pos);
         const uint32_t ba = take(w);
         const uint32_t bb = take(w >> ba); // (a first token that was not plain is looked at again, to no effect)
         pos += ba + bb;
-        if (todo && !bb) { // the token at pos is not a plain one
-            uint32_t n3, l3 = 0, run = 0, bits;
-            const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
-            const bool mine = todo > pad; // (the tokens behind this thread's bytes are their owners' to check)
-            if (kind != kTokMatch) { // the stream ends, or derails, with bytes still owed
-                if (mine) err |= kEmitBadStream;
-                break;
+        if (todo && !bb) { // the token at pos is not a plain one: a match (or the stream ends, or derails, with bytes still owed)
+            // Matches that follow one another repeat the same pixel (no literal in between, and none of them may leave its row):
+            // they are written as ONE run -- a flat row of a screenshot is a few dozen maximal matches.
+            const uint32_t px = C == 4 ? lastpx : lastpx >> 8;
+            uint32_t whole = 0; // bytes of the matches that lie wholly inside this thread's bytes
+            bool stop = false;
+            for (;;) {
+                uint32_t n3, l3 = 0, run = 0, bits;
+                const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
+                const bool mine = todo > pad; // (the tokens behind this thread's bytes are their owners' to check)
+                if (kind != kTokMatch) {
+                    // behind a match: an ordinary token, the loop's next iteration takes it; else the stream ends, or derails, with bytes still owed
+                    if (!whole) stop = true, err |= mine ? kEmitBadStream : 0u;
+                    break;
+                }
+                if (mine && (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)) {
+                    stop = true, err |= kEmitBadStream;
+                    break;
+                }
+                // A match at a row's FIRST pixel repeats a pixel of zeros (reference :2268: prev_delta_* start at 0), and so do the
+                // matches behind it until a literal pixel comes -- but "the last literal bytes" this decoder keeps know nothing
+                // of rows.  fpng's encoders never write such a match (a row's first pixel has no left neighbour); a file that
+                // has one is left to the CPU decoder.
+                if (mine && rowleft == bpl) {
+                    stop = true, err |= kEmitLeaveToCpu;
+                    break;
+                }
+                pos += bits;
+                const uint32_t r = run < todo ? run : todo;
+                rowleft -= r;
+                rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
+                todo -= r;
+                if (r == run && mine)
+                    whole += run;
+                else { // the match reaches into (or lies in) the pad: byte by byte
+                    if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
+                    whole = 0;
+                    for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1);
+                    break;
+                }
+                if (!todo || rowleft == stride) break; // (a row ended: a filter literal must follow)
             }
-            pos += bits;
-            if (mine && (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)) {
-                err |= kEmitBadStream;
-                break;
-            }
-            const uint32_t px = rowleft == bpl ? 0u : (C == 4 ? lastpx : lastpx >> 8); // (at a row's first pixel there is no previous one: zeros, reference :2262)
-            const uint32_t r = run < todo ? run : todo;
-            if (r == run) {
-                if (C == 4)
-                    out.run4(px, run >> 2);
-                else
-                    out.run3(px, run / 3u);
-            } else
-                for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1); // (r < run: inside the pad)
-            rowleft -= r;
-            rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
-            todo -= r;
+            if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
+            if (stop) break;
         }
+        sink.cooperate();
     }
     if (last && !err) { // the end-of-block symbol
         uint32_t n3, l3 = 0, run = 0, bits;

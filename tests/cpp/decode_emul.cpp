@@ -40,6 +40,14 @@ struct HostSink { // the filtered stream; every dword may be stored once
     {
         store32(4 * g, a), store32(4 * g + 1, b), store32(4 * g + 2, c), store32(4 * g + 3, d);
     }
+    // (a long run's whole groups: on the GPU left to the wave, here stored at once)
+    void fill(uint32_t g0, uint32_t groups, uint32_t d0, uint32_t d1, uint32_t d2)
+    {
+        const uint32_t d[3] = {d0, d1, d2};
+        for (uint32_t i = 0; i < groups; i++) store128(g0 + i, d[(4 * i) % 3], d[(4 * i + 1) % 3], d[(4 * i + 2) % 3], d[(4 * i + 3) % 3]);
+    }
+    static bool any(bool x) { return x; }
+    static void cooperate() {}
 };
 
 } // namespace

@@ -62,11 +62,23 @@ def _check(enc, pngs, desired, device=False, allow_undecided=False):
         got = enc.decode_device(_device_files(pngs, shift=1), desired, dims)
     else:
         got = enc.decode_batch(pngs, desired)
-    n_ok = n_bad = 0
+    n_ok = n_bad = n_left = 0
     for i, (png, (st, px, cf)) in enumerate(zip(pngs, got)):
         cst, cpx, w, h, c = judge(png, desired) if len(png) else (2, None, 0, 0, 0)
         if st == UNDECIDED and allow_undecided:
             assert cst != 0, i
+            continue
+        if st == UNDECIDED and cst == 0 and len(pngs) >= 100:
+            # "the CPU decoder's": the one documented case with a file the reference takes is a match at a row's first pixel
+            # (decode_core.h, walk_emit) -- no fpng encoder writes one, damage can.  What the drop-in then answers is checked.
+            os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+            try:
+                dst, dpx, *_ = dropin.decode(png, desired)
+            finally:
+                del os.environ["FPNG_AMD_DECODE_CPU"]
+            assert dst == 0 and np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired]), i
+            n_left = n_left + 1
+            assert n_left <= max(1, len(pngs) // 100), "too many files left to the CPU decoder"
             continue
         assert st == cst, (i, st, cst, len(png))
         if st == 0:

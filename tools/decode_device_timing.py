@@ -9,7 +9,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 enc = fpng_amd.Encoder(device=0)
 cases = [("8K RGBA grad x 8", "grad", 7680, 4320, 4, 8), ("4K RGBA grad x 16", "grad", 3840, 2160, 4, 16), ("1080p RGB grad x 64", "grad", 1920, 1080, 3, 64),
-         ("512x512 RGB grad x 256", "grad", 512, 512, 3, 256), ("8K RGBA blocks x 8", "blocks", 7680, 4320, 4, 8)]
+         ("512x512 RGB grad x 256", "grad", 512, 512, 3, 256), ("8K RGBA blocks x 8", "blocks", 7680, 4320, 4, 8),
+         ("8K RGBA noise x 8", "noise", 7680, 4320, 4, 8), ("1080p RGB noise x 64", "noise", 1920, 1080, 3, 64), ("8K RGBA solid x 8", "solid", 7680, 4320, 4, 8)]
 import ui_images
 for uname, (uimg, uw, uh, uc) in sorted(ui_images.all_images().items()):
     if uw == 3840:
@@ -32,6 +33,9 @@ for name, kind, w, h, c, n in cases:
         if not os.environ.get("FPNG_TIMING_NOCHECK"):
             assert all(st == 0 for st, _, _ in got)
             assert all(torch.equal(px, t) for (st, px, _), t in zip(got, ts))
+        ph = ""
+        if os.environ.get("FPNG_TIMING_PHASES"):
+            enc.set_profiling(True); enc.decode_device(dev, c, dims, outs); ph = "; phases " + " ".join(f"{k} {v:.3f}" for k, v in enc.last_decode_phase_ms().items()); enc.set_profiling(False)
         mb = sum(len(p) for p in pngs) / 1e6
         print(f"{name} flags={flags}: {best*1e3:7.3f} ms per step = {n*w*h/best/1e9:7.2f} GP/s ({mb:.0f} MB of PNG -> {n*w*h*c/1e6:.0f} MB of pixels; "
-              f"{(mb + n*w*h*c/1e6)/1e3/best:6.0f} GB/s algorithmic)", flush=True)
+              f"{(mb + n*w*h*c/1e6)/1e3/best:6.0f} GB/s algorithmic){ph}", flush=True)

@@ -74,6 +74,8 @@ struct DecFileRef {
     const uint8_t *data;
     uint32_t size, pad_;
 };
+// sizes: n x 288 code lengths (checked by the host) -> luts: n x FPNG_AMD_DECODE_LUT_WORDS
+void launch_dec_build_luts(hipStream_t s, const uint8_t *sizes, uint32_t n, uint32_t *luts);
 void launch_dec_fetch(hipStream_t s, const DecFileRef *files, uint32_t n, uint32_t head, uint32_t tail, uint8_t *out);
 
 // a file that is decoded piece by piece: what the pieces so far amount to (dec_offsets_range_kernel)

@@ -758,6 +758,82 @@ __global__ __launch_bounds__(kDecBlock) void dec_stored_kernel(const DecJob *job
     if (odd) atomicOr(&status[blockIdx.y], kDecStoredOdd);
 }
 
+// ---- the kernels' lookup table (decode_core.h) from a file's 288 literal / length code lengths, one workgroup per table: what
+//      build_multi_lut() (decode_api.cpp) does on the host -- a batch of 2-pass files has a table per file, and building and
+//      uploading 16 KB for each kept the host busy longer than the GPU decoded.  The lengths were checked by the host (a complete
+//      code of at most 12-bit codes, or a single code: png_parse.h).  Canonical codes (RFC 1951 3.2.2): symbols sorted by (length,
+//      value); entry k of the table is found by trying the 12 lengths on k's low bits. ----
+// length symbols 257 .. 285: base length and extra bits (RFC 1951 3.2.5)
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__global__ __launch_bounds__(kDecBlock) void dec_build_lut_kernel(const uint8_t *sizes_all, uint32_t *luts)
+{
+    __shared__ uint8_t len[288];
+    __shared__ uint16_t sorted[288];
+    __shared__ uint32_t first[16], count[16], offset[16];
+    __shared__ uint32_t t1[kLutEntries]; // symbol | length << 9 per 12-bit index (0: no code)
+    const uint8_t *sizes = sizes_all + (size_t)blockIdx.x * 288;
+    uint32_t *lut = luts + (size_t)blockIdx.x * kLutDwords;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t s = t; s < 288; s += kDecBlock) len[s] = sizes[s];
+    __syncthreads();
+    if (t < 16) {
+        uint32_t c = 0;
+        for (uint32_t s = 0; s < 288; s++) c += len[s] == t;
+        count[t] = t ? c : 0u;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t code = 0, off = 0;
+        first[0] = offset[0] = 0;
+        for (uint32_t l = 1; l < 16; l++) {
+            code = (code + count[l - 1]) << 1;
+            first[l] = code, offset[l] = off;
+            off += count[l];
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < 288; s += kDecBlock) {
+        const uint32_t l = len[s];
+        if (!l) continue;
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < s; q++) rank += len[q] == l;
+        sorted[offset[l] + rank] = (uint16_t)s;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < kLutEntries; k += kDecBlock) {
+        uint32_t e = 0;
+        for (uint32_t l = 1; l <= 12; l++) {
+            const uint32_t c = __brev(k << (32 - l)); // the low l bits of k, first bit highest: a code of l bits
+            if (c >= first[l] && c - first[l] < count[l]) e = sorted[offset[l] + (c - first[l])] | l << 9;
+        }
+        t1[k] = e;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < kLutEntries; k += kDecBlock) {
+        const uint32_t e1 = t1[k], l1 = (e1 >> 9) & 15u, s1 = e1 & 511u;
+        uint32_t ent = 0;
+        if (!l1 || s1 > 285)
+            ent = 0;
+        else if (s1 == 256)
+            ent = l1 << 28;
+        else if (s1 > 256)
+            ent = l1 << 28 | kEntMatch | (uint32_t)kLenExtra[s1 - 257] << 9 | kLenBase[s1 - 257];
+        else {
+            uint32_t L = l1, n = 1, lits = s1;
+            while (n < 3) { // the next code is whole if its length fits into the index bits that are left
+                const uint32_t e2 = t1[k >> L], l2 = (e2 >> 9) & 15u, s2 = e2 & 511u;
+                if (!l2 || s2 >= 256 || L + l2 > 12) break;
+                lits |= s2 << (8 * n);
+                n++, L += l2;
+            }
+            ent = L << 28 | n << 26 | lits;
+        }
+        lut[k] = ent;
+    }
+    if (t < 64) lut[kLutEntries + t] = len[4 * t] | len[4 * t + 1] << 8 | len[4 * t + 2] << 16 | (uint32_t)len[4 * t + 3] << 24;
+}
+
 // ---- device-resident files: the first `head` and the last `tail` bytes of every file gathered into one buffer (one copy to the
 //      host instead of two per file) ----
 __global__ __launch_bounds__(kDecBlock) void dec_fetch_kernel(const DecFileRef *files, uint32_t head, uint32_t tail, uint8_t *out)
@@ -772,6 +848,10 @@ __global__ __launch_bounds__(kDecBlock) void dec_fetch_kernel(const DecFileRef *
 
 } // namespace
 
+void launch_dec_build_luts(hipStream_t s, const uint8_t *sizes, uint32_t n, uint32_t *luts)
+{
+    if (n) hipLaunchKernelGGL(dec_build_lut_kernel, dim3(n), dim3(kDecBlock), 0, s, sizes, luts);
+}
 void launch_dec_fetch(hipStream_t s, const DecFileRef *files, uint32_t n, uint32_t head, uint32_t tail, uint8_t *out)
 {
     hipLaunchKernelGGL(dec_fetch_kernel, dim3(n), dim3(kDecBlock), 0, s, files, head, tail, out);

@@ -185,11 +185,11 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<Parsed> ps(n);
-    std::vector<uint32_t> luts;                   // unique lookup tables, dec::kLutDwords each (1-pass files share two): ONE upload
-    std::vector<std::vector<uint8_t>> lut_keys;   // the code lengths they were built from
+    std::vector<uint8_t> lut_keys;                // the code lengths (288 each) of the unique lookup tables (1-pass files share two): ONE upload,
+                                                  // the tables themselves are built on the GPU (dec_build_lut_kernel)
     std::unordered_multimap<uint64_t, uint32_t> lut_index; // ... found by their hash
-    static thread_local uint32_t table[1u << kTableBits];
-    HeaderMemo memo; // (of this call's `table`)
+    uint32_t *const table = nullptr; // (no host-side lookup table: the header reader only checks the code)
+    HeaderMemo memo;
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
     size_t z_total = 0, filt_total = 0, seg_total = 0;
@@ -253,13 +253,11 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             for (int q = 0; q < 288; q++) hsh = (hsh ^ sizes[q]) * 1099511628211ull;
             auto range = lut_index.equal_range(hsh);
             for (auto it = range.first; it != range.second && p.lut < 0; ++it)
-                if (!std::memcmp(lut_keys[it->second].data(), sizes, 288)) p.lut = (int)it->second;
+                if (!std::memcmp(lut_keys.data() + (size_t)it->second * 288, sizes, 288)) p.lut = (int)it->second;
             if (p.lut < 0) {
-                lut_index.emplace(hsh, (uint32_t)lut_keys.size());
-                p.lut = (int)lut_keys.size();
-                lut_keys.emplace_back(sizes, sizes + 288);
-                luts.resize(luts.size() + dec::kLutDwords);
-                build_multi_lut(table, sizes, luts.data() + luts.size() - dec::kLutDwords);
+                p.lut = (int)(lut_keys.size() / 288);
+                lut_index.emplace(hsh, (uint32_t)p.lut);
+                lut_keys.insert(lut_keys.end(), sizes, sizes + 288);
             }
         }
         DecJob j;
@@ -293,7 +291,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         job_file.push_back(i);
     }
     const uint32_t nj = (uint32_t)jobs.size();
-    if (trace_t) fprintf(stderr, "[decode] +%.0f us: %u files parsed, %zu lookup tables built\n", since(), n, lut_keys.size());
+    if (trace_t) fprintf(stderr, "[decode] +%.0f us: %u files parsed, %zu lookup tables wanted\n", since(), n, lut_keys.size() / 288);
     if (!nj) return FPNG_AMD_OK;
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
@@ -304,6 +302,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     DecBlockRec *d_recs;
     DecSubArrays d_sub;
     uint32_t *d_luts;
+    uint8_t *d_keys;
     DecJob *d_jobs;
     uint8_t *d_plan;
     const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + kDecSubBlock - 1) / kDecSubBlock;
@@ -316,7 +315,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         };
         const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
                      o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
-                     o_luts = carve(std::max<size_t>(luts.size(), dec::kLutDwords) * 4),
+                     o_luts = carve(std::max<size_t>(lut_keys.size() / 288, 1) * dec::kLutDwords * 4), o_keys = carve(std::max<size_t>(lut_keys.size(), 288)),
                      o_jobs = carve(nj * sizeof(DecJob)), o_plan = carve(((size_t)nj + kMaxGroups) * (sizeof(DecUnfPiece) + 8)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
         // the look-back granules of dec_unfilter_kernel: never cleared between calls -- every launch has its own epoch, and memory
@@ -332,7 +331,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
         d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
-        d_luts = (uint32_t *)(base + o_luts), d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
+        d_luts = (uint32_t *)(base + o_luts), d_keys = base + o_keys, d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
         d_plan = base + o_plan;
     }
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
@@ -412,7 +411,10 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             }
         });
     }
-    if (!luts.empty()) HIP_TRY(hipMemcpyAsync(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice, s));
+    if (!lut_keys.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_keys, lut_keys.data(), lut_keys.size(), hipMemcpyHostToDevice, s));
+        launch_dec_build_luts(s, d_keys, (uint32_t)(lut_keys.size() / 288), d_luts);
+    }
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
     {   // dec_unfilter_kernel's work items per group of files, numbered segment by segment (decode.h: DecUnfPlan)
         DecUnfPiece *d_pieces = (DecUnfPiece *)d_plan;

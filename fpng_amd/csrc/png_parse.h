@@ -146,8 +146,9 @@ struct Bits {
 
 const uint32_t kTableBits = 12;
 
-// 12-bit direct lookup: sym | len << 9 (0 = invalid)
-inline bool build_lookup(const uint8_t *len, uint32_t n, uint32_t *table)
+// direct lookup by the next `bits` bits (no code may be longer): sym | len << 9 (0 = invalid).  table == nullptr: only the answer --
+// do the lengths form a code?
+inline bool build_lookup(const uint8_t *len, uint32_t n, uint32_t *table, uint32_t bits = kTableBits)
 {
     uint32_t per_len[16] = {0};
     for (uint32_t i = 0; i < n; i++) per_len[len[i]]++;
@@ -158,23 +159,24 @@ inline bool build_lookup(const uint8_t *len, uint32_t n, uint32_t *table)
         used += per_len[l];
     }
     if (kraft != (1u << 15) && used != 1) return false; // complete code, or the single-code special case
+    if (!table) return true;
     uint32_t first[16] = {0}, code = 0;
     for (uint32_t l = 1; l <= 15; l++) {
         code = (code + per_len[l - 1]) << 1;
         first[l] = code;
     }
-    memset(table, 0, sizeof(uint32_t) << kTableBits);
+    memset(table, 0, sizeof(uint32_t) << bits);
     for (uint32_t s = 0; s < n; s++) {
         const uint32_t l = len[s];
         if (!l) continue;
         uint32_t c = first[l]++, r = 0;
         for (uint32_t i = 0; i < l; i++, c >>= 1) r = (r << 1) | (c & 1);
-        for (; r < (1u << kTableBits); r += 1u << l) table[r] = s | (l << 9);
+        for (; r < (1u << bits); r += 1u << l) table[r] = s | (l << 9);
     }
     return true;
 }
 
-// -> the literal/length lookup table; lit_sizes_out (optional): the 288 code lengths it was built from
+// -> the literal/length lookup table (lit_table == nullptr: not built, only checked); lit_sizes_out (optional): the 288 code lengths
 inline bool read_dynamic_header(Bits &in, uint32_t chans, uint32_t *lit_table, uint8_t *lit_sizes_out = nullptr)
 {
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -183,12 +185,12 @@ inline bool read_dynamic_header(Bits &in, uint32_t chans, uint32_t *lit_table, u
     const uint32_t n_clc = in.get(4) + 4;
     uint8_t clc[19] = {0};
     for (uint32_t i = 0; i < n_clc; i++) clc[order[i]] = (uint8_t)in.get(3);
-    static thread_local uint32_t clc_table[1u << kTableBits];
-    if (!build_lookup(clc, 19, clc_table)) return false;
+    uint32_t clc_table[1u << 7]; // (a code length code has at most 7 bits)
+    if (!build_lookup(clc, 19, clc_table, 7)) return false;
     uint8_t sizes[288 + 32];
     memset(sizes, 0, sizeof sizes);
     for (uint32_t cur = 0; cur < total;) {
-        const uint32_t e = clc_table[in.peek(kTableBits)];
+        const uint32_t e = clc_table[in.peek(7)];
         if (!(e >> 9)) return false;
         in.skip(e >> 9);
         const uint32_t sym = e & 511;

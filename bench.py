@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line, including
                  bounded sample of the same workload (falls back to the C port in oracle/)
 """
 import argparse
+import re
 import json
 import os
 import sys
@@ -500,8 +501,8 @@ def main():
         torch.cuda.set_device(args.device)
         print(json.dumps(end_to_end_here(args.device, w, h, c, args.kind, args.flags, args.end_to_end_only)), flush=True)
         return
-    if args.workload not in WORKLOADS:
-        raise SystemExit(f"--workload: one of {sorted(WORKLOADS)}")
+    if args.workload not in WORKLOADS and not re.fullmatch(r"\d+x\d+x[34]", args.workload):
+        raise SystemExit(f"--workload: one of {sorted(WORKLOADS)}, or WxHxC")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -519,7 +520,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import fpng_amd
-    w, h, c = WORKLOADS[args.workload]
+    w, h, c = WORKLOADS[args.workload] if args.workload in WORKLOADS else tuple(int(v) for v in args.workload.split("x"))  # (a name, or WxHxC)
     if args.mode == "rowband":
         return rowband(args, rank, local_rank, world, distributed, dev, w, h, c)
     if args.mode == "nodeimage":

@@ -50,8 +50,11 @@ struct DecBlockRec {
     uint32_t first_invalid; // first one whose decode derailed
     uint32_t entry_rel;     // where its first subsequence starts, in bits behind the workgroup's first nominal bit
     uint32_t exit_rel;      // where its last subsequence ends, in bits behind the next workgroup's first nominal bit
-    uint32_t pad_[3];
+    uint32_t bmap_lo, bmap_hi; // dec::CandList: what the workgroup does to the phases it can be entered in (entry -> exit pairs; one pair unless
+                               // the stream is periodic: decode_core.h)
+    uint32_t want_rel;      // dec_chain_kernel: where its first subsequence must start (kDecWantUnknown: ask the workgroup in front)
 };
+constexpr uint32_t kDecWantUnknown = 0xFFFFFFFFu;
 
 // dec_unfilter_kernel's work items -- (segment of rows, block of 256 dword columns) of a file -- numbered segment by segment over a
 // group of files: the files sorted by segment count (most first) in order[]; cbpre[k] = column blocks of the first k of them;
@@ -96,9 +99,10 @@ struct DecSubArrays {
 
 // the kernels work on the workgroups [first_block, first_block + n_blocks) of the batch's subsequences (one group of files);
 // jobs / n_jobs: the whole batch
-// resident: how many persistent workgroups to launch at most
+// resident: how many persistent workgroups to launch at most; changed: set by a border round that changed something; multi: set
+// once a workgroup's map has more than one pair (zero at the start of the call, never cleared inside it)
 void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round, DecSubArrays a,
-                     DecBlockRec *recs, uint32_t *changed);
+                     DecBlockRec *recs, uint32_t *changed, uint32_t *multi);
 // group_jobs: the group's first file; status / eob_index: batch-wide arrays
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index);

@@ -135,16 +135,59 @@ struct WaveVote {
     }
 };
 
+// ---- candidate lists (decode_core.h) across the threads of a workgroup ----
+__device__ __forceinline__ CandList shfl_up64(CandList v, int o)
+{
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o, kWave), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o, kWave);
+    return (CandList)hi << 32 | lo;
+}
+// the list of thread t - 1 (an empty one for thread 0); wtail: LDS, one entry per wave
+template <int WAVES> __device__ __forceinline__ CandList cand_of_prev_thread(CandList v, CandList *wtail)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    CandList r = shfl_up64(v, 1);
+    __syncthreads();
+    if (lane == 63) wtail[wave] = v;
+    __syncthreads();
+    if (lane == 0) r = wave ? wtail[wave - 1] : (CandList)0;
+    return r;
+}
+// inclusive prefix composition: thread t gets what the subsequences 0..t do to thread 0's starts
+template <int WAVES> __device__ __forceinline__ CandList cand_scan(CandList g, CandList *wtail)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const CandList p = shfl_up64(g, o);
+        if (lane >= (uint32_t)o) g = cand_compose(p, g);
+    }
+    __syncthreads();
+    if (lane == 63) wtail[wave] = g;
+    __syncthreads();
+    if (wave) {
+        CandList pre = wtail[0];
+        for (uint32_t q = 1; q < wave; q++) pre = cand_compose(pre, wtail[q]);
+        g = cand_compose(pre, g);
+    }
+    return g;
+}
+
 // ---- synchronisation ----
 constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 + 1 + 3;
 
+// CAND = false: round 0, the kernel nearly every subsequence of nearly every file is settled by -- kept lean: a workgroup whose
+// corrections have not ended after kRefixRounds steps (a periodic stream: decode_core.h) is left as it is, marked (an EMPTY map
+// in its record), and taken up by round 1.  CAND = true: the border rounds -- few workgroups have anything to do in them -- also
+// know the candidate lists.
+template <bool CAND>
 __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
-                                                             DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
+                                                             DecSubArrays a, DecBlockRec *recs, uint32_t *changed, uint32_t *multi)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kSyncDwords)];
     __shared__ uint32_t s_end[kSubBlock];
     __shared__ uint32_t red3[3 * (kSubBlock / kWave)];
+    __shared__ CandList wtail[kSubBlock / kWave + 1];
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
@@ -157,11 +200,15 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         const uint32_t g = g0 + t, i = local0 + t;
         const bool valid = i < job.n_sub;
         uint32_t want0 = 0;
+        bool cand_first = false;
         if (round) { // only the border to the previous block is open
-            if (!local0) continue; // (the file's first subsequence starts at the stream's first token: nothing to settle)
-            const uint32_t mine = recs[blk].entry_rel, prev = recs[blk - 1].exit_rel;
-            if (mine == prev) continue;
+            const DecBlockRec mine = recs[blk];
+            const uint32_t pairs = cand_count((CandList)mine.bmap_hi << 32 | mine.bmap_lo);
+            // (the file's first subsequence starts at the stream's first token: no border in front of the first block)
+            const uint32_t prev = !local0 ? mine.entry_rel : (mine.want_rel != kDecWantUnknown ? mine.want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
+            if (mine.entry_rel == prev && pairs) continue;
             want0 = prev;
+            cand_first = pairs != 1; // left unsettled by round 0, or it needed its candidate lists before: straight to them
         }
         const uint32_t lead0 = local0 ? kDecLeadIn : 0u;
         const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
@@ -190,7 +237,9 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         }
         want0 += nominal; // (thread 0's nominal: the block's first)
         s_end[t] = st.end;
-        for (;;) {
+        bool cand_done = false, crawls = false;
+        CandList bmap = 0;
+        for (uint32_t it = 0;; it++) {
             __syncthreads();
             uint32_t want = st.start;
             if (t)
@@ -199,10 +248,44 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
                 want = want0;
             const bool need = valid && want != st.start;
             if (!__syncthreads_or(need)) break;
-            if (need) {
-                sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
+            if (!CAND && it >= kRefixRounds) { // (round 0: left to round 1)
+                crawls = true;
+                break;
+            }
+            const bool cand_now = CAND && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
+            if (!cand_now) {
+                if (need) {
+                    sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
+                    s_end[t] = st.end;
+                    dirty = true;
+                }
+                continue;
+            }
+            // ---- the corrections crawl (a periodic stream): candidate lists, decode_core.h ----
+            if constexpr (CAND) {
+                cand_done = true;
+                CandList list = valid ? cand_one(st.start - nominal, st.end - boundary) : (CandList)0;
+                if (valid && i) cand_seed<VoteAlone>(in, lut, lenof, nominal - kDecLeadIn, nominal, boundary, data_limit, list);
+                for (;;) {
+                    const CandList pred = cand_of_prev_thread<kSubBlock / kWave>(list, wtail);
+                    const bool grew = valid && t && cand_grow<VoteAlone>(in, lut, lenof, pred, nominal, boundary, data_limit, list);
+                    if (!__syncthreads_or(grew)) break;
+                }
+                const CandList g = cand_scan<kSubBlock / kWave>(list, wtail);
+                const CandList gp = cand_of_prev_thread<kSubBlock / kWave>(g, wtail);
+                if (t == 0) wtail[kSubBlock / kWave] = (CandList)(st.start - nominal);
+                __syncthreads();
+                const uint32_t start0 = (uint32_t)wtail[kSubBlock / kWave];
+                uint32_t srel;
+                if (valid && t && cand_find(gp, start0, srel) && nominal + srel != st.start) {
+                    sub_refix<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st);
+                    dirty = true;
+                }
+                __syncthreads();
+                if (t == kSubBlock - 1) wtail[kSubBlock / kWave] = valid ? g : (CandList)0; // (a block with fewer subsequences is its file's last)
                 s_end[t] = st.end;
-                dirty = true;
+                __syncthreads();
+                bmap = wtail[kSubBlock / kWave];
             }
         }
         if (dirty && valid) {
@@ -230,10 +313,84 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             r.sum = sum, r.first_eob = e, r.first_invalid = inv;
             r.entry_rel = st.start - nominal;
             r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a block with fewer subsequences is its file's last)
-            r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+            if (!cand_count(bmap) && !crawls) bmap = cand_one(r.entry_rel, r.exit_rel & 31u);
+            r.bmap_lo = (uint32_t)bmap, r.bmap_hi = (uint32_t)(bmap >> 32), r.want_rel = kDecWantUnknown;
             recs[blk] = r;
             if (round) atomicOr(changed, 1u);
+            if (CAND && cand_count(bmap) > 1) atomicOr(multi, 1u); // (dec_chain_kernel has something to do from now on)
         }
+    }
+}
+
+// ---- dec_chain_kernel, one workgroup per file, in front of every border round: where must every workgroup of subsequences be
+//      entered?  Each one left a map (entry -> exit: one pair, or -- a periodic stream, decode_core.h -- one per phase); a workgroup
+//      that is entered in a phase its map does not know hands on its present exit (its neighbour then asks it again next round, as
+//      before).  The maps, completed that way to functions on the 18 possible phases, are composed along the file: a prefix "sum",
+//      thread by thread over chunks of workgroups, Hillis-Steele across the threads.  Blocks [first_block, first_block + n_blocks)
+//      of the batch: whole files, or (a file that arrives in pieces) a range of one file whose earlier blocks are settled. ----
+struct PhaseFn { // x -> f(x), x = 0..17, five bits each
+    uint32_t w[3];
+    __device__ __forceinline__ uint32_t at(uint32_t x) const
+    {
+        const uint32_t q = x / 6u, r = x - 6u * q;
+        return ((q == 0 ? w[0] : (q == 1 ? w[1] : w[2])) >> (5u * r)) & 31u;
+    }
+    __device__ __forceinline__ void set(uint32_t x, uint32_t v)
+    {
+        const uint32_t q = x / 6u, r = x - 6u * q, m = ~(31u << (5u * r)), b = v << (5u * r);
+        w[0] = q == 0 ? (w[0] & m) | b : w[0], w[1] = q == 1 ? (w[1] & m) | b : w[1], w[2] = q == 2 ? (w[2] & m) | b : w[2];
+    }
+};
+__device__ __forceinline__ uint32_t block_fn(const DecBlockRec &r, uint32_t x)
+{
+    uint32_t e;
+    return cand_find((CandList)r.bmap_hi << 32 | r.bmap_lo, x, e) ? e : (r.exit_rel & 31u);
+}
+__global__ __launch_bounds__(kDecBlock) void dec_chain_kernel(const DecJob *jobs, uint32_t first_block, uint32_t n_blocks, DecBlockRec *recs, const uint32_t *multi)
+{
+    __shared__ uint32_t fw[2][kDecBlock][3];
+    if (!*multi) return; // every workgroup's map is one pair: the neighbour's word is all there is to know (nearly every call ends here)
+    const DecJob &job = jobs[blockIdx.x];
+    if (job.mode != 0) return;
+    const uint32_t t = threadIdx.x, fb0 = job.sub_base / kSubBlock, fnb = (job.n_sub + kSubBlock - 1) / kSubBlock;
+    const uint32_t ra = max(fb0, first_block), rb = min(fb0 + fnb, first_block + n_blocks);
+    if (ra >= rb) return;
+    const uint32_t nb = rb - ra, per = (nb + kDecBlock - 1) / kDecBlock, i0 = min(t * per, nb), i1 = min(i0 + per, nb);
+    PhaseFn f; // what this thread's chunk of workgroups does to a phase
+    for (uint32_t x = 0; x < 18; x++) f.set(x, x);
+    f.w[0] &= 0x3FFFFFFFu, f.w[1] &= 0x3FFFFFFFu, f.w[2] &= 0x3FFFFFFFu;
+    for (uint32_t b = i0; b < i1; b++) {
+        const DecBlockRec r = recs[ra + b];
+        PhaseFn n2 = f;
+        for (uint32_t x = 0; x < 18; x++) n2.set(x, block_fn(r, f.at(x)));
+        f = n2;
+    }
+    int cur = 0;
+    fw[0][t][0] = f.w[0], fw[0][t][1] = f.w[1], fw[0][t][2] = f.w[2];
+    for (uint32_t d = 1; d < (uint32_t)kDecBlock; d <<= 1) { // inclusive: thread t's function = chunks 0..t
+        __syncthreads();
+        PhaseFn a = f;
+        if (t >= d) {
+            PhaseFn p;
+            p.w[0] = fw[cur][t - d][0], p.w[1] = fw[cur][t - d][1], p.w[2] = fw[cur][t - d][2];
+            for (uint32_t x = 0; x < 18; x++) a.set(x, f.at(p.at(x)));
+        }
+        f = a;
+        cur ^= 1;
+        fw[cur][t][0] = f.w[0], fw[cur][t][1] = f.w[1], fw[cur][t][2] = f.w[2];
+    }
+    __syncthreads();
+    // the phase the range is entered in: the file's first workgroup starts on the stream's first token; a later piece of a file
+    // where the piece in front ended
+    uint32_t ph = ra == fb0 ? recs[fb0].entry_rel : (recs[ra - 1].exit_rel & 31u);
+    if (t) {
+        PhaseFn p;
+        p.w[0] = fw[cur][t - 1][0], p.w[1] = fw[cur][t - 1][1], p.w[2] = fw[cur][t - 1][2];
+        ph = p.at(ph);
+    }
+    for (uint32_t b = i0; b < i1; b++) {
+        recs[ra + b].want_rel = ph;
+        ph = block_fn(recs[ra + b], ph);
     }
 }
 
@@ -264,7 +421,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     uint32_t bad = 0;
     for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
         const DecBlockRec r = recs[b0 + b];
-        if (b && r.entry_rel != recs[b0 + b - 1].exit_rel) bad |= kDecNotConverged;
+        if ((b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !(r.bmap_hi >> 28)) bad |= kDecNotConverged; // (an empty map: left unsettled by round 0)
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
@@ -326,7 +483,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
     uint32_t bad = 0;
     for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
         const DecBlockRec r = recs[b0 + b];
-        if (blk_a + b && r.entry_rel != recs[b0 + b - 1].exit_rel) bad |= kDecNotConverged;
+        if ((blk_a + b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !(r.bmap_hi >> 28)) bad |= kDecNotConverged;
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
@@ -859,9 +1016,18 @@ void launch_dec_fetch(hipStream_t s, const DecFileRef *files, uint32_t n, uint32
 
 // (the synchronisation and the emit run as persistent workgroups, `resident` of them: a few per compute unit)
 void launch_dec_sync(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
-                     DecSubArrays a, DecBlockRec *recs, uint32_t *changed)
+                     DecSubArrays a, DecBlockRec *recs, uint32_t *changed, uint32_t *multi)
 {
-    hipLaunchKernelGGL(dec_sync_kernel, dim3(FPNG_DEC_PERSISTENT ? std::min(n_blocks, resident) : n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a, recs, changed);
+    // (the workgroups' maps have more than one pair only behind round 1: no chain in front of it)
+    if (round >= 2) hipLaunchKernelGGL(dec_chain_kernel, dim3(n_jobs), dim3(kDecBlock), 0, s, jobs, first_block, n_blocks, recs, multi);
+    // a border round has something to do in a few workgroups' blocks only: `resident` workgroups walk over the records (5 us instead of
+    // 20 for the 14 400 blocks of 8 x 8K that a workgroup each would look at)
+    const dim3 block(kSubBlock);
+    if (round)
+        hipLaunchKernelGGL(dec_sync_kernel<true>, dim3(std::min(n_blocks, resident)), block, 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a, recs, changed, multi);
+    else
+        hipLaunchKernelGGL(dec_sync_kernel<false>, dim3(FPNG_DEC_PERSISTENT ? std::min(n_blocks, resident) : n_blocks), block, 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, round, a,
+                           recs, changed, multi);
 }
 void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, const DecJob *group_jobs,
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)

@@ -336,6 +336,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     }
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
     uint32_t *d_eob = d_status + nj + kMaxGroups;
+    uint32_t *d_multi = d_status + 2 * nj + kMaxGroups + 1; // (one word per group: launch_dec_sync)
     for (uint32_t k = 0; k < nj; k++) {
         DecJob &j = jobs[k];
         const Parsed &p = ps[job_file[k]];
@@ -488,7 +489,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         HIP_TRY(stamp(g, 0));
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
-        for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
+        for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi, d_multi + gi);
         HIP_TRY(finish_group(g));
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
@@ -513,7 +514,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             for (int k = 0; k < 4; k++) {
                 r++;
                 if (k == 3) HIP_TRY(hipMemsetAsync(d_changed + gi, 0, 4, s)); // (only the last of the four is asked)
-                launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi);
+                launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi, d_multi + gi);
             }
             HIP_TRY(hipMemcpyAsync(&changed, d_changed + gi, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -750,7 +751,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             HIP_TRY(hipStreamWaitEvent(s, ev_up[k], 0));
             const uint32_t a = k ? blk_end[k - 1] : 0, b = blk_end[k];
             if (b > a) {
-                for (uint32_t r = 0; r <= kBorderRounds; r++) launch_dec_sync(s, resident, d_job, 1, a, b - a, sub_total, r, d_sub, d_recs, d_status + 2);
+                for (uint32_t r = 0; r <= kBorderRounds; r++) launch_dec_sync(s, resident, d_job, 1, a, b - a, sub_total, r, d_sub, d_recs, d_status + 2, d_status + 3);
                 launch_dec_offsets_range(s, d_job, 0, a, b, k + 1 == np, sub_total, d_sub, d_recs, d_block_off, d_status, d_eob, d_carry);
                 launch_dec_emit(s, resident, d_job, 1, a, b - a, sub_total, d_sub, d_eob, d_block_off, d_status);
             }

@@ -199,6 +199,87 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
     s.end = s.c.flags ? boundary : e;
 }
 
+// ---- candidate lists: the way out of a PERIODIC stream ----
+// A stream that repeats itself (flat or striped content: every row the same few tokens) keeps wrongly started decoders in a stable
+// false phase -- they never fall into step -- and the corrections above then crawl through a workgroup one subsequence per step.
+// But the decoders of such a stream live in a handful of phases, and what a subsequence does to EACH of them can be found in
+// parallel: every thread keeps up to kCandMax pairs (where a decode of its subsequence starts -> where it ends, both as bits
+// behind the nominal boundary in front: 0..17, a token has at most 18 bits), takes over the ends of its predecessor's pairs as
+// starts of its own until no list grows (as many steps as there are phases), and the lists are then composed along the workgroup
+// (a prefix "sum" over maps) -- which yields every thread's true start at once, and the workgroup's own map (entry -> exit) for
+// the same game one level up (dec_chain_kernel).  A list is 64 bits: pair k in bits 10k..10k+9 (start | end << 5), the number
+// of pairs in bits 63..60.  A decode that derails or meets an end-of-block symbol "ends" on its nominal boundary (end 0), as in
+// SubState.
+constexpr uint32_t kCandMax = 6;
+constexpr uint32_t kRefixRounds = 3; // correction steps inside a workgroup before the candidate lists take over
+typedef uint64_t CandList;
+FPNG_DEC_HD uint32_t cand_count(CandList v) { return (uint32_t)(v >> 60); }
+FPNG_DEC_HD uint32_t cand_start(CandList v, uint32_t k) { return (uint32_t)(v >> (10 * k)) & 31u; }
+FPNG_DEC_HD uint32_t cand_end(CandList v, uint32_t k) { return (uint32_t)(v >> (10 * k + 5)) & 31u; }
+FPNG_DEC_HD CandList cand_one(uint32_t start, uint32_t end) { return (CandList)(start | end << 5) | (CandList)1 << 60; }
+FPNG_DEC_HD bool cand_find(CandList v, uint32_t start, uint32_t &end)
+{
+    for (uint32_t k = 0; k < kCandMax; k++)
+        if (k < cand_count(v) && cand_start(v, k) == start) {
+            end = cand_end(v, k);
+            return true;
+        }
+    return false;
+}
+FPNG_DEC_HD CandList cand_add(CandList v, uint32_t start, uint32_t end) // (cand_count(v) < kCandMax)
+{
+    const uint32_t n = cand_count(v);
+    return ((v & ~((CandList)15 << 60)) | (CandList)(start | end << 5) << (10 * n)) | (CandList)(n + 1) << 60;
+}
+// first the span `a` stands for, then `b`: the pairs of a whose end is a start of b
+FPNG_DEC_HD CandList cand_compose(CandList a, CandList b)
+{
+    CandList r = 0;
+    for (uint32_t k = 0; k < kCandMax; k++) {
+        uint32_t e;
+        if (k < cand_count(a) && cand_find(b, cand_end(a, k), e)) r = cand_add(r, cand_start(a, k), e);
+    }
+    return r;
+}
+// where a decode of [start, boundary) ends, without counting anything
+template <class Vote, class Bits>
+FPNG_DEC_HD uint32_t sub_probe(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit)
+{
+    SubCount d = {0, 0, 0, 0};
+    const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d);
+    return d.flags ? boundary : e;
+}
+// One growing step of a thread's list: every end of the predecessor's list (= a start here: its boundary is this thread's nominal
+// bit) that the list does not know yet is decoded.  Returns whether the list grew; full: a start had to be left out.
+template <class Vote, class Bits>
+FPNG_DEC_HD bool cand_grow(const Bits &in, const uint32_t *lut, const uint8_t *lenof, CandList pred, uint32_t nominal, uint32_t boundary, uint32_t data_limit, CandList &list)
+{
+    bool grew = false;
+    for (uint32_t k = 0; k < kCandMax; k++) {
+        uint32_t e;
+        if (k >= cand_count(pred) || cand_find(list, cand_end(pred, k), e) || cand_count(list) >= kCandMax) continue;
+        const uint32_t s = cand_end(pred, k);
+        list = cand_add(list, s, sub_probe<Vote>(in, lut, lenof, nominal + s, boundary, data_limit) - boundary);
+        grew = true;
+    }
+    return grew;
+}
+// A thread's first list: its own decode's pair is there; added are the phases in which decoders started at the bits lead_start + 1
+// ... lead_start + 17 cross the nominal bit (the true token sequence has a boundary among 18 consecutive bits, so the true start
+// is one of the arrivals -- if the list has room for it: a periodic stream has few phases, and a stream that is not periodic has
+// one).
+template <class Vote, class Bits>
+FPNG_DEC_HD void cand_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, CandList &list)
+{
+    for (uint32_t j = 1; j < 18; j++) {
+        SubCount d = {0, 0, 0, 0};
+        const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d);
+        uint32_t e;
+        if (d.flags || p < nominal || cand_find(list, p - nominal, e) || cand_count(list) >= kCandMax) continue;
+        list = cand_add(list, p - nominal, sub_probe<Vote>(in, lut, lenof, p, boundary, data_limit) - boundary);
+    }
+}
+
 // per-subsequence record in global memory: start - nominal (0..17) | end - boundary (0..17) << 5 | flags << 10 | literals << 13
 FPNG_DEC_HD uint32_t pack_info(uint32_t start_rel, uint32_t end_rel, const SubCount &c) { return start_rel | end_rel << 5 | c.flags << 10 | c.lits << 13; }
 FPNG_DEC_HD uint32_t info_start(uint32_t v) { return v & 31u; }

@@ -88,18 +88,23 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         const uint32_t n_sub = (uint32_t)((end_limit - first_bit + kSubBits - 1) / kSubBits), nb = (n_sub + sub_block - 1) / sub_block;
         std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub);
         struct Rec {
-            uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel;
+            uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel, want_rel;
+            CandList bmap;
         };
         std::vector<Rec> recs(nb);
         uint32_t max_inner = 0, fixed_subs = 0;
+        const uint32_t kUnknown = 0xFFFFFFFFu;
         // ---- dec_sync_kernel ----
         auto sync_block = [&](uint32_t blk, uint32_t round) -> bool { // returns "changed"
             const uint32_t local0 = blk * sub_block;
             uint32_t want0 = 0;
+            bool cand_first = false;
             if (round) {
-                if (!local0) return false;
-                if (recs[blk].entry_rel == recs[blk - 1].exit_rel) return false;
-                want0 = recs[blk - 1].exit_rel;
+                // (the file's first subsequence starts at the stream's first token: no border in front of the first block)
+                const uint32_t prev = !local0 ? recs[blk].entry_rel : (recs[blk].want_rel != kUnknown ? recs[blk].want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
+                if (recs[blk].entry_rel == prev && cand_count(recs[blk].bmap)) return false;
+                want0 = prev;
+                cand_first = cand_count(recs[blk].bmap) != 1; // left unsettled by round 0, or it needed its candidate lists before: straight to them
             }
             const uint32_t lead0 = local0 ? lead_in : 0u;
             const uint64_t first_nominal = first_bit + (uint64_t)local0 * kSubBits, d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
@@ -125,7 +130,9 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             }
             want0 += nominal_of(0);
             uint32_t inner = 0;
-            for (;;) {
+            CandList bmap = 0;
+            bool cand_done = false, crawls = false;
+            for (uint32_t it = 0;; it++) {
                 std::vector<uint32_t> want(nthreads);
                 bool any = false;
                 for (uint32_t t = 0; t < nthreads; t++) { // (all threads look before any of them writes: the kernel's barrier)
@@ -134,13 +141,51 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 }
                 if (!any) break;
                 inner++;
+                if (!round && it >= kRefixRounds) { // round 0's kernel is kept lean: the block is left to round 1
+                    crawls = true;
+                    break;
+                }
+                const bool cand_now = round && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
+                if (!cand_now) {
+                    for (uint32_t t = 0; t < nthreads; t++)
+                        if (want[t] != st[t].start) {
+                            sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                            s_end[t] = st[t].end;
+                            dirty[t] = true;
+                            if (!ever[t]) ever[t] = true, fixed_subs++;
+                        }
+                    continue;
+                }
+                // ---- candidate lists (decode_core.h) ----
+                cand_done = true;
+                std::vector<CandList> list(nthreads), pub(nthreads);
+                for (uint32_t t = 0; t < nthreads; t++) list[t] = cand_one(st[t].start - nominal_of(t), st[t].end - (nominal_of(t) + kSubBits));
+                // every phase a decoder can arrive in at a thread's nominal bit: lead-ins from 18 consecutive bits (cand_seed)
                 for (uint32_t t = 0; t < nthreads; t++)
-                    if (want[t] != st[t].start) {
-                        sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
-                        s_end[t] = st[t].end;
-                        dirty[t] = true;
-                        if (!ever[t]) ever[t] = true, fixed_subs++;
-                    }
+                    if (local0 + t && lead_in >= 18) cand_seed<VoteAlone>(in, lut.data(), lenof, nominal_of(t) - lead_in, nominal_of(t), nominal_of(t) + kSubBits, data_limit, list[t]);
+                for (;;) {
+                    pub = list;
+                    bool grew = false;
+                    for (uint32_t t = 1; t < nthreads; t++)
+                        grew |= cand_grow<VoteAlone>(in, lut.data(), lenof, pub[t - 1], nominal_of(t), nominal_of(t) + kSubBits, data_limit, list[t]);
+                    inner++;
+                    if (!grew) break;
+                }
+                // prefix composition (Hillis-Steele in the kernel): g[t] = what the subsequences 0..t do to thread 0's starts
+                std::vector<CandList> g = list;
+                for (uint32_t t = 1; t < nthreads; t++) g[t] = cand_compose(g[t - 1], list[t]);
+                bmap = nthreads == sub_block ? g[nthreads - 1] : (CandList)0;
+                const uint32_t start0 = st[0].start - nominal_of(0);
+                for (uint32_t t = 1; t < nthreads; t++) {
+                    uint32_t srel;
+                    if (!cand_find(g[t - 1], start0, srel)) continue;
+                    const uint32_t ws = nominal_of(t) + srel;
+                    if (ws == st[t].start) continue;
+                    sub_refix<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t]);
+                    dirty[t] = true;
+                    if (!ever[t]) ever[t] = true, fixed_subs++;
+                }
+                for (uint32_t t = 0; t < nthreads; t++) s_end[t] = st[t].end;
             }
             max_inner = std::max(max_inner, inner);
             bool any_dirty = false;
@@ -154,13 +199,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     any_dirty = true;
                 }
             if (!any_dirty) return false;
-            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0};
+            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, 0};
             for (uint32_t t = 0; t < nthreads; t++) {
                 r.sum += st[t].c.bytes;
                 if ((st[t].c.flags & kSubEob) && r.first_eob == sub_block) r.first_eob = t;
                 if ((st[t].c.flags & kSubInvalid) && r.first_invalid == sub_block) r.first_invalid = t;
             }
             r.exit_rel = nthreads == sub_block ? s_end[sub_block - 1] - (nominal_of(0) + sub_block * kSubBits) : 0u;
+            r.bmap = (cand_count(bmap) || crawls) ? bmap : cand_one(r.entry_rel, r.exit_rel);
             recs[blk] = r;
             return round != 0;
         };
@@ -169,8 +215,19 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         } catch (int) {
             return -1002;
         }
+        // ---- dec_chain_kernel: every block's true entry as far as the blocks' maps tell it (a block whose map does not know the phase
+        //      it is entered in hands on its present exit: the neighbour's word, as before) ----
+        auto chain = [&]() {
+            uint32_t cur = recs[0].entry_rel;
+            for (uint32_t b = 0; b < nb; b++) {
+                recs[b].want_rel = cur;
+                uint32_t e;
+                cur = cand_find(recs[b].bmap, cur, e) ? e : recs[b].exit_rel;
+            }
+        };
         uint32_t border_rounds = 0;
         for (uint32_t r = 1; r <= max_border_rounds; r++) {
+            if (r >= 2) chain(); // (the blocks' maps have more than one pair only behind round 1)
             // (the workgroups of one launch run at the same time; last to first, each one sees its predecessor's record of the
             //  launch before -- the least favourable of the schedules the kernel allows)
             bool changed = false;
@@ -190,7 +247,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         std::vector<uint64_t> block_off(nb, 0);
         uint64_t acc = 0;
         for (uint32_t b = 0; b < nb && b <= last_blk; b++) {
-            if (b && recs[b].entry_rel != recs[b - 1].exit_rel) status |= 1; // not converged
+            if ((b && recs[b].entry_rel != recs[b - 1].exit_rel) || !cand_count(recs[b].bmap)) status |= 1; // not converged
             block_off[b] = acc;
             if (b < last_blk) {
                 acc += recs[b].sum;

@@ -136,6 +136,37 @@ def test_correction_rounds_stay_few():
                 assert stats[0] <= 40 and stats[1] <= 12, (seed, w, h, cfg, stats)
 
 
+def periodic_images():
+    """Content whose token stream repeats itself: vertical stripes on a vertical ramp (every filtered row the same few bytes), tiles."""
+    import fpng_amd
+    out = []
+    for period, c in ((2, 4), (3, 4), (5, 3), (8, 4), (64, 3)):
+        w, h = 4096, 320
+        pal = np.random.default_rng(period).integers(0, 256, (period, c), dtype=np.uint8)
+        img = (pal[np.arange(w) % period][None] + (np.arange(h)[:, None, None] * 7).astype(np.uint8)).astype(np.uint8)
+        out.append((f"stripes{period}", np.ascontiguousarray(img).reshape(-1), w, h, c))
+    out.append(("blocks", np.asarray(fpng_amd.synth_image("blocks", 4096, 2048, 4)).reshape(-1), 4096, 2048, 4))
+    return out
+
+
+def test_periodic_streams_do_not_crawl():
+    """A stream that repeats itself keeps wrongly started decoders in a stable false phase; without the candidate lists
+    (decode_core.h) the corrections walk through a workgroup one subsequence per step (512 steps) and over the borders one
+    workgroup per round.  With them: a handful of steps, one border round, whatever the workgroup size."""
+    worst = [0, 0]
+    crawled = 0
+    for name, img, w, h, c in periodic_images():
+        for flags in (0, 1):
+            png = oracle().encode(img, w, h, c, flags)
+            for cfg in (CONFIGS[0], (64, 128, 1024), (16, 128, 256)):
+                st, px, ww, hh, cc, stats = emul_decode(png, c, cfg)
+                assert st == 0 and np.array_equal(px, img), (name, flags, cfg)
+                assert stats[0] <= 12 and stats[1] <= 2, (name, flags, cfg, stats)
+                worst = [max(worst[0], stats[0]), max(worst[1], stats[1])]
+                crawled += stats[0] > 3  # (more than kRefixRounds steps: the lists were used)
+    assert crawled >= 5, worst
+
+
 def test_too_few_border_rounds_leave_the_file_undecided():
     import fpng_amd
     img = fpng_amd.synth_image("grad", 640, 40, 4)

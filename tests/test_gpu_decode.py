@@ -161,6 +161,49 @@ def test_groups_of_files_and_a_stream_that_needs_many_rounds(enc):
                 assert torch.equal(px, want)
 
 
+def test_periodic_streams(enc):
+    """Content whose token stream repeats itself (stripes on a vertical ramp, tiles: tests/test_decode_model.py has the CPU side):
+    wrongly started decoders never fall into step, the candidate lists of dec_sync_kernel and dec_chain_kernel settle such files
+    without walking through them subsequence by subsequence.  Pixels and status of the reference's decoder, host- and
+    device-resident, whole and damaged; and a large striped frame must not take much longer than a gradient of its size."""
+    import time
+    import torch
+    from test_decode_model import _damage, periodic_images
+    rng = np.random.default_rng(17)
+    pngs = []
+    for name, img, w, h, c in periodic_images():
+        for flags in (0, 1):
+            png = oracle().encode(img, w, h, c, flags)
+            pngs.append(png)
+            pngs += [_damage(rng, png)[1] for _ in range(6)]
+    for desired in (4, 3):
+        n_ok, n_bad = _check(enc, pngs, desired)
+        assert n_ok >= 12 and n_bad >= 12
+    _check(enc, pngs, 4, device=True)
+    # 8K frames: stripes (1-pass and 2-pass) against a gradient, device-resident
+    w, h = 7680, 4320
+    pal = np.random.default_rng(3).integers(0, 256, (5, 4), dtype=np.uint8)
+    stripes = np.ascontiguousarray((pal[np.arange(w) % 5][None] + (np.arange(h)[:, None, None] * 7).astype(np.uint8)).astype(np.uint8))
+    import fpng_amd
+    frames = [torch.from_numpy(stripes).cuda(), torch.from_numpy(fpng_amd.synth_image("blocks", w, h, 4)).cuda(), torch.from_numpy(fpng_amd.synth_image("grad", w, h, 4)).cuda()]
+    times = {}
+    for flags in (0, 1):
+        files, _ = enc.encode_tensors(frames, flags)
+        for k, (f, t) in enumerate(zip(files, frames)):
+            dev = _device_files([f])
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                (st, px, cf), = enc.decode_device(dev, 4, [(w, h)])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                times[(flags, k)] = min(times.get((flags, k), 1e9), dt)
+            assert st == 0 and torch.equal(px, t), (flags, k)
+    print("periodic 8K decode times (ms):", {k: round(v * 1e3, 2) for k, v in times.items()})
+    for flags in (0, 1):
+        assert times[(flags, 0)] < 3 * times[(flags, 2)] + 2e-3 and times[(flags, 1)] < 3 * times[(flags, 2)] + 2e-3, times
+
+
 def test_dropin_decode_memory_uses_the_gpu_for_large_images(enc):
     """fpng::fpng_decode_memory (libfpng.so): images of 256K pixels and more go through fpng_amd_decode_host.  Pixels and status
     codes must be the REFERENCE decoder's (oracle/_ref): the photograph, synthetic frames of all three encode modes incl. a stored

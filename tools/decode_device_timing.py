@@ -11,6 +11,10 @@ enc = fpng_amd.Encoder(device=0)
 cases = [("8K RGBA grad x 8", "grad", 7680, 4320, 4, 8), ("4K RGBA grad x 16", "grad", 3840, 2160, 4, 16), ("1080p RGB grad x 64", "grad", 1920, 1080, 3, 64),
          ("512x512 RGB grad x 256", "grad", 512, 512, 3, 256), ("8K RGBA blocks x 8", "blocks", 7680, 4320, 4, 8),
          ("8K RGBA noise x 8", "noise", 7680, 4320, 4, 8), ("1080p RGB noise x 64", "noise", 1920, 1080, 3, 64), ("8K RGBA solid x 8", "solid", 7680, 4320, 4, 8)]
+# a periodic token stream: stripes of five colours on a vertical ramp (every filtered row the same few bytes)
+_pal = np.random.default_rng(3).integers(0, 256, (5, 4), dtype=np.uint8)
+_stripes = np.ascontiguousarray((_pal[np.arange(7680) % 5][None] + (np.arange(4320)[:, None, None] * 7).astype(np.uint8)).astype(np.uint8))
+cases.append(("8K RGBA stripes x 8", _stripes, 7680, 4320, 4, 8))
 import ui_images
 for uname, (uimg, uw, uh, uc) in sorted(ui_images.all_images().items()):
     if uw == 3840:

@@ -389,6 +389,16 @@ __device__ __forceinline__ void sink_zero(EmitSink &s, uint32_t lane, uint32_t n
 {
     for (uint32_t j = lane; j < ndw; j += kWave) s.stage[j] = 0;
 }
+// the whole window, once per row: four ds_write_b128 per lane instead of sixteen ds_write_b32 (the dump slots behind the window only
+// ever receive zeros)
+__device__ __forceinline__ void sink_zero_window(EmitSink &s, uint32_t lane)
+{
+    static_assert(kStageDwords % (4 * kWave) == 0, "whole 16-byte groups per lane");
+    u32x4 *st4 = (u32x4 *)s.stage;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < kStageDwords / (4 * kWave); k++) st4[lane + k * kWave] = zero4;
+}
 
 // OR a token of nbits (<= 60) at window bit position pos.  Lanes without a token pass code == 0:
 // two unconditional ds_or are cheaper than the exec juggling of conditional ones.
@@ -1157,7 +1167,10 @@ __device__ __forceinline__ void encode_rows_block(const Job &job, uint32_t by, u
     sink.base_dw = zero;
     sink.fill = zero;
     sink.wide = (C == 4); // the 3-channel walk has no registers to spare for the 16-byte flush (it would drop to 7 waves/SIMD)
-    sink_zero(sink, lane, kStageDwords);
+    if (C == 3)
+        sink_zero_window(sink, lane); // (in the 4-channel kernel the wider stores cost two more spilled registers in the walk)
+    else
+        sink_zero(sink, lane, kStageDwords);
     wave_lds_fence();
 
     const RowResult res = walk_row<C, Pass::Encode>(job, T, nullptr, r, lane, &sink);

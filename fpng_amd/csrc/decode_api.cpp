@@ -595,6 +595,13 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     int rc;
     if ((rc = ensure_copy_streams(e))) return rc;
     hipStream_t s = e->stream, s_up = e->host.up, s_down = e->host.down;
+    // The Up filter's undoing of a piece's rows runs on a stream of its own (a lane's: the lanes are drained), next to the following
+    // piece's synchronisation and decode instead of behind them: the rows go down one piece earlier.
+    static const bool unf_aside = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_UNF_STREAM");
+        return !(v && v[0] == '0');
+    }();
+    hipStream_t s_unf = (unf_aside && e->lane_stream[0]) ? e->lane_stream[0] : s;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
     const uint32_t resident = (uint32_t)std::max(cus, 1) * 3;
@@ -663,9 +670,17 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
         return v ? (uint32_t)std::max(1, atoi(v)) : 4u;
     }();
     const uint32_t np = std::max(1u, std::min<uint32_t>({kMaxPieces, n_blocks, p.idat_len / (piece_mb << 20)}));
+    // The first pieces are small -- a quarter, then half a share: the first rows are on their way down after 1 MiB instead of 4,
+    // and the download, which takes longer than everything else together, starts that much earlier.
+    static const bool ramp = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_RAMP");
+        return !(v && v[0] == '0');
+    }();
     uint32_t blk_end[kMaxPieces], byte_end[kMaxPieces];
     for (uint32_t k = 0; k < np; k++) {
-        blk_end[k] = (uint32_t)((uint64_t)n_blocks * (k + 1) / np);
+        // shares: 1/4, 1/2, 1, 1, ... of (np - 1.25) equal ones
+        const double done = (ramp && np >= 4) ? (k == 0 ? 0.25 : (k == 1 ? 0.75 : (double)k - 0.25)) / ((double)np - 1.25) : (double)(k + 1) / np;
+        blk_end[k] = k + 1 == np ? n_blocks : std::min<uint32_t>(n_blocks, std::max<uint32_t>(k + 1, (uint32_t)(n_blocks * done)));
         const uint64_t end_bit = j.first_bit + (uint64_t)blk_end[k] * kDecSubBlock * kSubBits;
         byte_end[k] = k + 1 == np ? p.idat_len : (uint32_t)std::min<uint64_t>(p.idat_len, (end_bit >> 3) + 64);
     }
@@ -766,9 +781,10 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             uint32_t segs = rows / kDecUnfRows; // whole segments only -- or, behind the last piece, everything
             if (q + 1 == np) segs = j.nseg, rows = p.h;
             else rows = segs * kDecUnfRows;
-            if (segs > segs_done) launch_dec_unfilter(s, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch);
+            if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s_unf, ev_carry[q], 0)); // (piece q's rows are in the filtered stream; the small words went up in front of piece 0)
+            if (segs > segs_done) launch_dec_unfilter(s_unf, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch);
             segs_done = std::max(segs_done, segs);
-            HIP_TRY(hipEventRecord(ev_rows[q], s));
+            HIP_TRY(hipEventRecord(ev_rows[q], s_unf));
             {
                 std::lock_guard<std::mutex> lk(mu);
                 row_end[q] = std::max(rows, q ? row_end[q - 1] : 0u);
@@ -778,6 +794,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
         }
     }
     HIP_TRY(hipGetLastError());
+    if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s, ev_rows[np - 1], 0)); // (the last rows' filter literals are part of the status)
     HIP_TRY(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     e->workers->down.wait();

@@ -665,11 +665,14 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     const uint32_t epoch = ++e->dec_epoch & 0x3FFFFFFFu; // (one epoch for all of this file's unfilter launches: later segments look back at earlier launches' sums)
     // ---- pieces: whole blocks of subsequences; a piece's kernels read up to 64 bytes behind its last block (a token's window, the pad) ----
     constexpr uint32_t kMaxPieces = 16;
+    // (a piece costs ~100 us of launches and a host round trip: pieces of 6 MiB, but at least four of them -- measured on one box,
+    //  2 / 3 / 4 / 6 MiB pieces: 8K RGBA 3.06 / 3.05 / 3.01 / 2.99 ms, an 11 MP photograph 2.46 / 1.90 / 1.53 / 1.38, 4K RGBA 1.03 / 0.95 / 1.02 / 1.06)
     static const uint32_t piece_mb = [] {
         const char *v = getenv("FPNG_AMD_DECODE_PIECE_MB");
-        return v ? (uint32_t)std::max(1, atoi(v)) : 4u;
+        return v ? (uint32_t)std::max(1, atoi(v)) : 0u;
     }();
-    const uint32_t np = std::max(1u, std::min<uint32_t>({kMaxPieces, n_blocks, p.idat_len / (piece_mb << 20)}));
+    const uint32_t np_want = piece_mb ? p.idat_len / (piece_mb << 20) : std::max(4u, p.idat_len / (6u << 20));
+    const uint32_t np = std::max(1u, std::min<uint32_t>({kMaxPieces, n_blocks, np_want}));
     // The first pieces are small -- a quarter, then half a share: the first rows are on their way down after 1 MiB instead of 4,
     // and the download, which takes longer than everything else together, starts that much earlier.
     static const bool ramp = [] {

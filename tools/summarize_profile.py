@@ -28,12 +28,15 @@ fscale = GiB / [v for k, v in cal_f.items() if "calib_read_kernel<unsigned int>"
 wscale = GiB / [v for k, v in cal_w.items() if "calib_write_kernel<unsigned int>" in k][0]
 args = " ".join(sys.argv[4:])
 only = os.environ.get("PROFILE_KERNELS", "")  # e.g. dec_ : the decoder's kernels of a bench.py --mode decode run
+# (the default bench.py run also decodes -- its `decode` object -- and checks pixels with torch: without PROFILE_KERNELS the summary
+#  is the ENCODE chain's, the decoder's kernels have their own file)
+skip = () if only else ("dec_", "at::")
 lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline {args}".rstrip()
          + (f"  [kernels {only}*]" if only else ""),
          f"# calibration (tools/pmc_calibrate.py, 1 GiB streams with 4-byte lanes): FETCH_SIZE unit = {fscale:.1f} B, WRITE_SIZE unit = {wscale:.1f} B",
          f"{'kernel':<22} {'FETCH_SIZE':>12} {'fetch_MB':>10} {'WRITE_SIZE':>12} {'write_MB':>10}"]
 tot = 0
-kernels = [k for k in f if k.endswith("_kernel") and "calib" not in k and k.startswith(only)]
+kernels = [k for k in f if k.endswith("_kernel") and "calib" not in k and k.startswith(only) and not k.startswith(skip)]
 for k in sorted(kernels, key=lambda k: -(f.get(k, 0) * fscale + w.get(k, 0) * wscale)):
     fb, wb = f.get(k, 0) * fscale, w.get(k, 0) * wscale
     tot += fb + wb

@@ -50,9 +50,10 @@ struct DecBlockRec {
     uint32_t first_invalid; // first one whose decode derailed
     uint32_t entry_rel;     // where its first subsequence starts, in bits behind the workgroup's first nominal bit
     uint32_t exit_rel;      // where its last subsequence ends, in bits behind the next workgroup's first nominal bit
-    uint32_t bmap_lo, bmap_hi; // dec::CandList: what the workgroup does to the phases it can be entered in (entry -> exit pairs; one pair unless
-                               // the stream is periodic: decode_core.h)
     uint32_t want_rel;      // dec_chain_kernel: where its first subsequence must start (kDecWantUnknown: ask the workgroup in front)
+    uint32_t map[3];        // dec::PhaseMap: what the workgroup does to the phases it can be entered in (entry -> exit: one pair unless the
+                            // stream is periodic, decode_core.h; no pair at all: round 0 left the workgroup unsettled)
+    uint32_t pad_;
 };
 constexpr uint32_t kDecWantUnknown = 0xFFFFFFFFu;
 

@@ -135,41 +135,48 @@ struct WaveVote {
     }
 };
 
-// ---- candidate lists (decode_core.h) across the threads of a workgroup ----
-__device__ __forceinline__ CandList shfl_up64(CandList v, int o)
+// ---- phase maps (decode_core.h) across the threads of a workgroup ----
+__device__ __forceinline__ PhaseMap pm_shfl_up(const PhaseMap &v, int o)
 {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o, kWave), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o, kWave);
-    return (CandList)hi << 32 | lo;
+    PhaseMap r;
+    r.w[0] = (uint32_t)__shfl_up((int)v.w[0], o, kWave), r.w[1] = (uint32_t)__shfl_up((int)v.w[1], o, kWave), r.w[2] = (uint32_t)__shfl_up((int)v.w[2], o, kWave);
+    return r;
 }
-// the list of thread t - 1 (an empty one for thread 0); wtail: LDS, one entry per wave
-template <int WAVES> __device__ __forceinline__ CandList cand_of_prev_thread(CandList v, CandList *wtail)
+// the map of thread t - 1 (one that knows nothing for thread 0); wtail: LDS, one entry per wave
+__device__ __forceinline__ PhaseMap pm_of_prev_thread(const PhaseMap &v, PhaseMap *wtail)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    CandList r = shfl_up64(v, 1);
+    PhaseMap r = pm_shfl_up(v, 1);
     __syncthreads();
     if (lane == 63) wtail[wave] = v;
     __syncthreads();
-    if (lane == 0) r = wave ? wtail[wave - 1] : (CandList)0;
+    if (lane == 0) r = wave ? wtail[wave - 1] : pm_none();
     return r;
 }
-// inclusive prefix composition: thread t gets what the subsequences 0..t do to thread 0's starts
-template <int WAVES> __device__ __forceinline__ CandList cand_scan(CandList g, CandList *wtail)
+// inclusive prefix composition: thread t gets what the subsequences 0..t do to the phases thread 0's map knows
+__device__ __forceinline__ PhaseMap pm_scan(PhaseMap g, PhaseMap *wtail)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
+#pragma unroll 1
     for (int o = 1; o < kWave; o <<= 1) {
-        const CandList p = shfl_up64(g, o);
-        if (lane >= (uint32_t)o) g = cand_compose(p, g);
+        const PhaseMap p = pm_shfl_up(g, o);
+        if (lane >= (uint32_t)o) g = pm_compose(p, g);
     }
     __syncthreads();
     if (lane == 63) wtail[wave] = g;
     __syncthreads();
     if (wave) {
-        CandList pre = wtail[0];
-        for (uint32_t q = 1; q < wave; q++) pre = cand_compose(pre, wtail[q]);
-        g = cand_compose(pre, g);
+        PhaseMap pre = wtail[0];
+        for (uint32_t q = 1; q < wave; q++) pre = pm_compose(pre, wtail[q]);
+        g = pm_compose(pre, g);
     }
     return g;
+}
+__device__ __forceinline__ PhaseMap rec_map(const DecBlockRec &r)
+{
+    PhaseMap m;
+    m.w[0] = r.map[0], m.w[1] = r.map[1], m.w[2] = r.map[2];
+    return m;
 }
 
 // ---- synchronisation ----
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
     __shared__ uint32_t bits[slice_slots(kSyncDwords)];
     __shared__ uint32_t s_end[kSubBlock];
     __shared__ uint32_t red3[3 * (kSubBlock / kWave)];
-    __shared__ CandList wtail[kSubBlock / kWave + 1];
+    __shared__ PhaseMap wtail[kSubBlock / kWave + 1];
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
@@ -203,12 +210,12 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         bool cand_first = false;
         if (round) { // only the border to the previous block is open
             const DecBlockRec mine = recs[blk];
-            const uint32_t pairs = cand_count((CandList)mine.bmap_hi << 32 | mine.bmap_lo);
+            const uint32_t pairs = pm_count(rec_map(mine));
             // (the file's first subsequence starts at the stream's first token: no border in front of the first block)
             const uint32_t prev = !local0 ? mine.entry_rel : (mine.want_rel != kDecWantUnknown ? mine.want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
             if (mine.entry_rel == prev && pairs) continue;
             want0 = prev;
-            cand_first = pairs != 1; // left unsettled by round 0, or it needed its candidate lists before: straight to them
+            cand_first = pairs != 1; // left unsettled by round 0, or it needed its phase maps before: straight to them
         }
         const uint32_t lead0 = local0 ? kDecLeadIn : 0u;
         const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         want0 += nominal; // (thread 0's nominal: the block's first)
         s_end[t] = st.end;
         bool cand_done = false, crawls = false;
-        CandList bmap = 0;
+        PhaseMap bmap = pm_none();
         for (uint32_t it = 0;; it++) {
             __syncthreads();
             uint32_t want = st.start;
@@ -261,28 +268,28 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
                 }
                 continue;
             }
-            // ---- the corrections crawl (a periodic stream): candidate lists, decode_core.h ----
+            // ---- the corrections crawl (a periodic stream): phase maps, decode_core.h ----
             if constexpr (CAND) {
                 cand_done = true;
-                CandList list = valid ? cand_one(st.start - nominal, st.end - boundary) : (CandList)0;
-                if (valid && i) cand_seed<VoteAlone>(in, lut, lenof, nominal - kDecLeadIn, nominal, boundary, data_limit, list);
-                for (;;) {
-                    const CandList pred = cand_of_prev_thread<kSubBlock / kWave>(list, wtail);
-                    const bool grew = valid && t && cand_grow<VoteAlone>(in, lut, lenof, pred, nominal, boundary, data_limit, list);
+                PhaseMap map = valid ? pm_one(st.start - nominal, st.end - boundary) : pm_none();
+                if (valid && i) pm_seed<VoteAlone>(in, lut, lenof, nominal - kDecLeadIn, nominal, boundary, data_limit, map);
+                for (uint32_t step = 0; step < kCandGrowSteps; step++) { // (as many steps as there are phases the seeds missed; a map that stays incomplete costs its threads the old walk)
+                    const PhaseMap pred = pm_of_prev_thread(map, wtail);
+                    const bool grew = valid && t && pm_grow<VoteAlone>(in, lut, lenof, pred, nominal, boundary, data_limit, map);
                     if (!__syncthreads_or(grew)) break;
                 }
-                const CandList g = cand_scan<kSubBlock / kWave>(list, wtail);
-                const CandList gp = cand_of_prev_thread<kSubBlock / kWave>(g, wtail);
-                if (t == 0) wtail[kSubBlock / kWave] = (CandList)(st.start - nominal);
+                const PhaseMap g = pm_scan(map, wtail);
+                const PhaseMap gp = pm_of_prev_thread(g, wtail);
+                if (t == 0) wtail[kSubBlock / kWave].w[0] = st.start - nominal;
                 __syncthreads();
-                const uint32_t start0 = (uint32_t)wtail[kSubBlock / kWave];
-                uint32_t srel;
-                if (valid && t && cand_find(gp, start0, srel) && nominal + srel != st.start) {
+                const uint32_t start0 = wtail[kSubBlock / kWave].w[0];
+                const uint32_t srel = (valid && t) ? pm_at(gp, start0) : kPhaseUnknown;
+                if (srel != kPhaseUnknown && nominal + srel != st.start) {
                     sub_refix<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st);
                     dirty = true;
                 }
                 __syncthreads();
-                if (t == kSubBlock - 1) wtail[kSubBlock / kWave] = valid ? g : (CandList)0; // (a block with fewer subsequences is its file's last)
+                if (t == kSubBlock - 1) wtail[kSubBlock / kWave] = valid ? g : pm_none(); // (a block with fewer subsequences is its file's last)
                 s_end[t] = st.end;
                 __syncthreads();
                 bmap = wtail[kSubBlock / kWave];
@@ -313,11 +320,12 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             r.sum = sum, r.first_eob = e, r.first_invalid = inv;
             r.entry_rel = st.start - nominal;
             r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a block with fewer subsequences is its file's last)
-            if (!cand_count(bmap) && !crawls) bmap = cand_one(r.entry_rel, r.exit_rel & 31u);
-            r.bmap_lo = (uint32_t)bmap, r.bmap_hi = (uint32_t)(bmap >> 32), r.want_rel = kDecWantUnknown;
+            const uint32_t known = pm_count(bmap);
+            if (!known && !crawls) bmap = pm_one(r.entry_rel, r.exit_rel & 31u);
+            r.map[0] = bmap.w[0], r.map[1] = bmap.w[1], r.map[2] = bmap.w[2], r.want_rel = kDecWantUnknown, r.pad_ = 0;
             recs[blk] = r;
             if (round) atomicOr(changed, 1u);
-            if (CAND && cand_count(bmap) > 1) atomicOr(multi, 1u); // (dec_chain_kernel has something to do from now on)
+            if (CAND && known > 1) atomicOr(multi, 1u); // (dec_chain_kernel has something to do from now on)
         }
     }
 }
@@ -328,23 +336,10 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
 //      before).  The maps, completed that way to functions on the 18 possible phases, are composed along the file: a prefix "sum",
 //      thread by thread over chunks of workgroups, Hillis-Steele across the threads.  Blocks [first_block, first_block + n_blocks)
 //      of the batch: whole files, or (a file that arrives in pieces) a range of one file whose earlier blocks are settled. ----
-struct PhaseFn { // x -> f(x), x = 0..17, five bits each
-    uint32_t w[3];
-    __device__ __forceinline__ uint32_t at(uint32_t x) const
-    {
-        const uint32_t q = x / 6u, r = x - 6u * q;
-        return ((q == 0 ? w[0] : (q == 1 ? w[1] : w[2])) >> (5u * r)) & 31u;
-    }
-    __device__ __forceinline__ void set(uint32_t x, uint32_t v)
-    {
-        const uint32_t q = x / 6u, r = x - 6u * q, m = ~(31u << (5u * r)), b = v << (5u * r);
-        w[0] = q == 0 ? (w[0] & m) | b : w[0], w[1] = q == 1 ? (w[1] & m) | b : w[1], w[2] = q == 2 ? (w[2] & m) | b : w[2];
-    }
-};
 __device__ __forceinline__ uint32_t block_fn(const DecBlockRec &r, uint32_t x)
 {
-    uint32_t e;
-    return cand_find((CandList)r.bmap_hi << 32 | r.bmap_lo, x, e) ? e : (r.exit_rel & 31u);
+    const uint32_t e = pm_at(rec_map(r), x);
+    return e != kPhaseUnknown ? e : (r.exit_rel & 31u);
 }
 __global__ __launch_bounds__(kDecBlock) void dec_chain_kernel(const DecJob *jobs, uint32_t first_block, uint32_t n_blocks, DecBlockRec *recs, const uint32_t *multi)
 {
@@ -356,24 +351,23 @@ __global__ __launch_bounds__(kDecBlock) void dec_chain_kernel(const DecJob *jobs
     const uint32_t ra = max(fb0, first_block), rb = min(fb0 + fnb, first_block + n_blocks);
     if (ra >= rb) return;
     const uint32_t nb = rb - ra, per = (nb + kDecBlock - 1) / kDecBlock, i0 = min(t * per, nb), i1 = min(i0 + per, nb);
-    PhaseFn f; // what this thread's chunk of workgroups does to a phase
-    for (uint32_t x = 0; x < 18; x++) f.set(x, x);
-    f.w[0] &= 0x3FFFFFFFu, f.w[1] &= 0x3FFFFFFFu, f.w[2] &= 0x3FFFFFFFu;
+    PhaseMap f = pm_none(); // what this thread's chunk of workgroups does to a phase (a function on all of them here)
+    for (uint32_t x = 0; x < kPhases; x++) pm_set(f, x, x);
     for (uint32_t b = i0; b < i1; b++) {
         const DecBlockRec r = recs[ra + b];
-        PhaseFn n2 = f;
-        for (uint32_t x = 0; x < 18; x++) n2.set(x, block_fn(r, f.at(x)));
+        PhaseMap n2 = f;
+        for (uint32_t x = 0; x < kPhases; x++) pm_set(n2, x, block_fn(r, pm_at(f, x)));
         f = n2;
     }
     int cur = 0;
     fw[0][t][0] = f.w[0], fw[0][t][1] = f.w[1], fw[0][t][2] = f.w[2];
     for (uint32_t d = 1; d < (uint32_t)kDecBlock; d <<= 1) { // inclusive: thread t's function = chunks 0..t
         __syncthreads();
-        PhaseFn a = f;
+        PhaseMap a = f;
         if (t >= d) {
-            PhaseFn p;
+            PhaseMap p;
             p.w[0] = fw[cur][t - d][0], p.w[1] = fw[cur][t - d][1], p.w[2] = fw[cur][t - d][2];
-            for (uint32_t x = 0; x < 18; x++) a.set(x, f.at(p.at(x)));
+            a = pm_compose(p, f);
         }
         f = a;
         cur ^= 1;
@@ -384,9 +378,9 @@ __global__ __launch_bounds__(kDecBlock) void dec_chain_kernel(const DecJob *jobs
     // where the piece in front ended
     uint32_t ph = ra == fb0 ? recs[fb0].entry_rel : (recs[ra - 1].exit_rel & 31u);
     if (t) {
-        PhaseFn p;
+        PhaseMap p;
         p.w[0] = fw[cur][t - 1][0], p.w[1] = fw[cur][t - 1][1], p.w[2] = fw[cur][t - 1][2];
-        ph = p.at(ph);
+        ph = pm_at(p, ph);
     }
     for (uint32_t b = i0; b < i1; b++) {
         recs[ra + b].want_rel = ph;
@@ -421,7 +415,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     uint32_t bad = 0;
     for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
         const DecBlockRec r = recs[b0 + b];
-        if ((b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !(r.bmap_hi >> 28)) bad |= kDecNotConverged; // (an empty map: left unsettled by round 0)
+        if ((b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !pm_count(rec_map(r))) bad |= kDecNotConverged; // (an empty map: left unsettled by round 0)
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
@@ -483,7 +477,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
     uint32_t bad = 0;
     for (uint32_t b = i0; b < i1 && b <= last_blk; b++) {
         const DecBlockRec r = recs[b0 + b];
-        if ((blk_a + b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !(r.bmap_hi >> 28)) bad |= kDecNotConverged;
+        if ((blk_a + b && r.entry_rel != recs[b0 + b - 1].exit_rel) || !pm_count(rec_map(r))) bad |= kDecNotConverged;
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;

@@ -199,45 +199,60 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
     s.end = s.c.flags ? boundary : e;
 }
 
-// ---- candidate lists: the way out of a PERIODIC stream ----
+// ---- phase maps: the way out of a PERIODIC stream ----
 // A stream that repeats itself (flat or striped content: every row the same few tokens) keeps wrongly started decoders in a stable
 // false phase -- they never fall into step -- and the corrections above then crawl through a workgroup one subsequence per step.
-// But the decoders of such a stream live in a handful of phases, and what a subsequence does to EACH of them can be found in
-// parallel: every thread keeps up to kCandMax pairs (where a decode of its subsequence starts -> where it ends, both as bits
-// behind the nominal boundary in front: 0..17, a token has at most 18 bits), takes over the ends of its predecessor's pairs as
-// starts of its own until no list grows (as many steps as there are phases), and the lists are then composed along the workgroup
-// (a prefix "sum" over maps) -- which yields every thread's true start at once, and the workgroup's own map (entry -> exit) for
-// the same game one level up (dec_chain_kernel).  A list is 64 bits: pair k in bits 10k..10k+9 (start | end << 5), the number
-// of pairs in bits 63..60.  A decode that derails or meets an end-of-block symbol "ends" on its nominal boundary (end 0), as in
-// SubState.
-constexpr uint32_t kCandMax = 6;
-constexpr uint32_t kRefixRounds = 3; // correction steps inside a workgroup before the candidate lists take over
-typedef uint64_t CandList;
-FPNG_DEC_HD uint32_t cand_count(CandList v) { return (uint32_t)(v >> 60); }
-FPNG_DEC_HD uint32_t cand_start(CandList v, uint32_t k) { return (uint32_t)(v >> (10 * k)) & 31u; }
-FPNG_DEC_HD uint32_t cand_end(CandList v, uint32_t k) { return (uint32_t)(v >> (10 * k + 5)) & 31u; }
-FPNG_DEC_HD CandList cand_one(uint32_t start, uint32_t end) { return (CandList)(start | end << 5) | (CandList)1 << 60; }
-FPNG_DEC_HD bool cand_find(CandList v, uint32_t start, uint32_t &end)
+// But a decoder crosses a subsequence's nominal first bit in one of only 18 PHASES (the bit its next token starts at, counted
+// from that nominal bit: a token has at most 18 bits), a periodic stream keeps a handful of them alive, and what a subsequence
+// does to EACH phase can be found in parallel.  Every thread keeps a map phase -> phase (where a decode of its subsequence that
+// starts in phase x ends, as a phase of the NEXT subsequence; kPhaseUnknown where nobody has looked): its own decode's pair, plus
+// the phases in which decoders started at 17 more consecutive bits of its lead-in arrive (the true token sequence has a boundary
+// among any 18 consecutive bits, so the true phase is among the arrivals), plus -- until no map grows -- the phases its
+// predecessor's map ends in.  The maps are then composed along the workgroup (an inclusive prefix "sum" over functions), which
+// yields every thread's true start at once and the workgroup's own map (entry -> exit) for the same game one level up
+// (dec_chain_kernel).  A map is three dwords: phase x in bits 5 (x % 6) .. of word x / 6.  A decode that derails or meets an
+// end-of-block symbol "ends" on its nominal boundary (phase 0), as in SubState.
+constexpr uint32_t kPhases = 18, kPhaseUnknown = 31;
+constexpr uint32_t kRefixRounds = 3;    // correction steps inside a workgroup before the phase maps take over
+constexpr uint32_t kCandGrowSteps = 12; // steps in which the maps take over their neighbours' ends (a bound, not a need: the seeds usually hold every phase)
+struct PhaseMap {
+    uint32_t w[3];
+};
+FPNG_DEC_HD PhaseMap pm_none()
 {
-    for (uint32_t k = 0; k < kCandMax; k++)
-        if (k < cand_count(v) && cand_start(v, k) == start) {
-            end = cand_end(v, k);
-            return true;
-        }
-    return false;
+    PhaseMap m;
+    m.w[0] = m.w[1] = m.w[2] = 0x3FFFFFFFu;
+    return m;
 }
-FPNG_DEC_HD CandList cand_add(CandList v, uint32_t start, uint32_t end) // (cand_count(v) < kCandMax)
+FPNG_DEC_HD uint32_t pm_at(const PhaseMap &m, uint32_t x) // x < kPhases
 {
-    const uint32_t n = cand_count(v);
-    return ((v & ~((CandList)15 << 60)) | (CandList)(start | end << 5) << (10 * n)) | (CandList)(n + 1) << 60;
+    const uint32_t q = x >= 12u ? 2u : (x >= 6u ? 1u : 0u), r = x - 6u * q;
+    return ((q == 0 ? m.w[0] : (q == 1 ? m.w[1] : m.w[2])) >> (5u * r)) & 31u;
 }
-// first the span `a` stands for, then `b`: the pairs of a whose end is a start of b
-FPNG_DEC_HD CandList cand_compose(CandList a, CandList b)
+FPNG_DEC_HD void pm_set(PhaseMap &m, uint32_t x, uint32_t v)
 {
-    CandList r = 0;
-    for (uint32_t k = 0; k < kCandMax; k++) {
-        uint32_t e;
-        if (k < cand_count(a) && cand_find(b, cand_end(a, k), e)) r = cand_add(r, cand_start(a, k), e);
+    const uint32_t q = x >= 12u ? 2u : (x >= 6u ? 1u : 0u), r = x - 6u * q, keep = ~(31u << (5u * r)), b = v << (5u * r);
+    m.w[0] = q == 0 ? (m.w[0] & keep) | b : m.w[0], m.w[1] = q == 1 ? (m.w[1] & keep) | b : m.w[1], m.w[2] = q == 2 ? (m.w[2] & keep) | b : m.w[2];
+}
+FPNG_DEC_HD PhaseMap pm_one(uint32_t start, uint32_t end)
+{
+    PhaseMap m = pm_none();
+    pm_set(m, start, end);
+    return m;
+}
+FPNG_DEC_HD uint32_t pm_count(const PhaseMap &m) // phases it knows
+{
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < kPhases; x++) n += pm_at(m, x) != kPhaseUnknown;
+    return n;
+}
+// first the span `a` stands for, then `b`
+FPNG_DEC_HD PhaseMap pm_compose(const PhaseMap &a, const PhaseMap &b)
+{
+    PhaseMap r = pm_none();
+    for (uint32_t x = 0; x < kPhases; x++) {
+        const uint32_t e = pm_at(a, x);
+        if (e != kPhaseUnknown) pm_set(r, x, pm_at(b, e));
     }
     return r;
 }
@@ -249,34 +264,30 @@ FPNG_DEC_HD uint32_t sub_probe(const Bits &in, const uint32_t *lut, const uint8_
     const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d);
     return d.flags ? boundary : e;
 }
-// One growing step of a thread's list: every end of the predecessor's list (= a start here: its boundary is this thread's nominal
-// bit) that the list does not know yet is decoded.  Returns whether the list grew; full: a start had to be left out.
+// One growing step of a thread's map: every phase the predecessor's map ends in (= a phase this subsequence is entered in: its
+// boundary is this thread's nominal bit) that the map does not know yet is decoded.  Returns whether the map grew.
 template <class Vote, class Bits>
-FPNG_DEC_HD bool cand_grow(const Bits &in, const uint32_t *lut, const uint8_t *lenof, CandList pred, uint32_t nominal, uint32_t boundary, uint32_t data_limit, CandList &list)
+FPNG_DEC_HD bool pm_grow(const Bits &in, const uint32_t *lut, const uint8_t *lenof, const PhaseMap &pred, uint32_t nominal, uint32_t boundary, uint32_t data_limit, PhaseMap &map)
 {
     bool grew = false;
-    for (uint32_t k = 0; k < kCandMax; k++) {
-        uint32_t e;
-        if (k >= cand_count(pred) || cand_find(list, cand_end(pred, k), e) || cand_count(list) >= kCandMax) continue;
-        const uint32_t s = cand_end(pred, k);
-        list = cand_add(list, s, sub_probe<Vote>(in, lut, lenof, nominal + s, boundary, data_limit) - boundary);
+    for (uint32_t x = 0; x < kPhases; x++) {
+        const uint32_t s = pm_at(pred, x);
+        if (s == kPhaseUnknown || pm_at(map, s) != kPhaseUnknown) continue;
+        pm_set(map, s, sub_probe<Vote>(in, lut, lenof, nominal + s, boundary, data_limit) - boundary);
         grew = true;
     }
     return grew;
 }
-// A thread's first list: its own decode's pair is there; added are the phases in which decoders started at the bits lead_start + 1
-// ... lead_start + 17 cross the nominal bit (the true token sequence has a boundary among 18 consecutive bits, so the true start
-// is one of the arrivals -- if the list has room for it: a periodic stream has few phases, and a stream that is not periodic has
-// one).
+// A thread's first map: its own decode's pair is there; added are the phases in which decoders started at the bits lead_start + 1
+// ... lead_start + 17 cross the nominal bit.
 template <class Vote, class Bits>
-FPNG_DEC_HD void cand_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, CandList &list)
+FPNG_DEC_HD void pm_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, PhaseMap &map)
 {
-    for (uint32_t j = 1; j < 18; j++) {
+    for (uint32_t j = 1; j < kPhases; j++) {
         SubCount d = {0, 0, 0, 0};
         const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d);
-        uint32_t e;
-        if (d.flags || p < nominal || cand_find(list, p - nominal, e) || cand_count(list) >= kCandMax) continue;
-        list = cand_add(list, p - nominal, sub_probe<Vote>(in, lut, lenof, p, boundary, data_limit) - boundary);
+        if (d.flags || p < nominal || pm_at(map, p - nominal) != kPhaseUnknown) continue;
+        pm_set(map, p - nominal, sub_probe<Vote>(in, lut, lenof, p, boundary, data_limit) - boundary);
     }
 }
 

@@ -89,7 +89,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub);
         struct Rec {
             uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel, want_rel;
-            CandList bmap;
+            PhaseMap bmap;
         };
         std::vector<Rec> recs(nb);
         uint32_t max_inner = 0, fixed_subs = 0;
@@ -102,9 +102,9 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             if (round) {
                 // (the file's first subsequence starts at the stream's first token: no border in front of the first block)
                 const uint32_t prev = !local0 ? recs[blk].entry_rel : (recs[blk].want_rel != kUnknown ? recs[blk].want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
-                if (recs[blk].entry_rel == prev && cand_count(recs[blk].bmap)) return false;
+                if (recs[blk].entry_rel == prev && pm_count(recs[blk].bmap)) return false;
                 want0 = prev;
-                cand_first = cand_count(recs[blk].bmap) != 1; // left unsettled by round 0, or it needed its candidate lists before: straight to them
+                cand_first = pm_count(recs[blk].bmap) != 1; // left unsettled by round 0, or it needed its phase maps before: straight to them
             }
             const uint32_t lead0 = local0 ? lead_in : 0u;
             const uint64_t first_nominal = first_bit + (uint64_t)local0 * kSubBits, d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
@@ -130,7 +130,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             }
             want0 += nominal_of(0);
             uint32_t inner = 0;
-            CandList bmap = 0;
+            PhaseMap bmap = pm_none();
             bool cand_done = false, crawls = false;
             for (uint32_t it = 0;; it++) {
                 std::vector<uint32_t> want(nthreads);
@@ -156,29 +156,29 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                         }
                     continue;
                 }
-                // ---- candidate lists (decode_core.h) ----
+                // ---- phase maps (decode_core.h) ----
                 cand_done = true;
-                std::vector<CandList> list(nthreads), pub(nthreads);
-                for (uint32_t t = 0; t < nthreads; t++) list[t] = cand_one(st[t].start - nominal_of(t), st[t].end - (nominal_of(t) + kSubBits));
-                // every phase a decoder can arrive in at a thread's nominal bit: lead-ins from 18 consecutive bits (cand_seed)
+                std::vector<PhaseMap> map(nthreads), pub(nthreads);
+                for (uint32_t t = 0; t < nthreads; t++) map[t] = pm_one(st[t].start - nominal_of(t), st[t].end - (nominal_of(t) + kSubBits));
+                // every phase a decoder can arrive in at a thread's nominal bit: lead-ins from 18 consecutive bits (pm_seed)
                 for (uint32_t t = 0; t < nthreads; t++)
-                    if (local0 + t && lead_in >= 18) cand_seed<VoteAlone>(in, lut.data(), lenof, nominal_of(t) - lead_in, nominal_of(t), nominal_of(t) + kSubBits, data_limit, list[t]);
-                for (;;) {
-                    pub = list;
+                    if (local0 + t && lead_in >= 18) pm_seed<VoteAlone>(in, lut.data(), lenof, nominal_of(t) - lead_in, nominal_of(t), nominal_of(t) + kSubBits, data_limit, map[t]);
+                for (uint32_t step = 0; step < kCandGrowSteps; step++) {
+                    pub = map;
                     bool grew = false;
                     for (uint32_t t = 1; t < nthreads; t++)
-                        grew |= cand_grow<VoteAlone>(in, lut.data(), lenof, pub[t - 1], nominal_of(t), nominal_of(t) + kSubBits, data_limit, list[t]);
+                        grew |= pm_grow<VoteAlone>(in, lut.data(), lenof, pub[t - 1], nominal_of(t), nominal_of(t) + kSubBits, data_limit, map[t]);
                     inner++;
                     if (!grew) break;
                 }
-                // prefix composition (Hillis-Steele in the kernel): g[t] = what the subsequences 0..t do to thread 0's starts
-                std::vector<CandList> g = list;
-                for (uint32_t t = 1; t < nthreads; t++) g[t] = cand_compose(g[t - 1], list[t]);
-                bmap = nthreads == sub_block ? g[nthreads - 1] : (CandList)0;
+                // prefix composition (shuffles and wave totals in the kernel): g[t] = what the subsequences 0..t do to the phases thread 0 knows
+                std::vector<PhaseMap> g = map;
+                for (uint32_t t = 1; t < nthreads; t++) g[t] = pm_compose(g[t - 1], map[t]);
+                bmap = nthreads == sub_block ? g[nthreads - 1] : pm_none();
                 const uint32_t start0 = st[0].start - nominal_of(0);
                 for (uint32_t t = 1; t < nthreads; t++) {
-                    uint32_t srel;
-                    if (!cand_find(g[t - 1], start0, srel)) continue;
+                    const uint32_t srel = pm_at(g[t - 1], start0);
+                    if (srel == kPhaseUnknown) continue;
                     const uint32_t ws = nominal_of(t) + srel;
                     if (ws == st[t].start) continue;
                     sub_refix<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t]);
@@ -199,14 +199,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     any_dirty = true;
                 }
             if (!any_dirty) return false;
-            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, 0};
+            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, pm_none()};
             for (uint32_t t = 0; t < nthreads; t++) {
                 r.sum += st[t].c.bytes;
                 if ((st[t].c.flags & kSubEob) && r.first_eob == sub_block) r.first_eob = t;
                 if ((st[t].c.flags & kSubInvalid) && r.first_invalid == sub_block) r.first_invalid = t;
             }
             r.exit_rel = nthreads == sub_block ? s_end[sub_block - 1] - (nominal_of(0) + sub_block * kSubBits) : 0u;
-            r.bmap = (cand_count(bmap) || crawls) ? bmap : cand_one(r.entry_rel, r.exit_rel);
+            r.bmap = (pm_count(bmap) || crawls) ? bmap : pm_one(r.entry_rel, r.exit_rel);
             recs[blk] = r;
             return round != 0;
         };
@@ -221,8 +221,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             uint32_t cur = recs[0].entry_rel;
             for (uint32_t b = 0; b < nb; b++) {
                 recs[b].want_rel = cur;
-                uint32_t e;
-                cur = cand_find(recs[b].bmap, cur, e) ? e : recs[b].exit_rel;
+                const uint32_t e = pm_at(recs[b].bmap, cur);
+                cur = e != kPhaseUnknown ? e : recs[b].exit_rel;
             }
         };
         uint32_t border_rounds = 0;
@@ -247,7 +247,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         std::vector<uint64_t> block_off(nb, 0);
         uint64_t acc = 0;
         for (uint32_t b = 0; b < nb && b <= last_blk; b++) {
-            if ((b && recs[b].entry_rel != recs[b - 1].exit_rel) || !cand_count(recs[b].bmap)) status |= 1; // not converged
+            if ((b && recs[b].entry_rel != recs[b - 1].exit_rel) || !pm_count(recs[b].bmap)) status |= 1; // not converged
             block_off[b] = acc;
             if (b < last_blk) {
                 acc += recs[b].sum;

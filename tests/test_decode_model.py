@@ -283,3 +283,34 @@ def test_plan_reports_container_and_stream_problems():
     big[16:24] = struct.pack(">II", 30000, 30000)
     big[29:33] = struct.pack(">I", zlib.crc32(bytes(big[12:29])))
     assert plan(bytes(big))[0].status == 1  # FPNG_DECODE_NOT_FPNG
+
+
+def test_periodic_streams_with_many_phases():
+    """Random periodic images -- periods 1..39, tiles, a few noisy pixels that break the period: some of their streams keep seven
+    and more decoder phases alive (a first version of the phase maps held six pairs and walked through those).  Pixels exact,
+    a handful of steps."""
+    rng = np.random.default_rng(99)
+    worst = 0
+    for trial in range(48):
+        period, c, w, h = int(rng.integers(1, 40)), int(rng.choice([3, 4])), int(rng.integers(600, 4200)), int(rng.integers(40, 200))
+        mode = int(rng.integers(0, 4))
+        pal = rng.integers(0, 256, (period, c), dtype=np.uint8)
+        if mode == 1:
+            pal &= 0xF0
+        img = (pal[np.arange(w) % period][None] + (np.arange(h)[:, None, None] * int(rng.integers(0, 9))).astype(np.uint8)).astype(np.uint8)
+        if mode == 2:
+            img = img[(np.arange(h) // 8 * 8) % h]
+        if mode == 3:
+            img.reshape(-1, c)[rng.integers(0, w * h, 20)] = rng.integers(0, 256, (20, c), dtype=np.uint8)
+        img = np.ascontiguousarray(img).reshape(-1)
+        for flags in (0, 1):
+            png = oracle().encode(img, w, h, c, flags)
+            for cfg in (CONFIGS[0], (64, 128, 1024)):
+                st, px, *_, stats = emul_decode(png, c, cfg)
+                assert st == 0 and np.array_equal(px, img), (trial, period, c, w, h, mode, flags, cfg)
+                assert stats[0] <= 12 and stats[1] <= 3, (trial, period, c, w, h, mode, flags, cfg, stats)
+                worst = max(worst, stats[0])
+    assert worst > kRefixRounds  # (the maps were needed somewhere)
+
+
+kRefixRounds = 3

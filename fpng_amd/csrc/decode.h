@@ -53,7 +53,7 @@ struct DecBlockRec {
     uint32_t want_rel;      // dec_chain_kernel: where its first subsequence must start (kDecWantUnknown: ask the workgroup in front)
     uint32_t map[3];        // dec::PhaseMap: what the workgroup does to the phases it can be entered in (entry -> exit: one pair unless the
                             // stream is periodic, decode_core.h; no pair at all: round 0 left the workgroup unsettled)
-    uint32_t pad_;
+    uint32_t left;          // ... and why (decode.hip: many threads to correct / corrections that do not end)
 };
 constexpr uint32_t kDecWantUnknown = 0xFFFFFFFFu;
 

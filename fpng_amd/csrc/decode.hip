@@ -8,8 +8,8 @@
 //   dec_sync_kernel     round 0, one workgroup per kDecSubBlock subsequences, their bits and the lookup table staged in LDS: every
 //                       thread starts kDecLeadIn bits EARLY, takes the first token boundary at or behind its nominal first bit as
 //                       its start and counts its tokens' output bytes; then, still inside the workgroup, every thread whose
-//                       predecessor ended elsewhere than it started is corrected (both decodes stepped until they meet:
-//                       sub_refix) until nothing changes.  Rounds 1..: the same across workgroup borders -- a workgroup whose first
+//                       predecessor ended elsewhere than it started is decoded again (those few gathered into one wave)
+//                       until nothing changes.  Rounds 1..: the same across workgroup borders -- a workgroup whose first
 //                       thread starts where the previous workgroup's last one ended leaves at once.  The lookup table decodes up
 //                       to three literals per lookup and a 32-bit window serves two lookups.
 //   dec_offsets_kernel  per file: the first end-of-block symbol of the chain ends the stream; up to there the chain must hold and
@@ -180,6 +180,8 @@ __device__ __forceinline__ PhaseMap rec_map(const DecBlockRec &r)
 }
 
 // ---- synchronisation ----
+constexpr uint32_t kGatherMin = 4; // threads of a workgroup to correct from which on they are gathered into one wave (dec_sync_kernel<true>)
+enum : uint32_t { kLeftMany = 1, kLeftCrawling = 2 }; // DecBlockRec::left: why round 0 left the workgroup unsettled
 constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 + 1 + 3;
 
 // CAND = false: round 0, the kernel nearly every subsequence of nearly every file is settled by -- kept lean: a workgroup whose
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             const uint32_t prev = !local0 ? mine.entry_rel : (mine.want_rel != kDecWantUnknown ? mine.want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
             if (mine.entry_rel == prev && pairs) continue;
             want0 = prev;
-            cand_first = pairs != 1; // left unsettled by round 0, or it needed its phase maps before: straight to them
+            cand_first = pairs > 1 || (!pairs && mine.left == kLeftCrawling); // its corrections did not end in round 0, or it needed its phase maps before: straight to them
         }
         const uint32_t lead0 = local0 ? kDecLeadIn : 0u;
         const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         }
         want0 += nominal; // (thread 0's nominal: the block's first)
         s_end[t] = st.end;
-        bool cand_done = false, crawls = false;
+        bool cand_done = false;
+        uint32_t unsettled = 0;
         PhaseMap bmap = pm_none();
         for (uint32_t it = 0;; it++) {
             __syncthreads();
@@ -254,18 +257,63 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             else if (round)
                 want = want0;
             const bool need = valid && want != st.start;
-            if (!__syncthreads_or(need)) break;
-            if (!CAND && it >= kRefixRounds) { // (round 0: left to round 1)
-                crawls = true;
+            const uint32_t n_need = (uint32_t)__syncthreads_count(need);
+            if (!n_need) break;
+            // round 0: a workgroup whose corrections do not end is left as it is, marked, and taken up by round 1, whose kernel knows the phase maps
+            if (!CAND && it >= kRefixRounds) {
+                unsettled = kLeftCrawling;
                 break;
             }
             const bool cand_now = CAND && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
             if (!cand_now) {
-                if (need) {
-                    sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
-                    s_end[t] = st.end;
-                    dirty = true;
+                // The threads that must be corrected: 0.04 % of a gradient's subsequences (one in every fifth workgroup: corrected where
+                // it is, both decodes stepped until they meet -- a few tokens), 2 % of a photograph's, more on flat content -- some lane
+                // of nearly every wave then, and eight waves each wait for a lane or two.  From kGatherMin of them on they are GATHERED:
+                // their slots are numbered over the workgroup, wave 0 decodes 64 of them per pass, the owners take the results back.
+                // (Measured, 8 x 8K grad / 8 x 11 MP photograph / 8 x 8K stripes, sync ms: in place 0.80 / 0.81 / 0.25; all gathered
+                //  and decoded again 1.01 / 0.65 / 0.13; all gathered and stepped until they meet 1.02 / 1.06 / 0.40.)
+                if (n_need < kGatherMin) {
+                    if (need) {
+                        sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
+                        s_end[t] = st.end;
+                        dirty = true;
+                    }
+                    continue;
                 }
+                // (the exchange lives in s_end -- every thread holds its own end in a register and writes it back afterwards: a kilobyte
+                //  more LDS would cost round 0's kernel its third workgroup per compute unit)
+                uint32_t(*redo)[4] = (uint32_t(*)[4])s_end;
+                uint32_t *redo_cnt = s_end + 4 * kWave;
+                const uint64_t nm = __ballot(need);
+                const uint32_t lane = t & 63, wv = t >> 6;
+                if (lane == 0) redo_cnt[wv] = (uint32_t)__popcll(nm);
+                __syncthreads();
+                uint32_t slot = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+                const uint32_t total = n_need;
+#pragma unroll
+                for (int q = 0; q < kSubBlock / kWave; q++) slot += (uint32_t)q < wv ? redo_cnt[q] : 0u;
+                for (uint32_t base_slot = 0; base_slot < total; base_slot += kWave) { // (uniform)
+                    const bool mine = need && slot >= base_slot && slot < base_slot + kWave;
+                    if (mine) redo[slot - base_slot][0] = t << 5 | (want - nominal);
+                    __syncthreads();
+                    if (t < min(total - base_slot, (uint32_t)kWave)) {
+                        uint32_t *q = redo[t];
+                        const uint32_t v = q[0], ot = v >> 5, o_nominal = nominal - t * kSubBits + ot * kSubBits; // (this thread's nominal -> the owner's)
+                        SubState r;
+                        sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r);
+                        q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c), q[2] = r.c.bytes, q[3] = r.c.tail;
+                    }
+                    __syncthreads();
+                    if (mine) {
+                        const uint32_t *q = redo[slot - base_slot];
+                        const uint32_t v = q[1];
+                        st.start = want, st.end = boundary + info_end(v);
+                        st.c.bytes = q[2], st.c.lits = info_lits(v), st.c.tail = q[3], st.c.flags = info_flags(v);
+                        dirty = true;
+                    }
+                }
+                __syncthreads();
+                s_end[t] = st.end;
                 continue;
             }
             // ---- the corrections crawl (a periodic stream): phase maps, decode_core.h ----
@@ -285,7 +333,7 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
                 const uint32_t start0 = wtail[kSubBlock / kWave].w[0];
                 const uint32_t srel = (valid && t) ? pm_at(gp, start0) : kPhaseUnknown;
                 if (srel != kPhaseUnknown && nominal + srel != st.start) {
-                    sub_refix<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st);
+                    sub_redo<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st);
                     dirty = true;
                 }
                 __syncthreads();
@@ -321,8 +369,8 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             r.entry_rel = st.start - nominal;
             r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a block with fewer subsequences is its file's last)
             const uint32_t known = pm_count(bmap);
-            if (!known && !crawls) bmap = pm_one(r.entry_rel, r.exit_rel & 31u);
-            r.map[0] = bmap.w[0], r.map[1] = bmap.w[1], r.map[2] = bmap.w[2], r.want_rel = kDecWantUnknown, r.pad_ = 0;
+            if (!known && !unsettled) bmap = pm_one(r.entry_rel, r.exit_rel & 31u);
+            r.map[0] = bmap.w[0], r.map[1] = bmap.w[1], r.map[2] = bmap.w[2], r.want_rel = kDecWantUnknown, r.left = unsettled;
             recs[blk] = r;
             if (round) atomicOr(changed, 1u);
             if (CAND && known > 1) atomicOr(multi, 1u); // (dec_chain_kernel has something to do from now on)

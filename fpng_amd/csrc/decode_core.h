@@ -199,6 +199,16 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
     s.end = s.c.flags ? boundary : e;
 }
 
+// ... decoded again as a whole (where the phase maps hand a thread its true start: nearly every thread of the workgroup changes then)
+template <class Vote, class Bits>
+FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s)
+{
+    s.start = want;
+    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
+    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c);
+    s.end = s.c.flags ? boundary : e;
+}
+
 // ---- phase maps: the way out of a PERIODIC stream ----
 // A stream that repeats itself (flat or striped content: every row the same few tokens) keeps wrongly started decoders in a stable
 // false phase -- they never fall into step -- and the corrections above then crawl through a workgroup one subsequence per step.
@@ -213,7 +223,10 @@ FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *l
 // (dec_chain_kernel).  A map is three dwords: phase x in bits 5 (x % 6) .. of word x / 6.  A decode that derails or meets an
 // end-of-block symbol "ends" on its nominal boundary (phase 0), as in SubState.
 constexpr uint32_t kPhases = 18, kPhaseUnknown = 31;
-constexpr uint32_t kRefixRounds = 3;    // correction steps inside a workgroup before the phase maps take over
+#ifndef FPNG_DEC_REFIX_ROUNDS
+#define FPNG_DEC_REFIX_ROUNDS 3
+#endif
+constexpr uint32_t kRefixRounds = FPNG_DEC_REFIX_ROUNDS; // correction steps inside a workgroup before the phase maps take over
 constexpr uint32_t kCandGrowSteps = 12; // steps in which the maps take over their neighbours' ends (a bound, not a need: the seeds usually hold every phase)
 struct PhaseMap {
     uint32_t w[3];

@@ -90,6 +90,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         struct Rec {
             uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel, want_rel;
             PhaseMap bmap;
+            uint32_t left;
         };
         std::vector<Rec> recs(nb);
         uint32_t max_inner = 0, fixed_subs = 0;
@@ -104,7 +105,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 const uint32_t prev = !local0 ? recs[blk].entry_rel : (recs[blk].want_rel != kUnknown ? recs[blk].want_rel : recs[blk - 1].exit_rel); // (dec_chain_kernel's word, else the neighbour's)
                 if (recs[blk].entry_rel == prev && pm_count(recs[blk].bmap)) return false;
                 want0 = prev;
-                cand_first = pm_count(recs[blk].bmap) != 1; // left unsettled by round 0, or it needed its phase maps before: straight to them
+                cand_first = pm_count(recs[blk].bmap) > 1 || (!pm_count(recs[blk].bmap) && recs[blk].left == 2); // its corrections did not end in round 0, or it needed its phase maps before
             }
             const uint32_t lead0 = local0 ? lead_in : 0u;
             const uint64_t first_nominal = first_bit + (uint64_t)local0 * kSubBits, d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
@@ -131,7 +132,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             want0 += nominal_of(0);
             uint32_t inner = 0;
             PhaseMap bmap = pm_none();
-            bool cand_done = false, crawls = false;
+            bool cand_done = false;
+            uint32_t unsettled = 0; // 1: many threads to correct, 2: corrections that do not end (decode.hip: kLeftMany, kLeftCrawling)
             for (uint32_t it = 0;; it++) {
                 std::vector<uint32_t> want(nthreads);
                 bool any = false;
@@ -141,15 +143,21 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 }
                 if (!any) break;
                 inner++;
+                uint32_t n_need = 0;
+                for (uint32_t t = 0; t < nthreads; t++) n_need += want[t] != st[t].start;
                 if (!round && it >= kRefixRounds) { // round 0's kernel is kept lean: the block is left to round 1
-                    crawls = true;
+                    unsettled = 2;
                     break;
                 }
                 const bool cand_now = round && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
                 if (!cand_now) {
+                    // (the kernel gathers them into one wave and decodes them again from four on, else corrects them in place)
                     for (uint32_t t = 0; t < nthreads; t++)
                         if (want[t] != st[t].start) {
-                            sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                            if (n_need >= 4)
+                                sub_redo<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                            else
+                                sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
                             s_end[t] = st[t].end;
                             dirty[t] = true;
                             if (!ever[t]) ever[t] = true, fixed_subs++;
@@ -181,7 +189,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     if (srel == kPhaseUnknown) continue;
                     const uint32_t ws = nominal_of(t) + srel;
                     if (ws == st[t].start) continue;
-                    sub_refix<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t]);
+                    sub_redo<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t]);
                     dirty[t] = true;
                     if (!ever[t]) ever[t] = true, fixed_subs++;
                 }
@@ -199,14 +207,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     any_dirty = true;
                 }
             if (!any_dirty) return false;
-            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, pm_none()};
+            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, pm_none(), unsettled};
             for (uint32_t t = 0; t < nthreads; t++) {
                 r.sum += st[t].c.bytes;
                 if ((st[t].c.flags & kSubEob) && r.first_eob == sub_block) r.first_eob = t;
                 if ((st[t].c.flags & kSubInvalid) && r.first_invalid == sub_block) r.first_invalid = t;
             }
             r.exit_rel = nthreads == sub_block ? s_end[sub_block - 1] - (nominal_of(0) + sub_block * kSubBits) : 0u;
-            r.bmap = (pm_count(bmap) || crawls) ? bmap : pm_one(r.entry_rel, r.exit_rel);
+            r.bmap = (pm_count(bmap) || unsettled) ? bmap : pm_one(r.entry_rel, r.exit_rel);
             recs[blk] = r;
             return round != 0;
         };

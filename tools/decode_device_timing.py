@@ -15,6 +15,9 @@ cases = [("8K RGBA grad x 8", "grad", 7680, 4320, 4, 8), ("4K RGBA grad x 16", "
 _pal = np.random.default_rng(3).integers(0, 256, (5, 4), dtype=np.uint8)
 _stripes = np.ascontiguousarray((_pal[np.arange(7680) % 5][None] + (np.arange(4320)[:, None, None] * 7).astype(np.uint8)).astype(np.uint8))
 cases.append(("8K RGBA stripes x 8", _stripes, 7680, 4320, 4, 8))
+import dropin, real_image
+_photo = real_image.variants(real_image.rgb_pixels(dropin.decode))["rgb_t4"]  # the reference's photograph, tiled 4 x 4: 2748 x 4048 RGB
+cases.append(("photo 11 MP RGB x 8", _photo, _photo.shape[1], _photo.shape[0], 3, 8))
 import ui_images
 for uname, (uimg, uw, uh, uc) in sorted(ui_images.all_images().items()):
     if uw == 3840:

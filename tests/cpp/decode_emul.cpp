@@ -225,17 +225,49 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         }
         // ---- dec_chain_kernel: every block's true entry as far as the blocks' maps tell it (a block whose map does not know the phase
         //      it is entered in hands on its present exit: the neighbour's word, as before) ----
+        auto block_fn = [&](uint32_t b, uint32_t x) {
+            const uint32_t e = pm_at(recs[b].bmap, x);
+            return e != kPhaseUnknown ? e : (recs[b].exit_rel & 31u);
+        };
         auto chain = [&]() {
             uint32_t cur = recs[0].entry_rel;
             for (uint32_t b = 0; b < nb; b++) {
                 recs[b].want_rel = cur;
-                const uint32_t e = pm_at(recs[b].bmap, cur);
-                cur = e != kPhaseUnknown ? e : recs[b].exit_rel;
+                cur = block_fn(b, cur);
+            }
+            // the kernel's PARALLEL form of the same walk (chunks of blocks per thread, the chunks' functions composed by a
+            // Hillis-Steele scan over kThreads threads) must ask for the same entries
+            const uint32_t kThreads = 256, per = (nb + kThreads - 1) / kThreads;
+            std::vector<PhaseMap> f(kThreads), g(kThreads);
+            for (uint32_t t = 0; t < kThreads; t++) {
+                f[t] = pm_none();
+                for (uint32_t x = 0; x < kPhases; x++) pm_set(f[t], x, x);
+                for (uint32_t b = std::min(t * per, nb); b < std::min(t * per + per, nb); b++) {
+                    PhaseMap n2 = f[t];
+                    for (uint32_t x = 0; x < kPhases; x++) pm_set(n2, x, block_fn(b, pm_at(f[t], x)));
+                    f[t] = n2;
+                }
+            }
+            for (uint32_t d = 1; d < kThreads; d <<= 1) {
+                g = f;
+                for (uint32_t t = d; t < kThreads; t++) f[t] = pm_compose(g[t - d], g[t]);
+            }
+            for (uint32_t t = 0; t < kThreads; t++) {
+                uint32_t ph = recs[0].entry_rel;
+                if (t) ph = pm_at(f[t - 1], ph);
+                for (uint32_t b = std::min(t * per, nb); b < std::min(t * per + per, nb); b++) {
+                    if (recs[b].want_rel != ph) throw 2;
+                    ph = block_fn(b, ph);
+                }
             }
         };
         uint32_t border_rounds = 0;
         for (uint32_t r = 1; r <= max_border_rounds; r++) {
-            if (r >= 2) chain(); // (the blocks' maps have more than one pair only behind round 1)
+            try {
+                if (r >= 2) chain(); // (the blocks' maps have more than one pair only behind round 1)
+            } catch (int) {
+                return -1006; // the parallel form of the chain disagrees with the walk
+            }
             // (the workgroups of one launch run at the same time; last to first, each one sees its predecessor's record of the
             //  launch before -- the least favourable of the schedules the kernel allows)
             bool changed = false;
@@ -326,3 +358,48 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
     }
     return 0;
 }
+
+// the phase map helpers of decode_core.h (tests/test_decode_model.py): set / at round trips, composition against its definition and
+// its associativity, on `n` random maps drawn from `seed`; 0 = all held
+extern "C" int fpng_emul_phase_map_selftest(uint32_t seed, uint32_t n)
+{
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() {
+        st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+        return (uint32_t)(st >> 32);
+    };
+    auto random_map = [&]() {
+        PhaseMap m = pm_none();
+        for (uint32_t x = 0; x < kPhases; x++)
+            if (rnd() % 3) pm_set(m, x, rnd() % kPhases);
+        return m;
+    };
+    for (uint32_t k = 0; k < n; k++) {
+        uint8_t ref[kPhases];
+        PhaseMap m = pm_none();
+        if (pm_count(m)) return 1;
+        uint32_t known = 0;
+        for (uint32_t x = 0; x < kPhases; x++) ref[x] = kPhaseUnknown;
+        for (uint32_t j = 0; j < 40; j++) {
+            const uint32_t x = rnd() % kPhases, v = rnd() % 4 ? rnd() % kPhases : kPhaseUnknown;
+            pm_set(m, x, v), ref[x] = (uint8_t)v;
+        }
+        for (uint32_t x = 0; x < kPhases; x++) {
+            if (pm_at(m, x) != ref[x]) return 2;
+            known += ref[x] != kPhaseUnknown;
+        }
+        if (pm_count(m) != known) return 3;
+        const PhaseMap a = random_map(), b = random_map(), c = random_map();
+        const PhaseMap ab = pm_compose(a, b), bc = pm_compose(b, c), l = pm_compose(ab, c), r = pm_compose(a, bc);
+        for (uint32_t x = 0; x < kPhases; x++) {
+            const uint32_t ax = pm_at(a, x), want = ax == kPhaseUnknown ? kPhaseUnknown : pm_at(b, ax);
+            if (pm_at(ab, x) != want) return 4;
+            if (pm_at(l, x) != pm_at(r, x)) return 5;
+        }
+        const uint32_t s0 = rnd() % kPhases, e0 = rnd() % kPhases;
+        const PhaseMap one = pm_one(s0, e0);
+        if (pm_count(one) != 1 || pm_at(one, s0) != e0) return 6;
+    }
+    return 0;
+}
+

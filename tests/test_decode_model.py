@@ -167,6 +167,15 @@ def test_periodic_streams_do_not_crawl():
     assert crawled >= 5, worst
 
 
+def test_phase_map_helpers():
+    """decode_core.h's phase maps (18 phases -> phase, three dwords): set / at round trips, composition against its definition,
+    associativity (what the prefix "sums" of dec_sync_kernel and dec_chain_kernel rest on) -- 20 000 random maps."""
+    L = emul()
+    L.fpng_emul_phase_map_selftest.restype = C.c_int
+    L.fpng_emul_phase_map_selftest.argtypes = [C.c_uint32, C.c_uint32]
+    assert L.fpng_emul_phase_map_selftest(7, 20000) == 0
+
+
 def test_too_few_border_rounds_leave_the_file_undecided():
     import fpng_amd
     img = fpng_amd.synth_image("grad", 640, 40, 4)

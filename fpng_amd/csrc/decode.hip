@@ -5,13 +5,17 @@
 // An fpng stream is ONE Huffman-coded bit string with no restart points, but Huffman decoders SELF-SYNCHRONISE: started at a
 // wrong bit, a decoder falls into step with the true token sequence after a few dozen bits.  So the token bits are cut into
 // subsequences of kSubBits bits, one thread each (the per-thread logic lives in decode_core.h, which also compiles for the host):
-//   dec_sync_kernel     round 0, one workgroup per kDecSubBlock subsequences, their bits and the lookup table staged in LDS: every
-//                       thread starts kDecLeadIn bits EARLY, takes the first token boundary at or behind its nominal first bit as
-//                       its start and counts its tokens' output bytes; then, still inside the workgroup, every thread whose
-//                       predecessor ended elsewhere than it started is decoded again (those few gathered into one wave)
-//                       until nothing changes.  Rounds 1..: the same across workgroup borders -- a workgroup whose first
-//                       thread starts where the previous workgroup's last one ended leaves at once.  The lookup table decodes up
-//                       to three literals per lookup and a 32-bit window serves two lookups.
+//   dec_build_lut_kernel the lookup table of every distinct set of code lengths (decode_core.h: up to three literals per lookup)
+//   dec_sync_kernel     round 0 (<false>), one workgroup per kDecSubBlock subsequences, their bits and the lookup table staged in
+//                       LDS: every thread starts kDecLeadIn bits EARLY, takes the first token boundary at or behind its nominal
+//                       first bit as its start and counts its tokens' output bytes; then, still inside the workgroup, every thread
+//                       whose predecessor ended elsewhere than it started is corrected -- a few where they are, from four on
+//                       gathered into one wave and decoded again -- until nothing changes, three steps at most: a workgroup that
+//                       still changes then (a periodic stream) is marked and left to round 1.  Rounds 1.. (<true>, persistent
+//                       workgroups): the same across workgroup borders -- a workgroup whose first thread starts where the previous
+//                       workgroup's last one ended is passed over -- plus the PHASE MAPS that settle periodic streams.
+//   dec_chain_kernel    in front of rounds 2..: the workgroups' phase maps composed along every file -> the entry each workgroup
+//                       must take (leaves at once unless some map has more than one pair)
 //   dec_offsets_kernel  per file: the first end-of-block symbol of the chain ends the stream; up to there the chain must hold and
 //                       no subsequence may be invalid; exclusive scan of the workgroups' byte counts; the total must be the image
 //   dec_subscan_kernel  per workgroup of subsequences: output offset of every subsequence and the four literal bytes in front of

@@ -138,3 +138,20 @@ def test_the_reference_example_and_damaged_files(loader):
     interlaced = bytearray(_png(4, 4, 2, 8, [bytes(12)] * 4))
     interlaced[28] = 1
     assert loader(bytes(interlaced))[0] is None
+
+
+def test_corpus_files_of_screenshot_like_content(loader, tmp_path):
+    """The corpus workflow's ordinary PNGs of screenshot-like content (tools/make_corpus.py writes them from tests/ui_images.py:
+    Up-filtered rows, two IDAT chunks) come back through the harness's loader as the generators' pixels."""
+    import importlib.util
+    import ui_images
+    spec = importlib.util.spec_from_file_location("make_corpus", os.path.join(ROOT, "tools", "make_corpus.py"))
+    mc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mc)
+    for arr, ctype in ((ui_images.glyphs(1920, 1080, 3), 2), (ui_images.matte(1920, 1080), 6), (ui_images.dither(640, 360, 4), 6)):
+        path = str(tmp_path / "ui.png")
+        mc.write_png(path, arr, ctype)
+        got, err = loader(open(path, "rb").read())
+        assert got is not None, err
+        c = arr.shape[2]
+        assert np.array_equal(got[:, :, :c], arr) and (c == 4 or (got[:, :, 3] == 255).all())

@@ -52,6 +52,11 @@ def main(out_dir):
     pal = np.array([[(i >> 4) * 85, ((i >> 2) & 3) * 85, (i & 3) * 85] for i in range(64)], dtype=np.uint8)
     write_png(os.path.join(out_dir, "photo_palette64.png"), idx[:, :, None], 3, extra=chunk(b"PLTE", pal.tobytes()))
     write_png(os.path.join(out_dir, "photo_tiled_2x2.png"), np.tile(rgb, (2, 2, 1)), 2)
+    # screenshot-like content (tests/ui_images.py: glyph rows, panels with anti-aliased edges, ordered dither, alpha mattes) at
+    # 1080p RGB and 4K RGBA -- what the reference's README corpus has and a photograph does not: long exact runs, few colours
+    import ui_images
+    for name, (arr, uw, uh, uc) in sorted(ui_images.all_images().items()):
+        write_png(os.path.join(out_dir, f"ui_{name}.png"), arr, 2 if uc == 3 else 6)
     with open(os.path.join(out_dir, "fpng_written.png"), "wb") as f:  # a file fpng itself wrote
         f.write(real_image.fixture_bytes())
     print(sorted(os.listdir(out_dir)))

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""A long differential campaign of the GPU decoder's LOGIC on the CPU (no GPU needed): tests/cpp/decode_emul.cpp runs the kernels' own
+per-thread code (fpng_amd/csrc/decode_core.h) thread by thread; the judge is the reference's decoder (oracle/_ref), status AND pixels.
+
+    python tools/emul_campaign.py <seconds> [seed]           # one process; run several with different seeds
+
+Content: the fuzz generator's images, crops of the screenshot-like generators, periodic stripes / tiles, crops of the photograph,
+flat images; 1-pass and 2-pass files; random workgroup size / lead-in / tile parameters (small ones put many borders and seams into
+small images).  Every valid file must decode to its pixels; then damaged copies (bit flips stratified over the stream, truncations,
+header edits, token-bit flips, spliced streams) must get the reference's status and, where it decodes them, its pixels."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_decode_model as M  # noqa: E402
+import ui_images  # noqa: E402
+from cpu_ref import fuzz_image, oracle, ref  # noqa: E402
+
+
+def content(rng, photo):
+    k = int(rng.integers(0, 7))
+    if k == 0:
+        return fuzz_image(rng)
+    if k == 1:
+        return fuzz_image(rng, force_dims=(int(rng.integers(100, 900)), int(rng.integers(2, 24))))
+    if k == 2:  # a crop of a screenshot-like image
+        c = int(rng.choice([3, 4]))
+        gen = [ui_images.glyphs, ui_images.panels, ui_images.dither][int(rng.integers(0, 3))]
+        w, h = int(rng.integers(64, 700)), int(rng.integers(16, 90))
+        a = gen(w, h, c, seed=int(rng.integers(1, 1 << 30)))
+        return np.ascontiguousarray(a).reshape(-1), w, h, c
+    if k == 3:  # periodic stripes / tiles, sometimes sprinkled
+        period, c, w, h = int(rng.integers(1, 40)), int(rng.choice([3, 4])), int(rng.integers(200, 3000)), int(rng.integers(8, 80))
+        pal = rng.integers(0, 256, (period, c), dtype=np.uint8)
+        img = (pal[np.arange(w) % period][None] + (np.arange(h)[:, None, None] * int(rng.integers(0, 9))).astype(np.uint8)).astype(np.uint8)
+        if rng.random() < 0.3:
+            img.reshape(-1, c)[rng.integers(0, w * h, 10)] = rng.integers(0, 256, (10, c), dtype=np.uint8)
+        return np.ascontiguousarray(img).reshape(-1), w, h, c
+    if k == 4 and photo is not None:  # a crop of the photograph
+        H, W, _ = photo.shape
+        w, h = int(rng.integers(32, 500)), int(rng.integers(8, 60))
+        x0, y0 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+        c = int(rng.choice([3, 4]))
+        a = photo[y0:y0 + h, x0:x0 + w]
+        if c == 4:
+            a = np.concatenate([a, np.full((h, w, 1), int(rng.integers(0, 256)), np.uint8)], axis=2)
+        return np.ascontiguousarray(a).reshape(-1), w, h, c
+    if k == 5:  # flat / two-colour: long runs, the wave-filled kind
+        c, w, h = int(rng.choice([3, 4])), int(rng.integers(100, 5000)), int(rng.integers(2, 40))
+        img = np.empty((h, w, c), np.uint8)
+        img[:] = rng.integers(0, 256, c, dtype=np.uint8)
+        if rng.random() < 0.5:
+            x = int(rng.integers(0, w))
+            img[:, x:] = rng.integers(0, 256, c, dtype=np.uint8)
+        return img.reshape(-1), w, h, c
+    import fpng_amd
+    kind = ["grad", "blocks", "noise", "solid"][int(rng.integers(0, 4))]
+    c, w, h = int(rng.choice([3, 4])), int(rng.integers(8, 1200)), int(rng.integers(1, 50))
+    return np.asarray(fpng_amd.synth_image(kind, w, h, c, seed=int(rng.integers(0, 1 << 30)))).reshape(-1), w, h, c
+
+
+def damage(rng, png, other):
+    bad = bytearray(png)
+    kind = int(rng.integers(0, 8))
+    n = len(bad)
+    if kind == 0:
+        i = int(rng.integers(0, n)); bad[i] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        bad = bad[: int(rng.integers(1, n))]
+    elif kind == 2:
+        i = int(rng.integers(58, min(140, n))); bad[i] = int(rng.integers(0, 256))
+    elif kind == 3:
+        i = int(rng.integers(58, n)); bad[i] = int(rng.integers(0, 256))
+    elif kind == 4:
+        i = int(rng.integers(min(125, n - 1), n)); bad[i] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 5:  # several flips spread over the token bits
+        for _ in range(int(rng.integers(2, 6))):
+            i = int(rng.integers(min(125, n - 1), n)); bad[i] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 6:  # a stretch of the stream zeroed / set
+        i = int(rng.integers(58, n)); j = min(n - 16, i + int(rng.integers(1, 40)))
+        for q in range(i, max(i, j)):
+            bad[q] = 0 if rng.random() < 0.5 else 255
+    else:  # the tail of another file's stream spliced in (same container head)
+        if other is not None and len(other) > 200 and n > 200:
+            i = int(rng.integers(130, min(n, len(other)) - 20))
+            bad[i:n - 16] = other[i:i + (n - 16 - i)].ljust(n - 16 - i, b"\0")[: n - 16 - i]
+    return kind, bytes(bad)
+
+
+def main():
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    judge = ref().decode
+    photo = None
+    try:
+        import real_image
+        photo = real_image.rgb_pixels(judge)
+    except Exception:
+        pass
+    t_end = time.time() + secs
+    files = valid = damaged = rejected = undecided = 0
+    by_kind = {}
+    prev_png = None
+    while time.time() < t_end:
+        img, w, h, c = content(rng, photo)
+        flags = int(rng.integers(0, 2))
+        png = oracle().encode(img, w, h, c, flags)
+        files += 1
+        cfgs = [M.CONFIGS[0], M.CONFIGS[int(rng.integers(1, len(M.CONFIGS)))],
+                (int(rng.choice([2, 3, 4, 8, 16, 64, 512])), int(rng.choice([0, 32, 64, 128])), int(rng.choice([4, 52, 64, 100, 1024, 18432])))]
+        for cfg in cfgs:
+            for desired in (3, 4):
+                st, px, ww, hh, cc, stats = M.emul_decode(png, desired, cfg)
+                if st != 0 or not np.array_equal(px, M.expected_pixels(img, w, h, c, desired)):
+                    print(f"MISMATCH valid file: seed {seed} file {files} {w}x{h}x{c} flags {flags} cfg {cfg} desired {desired} status {st}", flush=True)
+                    open(f"/tmp/emul_campaign_fail_{seed}_{files}.png", "wb").write(png)
+                valid += 1
+        for _ in range(12):
+            kind, bad = damage(rng, png, prev_png)
+            cfg = cfgs[int(rng.integers(0, len(cfgs)))]
+            desired = int(rng.choice([3, 4]))
+            st_r, out_r, *_ = judge(bad, desired)
+            st_m, out_m, *_ = M.emul_decode(bad, desired, cfg)
+            damaged += 1
+            rejected += st_r != 0
+            by_kind[kind] = by_kind.get(kind, 0) + 1
+            ok = st_m == st_r and (st_r != 0 or np.array_equal(np.asarray(out_r)[: out_m.size], out_m))
+            if st_m == M.UNDECIDED:
+                undecided += 1
+            if not ok:
+                print(f"MISMATCH damaged file: seed {seed} file {files} {w}x{h}x{c} flags {flags} kind {kind} cfg {cfg} desired {desired} reference {st_r} emulator {st_m}", flush=True)
+                open(f"/tmp/emul_campaign_fail_{seed}_{files}_{damaged}.png", "wb").write(bad)
+        prev_png = png
+    print(f"seed {seed}: {files} files, {valid} decodes of valid files, {damaged} damaged copies ({rejected} rejected by the reference, {undecided} left undecided), by kind {dict(sorted(by_kind.items()))}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -33,10 +33,10 @@ def write_png(path, arr, ctype, extra=b"", depth=8):
 
 
 def main(out_dir):
-    import dropin
     import real_image
     os.makedirs(out_dir, exist_ok=True)
-    rgb = real_image.rgb_pixels(dropin.decode if os.environ.get("FPNG_CORPUS_DROPIN") else __import__("cpu_ref").ref().decode)
+    # (the drop-in's door imports torch -- a minute or two on a fresh box -- so it is only opened when asked for)
+    rgb = real_image.rgb_pixels(__import__("dropin").decode if os.environ.get("FPNG_CORPUS_DROPIN") else __import__("cpu_ref").ref().decode)
     h, w, _ = rgb.shape
     write_png(os.path.join(out_dir, "photo_rgb.png"), rgb, 2)
     write_png(os.path.join(out_dir, "photo_crop_odd.png"), rgb[101:614, 33:550], 2)

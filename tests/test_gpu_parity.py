@@ -544,9 +544,11 @@ def test_command_line_harness_on_ordinary_png_files(tmp_path):
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_corpus.sh"), corpus, csv], capture_output=True, text=True, timeout=900, env=env)
     lines = [ln for ln in open(csv).read().splitlines() if ln and not ln.startswith("#")]
     assert r.returncode == 0 and "corpus rc=0" in r.stdout, (r.stdout[-600:], r.stderr[-600:], lines[-3:])
-    assert len(lines) == 2 * 9 + 2 and not any("FAILED" in ln for ln in lines)
+    n_png = len([f for f in os.listdir(corpus) if f.endswith(".png")])  # (photograph-derived files + the screenshot-like content)
+    assert n_png >= 17 and len(lines) == 2 * n_png + 2 and not any("FAILED" in ln for ln in lines)
     chans = {ln.split(",")[0].split("/")[-1]: int(ln.split(",")[3]) for ln in lines}
     assert chans["photo_rgba.png"] == 4 and chans["photo_grey.png"] == 3 and chans["photo_palette64.png"] == 3
+    assert chans["ui_glyphs_1920x1080x3.png"] == 3 and chans["ui_matte_3840x2160x4.png"] == 4
     assert int(lines[-1].split(",")[3]) == 4 and int(lines[-2].split(",")[3]) == 4   # alpha file / -a: 32 bpp
 
     def run(*args):

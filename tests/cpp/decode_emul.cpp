@@ -340,6 +340,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             err |= fl;
         }
         if (fault) return -1004;
+        if (err & kEmitLeaveToCpu) return FPNG_AMD_DECODE_UNDECIDED; // (decode_api.cpp: kDecStalled goes first -- a match at a row's first pixel is the CPU decoder's)
         if (err & 2) return 1;
         if (!(err & kEmitSawEob)) return 1;
         for (size_t d = 0; d < ndw; d++)

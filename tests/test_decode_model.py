@@ -221,12 +221,33 @@ def test_damaged_files_get_the_cpu_decoders_status():
             for desired in (3, 4):
                 st_r, out_r, *_ = judge(bad, desired)
                 st_m, out_m, *_ = emul_decode(bad, desired, cfg)
+                if st_m == UNDECIDED:  # (left to the CPU decoder, as fpng::fpng_decode_memory does: a match at a row's first pixel)
+                    st_m, out_m, *_ = dropin.decode(bad, desired)
                 checked += 1
                 rejected += st_r != 0
                 assert st_m == st_r, (w, h, c, kind, cfg, st_r, st_m)
                 if st_r == 0:
                     assert np.array_equal(np.asarray(out_r)[: out_m.size], out_m), (w, h, c, kind, cfg)
     assert checked >= 900 and rejected >= 300
+
+
+def test_a_match_at_a_rows_first_pixel_is_left_to_the_cpu_decoder():
+    """tests/golden/first_pixel_match.png: a 2-pass file of a 65 x 16 RGBA image with ONE flipped bit (found by tools/emul_campaign.py)
+    that turns the first token of row 15 into a match -- it repeats a pixel of zeros there (reference src/fpng.cpp:2268: the
+    previous-pixel deltas start at 0 in every row), which no fpng encoder writes and the kernels' "last literal bytes" know nothing
+    about.  The reference decodes the file; the kernels' logic must say UNDECIDED (kEmitLeaveToCpu), never NOT_FPNG, and the
+    drop-in's CPU decoder, which takes over then, must give the reference's pixels."""
+    bad = open(os.path.join(ROOT, "tests", "golden", "first_pixel_match.png"), "rb").read()
+    for cfg in CONFIGS:
+        for desired in (3, 4):
+            st, px, *_ = emul_decode(bad, desired, cfg)
+            assert st == UNDECIDED and px is None, (cfg, desired, st)
+    for desired in (3, 4):
+        st_c, out_c, w, h, c = dropin.decode(bad, desired)
+        assert st_c == 0 and (w, h, c) == (65, 16, 4)
+        if have_ref():
+            st_r, out_r, *_ = ref().decode(bad, desired)
+            assert st_r == 0 and np.array_equal(np.asarray(out_r)[: out_c.size], out_c)
 
 
 # ---- the table's format, pinned by a decoder of a dozen lines ----

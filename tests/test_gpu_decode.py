@@ -460,3 +460,22 @@ def test_command_line_decoder_fuzz_mode(enc, tmp_path):
             assert "fpng::fpng_decode() failed with error" in r.stderr
             n_fail += 1
     assert n_ok >= 1 and n_fail >= 10
+
+
+def test_a_match_at_a_rows_first_pixel_is_left_to_the_cpu_decoder(enc):
+    """tests/golden/first_pixel_match.png (found by tools/emul_campaign.py; tests/test_decode_model.py holds the kernels' logic against
+    it on the CPU): one flipped bit makes the first token of a row a match.  The reference decodes the file; both batch entry
+    points must leave it to the CPU decoder (never NOT_FPNG), next to valid files that decode, and the drop-in gives the reference's pixels."""
+    import torch
+    import fpng_amd
+    bad = open(os.path.join(ROOT, "tests", "golden", "first_pixel_match.png"), "rb").read()
+    t = torch.from_numpy(fpng_amd.synth_image("grad", 300, 40, 4)).cuda()
+    (good,), _ = enc.encode_tensors([t], 1)
+    for desired in (3, 4):
+        cst, cpx, w, h, c = judge(bad, desired)
+        assert cst == 0 and (w, h, c) == (65, 16, 4)
+        for got in (enc.decode_batch([good, bad, good], desired), enc.decode_device(_device_files([good, bad, good], shift=1), desired, [(300, 40), (65, 16), (300, 40)])):
+            assert [st for st, _, _ in got] == [0, UNDECIDED, 0]
+            assert torch.equal(got[0][1], t[:, :, :desired]) and torch.equal(got[2][1], t[:, :, :desired])
+        dst, dpx, *_ = dropin.decode(bad, desired)
+        assert dst == 0 and np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])

@@ -250,6 +250,56 @@ def test_a_match_at_a_rows_first_pixel_is_left_to_the_cpu_decoder():
             assert st_r == 0 and np.array_equal(np.asarray(out_r)[: out_c.size], out_c)
 
 
+def edited_files(rng, n_images, per_image=8):
+    """[(name of the edit, file)]: valid code streams whose TOKENS were edited (tests/token_mutator.py), raw and with the byte count
+    made good again"""
+    import token_mutator as TM
+    out = []
+    for _ in range(n_images):
+        img, w, h, c = fuzz_image(rng) if rng.random() < 0.6 else fuzz_image(rng, force_dims=(int(rng.integers(20, 300)), int(rng.integers(2, 12))))
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 2)))
+        if plan(png)[1]:
+            continue  # (stored blocks: no tokens)
+        s = TM.Stream(png, plan)
+        same = s.write(s.tokens)
+        assert same is not None and dropin.decode(same, c)[0] == 0
+        for _ in range(per_image):
+            T, name = TM.mutate(s, rng)
+            if name == "none":
+                continue
+            for f in (s.write(T), s.write(TM.balanced(s, T, rng))):
+                if f is not None:
+                    out.append((name, f))
+    return out
+
+
+def test_edited_token_streams_get_the_references_answer():
+    """Flipped bits derail a Huffman stream; these files are VALID code streams that bend or break the decoder's semantic rules
+    (reference src/fpng.cpp:2255-2330): matches lengthened / shortened by pixels or by bytes, split, merged, put where no pixel
+    starts, at a row's first pixel, up to and over the row's end, the other distance bit, filter literals changed, tokens doubled
+    or dropped, the end-of-block symbol early or late.  The reference's decoder judges; the kernels' logic (the CPU decoder where it
+    says UNDECIDED) and the drop-in's CPU decoder must give its status and its pixels."""
+    if not have_ref():
+        pytest.skip("the reference's decoder is the judge")
+    rng = np.random.default_rng(2024)
+    seen, accepted, left = {}, 0, 0
+    for name, f in edited_files(rng, 70):
+        cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
+        desired = int(rng.choice([3, 4]))
+        st_r, out_r, *_ = ref().decode(f, desired)
+        st_c, out_c, *_ = dropin.decode(f, desired)
+        st_m, out_m, *_ = emul_decode(f, desired, cfg)
+        if st_m == UNDECIDED:
+            left += 1
+            st_m, out_m = st_c, out_c
+        for st, o in ((st_m, out_m), (st_c, out_c)):
+            assert st == st_r, (name, cfg, desired, st_r, st_m, st_c)
+            assert st_r != 0 or np.array_equal(np.asarray(out_r)[: o.size], o), (name, cfg, desired)
+        seen[name.split("+")[0].split("-")[0]] = 1
+        accepted += st_r == 0
+    assert len(seen) >= 12 and accepted >= 200 and left >= 10, (sorted(seen), accepted, left)
+
+
 # ---- the table's format, pinned by a decoder of a dozen lines ----
 def _serial_decode(png):
     res, mode, ofs, ln, first, limit, lut = plan(png)

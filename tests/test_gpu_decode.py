@@ -479,3 +479,39 @@ def test_a_match_at_a_rows_first_pixel_is_left_to_the_cpu_decoder(enc):
             assert torch.equal(got[0][1], t[:, :, :desired]) and torch.equal(got[2][1], t[:, :, :desired])
         dst, dpx, *_ = dropin.decode(bad, desired)
         assert dst == 0 and np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_edited_token_streams_get_the_references_answer(enc, device):
+    """tests/token_mutator.py through the kernels: valid code streams whose tokens bend or break the decoder's semantic rules (matches
+    lengthened, split, off a pixel boundary, at a row's first pixel, over the row's end, filter literals changed, the end-of-block
+    symbol moved ...).  Status and pixels of the reference's decoder; where the kernels say UNDECIDED (a match at a row's first
+    pixel), the drop-in's CPU decoder must give them."""
+    from test_decode_model import edited_files
+    rng = np.random.default_rng(77)
+    files = edited_files(rng, 60)
+    pngs = [f for _, f in files]
+    for desired in (3, 4):
+        if device:
+            import struct
+            dims = [struct.unpack(">II", bytes(p[16:24])) for p in pngs]
+            got = enc.decode_device(_device_files(pngs, shift=1), desired, dims)
+        else:
+            got = enc.decode_batch(pngs, desired)
+        accepted = left = 0
+        for (name, png), (st, px, cf) in zip(files, got):
+            cst, cpx, w, h, c = judge(png, desired)
+            if st == UNDECIDED:
+                left += 1
+                os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+                try:
+                    dst, dpx, *_ = dropin.decode(png, desired)
+                finally:
+                    del os.environ["FPNG_AMD_DECODE_CPU"]
+                assert dst == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])), name
+                continue
+            assert st == cst, (name, st, cst)
+            if st == 0:
+                accepted += 1
+                assert np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
+        assert accepted >= 150 and left >= 10, (accepted, left)

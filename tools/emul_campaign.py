@@ -7,7 +7,9 @@ per-thread code (fpng_amd/csrc/decode_core.h) thread by thread; the judge is the
 Content: the fuzz generator's images, crops of the screenshot-like generators, periodic stripes / tiles, crops of the photograph,
 flat images; 1-pass and 2-pass files; random workgroup size / lead-in / tile parameters (small ones put many borders and seams into
 small images).  Every valid file must decode to its pixels; then damaged copies (bit flips stratified over the stream, truncations,
-header edits, token-bit flips, spliced streams) must get the reference's status and, where it decodes them, its pixels."""
+header edits, token-bit flips, spliced streams) must get the reference's status and, where it decodes them, its pixels; so must
+files whose TOKENS were edited (tests/token_mutator.py: matches lengthened, split, moved to a row's first pixel or off a pixel
+boundary, filter literals changed, the end-of-block symbol moved ...), by the kernels' logic and by the drop-in's CPU decoder."""
 import os
 import sys
 import time
@@ -19,6 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import test_decode_model as M  # noqa: E402
+import token_mutator as TM  # noqa: E402
 import ui_images  # noqa: E402
 from cpu_ref import fuzz_image, oracle, ref  # noqa: E402
 
@@ -108,7 +111,7 @@ def main():
     except Exception:
         pass
     t_end = time.time() + secs
-    files = valid = damaged = rejected = undecided = 0
+    files = valid = damaged = rejected = undecided = edits = edits_accepted = edits_undecided = 0
     by_kind = {}
     prev_png = None
     while time.time() < t_end:
@@ -147,7 +150,38 @@ def main():
             if not ok:
                 print(f"MISMATCH damaged file: seed {seed} file {files} {w}x{h}x{c} flags {flags} kind {kind} cfg {cfg} desired {desired} reference {st_r} emulator {st_m}", flush=True)
                 open(f"/tmp/emul_campaign_fail_{seed}_{files}_{damaged}.png", "wb").write(bad)
+        # token-level edits (tests/token_mutator.py): valid code streams that bend or break the decoder's semantic rules
+        if w * h * c <= 60000 and M.plan(png)[1] == 0:
+            ts = TM.Stream(png, M.plan)
+            for _ in range(6):
+                T, name = TM.mutate(ts, rng)
+                if name == "none":
+                    continue
+                for bal in (False, True):
+                    f = ts.write(TM.balanced(ts, T, rng) if bal else T)
+                    if f is None:
+                        continue
+                    desired = int(rng.choice([3, 4]))
+                    cfg = cfgs[int(rng.integers(0, len(cfgs)))]
+                    st_r, out_r, *_ = judge(f, desired)
+                    st_c, out_c, *_ = cpu_tier(f, desired)
+                    try:
+                        st_m, out_m, *_ = M.emul_decode(f, desired, cfg)
+                    except AssertionError as ex:
+                        print(f"EMULATOR ERROR {ex}: seed {seed} file {files} {w}x{h}x{c} flags {flags} edit {name} cfg {cfg} desired {desired} reference {st_r}", flush=True)
+                        open(f"/tmp/emul_campaign_err_{seed}_{files}_{edits}.png", "wb").write(f)
+                        continue
+                    if st_m == M.UNDECIDED:
+                        edits_undecided += 1
+                        st_m, out_m = st_c, out_c
+                    edits += 1
+                    edits_accepted += st_r == 0
+                    ok = all(st == st_r and (st_r != 0 or np.array_equal(np.asarray(out_r)[: o.size], o)) for st, o in ((st_m, out_m), (st_c, out_c)))
+                    if not ok:
+                        print(f"MISMATCH edited tokens: seed {seed} file {files} {w}x{h}x{c} flags {flags} edit {name} balanced {bal} cfg {cfg} desired {desired} reference {st_r} emulator {st_m} cpu tier {st_c}", flush=True)
+                        open(f"/tmp/emul_campaign_fail_{seed}_{files}_e{edits}.png", "wb").write(f)
         prev_png = png
+    print(f"seed {seed}: {edits} files with edited tokens ({edits_accepted} accepted by the reference, {edits_undecided} left to the CPU decoder by the kernels' logic)", flush=True)
     print(f"seed {seed}: {files} files, {valid} decodes of valid files, {damaged} damaged copies ({rejected} rejected by the reference, {undecided} left undecided), by kind {dict(sorted(by_kind.items()))}", flush=True)
 
 

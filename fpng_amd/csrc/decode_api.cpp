@@ -39,7 +39,8 @@ struct Parsed {
 
 // The stored-block layout the reference accepts (src/fpng.cpp:2107-2207): block headers, sizes, filter bytes 0, exact end.
 // 0 = the encoder's own layout (full 65535-byte blocks, then the rest: what dec_stored_kernel copies), 1 = not acceptable,
-// 2 = acceptable to the reference but cut into other block sizes: left to the CPU decoder.
+// 2 = acceptable to the reference but cut into other block sizes (or with the one zero byte behind the image that the reference
+// lets pass): left to the CPU decoder.
 int check_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint32_t w, uint32_t h, uint32_t c)
 {
     const uint64_t stride = (uint64_t)w * c + 1, total = stride * h;
@@ -59,7 +60,11 @@ int check_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint32_t w
         src += len;
         if (final_block) break;
     }
-    if (got != total || src + 4 != zlib_len) return 1;
+    if (src + 4 != zlib_len) return 1;
+    // (the reference reads ONE byte more than the image holds if it is 0: it takes it for the filter byte of a row that never
+    //  comes -- :2158-2166 look at a row's first byte before they ask whether there is room; the loop above has checked it)
+    if (got == total + 1) return 2;
+    if (got != total) return 1;
     return usual ? 0 : 2;
 }
 

@@ -515,3 +515,45 @@ def test_edited_token_streams_get_the_references_answer(enc, device):
                 accepted += 1
                 assert np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
         assert accepted >= 150 and left >= 10, (accepted, left)
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_container_and_block_edits_get_the_references_answer(enc, device):
+    """tests/container_mutator.py through both batch entry points (host files: the whole container is parsed; device-resident files:
+    only a head and a tail visit the host, anything unusual makes the whole file come back): chunks inserted / missing / doubled /
+    out of order, IHDR fields and dimensions changed, several IDATs, junk behind IEND, other zlib headers and block types, stored
+    blocks of other sizes or with damaged headers, the one zero byte behind a stored image that the reference lets pass, dynamic
+    headers with other counts -- all with good CRCs.  Status, geometry and pixels of the reference; UNDECIDED only where the
+    drop-in's CPU decoder then gives the reference's answer."""
+    import container_mutator as CM
+    from test_dropin_decode import edited_containers
+    rng = np.random.default_rng(88)
+    files = edited_containers(rng, 50)
+    for (w, h, c) in ((5, 4, 4), (300, 250, 3)):
+        img = rng.integers(0, 256, w * h * c, dtype=np.uint8)
+        png = oracle().encode(img, w, h, c, 2)
+        files += [("stored_tail", CM.stored_with_tail(png, tail)) for tail in (b"", b"\0", b"\1", b"\0\0")]
+    pngs = [f for _, f in files]
+    for desired in (3, 4):
+        judged = [judge(p, desired) for p in pngs]
+        if device:
+            dims = [(w, h) if st == 0 or w else (0, 0) for st, _, w, h, _ in judged]
+            got = enc.decode_device(_device_files(pngs, shift=1), desired, dims)
+        else:
+            got = enc.decode_batch(pngs, desired)
+        accepted = left = 0
+        for (name, png), (cst, cpx, w, h, c), (st, px, cf) in zip(files, judged, got):
+            if st == UNDECIDED:
+                left += 1
+                os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+                try:
+                    dst, dpx, *_ = dropin.decode(png, desired)
+                finally:
+                    del os.environ["FPNG_AMD_DECODE_CPU"]
+                assert dst == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])), name
+                continue
+            assert st == cst, (name, st, cst)
+            if st == 0:
+                accepted += 1
+                assert cf == c and np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
+        assert accepted >= 50 and left >= 5, (accepted, left)

@@ -150,6 +150,9 @@ int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint
         const bool ok = read_dynamic_header(in, p.c, table, sizes);
         if (!complete && in.byte + 8 > avail) return kParseNeedMore; // (the header reader may have run off the head)
         if (!ok) return fpng::FPNG_DECODE_NOT_FPNG;
+        // a table with codes for the reserved length symbols 286 / 287: the reference's 4-channel decoder gives them a meaning of its
+        // own (fpng_decode.cpp: inflate_rows) -- no fpng encoder writes such a table; the CPU decoder's
+        if (sizes[286] | sizes[287]) return FPNG_AMD_DECODE_UNDECIDED;
         p.first_bit = in.bitpos();
         if (memo && (p.first_bit >> 3) < sizeof memo->bytes && (p.first_bit >> 3) < avail) {
             memo->bits = (uint32_t)p.first_bit, memo->chans = p.c;

@@ -139,7 +139,17 @@ template <int SC, int DC> bool inflate_rows(FastBits &in, const uint32_t *tab, u
             const uint32_t sym = e & 511u;
             uint32_t npix = 1;
             if (sym & 256u) {
-                if (sym == 256u || sym > 285u) return false; // EOB with pixels left, or not a length symbol
+                if (sym == 256u) return false; // EOB with pixels left
+                if (sym > 285u) {
+                    // 286 / 287, the length symbols Deflate reserves (a hand-made table can give them codes): the reference's 3-channel
+                    // decoder turns them away; its 4-channel decoder takes them for a match of length ZERO, and its copy loops run once
+                    // before they ask (src/fpng.cpp:2668-2760): nothing happens where the previous pixel's deltas are all zero and there
+                    // is a row above, elsewhere ONE more pixel is written.  No fpng encoder writes such a file; the answer is the reference's.
+                    if (SC != 4) return false;
+                    in.consume(1); // the distance code
+                    if (y != 0 && !(d0 | d1 | d2 | d3)) continue;
+                    goto write_pixels; // (npix = 1)
+                }
                 const uint32_t xb = len_extra[sym - 257];
                 const uint32_t run = len_base[sym - 257] + (uint32_t)(in.buf & ((1u << xb) - 1u));
                 in.consume(xb + 1); // extra bits + the distance code: always the 1-bit code of "previous pixel"
@@ -163,6 +173,7 @@ template <int SC, int DC> bool inflate_rows(FastBits &in, const uint32_t *tab, u
                     d3 = e & 255u;
                 }
             }
+        write_pixels:
             uint8_t *o = row + (size_t)x * DC;
             const uint8_t *u = up + (size_t)x * DC;
             if (DC == 4) {

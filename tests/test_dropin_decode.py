@@ -151,3 +151,60 @@ def test_container_and_block_edits_get_the_references_answer():
                 assert st_m == (M.UNDECIDED if tail == b"\0" else want), (w, h, c, tail, st_m)  # (the odd layout is the CPU decoder's)
                 if want == 0:
                     assert np.array_equal(out_r, out_c) and np.array_equal(out_c, M.expected_pixels(img, w, h, c, desired))
+
+
+def other_tables(rng, n_images, per_image=8):
+    """[(what was done, file)]: token streams (as they are, edited, or with the reserved length symbols 286 / 287 put in) written
+    again under random dynamic Huffman tables (tests/header_mutator.py)"""
+    import header_mutator as HM
+    import test_decode_model as M
+    import token_mutator as TM
+    out = []
+    for _ in range(n_images):
+        img, w, h, c = fuzz_image(rng) if rng.random() < 0.6 else fuzz_image(rng, force_dims=(int(rng.integers(20, 300)), int(rng.integers(2, 12))))
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 2)))
+        if M.plan(png)[1]:
+            continue
+        s = TM.Stream(png, M.plan)
+        for k in range(per_image):
+            toks, tag = None, ""
+            if k >= 5:
+                toks, tag = HM.with_reserved_symbols(s, rng), "+sym"
+            elif k >= 3:
+                toks, _ = TM.mutate(s, rng)
+                if rng.random() < 0.5:
+                    toks = TM.balanced(s, toks, rng)
+            name, f = HM.reencode(s, rng, toks)
+            out.append((name + tag, c, f))
+    return out
+
+
+@pytest.mark.skipif(not have_ref(), reason="the reference's decoder is the judge")
+def test_other_huffman_tables_and_the_reserved_length_symbols():
+    """The block header's reader and the table builders under tables no fpng encoder writes: random complete codes up to 12 bits
+    (and longer: turned away), single-code tables, HLIT / HDIST / HCLEN larger than needed, the code lengths spelled with the repeat
+    symbols in every way, distance tables the reference lets through (one or two 1-bit codes, other lengths next to them) or not.
+    And the length symbols 286 / 287: the reference's 4-channel decoder takes them for matches of length zero whose copy loop runs
+    once (src/fpng.cpp:2668-2760) -- the drop-in's CPU decoder does the same, the GPU decoder's host side leaves such tables to it.
+    Status and pixels of the reference."""
+    import test_decode_model as M
+    rng = np.random.default_rng(909)
+    R = ref()
+    accepted = reserved_accepted = left = 0
+    seen = set()
+    for name, c, f in other_tables(rng, 45):
+        desired = int(rng.choice([3, 4]))
+        st_r, out_r, *_ = R.decode(f, desired)
+        st_c, out_c, *_ = dropin.decode(f, desired)
+        st_m, out_m, *_ = M.emul_decode(f, desired, M.CONFIGS[int(rng.integers(0, len(M.CONFIGS)))])
+        if st_m == M.UNDECIDED:
+            left += 1
+            st_m, out_m = st_c, out_c
+        assert st_c == st_r and st_m == st_r, (name, c, st_r, st_c, st_m)
+        if st_r == 0:
+            accepted += 1
+            reserved_accepted += name.endswith("+sym")
+            assert np.array_equal(out_r, out_c) and np.array_equal(np.asarray(out_r)[: out_m.size], out_m), name
+        seen |= set(name.split("+"))
+    assert accepted >= 70 and reserved_accepted >= 5 and left >= 20, (accepted, reserved_accepted, left)
+    assert {"codes_longer_than_12", "kraft_off", "all_symbols", "two_dist_codes", "other_dist_lengths", "reserved_symbols_coded"} <= seen, seen

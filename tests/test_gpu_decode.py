@@ -557,3 +557,37 @@ def test_container_and_block_edits_get_the_references_answer(enc, device):
                 accepted += 1
                 assert cf == c and np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
         assert accepted >= 50 and left >= 5, (accepted, left)
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_other_huffman_tables_and_the_reserved_length_symbols(enc, device):
+    """tests/header_mutator.py through the kernels -- dec_build_lut_kernel builds the lookup tables of these files on the GPU: random
+    complete codes up to 12 bits, single-code tables, every symbol coded, other HLIT / HDIST / HCLEN, distance tables of every shape,
+    codes for the reserved length symbols 286 / 287 (left to the CPU decoder, which follows the reference's 4-channel decoder).
+    Status and pixels of the reference."""
+    from test_dropin_decode import other_tables
+    rng = np.random.default_rng(99)
+    files = other_tables(rng, 40)
+    pngs = [f for _, _, f in files]
+    for desired in (3, 4):
+        judged = [judge(p, desired) for p in pngs]
+        if device:
+            got = enc.decode_device(_device_files(pngs, shift=1), desired, [(w, h) for _, _, w, h, _ in judged])
+        else:
+            got = enc.decode_batch(pngs, desired)
+        accepted = left = 0
+        for (name, _, png), (cst, cpx, w, h, c), (st, px, cf) in zip(files, judged, got):
+            if st == UNDECIDED:
+                left += 1
+                os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+                try:
+                    dst, dpx, *_ = dropin.decode(png, desired)
+                finally:
+                    del os.environ["FPNG_AMD_DECODE_CPU"]
+                assert dst == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])), name
+                continue
+            assert st == cst, (name, st, cst)
+            if st == 0:
+                accepted += 1
+                assert cf == c and np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
+        assert accepted >= 50 and left >= 10, (accepted, left)

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_decode_model as M  # noqa: E402
 import token_mutator as TM  # noqa: E402
 import container_mutator as CM  # noqa: E402
+import header_mutator as HM  # noqa: E402
 import ctypes as C  # noqa: E402
 import ui_images  # noqa: E402
 from cpu_ref import fuzz_image, oracle, ref  # noqa: E402
@@ -113,7 +114,7 @@ def main():
     except Exception:
         pass
     t_end = time.time() + secs
-    files = valid = damaged = rejected = undecided = edits = edits_accepted = edits_undecided = containers = containers_accepted = 0
+    files = valid = damaged = rejected = undecided = edits = edits_accepted = edits_undecided = containers = containers_accepted = tables = tables_accepted = 0
     by_kind = {}
     prev_png = None
     while time.time() < t_end:
@@ -182,6 +183,35 @@ def main():
                     if not ok:
                         print(f"MISMATCH edited tokens: seed {seed} file {files} {w}x{h}x{c} flags {flags} edit {name} balanced {bal} cfg {cfg} desired {desired} reference {st_r} emulator {st_m} cpu tier {st_c}", flush=True)
                         open(f"/tmp/emul_campaign_fail_{seed}_{files}_e{edits}.png", "wb").write(f)
+        # the tokens (as they are, edited, with the reserved length symbols put in) under other dynamic Huffman tables (tests/header_mutator.py)
+        if w * h * c <= 60000 and M.plan(png)[1] == 0:
+            ts = TM.Stream(png, M.plan)
+            for k in range(6):
+                toks = None
+                if k >= 4:
+                    toks = HM.with_reserved_symbols(ts, rng)
+                elif k >= 2:
+                    toks, _ = TM.mutate(ts, rng)
+                    if rng.random() < 0.5:
+                        toks = TM.balanced(ts, toks, rng)
+                name, f = HM.reencode(ts, rng, toks)
+                desired = int(rng.choice([3, 4]))
+                st_r, out_r, *_ = judge(f, desired)
+                st_c, out_c, *_ = cpu_tier(f, desired)
+                try:
+                    st_m, out_m, *_ = M.emul_decode(f, desired, cfgs[int(rng.integers(0, len(cfgs)))])
+                except AssertionError as ex:
+                    print(f"EMULATOR ERROR {ex}: seed {seed} file {files} {w}x{h}x{c} table edit {name}", flush=True)
+                    open(f"/tmp/emul_campaign_err_{seed}_{files}_t{tables}.png", "wb").write(f)
+                    continue
+                if st_m == M.UNDECIDED:
+                    st_m, out_m = st_c, out_c
+                tables += 1
+                tables_accepted += st_r == 0
+                ok = all(st == st_r and (st_r != 0 or np.array_equal(np.asarray(out_r)[: o.size], o)) for st, o in ((st_m, out_m), (st_c, out_c)))
+                if not ok:
+                    print(f"MISMATCH other table: seed {seed} file {files} {w}x{h}x{c} {name} reserved symbols {k >= 4} desired {desired} reference {st_r} emulator {st_m} cpu tier {st_c}", flush=True)
+                    open(f"/tmp/emul_campaign_fail_{seed}_{files}_t{tables}.png", "wb").write(f)
         # chunk- and block-level edits with good CRCs (tests/container_mutator.py): the container walk, zlib header, stored-block layout,
         # dynamic header -- fpng_get_info and fpng_decode_memory of the reference judge the drop-in's functions and the GPU decoder's host side
         for png2 in (png, oracle().encode(img, w, h, c, 2)) if w * h * c <= 200000 else ():
@@ -212,6 +242,7 @@ def main():
                     print(f"MISMATCH container edit: seed {seed} file {files} {w}x{h}x{c} edit {name} desired {desired} reference {st_r} / info {gst} cpu tier {st_c} / info {mine[0]} emulator {st_m}", flush=True)
                     open(f"/tmp/emul_campaign_fail_{seed}_{files}_c{containers}.png", "wb").write(f)
         prev_png = png
+    print(f"seed {seed}: {tables} files under other Huffman tables ({tables_accepted} accepted by the reference)", flush=True)
     print(f"seed {seed}: {containers} files with edited containers / blocks ({containers_accepted} accepted by the reference)", flush=True)
     print(f"seed {seed}: {edits} files with edited tokens ({edits_accepted} accepted by the reference, {edits_undecided} left to the CPU decoder by the kernels' logic)", flush=True)
     print(f"seed {seed}: {files} files, {valid} decodes of valid files, {damaged} damaged copies ({rejected} rejected by the reference, {undecided} left undecided), by kind {dict(sorted(by_kind.items()))}", flush=True)

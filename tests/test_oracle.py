@@ -181,3 +181,44 @@ def test_oracle_vs_reference_wide_rows():
         img, w, h, c = ns["wide_image"](rng)
         for fl in (0, 1, 2):
             assert oracle().encode(img, w, h, c, fl) == ref().encode(img, w, h, c, fl), (w, h, c, fl)
+
+
+def _is_stored(png):
+    return (png[58 + 2] & 6) == 0  # (58 = signature + IHDR + fdEC + the IDAT's prefix; the block's type bits sit behind the zlib header)
+
+
+@pytest.mark.skipif(not have_ref(), reason="reference build not available")
+def test_oracle_vs_reference_at_the_stored_or_compressed_boundary():
+    """The reference keeps the compressed stream unless its coder "ran out of buffer" -- a rule with a closed form in the final bit
+    position and 8 bytes of slack (reference src/fpng.cpp:567-588 / :1728-1758).  Images whose first K pixels are noise and
+    whose rest is flat: the compressed size grows with K; around the K where the outcome flips (and for some K on either side)
+    the checker must write the reference's bytes, 1-pass and 2-pass."""
+    rng = np.random.default_rng(2718)
+    flips = 0
+    for (w, h, c) in ((64, 32, 4), (61, 17, 3), (256, 9, 4), (85, 30, 3), (33, 33, 4), (1024, 3, 3), (7, 200, 4)):
+        noise = rng.integers(0, 256, (w * h, c), dtype=np.uint8)
+        flat = np.full((w * h, c), 77, dtype=np.uint8)
+        for flags in (0, 1):
+            def make(k):
+                img = flat.copy()
+                img[:k] = noise[:k]
+                return img.reshape(-1)
+            lo, hi = 0, w * h  # invariant: make(lo) compressed, make(hi) stored (noise all over does not compress)
+            assert not _is_stored(ref().encode(make(lo), w, h, c, flags))
+            if not _is_stored(ref().encode(make(hi), w, h, c, flags)):
+                continue  # (a 2-pass table can hold noise in 8 bits a byte: narrow images stay compressed)
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if _is_stored(ref().encode(make(mid), w, h, c, flags)):
+                    hi = mid
+                else:
+                    lo = mid
+            outcomes = set()
+            for k in range(max(0, hi - 40), min(w * h, hi + 40) + 1):
+                img = make(k)
+                want = ref().encode(img, w, h, c, flags)
+                got = oracle().encode(img, w, h, c, flags)
+                assert got == want, (w, h, c, flags, k, len(got), len(want))
+                outcomes.add(_is_stored(want))
+            flips += outcomes == {False, True}
+    assert flips >= 10, flips

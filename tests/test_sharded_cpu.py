@@ -103,3 +103,51 @@ def test_plan_bands_matches_whole_image_layout():
         if not plan.stored:
             assert plan.zlib_size == len(exp) - 58 - 16
             assert plan.adler == int.from_bytes(exp[-20:-16], "big")
+
+
+def test_plan_bands_at_the_stored_or_compressed_boundary():
+    """The reference's "ran out of buffer" rule as the band plan states it (closed form in the stream's final bit): images
+    whose first K pixels are noise, K swept over the point where the reference's outcome flips (found with the reference where its
+    build is present, else with the checker -- itself held against the reference there by tests/test_oracle.py); the rows cut into
+    1-4 bands.  fpng_amd/sharded.py's plan_bands and the C function fpng_amd_plan_bands (what the kernels' host side and the node
+    image path use) must decide as the whole-image encoder does, and agree on size and Adler-32 where the file stays compressed."""
+    import fpng_amd
+    from band_backend import OracleBandBackend
+    from cpu_ref import have_ref, ref
+    from fpng_amd import _lib, sharded
+    enc = ref().encode if have_ref() else oracle().encode
+    rng = np.random.default_rng(31415)
+    flips = 0
+    for (w, h, c) in ((64, 32, 4), (61, 17, 3), (256, 9, 4), (85, 30, 3), (1024, 4, 3)):
+        noise = rng.integers(0, 256, (w * h, c), dtype=np.uint8)
+
+        def make(k):
+            img = np.full((w * h, c), 77, dtype=np.uint8)
+            img[:k] = noise[:k]
+            return img.reshape(h, w, c)
+        stored = lambda png: (png[60] >> 1) & 3 == 0
+        lo, hi = 0, w * h
+        assert not stored(enc(make(lo), w, h, c, 0)) and stored(enc(make(hi), w, h, c, 0))
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if stored(enc(make(mid), w, h, c, 0)):
+                hi = mid
+            else:
+                lo = mid
+        seen = set()
+        for k in range(max(0, hi - 12), min(w * h, hi + 12) + 1):
+            img = make(k)
+            exp = enc(img, w, h, c, 0)
+            be = OracleBandBackend(img)
+            for nb in (1, 2, 3, 4):
+                cuts = [h * i // nb for i in range(nb + 1)]
+                stats = [be.encode(None, None, w, c, a, b, h, 0, None) for a, b in zip(cuts[:-1], cuts[1:])]
+                plan = sharded.plan_bands(stats, w, h, c, stats[0].first_token_bit, stats[0].eob_bits)
+                cs = [_lib.BandStats(s.token_bits, s.s1, s.s2, s.nbytes, s.last_unit_bits, s.first_token_bit, s.eob_bits, 0) for s in stats]
+                _, cplan = fpng_amd.plan_bands(cs, w, h, c, 0)
+                assert plan.stored == stored(exp) and bool(cplan.stored) == stored(exp), (w, h, c, k, nb)
+                if not plan.stored:
+                    assert plan.zlib_size == cplan.zlib_size == len(exp) - 58 - 16 and plan.adler == cplan.adler == int.from_bytes(exp[-20:-16], "big")
+            seen.add(stored(exp))
+        flips += seen == {False, True}
+    assert flips == 5

@@ -433,7 +433,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.bpl = im.w * im.num_chans;
         j.nrows = j.h_total = im.h;
         j.y0 = 0;
-        j.flags = flags;
+        j.flags = flags & (FPNG_AMD_ENCODE_SLOWER | FPNG_AMD_FORCE_UNCOMPRESSED); // (the reference looks at these two bits only; the bits above are the kernels' own)
         j.row_base = (uint32_t)sub.total_rows;
         j.one_pass = two_pass ? 0 : 1;
         j.whole_png = j.is_first = j.is_last = 1;

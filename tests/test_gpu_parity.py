@@ -648,3 +648,23 @@ def test_wide_rows_fuzz(enc, flags):
         pngs, _ = _gpu_encode(enc, [c[0] for c in cases], flags)
         for (img, w, h, c), p in zip(cases, pngs):
             _assert_same(p, oracle().encode(img, w, h, c, flags), f"wide fuzz {w}x{h}x{c}")
+
+
+def test_flag_bits_the_reference_does_not_know_are_ignored(enc):
+    """reference src/fpng.cpp:1662-1803 looks at FPNG_ENCODE_SLOWER and FPNG_FORCE_UNCOMPRESSED only (flags = 3: stored wins); every
+    other bit of `flags` must change nothing -- the kernels keep bits of their own in a job's flag word, a caller's bits must never
+    reach them.  Device-resident submission and the drop-in's host path."""
+    import torch
+    import dropin
+    import fpng_amd
+    rng = np.random.default_rng(808)
+    cases = [fuzz_image(rng) for _ in range(6)] + [(fpng_amd.synth_image("grad", 300, 40, 4), 300, 40, 4), (fpng_amd.synth_image("blocks", 129, 33, 3), 129, 33, 3)]
+    for img, w, h, c in cases:
+        t = torch.from_numpy(np.ascontiguousarray(img).reshape(h, w, c)).cuda()
+        for fl in (0, 1, 2, 3):
+            want = oracle().encode(img, w, h, c, fl)
+            assert want == oracle().encode(img, w, h, c, fl | 0x700) and (not have_ref() or want == ref().encode(img, w, h, c, fl | 0x80000700))
+            for high in (0, 0x100, 0x200, 0x400, 0x80000704):
+                (png,), _ = enc.encode_tensors([t], fl | high)
+                assert png == want, (w, h, c, fl, hex(high))
+                assert dropin.encode(img, w, h, c, fl | high) == want, (w, h, c, fl, hex(high), "drop-in")

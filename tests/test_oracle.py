@@ -222,3 +222,38 @@ def test_oracle_vs_reference_at_the_stored_or_compressed_boundary():
                 outcomes.add(_is_stored(want))
             flips += outcomes == {False, True}
     assert flips >= 10, flips
+
+
+def skewed_images(rng, max_bytes=400_000):
+    """Images whose FILTERED bytes hold `levels` byte values with counts ratio^0, ratio^1, ...: the optimal prefix code of such a
+    histogram is deeper than the 12 bits fpng allows from 13 levels on, so the 2-pass builder's length limiting and, for the large
+    ones, adjust_freq32's scaling (reference src/fpng.cpp:909-988, :990-1161) decide the table."""
+    out = []
+    for levels in (2, 3, 8, 12, 13, 14, 16, 19, 23):
+        for c in (3, 4):
+            for ratio in (1.3, 1.62, 2.0, 3.0):
+                counts = [max(1, int(ratio ** k)) for k in range(levels)]
+                if sum(counts) > max_bytes:
+                    continue
+                vals = rng.permutation(256)[:levels]
+                data = np.concatenate([np.full(n, v, np.uint8) for v, n in zip(vals, counts)])
+                if rng.random() < 0.5:
+                    rng.shuffle(data)
+                n = len(data)
+                w = max(1, int(np.sqrt(n / c)))
+                h = max(1, n // (w * c))
+                if w * h * c > n:
+                    data = np.concatenate([data, np.full(w * h * c - n, vals[0], np.uint8)])
+                f = data[: w * h * c].reshape(h, w * c)
+                out.append((np.cumsum(f.astype(np.uint32), axis=0).astype(np.uint8).reshape(-1), w, h, c))  # (Up-filtered: back to f)
+    return out
+
+
+@pytest.mark.skipif(not have_ref(), reason="reference build not available")
+def test_oracle_vs_reference_on_skewed_histograms():
+    rng = np.random.default_rng(1618)
+    imgs = skewed_images(rng)
+    assert len(imgs) >= 40
+    for img, w, h, c in imgs:
+        for flags in (0, 1):
+            assert oracle().encode(img, w, h, c, flags) == ref().encode(img, w, h, c, flags), (w, h, c, flags)

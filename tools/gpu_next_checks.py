@@ -1,9 +1,13 @@
 #!/usr/bin/env python
-"""GPU-box check for the next round (not run yet: round 4's GPU minutes were spent): the encode kernels' stored-or-compressed decision
-at the exact point where the reference's outcome flips -- images whose first K pixels are noise, K swept over the flip, 1-pass and
-2-pass, as whole images and as 2-4 row bands through one GPU (tests/test_oracle.py and tests/test_sharded_cpu.py hold the CPU
-checker and the band plan against the reference at the same points).  Prints one line per case; exit code 1 on any difference.
-Becomes a -m gpu test once it has passed on a box."""
+"""GPU-box checks for the next round (not run yet: round 4's GPU minutes were spent when they were written).  Each is held on the
+CPU already -- checker and band plans against the reference: tests/test_oracle.py, tests/test_sharded_cpu.py -- and becomes a
+-m gpu test once it has passed on a box:
+ 1. the encode kernels' stored-or-compressed decision at the exact point where the reference's outcome flips: images whose first K
+    pixels are noise, K swept over the flip, 1-pass and 2-pass;
+ 2. the device-side table builder (build_dynamic_kernel) on skewed histograms: filtered bytes with `levels` values whose counts
+    grow like ratio^k -- from 13 levels on the optimal code is deeper than fpng's 12 bits and the length limiting decides -- and
+    the GPU decoder on those files (dec_build_lut_kernel with 12-bit codes).
+Prints one line per case; exit code 1 on any difference."""
 import os
 import sys
 
@@ -41,6 +45,15 @@ def main():
             n_bad = sum(bytes(p) != ref().encode(i, w, h, c, flags) for p, i in zip(pngs, imgs))
             bad += n_bad
             print(f"{w}x{h}x{c} flags {flags}: flip at K = {hi}, {len(ks)} images around it, {n_bad} differ from the reference", flush=True)
+    from test_oracle import skewed_images
+    imgs = skewed_images(np.random.default_rng(1618), max_bytes=3_000_000)
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors([torch.from_numpy(i.reshape(h, w, c)).cuda() for i, w, h, c in imgs], flags)
+        n_bad = sum(bytes(p) != ref().encode(i, w, h, c, flags) for p, (i, w, h, c) in zip(pngs, imgs))
+        back = enc.decode_batch(pngs, 4)
+        n_dec = sum(st != 0 or not np.array_equal(px.cpu().numpy()[:, :, :c].reshape(-1), i) for (st, px, _), (i, w, h, c) in zip(back, imgs))
+        bad += n_bad + n_dec
+        print(f"skewed histograms, flags {flags}: {len(imgs)} images, {n_bad} files differ from the reference, {n_dec} do not decode back", flush=True)
     enc.close()
     sys.exit(1 if bad else 0)
 

@@ -404,3 +404,43 @@ extern "C" int fpng_emul_phase_map_selftest(uint32_t seed, uint32_t n)
     return 0;
 }
 
+
+// The tokens of a dynamic-block fpng file, one by one (tests/token_mutator.py edits large files with it): kind 0 = literal (value =
+// the byte), 1 = match (value = its length, aux = the distance bit), 2 = end of block; bitpos = the token's first bit, counted from
+// the zlib stream's first byte.  Returns the number of tokens (the end-of-block symbol included), -1 if the file has no such
+// stream, -2 if it derails, -3 if `cap` is too small.
+extern "C" long long fpng_emul_tokenize(const uint8_t *png, uint32_t size, long long cap, uint8_t *kind, uint16_t *value, uint8_t *aux, uint64_t *bitpos)
+{
+    fpng_amd_decode_result res;
+    uint32_t mode = 0, idat_ofs = 0, idat_len = 0;
+    uint64_t first_bit = 0, end_limit = 0;
+    std::vector<uint32_t> lut(FPNG_AMD_DECODE_LUT_WORDS);
+    if (fpng_amd_decode_plan(png, size, &res, &mode, &idat_ofs, &idat_len, &first_bit, &end_limit, lut.data()) || res.status || mode) return -1;
+    std::vector<uint32_t> zdw((size_t)idat_len / 4 + 8, 0);
+    memcpy(zdw.data(), png + idat_ofs + 8, idat_len);
+    const uint8_t *lenof = (const uint8_t *)(lut.data() + kLutEntries);
+    long long n = 0;
+    uint64_t pos = first_bit;
+    for (;;) {
+        if (pos >= end_limit) return -2;
+        if (n >= cap) return -3;
+        const uint64_t d = pos >> 5;
+        const uint32_t w = funnel(zdw[d + 1], zdw[d], (uint32_t)(pos & 31));
+        const uint32_t e = lut[w & (kLutEntries - 1)], L = e >> 28, nl = (e >> 26) & 3u;
+        if (!L) return -2;
+        bitpos[n] = pos;
+        if (nl) {
+            const uint32_t b = e & 255u;
+            kind[n] = 0, value[n] = (uint16_t)b, aux[n] = 0;
+            pos += lenof[b];
+        } else if (e & kEntMatch) {
+            const uint32_t xb = (e >> 9) & 7u;
+            kind[n] = 1, value[n] = (uint16_t)((e & 511u) + ((w >> L) & ((1u << xb) - 1u))), aux[n] = (uint8_t)((w >> (L + xb)) & 1u);
+            pos += L + xb + 1;
+        } else {
+            kind[n] = 2, value[n] = 0, aux[n] = 0;
+            return n + 1;
+        }
+        n++;
+    }
+}

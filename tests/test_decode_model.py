@@ -300,6 +300,43 @@ def test_edited_token_streams_get_the_references_answer():
     assert len(seen) >= 12 and accepted >= 200 and left >= 10, (sorted(seen), accepted, left)
 
 
+def test_edited_token_streams_of_megapixel_images():
+    """The same kind of edits, ONE at a random place of a stream that spans dozens of workgroups of the kernels' own size (512
+    subsequences of 512 bits): a pixel of literals turned into a match (also at a row's first pixel: left to the CPU decoder),
+    matches split, merged, a pixel longer or shorter with the byte count made good, filter literals and pixels changed, matches
+    over the row's end or off the pixel grid.  The reference's decoder judges the kernels' logic and the drop-in's CPU decoder."""
+    if not have_ref():
+        pytest.skip("the reference's decoder is the judge")
+    import fpng_amd
+    import token_mutator as TM
+    import ui_images
+    rng = np.random.default_rng(4242)
+    imgs = [(np.asarray(fpng_amd.synth_image("grad", 1500, 700, 4)).reshape(-1), 1500, 700, 4),
+            (np.ascontiguousarray(ui_images.glyphs(1280, 600, 3, seed=5)).reshape(-1), 1280, 600, 3),
+            (np.asarray(fpng_amd.synth_image("blocks", 1100, 900, 3)).reshape(-1), 1100, 900, 3)]
+    seen, accepted, left = set(), 0, 0
+    for k, (img, w, h, c) in enumerate(imgs):
+        png = oracle().encode(img, w, h, c, k % 2)
+        s = TM.LargeStream(png, plan, emul())
+        assert ref().decode(s.splice(0, 0, []), c)[0] == 0 and s.n > 10000
+        for _ in range(14):
+            name, f = TM.mutate_large(s, rng)
+            if f is None:
+                continue
+            desired = int(rng.choice([3, 4]))
+            st_r, out_r, *_ = ref().decode(f, desired)
+            st_c, out_c, *_ = dropin.decode(f, desired)
+            st_m, out_m, *_ = emul_decode(f, desired)
+            if st_m == UNDECIDED:
+                left += 1
+                st_m, out_m = st_c, out_c
+            for st, o in ((st_m, out_m), (st_c, out_c)):
+                assert st == st_r and (st_r != 0 or np.array_equal(np.asarray(out_r)[: o.size], o)), (name, w, h, c, st_r, st_m, st_c)
+            seen.add(name)
+            accepted += st_r == 0
+    assert len(seen) >= 7 and accepted >= 15 and left >= 2, (sorted(seen), accepted, left)
+
+
 # ---- the table's format, pinned by a decoder of a dozen lines ----
 def _serial_decode(png):
     res, mode, ofs, ln, first, limit, lut = plan(png)

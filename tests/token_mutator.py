@@ -206,3 +206,158 @@ def balanced(s, T, rng):
         body.append(("lit", (2 if n >= s.stride else 0) if col == 0 else int(rng.integers(0, 256))))
         n += 1
     return body + [("eob",)]
+
+
+class LargeStream:
+    """The same for LARGE files: the tokens come from a C loop (tests/cpp/decode_emul.cpp: fpng_emul_tokenize), edits are local and
+    written by splicing bits into the stream -- megapixel images whose streams span many workgroups of the GPU decoder."""
+
+    def __init__(self, png, plan, emul_lib):
+        import ctypes as C
+        res, mode, ofs, ln, first, limit, lut = plan(png)
+        assert res.status == 0 and mode == 0
+        self.png, self.ofs, self.ln, self.first = bytes(png), ofs, ln, first
+        self.w, self.h, self.c = res.w, res.h, res.channels_in_file
+        self.stride = self.w * self.c + 1
+        lenof = lut[4096:].view(np.uint8)
+        self.lit_code, self.len_syms, self.eob = {}, {}, None
+        for i in range(4096):
+            e = int(lut[i])
+            L, n = e >> 28, (e >> 26) & 3
+            if not L:
+                continue
+            if n:
+                b = e & 255
+                self.lit_code[b] = (i & ((1 << int(lenof[b])) - 1), int(lenof[b]))
+            elif e & (1 << 25):
+                self.len_syms[(e & 511, (e >> 9) & 7)] = (i & ((1 << L) - 1), L)
+            else:
+                self.eob = (i & ((1 << L) - 1), L)
+        cap = self.stride * self.h + 16
+        self.kind, self.value, self.aux, self.bitpos = np.zeros(cap, np.uint8), np.zeros(cap, np.uint16), np.zeros(cap, np.uint8), np.zeros(cap, np.uint64)
+        b = np.frombuffer(self.png, dtype=np.uint8)
+        emul_lib.fpng_emul_tokenize.restype = C.c_longlong
+        emul_lib.fpng_emul_tokenize.argtypes = [C.c_void_p, C.c_uint32, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = emul_lib.fpng_emul_tokenize(b.ctypes.data, b.size, cap, self.kind.ctypes.data, self.value.ctypes.data, self.aux.ctypes.data, self.bitpos.ctypes.data)
+        assert n > 0, n
+        self.n = int(n)
+        self.kind, self.value, self.aux, self.bitpos = self.kind[:n], self.value[:n], self.aux[:n], self.bitpos[:n]
+        size = np.where(self.kind == 0, 1, np.where(self.kind == 1, self.value, 0)).astype(np.int64)
+        self.out_pos = np.concatenate([[0], np.cumsum(size)[:-1]])
+        self.end_bit = int(self.bitpos[-1]) + self.eob[1]
+        self.zint = int.from_bytes(self.png[ofs + 8: ofs + 8 + ln], "little") & ((1 << self.end_bit) - 1)
+
+    def token(self, i):
+        k = int(self.kind[i])
+        return ("lit", int(self.value[i])) if k == 0 else (("match", int(self.value[i]), int(self.aux[i])) if k == 1 else ("eob",))
+
+    def _bits(self, tokens):
+        v = n = 0
+        for t in tokens:
+            if t[0] == "lit":
+                if t[1] not in self.lit_code:
+                    return None
+                code, l = self.lit_code[t[1]]
+                v |= code << n
+                n += l
+            else:
+                sym = [(base, xb) for (base, xb) in self.len_syms if base <= t[1] < base + (1 << xb)]
+                if not sym:
+                    return None
+                base, xb = sym[0]
+                code, l = self.len_syms[(base, xb)]
+                v |= (code | (t[1] - base) << l | (t[2] & 1) << (l + xb)) << n
+                n += l + xb + 1
+        return v, n
+
+    def splice(self, i0, i1, tokens):
+        """the file with tokens [i0, i1) replaced (i1 < n: the end-of-block symbol stays); None if a token has no code in this table"""
+        enc = self._bits(tokens)
+        if enc is None:
+            return None
+        v, nb = enc
+        p0, p1 = int(self.bitpos[i0]), int(self.bitpos[i1])
+        bits = (self.zint & ((1 << p0) - 1)) | v << p0 | (self.zint >> p1) << (p0 + nb)
+        n = p0 + nb + self.end_bit - p1
+        z = bits.to_bytes((n + 7) // 8, "little") + b"\x12\x34\x56\x78"
+        head = self.png[: self.ofs]
+        return head + struct.pack(">I", len(z)) + b"IDAT" + z + struct.pack(">I", zlib.crc32(b"IDAT" + z)) + struct.pack(">I", 0) + b"IEND" + struct.pack(">I", zlib.crc32(b"IEND"))
+
+
+def mutate_large(s, rng):
+    """-> (name, file) or (name, None): ONE local edit of a LargeStream, most of them keeping the byte count (the edit itself is
+    what the decoders judge), at a random place of the stream"""
+    C, stride, n = s.c, s.stride, s.n
+    kind = int(rng.integers(0, 10))
+    i = int(rng.integers(0, n - 1))
+    lo, hi = i, min(n - 1, i + 4000)
+    k, v, col = s.kind[lo:hi], s.value[lo:hi].astype(np.int64), (s.out_pos[lo:hi] % stride)
+    px_start = (col >= 1) & ((col - 1) % C == 0)
+    lits = k == 0
+    runC = lits.copy()
+    for d in range(1, C):
+        runC[:-d] &= lits[d:]
+        runC[-d:] = False
+
+    def pick(mask):
+        idx = np.flatnonzero(mask)
+        return lo + int(idx[int(rng.integers(0, len(idx)))]) if len(idx) else None
+    if kind in (0, 1):  # C literals that are a pixel -> a match of one pixel; kind 1: at a row's FIRST pixel
+        j = pick(px_start & runC & ((col == 1) if kind == 1 else (col > 1)))
+        if j is None:
+            return "none", None
+        return ("lit2match_firstpx" if kind == 1 else "lit2match"), s.splice(j, j + C, [("match", C, 0)])
+    if kind == 2:  # a match split in two
+        j = pick((k == 1) & (v >= 2 * max(C, 3)))
+        if j is None:
+            return "none", None
+        L = int(s.value[j])
+        a = int(rng.integers(1, L // C)) * C
+        if a < 3 or L - a < 3:
+            return "none", None
+        return "split", s.splice(j, j + 1, [("match", a, 0), ("match", L - a, 0)])
+    if kind == 3:  # two neighbouring matches merged
+        m = (k == 1)
+        j = pick(m[:-1] & m[1:] & (v[:-1] + v[1:] <= 258)) if len(m) > 1 else None
+        if j is None:
+            return "none", None
+        return "merge", s.splice(j, j + 2, [("match", int(s.value[j]) + int(s.value[j + 1]), 0)])
+    if kind == 4:  # a match one pixel longer, the pixel of literals behind it dropped
+        ok = (k[:-C] == 1) & (v[:-C] + C <= 258) & runC[1:len(k) - C + 1] if len(k) > C + 1 else np.zeros(0, bool)
+        j = pick(ok) if len(ok) else None
+        if j is None:
+            return "none", None
+        return "match_takes_next_pixel", s.splice(j, j + 1 + C, [("match", int(s.value[j]) + C, 0)])
+    if kind == 5:  # a match one pixel shorter, a pixel of literals behind it instead
+        j = pick((k == 1) & (v - C >= 3))
+        if j is None:
+            return "none", None
+        return "match_gives_last_pixel", s.splice(j, j + 1, [("match", int(s.value[j]) - C, 0)] + [("lit", int(b)) for b in rng.integers(0, 256, C)])
+    if kind == 6:  # literal values changed
+        j = pick(lits & (col != 0))
+        if j is None:
+            return "none", None
+        return "literal", s.splice(j, j + 1, [("lit", int(rng.integers(0, 256)))])
+    if kind == 7:  # a filter literal changed
+        j = pick(lits & (col == 0))
+        if j is None:
+            return "none", None
+        return "filter_byte", s.splice(j, j + 1, [("lit", int(rng.choice([0, 1, 2, 3, 4])))])
+    if kind == 8:  # a match that reaches over its row's end (a pixel of literals dropped behind it where there is one)
+        j = pick(k == 1)
+        if j is None:
+            return "none", None
+        left = stride - int(s.out_pos[j] % stride)
+        want = left + C
+        if not (3 <= want <= 258):
+            return "none", None
+        return "match_over_row_end", s.splice(j, j + 1, [("match", want, 0)])
+    j = pick(k == 1)  # a match that is no whole number of pixels, the byte count made good with a literal more or less
+    if j is None or j + 2 >= n or s.kind[j + 1] != 0:
+        return "none", None
+    L = int(s.value[j])
+    if L + 1 <= 258 and rng.random() < 0.5:
+        return "match_plus_a_byte", s.splice(j, j + 2, [("match", L + 1, 0)])
+    if L - 1 >= 3:
+        return "match_minus_a_byte", s.splice(j, j + 1, [("match", L - 1, 0), ("lit", int(rng.integers(0, 256)))])
+    return "none", None

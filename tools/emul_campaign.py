@@ -3,6 +3,7 @@
 per-thread code (fpng_amd/csrc/decode_core.h) thread by thread; the judge is the reference's decoder (oracle/_ref), status AND pixels.
 
     python tools/emul_campaign.py <seconds> [seed]           # one process; run several with different seeds
+    python tools/emul_campaign.py --large <seconds> [seed]   # megapixel images, one local token edit per file
 
 Content: the fuzz generator's images, crops of the screenshot-like generators, periodic stripes / tiles, crops of the photograph,
 flat images; 1-pass and 2-pass files; random workgroup size / lead-in / tile parameters (small ones put many borders and seams into
@@ -99,7 +100,80 @@ def damage(rng, png, other):
     return kind, bytes(bad)
 
 
+def large_images(rng, photo):
+    """megapixel content: streams that span many workgroups of the kernels' own size"""
+    import fpng_amd
+    while True:
+        k = int(rng.integers(0, 5))
+        c = int(rng.choice([3, 4]))
+        if k == 0:
+            w, h = int(rng.integers(600, 2000)), int(rng.integers(300, 1100))
+            yield np.asarray(fpng_amd.synth_image("grad", w, h, c, seed=int(rng.integers(0, 1 << 30)))).reshape(-1), w, h, c
+        elif k == 1 and photo is not None:
+            t = np.tile(photo, (2, 2, 1))
+            w, h = int(rng.integers(500, t.shape[1])), int(rng.integers(300, t.shape[0]))
+            yield np.ascontiguousarray(t[:h, :w]).reshape(-1), w, h, 3
+        elif k == 2:
+            gen = [ui_images.glyphs, ui_images.panels, ui_images.dither][int(rng.integers(0, 3))]
+            w, h = int(rng.integers(800, 1920)), int(rng.integers(400, 1080))
+            yield np.ascontiguousarray(gen(w, h, c, seed=int(rng.integers(1, 1 << 30)))).reshape(-1), w, h, c
+        elif k == 3:
+            w, h = int(rng.integers(800, 1920)), int(rng.integers(400, 1080))
+            yield np.ascontiguousarray(ui_images.matte(w, h, seed=int(rng.integers(1, 1 << 30)))).reshape(-1), w, h, 4
+        else:
+            w, h = int(rng.integers(600, 2000)), int(rng.integers(300, 1100))
+            yield np.asarray(fpng_amd.synth_image("blocks", w, h, c, seed=int(rng.integers(0, 1 << 30)))).reshape(-1), w, h, c
+
+
+def main_large(secs, seed):
+    """--large: ONE local token edit per file of a megapixel image (tests/token_mutator.py: LargeStream, mutate_large), the kernels'
+    own workgroup size"""
+    rng = np.random.default_rng(seed)
+    judge = ref().decode
+    import dropin
+    import real_image
+    os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+    photo = real_image.rgb_pixels(judge)
+    t_end = time.time() + secs
+    stats, n, images = {}, 0, 0
+    for img, w, h, c in large_images(rng, photo):
+        if time.time() > t_end:
+            break
+        flags = int(rng.integers(0, 2))
+        png = oracle().encode(img, w, h, c, flags)
+        if M.plan(png)[1]:
+            continue
+        images += 1
+        s = TM.LargeStream(png, M.plan, M.emul())
+        for _ in range(6):
+            name, f = TM.mutate_large(s, rng)
+            if f is None:
+                continue
+            desired = int(rng.choice([3, 4]))
+            st_r, out_r, *_ = judge(f, desired)
+            st_c, out_c, *_ = dropin.decode(f, desired)
+            try:
+                st_m, out_m, *_ = M.emul_decode(f, desired, M.CONFIGS[0])
+            except AssertionError as ex:
+                print(f"EMULATOR ERROR {ex}: seed {seed} {w}x{h}x{c} flags {flags} edit {name}", flush=True)
+                open(f"/tmp/emul_campaign_err_{seed}_L{n}.png", "wb").write(f)
+                continue
+            und = st_m == M.UNDECIDED
+            if und:
+                st_m, out_m = st_c, out_c
+            key = (name, st_r == 0, und)
+            stats[key] = stats.get(key, 0) + 1
+            n += 1
+            if not all(st == st_r and (st_r != 0 or np.array_equal(np.asarray(out_r)[: o.size], o)) for st, o in ((st_m, out_m), (st_c, out_c))):
+                print(f"MISMATCH large file: seed {seed} {w}x{h}x{c} flags {flags} edit {name} desired {desired} reference {st_r} emulator {st_m} cpu tier {st_c}", flush=True)
+                open(f"/tmp/emul_campaign_fail_{seed}_L{n}.png", "wb").write(f)
+    print(f"seed {seed} (large): {images} images of 0.2-2 MP, {n} files with one edited token each; (edit, accepted by the reference, left to the CPU decoder): count = {dict(sorted(stats.items()))}", flush=True)
+
+
 def main():
+    if "--large" in sys.argv:
+        a = [v for v in sys.argv[1:] if v != "--large"]
+        return main_large(float(a[0]) if a else 60.0, int(a[1]) if len(a) > 1 else 1)
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)

@@ -7,6 +7,9 @@ CPU already -- checker and band plans against the reference: tests/test_oracle.p
  2. the device-side table builder (build_dynamic_kernel) on skewed histograms: filtered bytes with `levels` values whose counts
     grow like ratio^k -- from 13 levels on the optimal code is deeper than fpng's 12 bits and the length limiting decides -- and
     the GPU decoder on those files (dec_build_lut_kernel with 12-bit codes).
+ 3. token-edited MEGAPIXEL files (tests/token_mutator.py: LargeStream / mutate_large -- one local edit at a random place of a stream that
+    spans many workgroups) through fpng_amd_decode_batch, fpng_amd_decode_batch_device and fpng::fpng_decode_memory (the streamed
+    form from 8 MiB of IDAT on): status and pixels of the reference's decoder.
 Prints one line per case; exit code 1 on any difference."""
 import os
 import sys
@@ -54,6 +57,32 @@ def main():
         n_dec = sum(st != 0 or not np.array_equal(px.cpu().numpy()[:, :, :c].reshape(-1), i) for (st, px, _), (i, w, h, c) in zip(back, imgs))
         bad += n_bad + n_dec
         print(f"skewed histograms, flags {flags}: {len(imgs)} images, {n_bad} files differ from the reference, {n_dec} do not decode back", flush=True)
+    import dropin
+    import test_decode_model as M
+    import token_mutator as TM
+    import ui_images
+    big = [(np.asarray(fpng_amd.synth_image("grad", 3840, 2160, 4)).reshape(-1), 3840, 2160, 4),   # (IDAT > 8 MiB: the drop-in streams it)
+           (np.ascontiguousarray(ui_images.glyphs(1920, 1080, 3, seed=5)).reshape(-1), 1920, 1080, 3),
+           (np.asarray(fpng_amd.synth_image("blocks", 2048, 1500, 3)).reshape(-1), 2048, 1500, 3)]
+    for k, (img, w, h, c) in enumerate(big):
+        s = TM.LargeStream(ref().encode(img, w, h, c, k % 2), M.plan, M.emul())
+        files = [(name, f) for name, f in (TM.mutate_large(s, rng) for _ in range(24)) if f is not None]
+        n_bad = 0
+        for desired in (3, 4):
+            judged = [ref().decode(f, desired) for _, f in files]
+            for got in (enc.decode_batch([f for _, f in files], desired),):
+                for (name, f), (cst, cpx, *_), (st, px, _) in zip(files, judged, got):
+                    if st == 64:  # left to the CPU decoder: the drop-in's answer counts
+                        st, dpx, *_ = dropin.decode(f, desired)
+                        ok = st == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired]))
+                    else:
+                        ok = st == cst and (cst != 0 or np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]))
+                    n_bad += not ok
+            for (name, f), (cst, cpx, *_) in zip(files, judged):  # the drop-in itself (GPU tier, streamed where the file is large)
+                st, dpx, *_ = dropin.decode(f, desired)
+                n_bad += not (st == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])))
+        bad += n_bad
+        print(f"token-edited {w}x{h}x{c}: {len(files)} files, {n_bad} answers differ from the reference's", flush=True)
     enc.close()
     sys.exit(1 if bad else 0)
 

@@ -74,7 +74,7 @@ def build(force=False, verbose=False):
     # the fpng_test-style command line harness (tools/fpng_amd_test.cpp) over the drop-in
     cli_src = os.path.join(ROOT, "tools", "fpng_amd_test.cpp")
     cli = os.path.join(LIB_DIR, "fpng_amd_test")
-    if os.path.exists(cli_src) and (force or _stale(cli, [cli_src, LIB, DROPIN_LIB, os.path.join(ROOT, "include", "fpng.h")])):
+    if os.path.exists(cli_src) and (force or _stale(cli, [cli_src, os.path.join(ROOT, "tools", "png_loader.h"), LIB, DROPIN_LIB, os.path.join(ROOT, "include", "fpng.h")])):
         rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
                cli_src, "-o", cli, "-L", LIB_DIR, "-lfpng", "-lfpng_amd", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-ldl", "-lpthread",

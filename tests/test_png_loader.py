@@ -136,7 +136,7 @@ def test_the_reference_example_and_damaged_files(loader):
     assert hashlib.sha256(np.ascontiguousarray(got[:, :, :3]).tobytes()).hexdigest() == g["pixels_sha256"]
     assert loader(png[:1000])[0] is None and loader(b"not a png at all" * 10)[0] is None
     interlaced = bytearray(_png(4, 4, 2, 8, [bytes(12)] * 4))
-    interlaced[28] = 1
+    interlaced[28] = 1  # (says Adam7, holds one pass: the sizes cannot match; the IHDR CRC is not looked at by this loader)
     assert loader(bytes(interlaced))[0] is None
 
 
@@ -155,3 +155,56 @@ def test_corpus_files_of_screenshot_like_content(loader, tmp_path):
         assert got is not None, err
         c = arr.shape[2]
         assert np.array_equal(got[:, :, :c], arr) and (c == 4 or (got[:, :, 3] == 255).all())
+
+
+def _png_adam7(w, h, ctype, depth, samples, extra=b""):
+    """samples: uint array (h, w, chans) of `depth`-bit values -> an INTERLACED PNG: seven sub-images, each filtered like an image"""
+    chans = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, chans * depth // 8)
+    stream = bytearray()
+    for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        rows = []
+        for r in sub:
+            if depth == 8:
+                rows.append(r.astype(np.uint8).tobytes())
+            elif depth == 16:
+                rows.append(r.astype(">u2").tobytes())
+            else:
+                bits = "".join(format(int(v), f"0{depth}b") for v in r.reshape(-1))
+                bits += "0" * (-len(bits) % 8)
+                rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+        stream += _filter_rows(rows, bpp)
+    z = zlib.compress(bytes(stream), 6)
+    return (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + extra + _chunk(b"IDAT", z[: len(z) // 3]) +
+            _chunk(b"IDAT", z[len(z) // 3:]) + _chunk(b"IEND", b""))
+
+
+def test_interlaced_files(loader):
+    """Adam7 (RFC 2083 section 2.6): the seven passes of every colour type and depth, at sizes where some passes are empty (1 x 1,
+    2 x 3, 5 x 1), narrow, and ordinary -- lodepng, the reference harness's loader, reads such files too."""
+    rng = np.random.default_rng(7)
+    for (w, h) in ((1, 1), (2, 3), (5, 1), (1, 9), (8, 8), (9, 17), (37, 23), (64, 5)):
+        for ctype, chans, depths in ((0, 1, (1, 2, 4, 8, 16)), (2, 3, (8, 16)), (3, 1, (1, 2, 4, 8)), (4, 2, (8, 16)), (6, 4, (8, 16))):
+            for depth in depths:
+                v = rng.integers(0, 1 << depth, (h, w, chans))
+                extra = b""
+                if ctype == 3:
+                    pal = rng.integers(0, 256, (1 << depth, 3)).astype(np.uint8)
+                    extra = _chunk(b"PLTE", pal.tobytes())
+                got, err = loader(_png_adam7(w, h, ctype, depth, v, extra))
+                assert got is not None, (w, h, ctype, depth, err)
+                v8 = (v >> 8) if depth == 16 else ((v * 255 // ((1 << depth) - 1)) if ctype == 0 and depth < 8 else v)
+                if ctype == 0:
+                    exp = np.concatenate([v8.repeat(3, axis=2), np.full((h, w, 1), 255)], axis=2)
+                elif ctype == 2:
+                    exp = np.concatenate([v8, np.full((h, w, 1), 255)], axis=2)
+                elif ctype == 3:
+                    exp = np.concatenate([pal[v[:, :, 0]], np.full((h, w, 1), 255)], axis=2)
+                elif ctype == 4:
+                    exp = np.concatenate([v8[:, :, :1].repeat(3, axis=2), v8[:, :, 1:]], axis=2)
+                else:
+                    exp = v8
+                assert np.array_equal(got, exp.astype(np.uint8)), (w, h, ctype, depth)

@@ -1,4 +1,4 @@
-// png_loader.h -- a small, self-contained PNG reader for the fpng_amd_test harness: ANY non-interlaced PNG (grey, RGB,
+// png_loader.h -- a small, self-contained PNG reader for the fpng_amd_test harness: ANY PNG, interlaced (Adam7) or not (grey, RGB,
 // palette, grey+alpha, RGBA; 1/2/4/8/16 bits per sample; tRNS) to 8-bit RGBA, the role lodepng_decode_memory(..., LCT_RGBA, 8)
 // plays in the reference's harness (reference src/fpng_test.cpp:1116-1122).  Plain RFC 1950/1951 inflate + PNG filters 0-4
 // (RFC 2083), no dependencies.  Test-tool code: the product never reads PNGs other than its own (fpng_decode.cpp).
@@ -179,77 +179,100 @@ inline bool load_rgba(const uint8_t *d, size_t n, std::vector<uint8_t> &rgba, ui
         o += (size_t)len + 12;
     }
     if (!have_ihdr || !w || !h || (uint64_t)w * h > (1ull << 30)) return err = "bad IHDR", false;
-    if (interlace) return err = "interlaced PNGs are not supported by this loader", false;
+    if (interlace > 1) return err = "unknown interlace method", false;
     const uint32_t chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
                           (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) || ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
     if (!chans || !depth_ok) return err = "unsupported colour type / bit depth", false;
     const uint32_t bpp_bits = chans * depth, bpp = (bpp_bits + 7) / 8; // filter unit in bytes
-    const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
-    std::vector<uint8_t> raw;
-    if (!inflate_zlib(idat.data(), idat.size(), raw, (stride + 1) * h) || raw.size() < (stride + 1) * h) return err = "IDAT does not inflate to the image", false;
-    // ---- undo the row filters in place (RFC 2083 section 6) ----
-    std::vector<uint8_t> zero(stride, 0);
-    for (uint32_t y = 0; y < h; y++) {
-        uint8_t *row = raw.data() + (size_t)y * (stride + 1) + 1;
-        const uint8_t *up = y ? row - (stride + 1) : zero.data();
-        const uint32_t f = row[-1];
-        if (f > 4) return err = "bad filter type", false;
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? row[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-            int pred = 0;
-            if (f == 1)
-                pred = a;
-            else if (f == 2)
-                pred = b;
-            else if (f == 3)
-                pred = (a + b) >> 1;
-            else if (f == 4) {
-                const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-            }
-            row[i] = (uint8_t)(row[i] + pred);
-        }
+    // the image as ONE pass, or as the seven passes of Adam7 (RFC 2083 section 2.6): sub-images of every dx-th column from x0 and
+    // every dy-th row from y0, each filtered and stored like a small image of its own
+    struct Pass {
+        uint32_t x0, y0, dx, dy;
+    };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass *passes = interlace ? adam7 : &whole;
+    const int n_passes = interlace ? 7 : 1;
+    size_t expect = 0;
+    for (int q = 0; q < n_passes; q++) {
+        const Pass &ps = passes[q];
+        const uint32_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        if (pw && ph) expect += (((size_t)pw * bpp_bits + 7) / 8 + 1) * ph;
     }
-    // ---- to RGBA8 ----
+    std::vector<uint8_t> raw;
+    if (!inflate_zlib(idat.data(), idat.size(), raw, expect) || raw.size() < expect) return err = "IDAT does not inflate to the image", false;
     rgba.resize((size_t)w * h * 4);
     const uint32_t maxv = (1u << (depth > 8 ? 8 : depth)) - 1;
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t *row = raw.data() + (size_t)y * (stride + 1) + 1;
-        for (uint32_t x = 0; x < w; x++) {
-            uint32_t s[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
-            for (uint32_t k = 0; k < chans; k++) {
-                if (depth == 8)
-                    s[k] = row[(size_t)x * chans + k];
-                else if (depth == 16) {
-                    s[k] = row[((size_t)x * chans + k) * 2]; // the high byte, as lodepng's 16 -> 8 conversion
-                    s16[k] = ((uint32_t)s[k] << 8) | row[((size_t)x * chans + k) * 2 + 1];
-                } else {
-                    const size_t bit = (size_t)x * depth;
-                    s[k] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+    size_t at = 0;
+    for (int q = 0; q < n_passes; q++) {
+        const Pass &ps = passes[q];
+        const uint32_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        if (!pw || !ph) continue;
+        const size_t stride = ((size_t)pw * bpp_bits + 7) / 8;
+        uint8_t *base = raw.data() + at;
+        at += (stride + 1) * ph;
+        // ---- undo the row filters in place (RFC 2083 section 6) ----
+        std::vector<uint8_t> zero(stride, 0);
+        for (uint32_t y = 0; y < ph; y++) {
+            uint8_t *row = base + (size_t)y * (stride + 1) + 1;
+            const uint8_t *up = y ? row - (stride + 1) : zero.data();
+            const uint32_t f = row[-1];
+            if (f > 4) return err = "bad filter type", false;
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= bpp ? row[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+                int pred = 0;
+                if (f == 1)
+                    pred = a;
+                else if (f == 2)
+                    pred = b;
+                else if (f == 3)
+                    pred = (a + b) >> 1;
+                else if (f == 4) {
+                    const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
                 }
+                row[i] = (uint8_t)(row[i] + pred);
             }
-            uint8_t *px = &rgba[((size_t)y * w + x) * 4];
-            px[3] = 255;
-            if (ctype == 3) {
-                if ((size_t)s[0] * 3 + 2 >= plte.size() + 0 && plte.size() < (size_t)s[0] * 3 + 3) return err = "palette index out of range", false;
-                px[0] = plte[s[0] * 3], px[1] = plte[s[0] * 3 + 1], px[2] = plte[s[0] * 3 + 2];
-                if (s[0] < trns.size()) px[3] = trns[s[0]];
-            } else if (ctype == 0 || ctype == 4) {
-                const uint8_t g = depth < 8 ? (uint8_t)(s[0] * 255 / maxv) : (uint8_t)s[0];
-                px[0] = px[1] = px[2] = g;
-                if (ctype == 4) px[3] = (uint8_t)s[1];
-                if (ctype == 0 && trns.size() >= 2) {
-                    const uint32_t key = ((uint32_t)trns[0] << 8) | trns[1];
-                    if ((depth == 16 ? s16[0] : s[0]) == key) px[3] = 0;
+        }
+        // ---- to RGBA8 ----
+        for (uint32_t y = 0; y < ph; y++) {
+            const uint8_t *row = base + (size_t)y * (stride + 1) + 1;
+            for (uint32_t x = 0; x < pw; x++) {
+                uint32_t s[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < chans; k++) {
+                    if (depth == 8)
+                        s[k] = row[(size_t)x * chans + k];
+                    else if (depth == 16) {
+                        s[k] = row[((size_t)x * chans + k) * 2]; // the high byte, as lodepng's 16 -> 8 conversion
+                        s16[k] = ((uint32_t)s[k] << 8) | row[((size_t)x * chans + k) * 2 + 1];
+                    } else {
+                        const size_t bit = (size_t)x * depth;
+                        s[k] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+                    }
                 }
-            } else {
-                px[0] = (uint8_t)s[0], px[1] = (uint8_t)s[1], px[2] = (uint8_t)s[2];
-                if (ctype == 6) px[3] = (uint8_t)s[3];
-                if (ctype == 2 && trns.size() >= 6) {
-                    bool eq = true;
-                    for (int k = 0; k < 3; k++) eq = eq && (depth == 16 ? s16[k] : s[k]) == (((uint32_t)trns[2 * k] << 8) | trns[2 * k + 1]);
-                    if (eq) px[3] = 0;
+                uint8_t *px = &rgba[((size_t)(ps.y0 + y * ps.dy) * w + (ps.x0 + x * ps.dx)) * 4];
+                px[3] = 255;
+                if (ctype == 3) {
+                    if (plte.size() < (size_t)s[0] * 3 + 3) return err = "palette index out of range", false;
+                    px[0] = plte[s[0] * 3], px[1] = plte[s[0] * 3 + 1], px[2] = plte[s[0] * 3 + 2];
+                    if (s[0] < trns.size()) px[3] = trns[s[0]];
+                } else if (ctype == 0 || ctype == 4) {
+                    const uint8_t g = depth < 8 ? (uint8_t)(s[0] * 255 / maxv) : (uint8_t)s[0];
+                    px[0] = px[1] = px[2] = g;
+                    if (ctype == 4) px[3] = (uint8_t)s[1];
+                    if (ctype == 0 && trns.size() >= 2) {
+                        const uint32_t key = ((uint32_t)trns[0] << 8) | trns[1];
+                        if ((depth == 16 ? s16[0] : s[0]) == key) px[3] = 0;
+                    }
+                } else {
+                    px[0] = (uint8_t)s[0], px[1] = (uint8_t)s[1], px[2] = (uint8_t)s[2];
+                    if (ctype == 6) px[3] = (uint8_t)s[3];
+                    if (ctype == 2 && trns.size() >= 6) {
+                        bool eq = true;
+                        for (int k = 0; k < 3; k++) eq = eq && (depth == 16 ? s16[k] : s[k]) == (((uint32_t)trns[2 * k] << 8) | trns[2 * k + 1]);
+                        if (eq) px[3] = 0;
+                    }
                 }
             }
         }

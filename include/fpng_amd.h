@@ -344,8 +344,11 @@ int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_
  *      when they are there.  status = the reference's fpng::FPNG_DECODE_* code for this file (0 = success);
  *      FPNG_AMD_DECODE_UNDECIDED: the GPU path leaves the file to the CPU decoder -- its token boundaries did not synchronise
  *      in the allotted rounds (FPNG_AMD_DECODE_MAX_ROUNDS in the environment, default 64; 0 = every compressed file), or it is
- *      a stored-block file cut into other block sizes than the encoder's -- decode it with fpng::fpng_decode_memory()
- *      instead; never reported for a file the CPU decoder would reject with a different code than FPNG_DECODE_NOT_FPNG. ---- */
+ *      a stored-block file cut into other block sizes than the encoder's (or with the one zero byte behind the image that the
+ *      reference lets pass), a match at a row's first pixel, a table with codes for the reserved length symbols 286 / 287 (the
+ *      reference's 4-channel decoder gives them a meaning) -- nothing an fpng encoder writes; decode it with
+ *      fpng::fpng_decode_memory() instead; never reported for a file the CPU decoder would reject with a different code than
+ *      FPNG_DECODE_NOT_FPNG. ---- */
 #define FPNG_AMD_DECODE_UNDECIDED 64
 typedef struct fpng_amd_png {
     const void *data; /* the file: HOST memory for fpng_amd_decode_batch, DEVICE memory for fpng_amd_decode_batch_device */

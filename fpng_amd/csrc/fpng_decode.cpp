@@ -21,6 +21,9 @@
 
 #include <atomic>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -113,95 +116,167 @@ struct FastBits {
     size_t bitpos() const { return byte * 8 - cnt; }
 };
 
-// one final dynamic block: rows of (filter literal, pixels); SC channels in the file, DC channels out
-template <int SC, int DC> bool inflate_rows(FastBits &in, const uint32_t *tab, uint8_t *dst, uint32_t w, uint32_t h, size_t *end_bit)
+// ---- one final dynamic block: rows of (filter literal, pixels) ----
+// The rows are decoded as what they are to Deflate -- a stream of BYTES -- into a row buffer, then un-filtered with plain byte adds
+// the compiler vectorises: a lookup yields up to three literals at once (as many whole literal codes as fit the 12 index bits; the
+// GPU decoder's table idea, decode_core.h), stored with one unaligned 32-bit write; a match repeats the previous FILTERED pixel.  The
+// reference's rules, stated on byte positions (col = place in the row, 0 = the filter literal): a length symbol (or the end of the
+// block) may only stand where a pixel starts -- "a pixel is never split by a match" --, a match is whole pixels and ends inside its
+// row, the filter literal is 0 then 2, nothing follows the last row but the end-of-block symbol.
+//   entry: literals: bits 23..0 the bytes (first one lowest), 25..24 their number n (1..3), 29..26 code bits of the whole group
+//          n == 0: bit 12 match (8..0 base length, 11..9 extra bits), bit 13 end of block, bit 14 reserved length symbol (286 / 287);
+//          29..26 the symbol's code bits; 0 = no such code
+enum : uint32_t { kRowMatch = 1u << 12, kRowEob = 1u << 13, kRowReserved = 1u << 14 };
+void build_row_table(const uint32_t *tab, uint32_t *rt)
 {
     static const uint16_t len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
                                           31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const size_t dst_bpl = (size_t)w * DC;
-    std::vector<uint8_t> zero_row(dst_bpl, 0); // "the row above" of row 0
+    for (uint32_t k = 0; k < (1u << kTableBits); k++) {
+        const uint32_t e1 = tab[k], l1 = e1 >> 9, s1 = e1 & 511u;
+        uint32_t ent = 0;
+        if (!l1)
+            ent = 0;
+        else if (s1 == 256)
+            ent = l1 << 26 | kRowEob;
+        else if (s1 > 285)
+            ent = l1 << 26 | kRowReserved;
+        else if (s1 > 256)
+            ent = l1 << 26 | kRowMatch | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257];
+        else {
+            uint32_t L = l1, n = 1, lits = s1;
+            while (n < 3) {
+                const uint32_t e2 = tab[k >> L], l2 = e2 >> 9, s2 = e2 & 511u;
+                if (!l2 || s2 >= 256 || L + l2 > kTableBits) break;
+                lits |= s2 << (8 * n);
+                n++, L += l2;
+            }
+            ent = L << 26 | n << 24 | lits;
+        }
+        rt[k] = ent;
+    }
+}
+
+// out = up + f, byte-wise (the Up filter undone; row 0 has filter 0 and a row of zeros above it), SC channels in, DC channels out.
+// Packed byte adds in 64-bit words (the compilers at hand do not vectorise the plain byte loop: 2.8 cycles a byte, more than the
+// Huffman decoding in front of it).
+inline uint64_t add_bytes64(uint64_t a, uint64_t b) { return ((a & 0x7F7F7F7F7F7F7F7Full) + (b & 0x7F7F7F7F7F7F7F7Full)) ^ ((a ^ b) & 0x8080808080808080ull); }
+inline uint32_t add_bytes32(uint32_t a, uint32_t b) { return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u); }
+template <int SC, int DC> void unfilter_row(const uint8_t *f, const uint8_t *up, uint8_t *out, uint32_t w)
+{
+    if (SC == DC) {
+        const size_t n = (size_t)w * SC;
+        size_t i = 0;
+#if defined(__SSE2__)
+        for (; i + 16 <= n; i += 16)
+            _mm_storeu_si128((__m128i *)(out + i), _mm_add_epi8(_mm_loadu_si128((const __m128i *)(up + i)), _mm_loadu_si128((const __m128i *)(f + i))));
+#endif
+        for (; i + 8 <= n; i += 8) {
+            uint64_t a, b;
+            memcpy(&a, up + i, 8), memcpy(&b, f + i, 8);
+            a = add_bytes64(a, b);
+            memcpy(out + i, &a, 8);
+        }
+        for (; i < n; i++) out[i] = (uint8_t)(up[i] + f[i]);
+    } else if (SC == 3) { // -> RGBA, alpha 0xFF: one 32-bit load (the fourth byte is the next pixel's, or slack), one store a pixel
+        for (uint32_t x = 0; x < w; x++) {
+            uint32_t a, b;
+            memcpy(&a, up + 4 * (size_t)x, 4), memcpy(&b, f + 3 * (size_t)x, 4);
+            a = add_bytes32(a, b) | 0xFF000000u;
+            memcpy(out + 4 * (size_t)x, &a, 4);
+        }
+    } else { // RGBA -> RGB: the alpha deltas only ever mattered to the decoder's rules
+        for (uint32_t x = 0; x < w; x++) {
+            uint32_t b;
+            memcpy(&b, f + 4 * (size_t)x, 4);
+            out[3 * (size_t)x] = (uint8_t)(up[3 * (size_t)x] + b);
+            out[3 * (size_t)x + 1] = (uint8_t)(up[3 * (size_t)x + 1] + (b >> 8));
+            out[3 * (size_t)x + 2] = (uint8_t)(up[3 * (size_t)x + 2] + (b >> 16));
+        }
+    }
+}
+
+// SC channels in the file, DC channels out
+template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t *rt, uint8_t *dst, uint32_t w, uint32_t h, size_t *end_bit)
+{
+    FastBits in = in_; // (a local copy: its fields live in registers, byte stores into the row buffer cannot alias them)
+    const size_t bpl = (size_t)w * SC, stride = bpl + 1, dst_bpl = (size_t)w * DC;
+    std::vector<uint8_t> rows(2 * (stride + 16), 0), zero_row(dst_bpl, 0);
+    uint8_t *rb = rows.data(), *nb = rows.data() + stride + 16; // this row's filtered bytes (filter literal first), the next row's
     const uint8_t *up = zero_row.data();
-    uint8_t *row = dst;
+    uint8_t *out = dst;
+    size_t fill = 0; // bytes of the current row that are there (a group of literals may have run over the previous row's end)
     for (uint32_t y = 0; y < h; y++) {
-        in.refill();
-        uint32_t e = tab[in.buf & 4095u];
-        if (!(e >> 9)) return false;
-        in.consume(e >> 9);
-        if ((e & 511u) != (y ? 2u : 0u)) return false; // filter type literal
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;         // previous pixel in FILTERED space
-        uint32_t x = 0;
-        while (x < w) {
-            in.refill();
-            e = tab[in.buf & 4095u];
-            if (!(e >> 9)) return false;
-            in.consume(e >> 9);
-            const uint32_t sym = e & 511u;
-            uint32_t npix = 1;
-            if (sym & 256u) {
-                if (sym == 256u) return false; // EOB with pixels left
-                if (sym > 285u) {
+        while (fill < stride) {
+            in.refill(); // >= 56 bits: three tokens (a match: 12 + 5 + 1 bits at most)
+            for (int k = 0; k < 3 && fill < stride; k++) {
+                const uint32_t e = rt[in.buf & 4095u], L = e >> 26, n = (e >> 24) & 3u;
+                if (n) {
+                    const uint32_t v = e & 0xFFFFFFu;
+                    memcpy(rb + fill, &v, 4); // (one byte of slack behind n <= 3)
+                    fill += n;
+                    in.consume(L);
+                    continue;
+                }
+                if (!L || (e & kRowEob)) return false; // no such code, or the block ends with pixels left
+                // a length symbol: only where a pixel starts
+                if (fill < 1 || (fill - 1) % SC) return false;
+                in.consume(L);
+                uint8_t *o = rb + fill;
+                if (e & kRowReserved) {
                     // 286 / 287, the length symbols Deflate reserves (a hand-made table can give them codes): the reference's 3-channel
                     // decoder turns them away; its 4-channel decoder takes them for a match of length ZERO, and its copy loops run once
                     // before they ask (src/fpng.cpp:2668-2760): nothing happens where the previous pixel's deltas are all zero and there
                     // is a row above, elsewhere ONE more pixel is written.  No fpng encoder writes such a file; the answer is the reference's.
                     if (SC != 4) return false;
                     in.consume(1); // the distance code
-                    if (y != 0 && !(d0 | d1 | d2 | d3)) continue;
-                    goto write_pixels; // (npix = 1)
+                    uint32_t prev = 0;
+                    if (fill > 1) memcpy(&prev, o - 4, 4);
+                    if (y != 0 && !prev) continue;
+                    memcpy(o, &prev, 4);
+                    fill += 4;
+                    continue;
                 }
-                const uint32_t xb = len_extra[sym - 257];
-                const uint32_t run = len_base[sym - 257] + (uint32_t)(in.buf & ((1u << xb) - 1u));
+                const uint32_t xb = (e >> 9) & 7u;
+                const uint32_t run = (e & 511u) + (uint32_t)(in.buf & ((1u << xb) - 1u));
                 in.consume(xb + 1); // extra bits + the distance code: always the 1-bit code of "previous pixel"
-                if (run % SC) return false;
-                npix = run / SC;
-                if (!npix || x + npix > w) return false; // whole pixels, inside the row
-            } else {
-                d0 = sym;
-                e = tab[in.buf & 4095u];
-                if (!(e >> 9) || (e & 256u)) return false; // (a pixel is never split by a match)
-                in.consume(e >> 9);
-                d1 = e & 255u;
-                e = tab[in.buf & 4095u];
-                if (!(e >> 9) || (e & 256u)) return false;
-                in.consume(e >> 9);
-                d2 = e & 255u;
-                if (SC == 4) {
-                    e = tab[in.buf & 4095u];
-                    if (!(e >> 9) || (e & 256u)) return false;
-                    in.consume(e >> 9);
-                    d3 = e & 255u;
+                if (run % SC || fill + run > stride) return false; // whole pixels, inside the row
+                // the previous FILTERED pixel, `run` bytes of it (the pixel in front of a row's first one is all zeros: reference :2268);
+                // flat content is runs of zero deltas
+                uint32_t px = 0;
+                if (fill > 1) memcpy(&px, o - 4, 4), px = SC == 4 ? px : px >> 8;
+                if (!px) {
+                    if (run <= 16)
+                        memset(o, 0, 16); // (two inline stores; the row buffer has 16 bytes of slack)
+                    else
+                        memset(o, 0, run);
+                } else if (SC == 4) {
+                    const uint64_t p2 = (uint64_t)px << 32 | px;
+                    for (uint32_t i = 0; i < run; i += 8) memcpy(o + i, &p2, 8); // (run is a multiple of 4; up to 4 bytes of slack behind the row)
+                } else {
+                    // 3-byte pixels: 12 bytes = 4 pixels at a time from three rotated words
+                    const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
+                    const uint32_t w0 = (uint32_t)wrap, w1 = (uint32_t)(wrap >> 8), w2 = (uint32_t)(wrap >> 16);
+                    for (uint32_t i = 0; i < run; i += 12) memcpy(o + i, &w0, 4), memcpy(o + i + 4, &w1, 4), memcpy(o + i + 8, &w2, 4); // (up to 9 bytes of slack)
                 }
+                fill += run;
             }
-        write_pixels:
-            uint8_t *o = row + (size_t)x * DC;
-            const uint8_t *u = up + (size_t)x * DC;
-            if (DC == 4) {
-                // four byte-wise sums in one 32-bit operation (SWAR); an RGB file's alpha is 0xFF whatever the row above holds
-                const uint32_t d = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
-                for (uint32_t i = 0; i < npix; i++, o += 4, u += 4) {
-                    uint32_t a;
-                    memcpy(&a, u, 4);
-                    uint32_t s = ((a & 0x7F7F7F7Fu) + (d & 0x7F7F7F7Fu)) ^ ((a ^ d) & 0x80808080u);
-                    if (SC == 3) s |= 0xFF000000u;
-                    memcpy(o, &s, 4);
-                }
-            } else {
-                for (uint32_t i = 0; i < npix; i++, o += 3, u += 3) {
-                    o[0] = (uint8_t)(u[0] + d0);
-                    o[1] = (uint8_t)(u[1] + d1);
-                    o[2] = (uint8_t)(u[2] + d2);
-                }
-            }
-            x += npix;
         }
-        up = row;
-        row += dst_bpl;
+        if (rb[0] != (y ? 2u : 0u)) return false; // filter type literal
+        const size_t over = fill - stride;        // literals of the next row (at most two)
+        if (over && y + 1 == h) return false;
+        nb[0] = rb[stride], nb[1] = rb[stride + 1];
+        // ---- Up filter undone (row 0: filter 0 = the bytes themselves; `up` is a row of zeros there), channels converted ----
+        unfilter_row<SC, DC>(rb + 1, up, out, w);
+        up = out;
+        out += dst_bpl;
+        std::swap(rb, nb);
+        fill = over;
     }
     in.refill();
-    const uint32_t e = tab[in.buf & 4095u];
-    if (!(e >> 9) || (e & 511u) != 256u) return false;
-    in.consume(e >> 9);
+    const uint32_t e = rt[in.buf & 4095u];
+    if (!(e >> 26) || ((e >> 24) & 3u) || !(e & kRowEob)) return false;
+    in.consume(e >> 26);
     *end_bit = in.bitpos();
     return true;
 }
@@ -214,15 +289,19 @@ bool inflate_pixels(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t
     if ((z[2] & 6) == 0) return inflate_stored(z, avail, zlib_len, dst, w, h, src_chans, dst_chans);
     Bits in = {z, avail, 2, 0, 0, false};
     if (in.get(1) != 1 || in.get(2) != 2) return false; // one final dynamic block
-    static thread_local uint32_t lit_table[1u << kTableBits];
+    // (one heap block for both tables: thread-local arrays cost a __tls_get_addr call at every use in a shared library, and the
+    //  compiler keeps some of them inside the row loop -- 45 % slower)
+    std::vector<uint32_t> tables(2u << kTableBits);
+    uint32_t *const lit_table = tables.data(), *const row_table = tables.data() + (1u << kTableBits);
     if (!read_dynamic_header(in, src_chans, lit_table)) return false;
+    build_row_table(lit_table, row_table);
     FastBits fb = {in.p, in.n, in.byte, in.buf, in.cnt};
     size_t end_bit = 0;
     bool ok;
     if (src_chans == 3)
-        ok = dst_chans == 3 ? inflate_rows<3, 3>(fb, lit_table, dst, w, h, &end_bit) : inflate_rows<3, 4>(fb, lit_table, dst, w, h, &end_bit);
+        ok = dst_chans == 3 ? inflate_rows<3, 3>(fb, row_table, dst, w, h, &end_bit) : inflate_rows<3, 4>(fb, row_table, dst, w, h, &end_bit);
     else
-        ok = dst_chans == 3 ? inflate_rows<4, 3>(fb, lit_table, dst, w, h, &end_bit) : inflate_rows<4, 4>(fb, lit_table, dst, w, h, &end_bit);
+        ok = dst_chans == 3 ? inflate_rows<4, 3>(fb, row_table, dst, w, h, &end_bit) : inflate_rows<4, 4>(fb, row_table, dst, w, h, &end_bit);
     if (!ok) return false;
     return ((end_bit + 7) >> 3) + 4 == zlib_len;
 }

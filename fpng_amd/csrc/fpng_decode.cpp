@@ -209,6 +209,7 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
     for (uint32_t y = 0; y < h; y++) {
         while (fill < stride) {
             in.refill(); // >= 56 bits: three tokens (a match: 12 + 5 + 1 bits at most)
+            if (in.byte > in.n + 16) return false; // far behind the end of the data (zeros from there on): the reference's reader has given up long ago
             for (int k = 0; k < 3 && fill < stride; k++) {
                 const uint32_t e = rt[in.buf & 4095u], L = e >> 26, n = (e >> 24) & 3u;
                 if (n) {

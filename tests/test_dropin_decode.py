@@ -1,5 +1,7 @@
 """CPU tests of the decoder half of the `namespace fpng` drop-in (fpng_amd/csrc/fpng_decode.cpp)
 against the reference decoder: same pixels, same status codes, including on damaged files."""
+import os
+
 import numpy as np
 import pytest
 
@@ -208,3 +210,46 @@ def test_other_huffman_tables_and_the_reserved_length_symbols():
         seen |= set(name.split("+"))
     assert accepted >= 70 and reserved_accepted >= 5 and left >= 20, (accepted, reserved_accepted, left)
     assert {"codes_longer_than_12", "kraft_off", "all_symbols", "two_dist_codes", "other_dist_lengths", "reserved_symbols_coded"} <= seen, seen
+
+
+def test_cpu_decoder_under_the_sanitizers(tmp_path):
+    """fpng_decode.cpp built with AddressSanitizer + UndefinedBehaviorSanitizer over a few thousand valid, damaged and hand-edited files
+    (containers, stored blocks, tokens, other Huffman tables, reserved symbols), each decoded from an exact-size copy: its row
+    buffers are written with 4- to 16-byte stores that run past the bytes wanted -- the slack must always be there."""
+    import shutil
+    import subprocess
+    import test_decode_model as M
+    from cpu_ref import ROOT
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    rng = np.random.default_rng(5150)
+    files = [f for _, f in edited_containers(rng, 60)] + [f for _, _, f in other_tables(rng, 25)] + [f for _, f in M.edited_files(rng, 25)]
+    for _ in range(150):
+        img, w, h, c = fuzz_image(rng)
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 3)))
+        files.append(png)
+        for _ in range(4):
+            bad = bytearray(png)
+            if rng.random() < 0.3:
+                bad = bad[: int(rng.integers(1, len(bad)))]
+            else:
+                bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            files.append(bytes(bad))
+    corpus = tmp_path / "corpus.bin"
+    with open(corpus, "wb") as f:
+        for p in files:
+            f.write(len(p).to_bytes(4, "little") + p)
+    exe = str(tmp_path / "drv")
+    csrc = os.path.join(ROOT, "fpng_amd", "csrc")
+    lib_dir = os.path.join(ROOT, "fpng_amd", "lib")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                        os.path.join(ROOT, "tests", "cpp", "decoder_sanitizer_driver.cpp"), os.path.join(csrc, "fpng_decode.cpp"), os.path.join(csrc, "fpng_dropin.cpp"),
+                        "-o", exe, "-L", lib_dir, "-lfpng_amd", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert r.returncode == 0, r.stderr[-800:]
+    env = dict({k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}, FPNG_AMD_DECODE_CPU="1", ASAN_OPTIONS="detect_leaks=0")
+    q = subprocess.run([exe, str(corpus)], capture_output=True, text=True, env=env, timeout=600)
+    assert q.returncode == 0 and "Sanitizer" not in q.stderr and "runtime error" not in q.stderr, q.stderr[-1500:]
+    n, ok = int(q.stdout.split()[0]), int(q.stdout.split()[2])
+    assert n == 2 * len(files) and 0.2 * n < ok < 0.9 * n, q.stdout

@@ -210,6 +210,17 @@ def end_to_end_here(enc_device, w, h, c, kind, flags, part):
             out["dropin_decode_ms"] = round(td * 1e3, 3)
             out["dropin_decode_MPs"] = round(mp / td, 1)
             out["dropin_decode_on_gpu"] = bool(dropin.gpu_decodes() > 0)
+            # images under 256K pixels stay on the drop-in's CPU decoder (fpng_decode.cpp): one host core, next to the reference's
+            sw, sh = 512, 500
+            simg = fpng_amd.synth_image(kind, sw, sh, c, seed=12345)
+            spng = dropin.encode(simg, sw, sh, c, flags)
+            n0 = dropin.gpu_decodes()
+            ts = min(dropin.time_decode(spng, c, reps=20) for _ in range(3))
+            out["dropin_small_decode"] = {"image": f"{sw}x{sh}x{c}", "MPs": round(sw * sh / ts / 1e6, 1), "on_gpu": bool(dropin.gpu_decodes() > n0)}
+            import cpu_ref
+            if cpu_ref.have_ref():
+                tr = min(cpu_ref.ref().time_decode(spng, c, 20) for _ in range(3))
+                out["dropin_small_decode"]["reference_MPs"] = round(sw * sh / tr / 1e6, 1)
         except Exception as e:  # (needs g++ for the test shim)
             out["dropin_error"] = str(e)[:80]
         return out

@@ -40,47 +40,76 @@ std::atomic<uint64_t> g_gpu_decodes{0};
 
 using namespace parse;
 
+// Stored blocks (reference src/fpng.cpp:2107-2207): the filtered bytes -- filter 0 on every row -- lie in the blocks' payloads.  The
+// reference walks them a byte at a time; here whole rows are copied.  What it accepts, kept: every block header up to the final
+// block must be sound (type 0, LEN = ~NLEN, payload inside the data) whether or not its bytes are wanted; the rows' filter bytes are
+// 0; the payloads hold the image exactly -- or ONE more byte if it is 0 (read as the filter byte of a row that never comes: the
+// reference looks at a row's first byte before it asks whether there is room); the Adler-32 follows the final block.
+struct StoredBlocks {
+    const uint8_t *z;
+    uint64_t src, avail;
+    uint32_t left = 0; // payload bytes of the current block not taken yet
+    bool final_seen = false, bad = false;
+    // -> bytes copied (fewer than n: the final block is used up, or a header is bad)
+    size_t read(uint8_t *dst, size_t n)
+    {
+        size_t got = 0;
+        while (got < n) {
+            if (!left) {
+                if (final_seen || bad) break;
+                if (src + 1 > avail || ((z[src] >> 1) & 3) != 0 || src + 5 > avail) {
+                    bad = true;
+                    break;
+                }
+                final_seen = z[src] & 1;
+                const uint32_t len = z[src + 1] | (z[src + 2] << 8), nlen = z[src + 3] | (z[src + 4] << 8);
+                src += 5;
+                if (len != (~nlen & 0xFFFFu) || src + len > avail) {
+                    bad = true;
+                    break;
+                }
+                left = len;
+                continue;
+            }
+            const size_t k = n - got < left ? n - got : left;
+            memcpy(dst + got, z + src, k);
+            got += k, src += k, left -= (uint32_t)k;
+        }
+        return got;
+    }
+};
+
 bool inflate_stored(const uint8_t *z, uint32_t avail, uint32_t zlib_len, uint8_t *dst, uint32_t w, uint32_t h, uint32_t src_chans,
                     uint32_t dst_chans)
 {
-    const uint64_t src_bpl = (uint64_t)w * src_chans, dst_len = (uint64_t)w * dst_chans * h;
-    uint64_t src = 2, out = 0, raster = 0;
-    uint32_t comp = 0;
-    for (;;) {
-        if (src + 1 > avail) return false;
-        const bool final_block = z[src] & 1;
-        if (((z[src] >> 1) & 3) != 0) return false;
-        src++;
-        if (src + 4 > avail) return false;
-        const uint32_t len = z[src] | (z[src + 1] << 8), nlen = z[src + 2] | (z[src + 3] << 8);
-        src += 4;
-        if (len != (~nlen & 0xFFFF)) return false;
-        if (src + len > avail) return false;
-        for (uint32_t i = 0; i < len; i++) {
-            const uint8_t c = z[src + i];
-            if (!raster) {
-                if (c != 0) return false; // stored files use filter 0 on every row
-            } else {
-                if (comp < dst_chans) {
-                    if (out == dst_len) return false;
-                    dst[out++] = c;
+    const size_t src_bpl = (size_t)w * src_chans, dst_bpl = (size_t)w * dst_chans;
+    StoredBlocks in = {z, 2, avail};
+    std::vector<uint8_t> tmp(src_chans == dst_chans ? 0 : src_bpl + 4);
+    for (uint32_t y = 0; y < h; y++) {
+        uint8_t f;
+        if (in.read(&f, 1) != 1 || f != 0) return false; // stored files use filter 0 on every row
+        uint8_t *o = dst + (size_t)y * dst_bpl;
+        if (src_chans == dst_chans) {
+            if (in.read(o, src_bpl) != src_bpl) return false;
+        } else {
+            if (in.read(tmp.data(), src_bpl) != src_bpl) return false;
+            const uint8_t *t = tmp.data();
+            if (dst_chans == 4)
+                for (uint32_t x = 0; x < w; x++, t += 3, o += 4) { // (one 32-bit load -- the row buffer has the slack --, one store)
+                    uint32_t v;
+                    memcpy(&v, t, 4);
+                    v |= 0xFF000000u;
+                    memcpy(o, &v, 4);
                 }
-                if (++comp == src_chans) {
-                    if (dst_chans > src_chans) {
-                        if (out == dst_len) return false;
-                        dst[out++] = 0xFF;
-                    }
-                    comp = 0;
-                }
-            }
-            if (++raster == src_bpl + 1) raster = 0;
+            else
+                for (uint32_t x = 0; x < w; x++, t += 4, o += 3) o[0] = t[0], o[1] = t[1], o[2] = t[2];
         }
-        src += len;
-        if (final_block) break;
     }
-    if (comp) return false;
-    if (src + 4 != zlib_len) return false;
-    return out == dst_len;
+    uint8_t extra[2];
+    const size_t more = in.read(extra, 2); // (walks through whatever blocks follow, empty ones included, up to the final one)
+    if (in.bad || !in.final_seen || in.left) return false;
+    if (more > 1 || (more == 1 && extra[0] != 0)) return false;
+    return in.src + 4 == zlib_len;
 }
 
 // The pixel loops' bit reader: like parse::Bits (bytes behind the input read as zero), refilled eight bytes at a time.  After

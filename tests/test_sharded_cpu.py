@@ -68,14 +68,15 @@ def _worker(rank, world, port, seed, n_cases, q, root=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,root", [(2, 0), (3, 0), (3, 1), (2, 1)])
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 0), (3, 1), (2, 1), (8, 0), (8, 5)])
 def test_row_sharded_image_and_batch_gather(world, root):
     """root != 0: the root's own band is not the image's first one, so its window shares its first 16-byte piece with the
     predecessor's window, which arrives from another rank and is received straight into the file buffer."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 77 + world, 60, q, root)) for r in range(world)]
+    # (world 8 = BASELINE config 4's rank count: fewer cases, eight processes on the dev container's cores)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 77 + world, 60 if world < 8 else 24, q, root)) for r in range(world)]
     for p in procs:
         p.start()
     bad, stored, ok_batch = q.get(timeout=300)
@@ -83,7 +84,7 @@ def test_row_sharded_image_and_batch_gather(world, root):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert not bad, bad[:5]
-    assert stored > 3      # the stored-block decision path was exercised too
+    assert stored > (3 if world < 8 else 0)      # the stored-block decision path was exercised too
     assert ok_batch
 
 

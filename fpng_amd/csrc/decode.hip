@@ -58,7 +58,15 @@ struct LdsBits {
     const uint32_t *l;
     __device__ __forceinline__ uint32_t window(uint32_t pos) const
     {
+#if FPNG_DEC_LEAN
+        // (the dword index hidden from the optimiser, which otherwise spreads the "* 4" of the address over both shifts: five vector
+        //  instructions for the slot's byte address instead of shift, shift, add-shift)
+        uint32_t d = pos >> 5;
+        asm("" : "+v"(d));
+        const uint32_t s = d + (d >> 5);
+#else
         const uint32_t s = slice_slot(pos >> 5);
+#endif
         return __builtin_amdgcn_alignbit(l[s + 1], l[s], pos & 31u);
     }
 };

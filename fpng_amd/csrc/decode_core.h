@@ -24,6 +24,13 @@
 namespace fpng_amd {
 namespace dec {
 
+// FPNG_DEC_LEAN = 1: a build variant for the next GPU session (fpng_amd/build.py --variant lean; default 0 = the measured tree): the
+// same walk with fewer vector instructions where tools/isa_loops.py shows them -- the literal mask as a bit-field extract, the row
+// bookkeeping as subtract / add / minimum, the staged bits' slot address as shift + add-shift.  Same results (the CPU emulation runs
+// both: tests/test_decode_model.py).
+#ifndef FPNG_DEC_LEAN
+#define FPNG_DEC_LEAN 0
+#endif
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
@@ -38,6 +45,16 @@ FPNG_DEC_HD uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 #else
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+}
+
+// the low `bits` bits of v (bits <= 24; 0 -> 0)
+FPNG_DEC_HD uint32_t low_bits(uint32_t v, uint32_t bits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, 0u, bits);
+#else
+    return v & ((1u << bits) - 1u);
 #endif
 }
 
@@ -423,6 +440,23 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
     uint32_t rowleft = stride - col; // bytes up to the end of the row, the next one included (== stride: the next byte is a filter byte)
     uint32_t err = 0;
     // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one, or nothing left to do)
+#if FPNG_DEC_LEAN
+    // (the straight-line part keeps rl = rowleft - 1, 0 .. stride - 1: "wrap at the row's end" is then min(t, t + stride) of
+    //  t = rl - bytes taken -- the unsigned difference is huge exactly when the row ended; the match branch below works on rowleft)
+    uint32_t rl = rowleft - 1;
+    auto take = [&](uint32_t wk) -> uint32_t {
+        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
+        const bool m1 = (e & 0x0FFFFFFFu) == (kEntMatch | (uint32_t)C) && (rl + 1) % C == 0 && rl != bpl - 1 && todo >= (uint32_t)C;
+        const uint32_t nl = n < todo ? n : todo, nb = m1 ? (uint32_t)C : nl;
+        const uint32_t lits = low_bits(e, 8 * nl); // (nl = 0: no byte)
+        out.put(m1 ? (C == 4 ? lastpx : lastpx >> 8) : lits, nb);
+        lastpx = funnel(lits, lastpx, m1 ? 0u : 8 * nl);
+        const uint32_t t = rl - nb, t2 = t + stride;
+        rl = t < t2 ? t : t2;
+        todo -= nb;
+        return nb ? L + (m1 ? 1u : 0u) : 0u;
+    };
+#else
     auto take = [&](uint32_t wk) -> uint32_t {
         const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
         const bool m1 = (e & 0x0FFFFFFFu) == (kEntMatch | (uint32_t)C) && rowleft % C == 0 && rowleft != bpl && todo >= (uint32_t)C;
@@ -435,12 +469,16 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
         todo -= nb;
         return nb ? L + (m1 ? 1u : 0u) : 0u;
     };
+#endif
     while (sink.any(todo != 0)) { // (the whole wave stays until its last thread is done: Sink::cooperate() needs them all)
         const uint32_t w = in.window(pos);
         const uint32_t ba = take(w);
         const uint32_t bb = take(w >> ba); // (a first token that was not plain is looked at again, to no effect)
         pos += ba + bb;
         if (todo && !bb) { // the token at pos is not a plain one: a match (or the stream ends, or derails, with bytes still owed)
+#if FPNG_DEC_LEAN
+            rowleft = rl + 1;
+#endif
             // Matches that follow one another repeat the same pixel (no literal in between, and none of them may leave its row):
             // they are written as ONE run -- a flat row of a screenshot is a few dozen maximal matches.
             const uint32_t px = C == 4 ? lastpx : lastpx >> 8;
@@ -483,6 +521,9 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
                 if (!todo || rowleft == stride) break; // (a row ended: a filter literal must follow)
             }
             if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
+#if FPNG_DEC_LEAN
+            rl = rowleft - 1;
+#endif
             if (stop) break;
         }
         sink.cooperate();

@@ -27,29 +27,30 @@ UNDECIDED = 64
 # (workgroup size, lead-in bits, tile bytes): the kernels' own constants first
 CONFIGS = [(512, 128, 18432), (4, 128, 64), (3, 0, 100), (8, 32, 52), (2, 64, 4), (64, 128, 1024)]
 
-_emul = None
+_emul = {}
 
 
-def emul():
-    global _emul
-    if _emul is None:
+def emul(variant=""):
+    """the emulator library; variant "lean": decode_core.h compiled with FPNG_DEC_LEAN=1 (the build variant of the same name)"""
+    if variant not in _emul:
         from fpng_amd import build
         build.build()
         lib_dir = os.path.join(ROOT, "fpng_amd", "lib")
         src = os.path.join(ROOT, "tests", "cpp", "decode_emul.cpp")
-        so = os.path.join(lib_dir, "libfpng_decode_emul.so")
+        so = os.path.join(lib_dir, f"libfpng_decode_emul{'_' + variant if variant else ''}.so")
         deps = [src, os.path.join(ROOT, "fpng_amd", "csrc", "decode_core.h"), os.path.join(lib_dir, "libfpng_amd.so")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"), "-I",
+            defs = ["-DFPNG_DEC_LEAN=1"] if variant == "lean" else []
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + defs + ["-I", os.path.join(ROOT, "include"), "-I",
                                    os.path.join(ROOT, "fpng_amd", "csrc"), src, "-o", so, "-L", lib_dir, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
         L = C.CDLL(so)
         L.fpng_emul_decode.restype = C.c_int
         L.fpng_emul_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 3 + [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
-        _emul = L
-    return _emul
+        _emul[variant] = L
+    return _emul[variant]
 
 
-def emul_decode(png, desired, cfg=CONFIGS[0], border_rounds=1000):
+def emul_decode(png, desired, cfg=CONFIGS[0], border_rounds=1000, variant=""):
     """-> (status, pixels or None, w, h, c, stats)"""
     b = np.frombuffer(bytes(png), dtype=np.uint8)
     w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
@@ -57,7 +58,7 @@ def emul_decode(png, desired, cfg=CONFIGS[0], border_rounds=1000):
     cap = ww * hh * desired + 16 if st == 0 else 16
     out = np.zeros(cap, dtype=np.uint8)
     stats = (C.c_uint32 * 4)()
-    st = emul().fpng_emul_decode(b.ctypes.data, b.size, desired, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), cfg[0], cfg[1], cfg[2], border_rounds, stats)
+    st = emul(variant or os.environ.get("FPNG_EMUL_VARIANT", "")).fpng_emul_decode(b.ctypes.data, b.size, desired, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(c), cfg[0], cfg[1], cfg[2], border_rounds, stats)
     assert st > -1000, f"emulator internal error {st}"
     return st, (out[: w.value * h.value * desired] if st == 0 else None), w.value, h.value, c.value, list(stats)
 
@@ -335,6 +336,33 @@ def test_edited_token_streams_of_megapixel_images():
             seen.add(name)
             accepted += st_r == 0
     assert len(seen) >= 7 and accepted >= 15 and left >= 2, (sorted(seen), accepted, left)
+
+
+def test_the_lean_variant_of_the_walk_gives_the_same_answers():
+    """FPNG_DEC_LEAN=1 (decode_core.h; fpng_amd/build.py --variant lean): the emit walk's straight-line part with fewer vector
+    instructions (tools/isa_loops.py: 92 instead of 102 per two-lookup iteration) -- not the default until a GPU has timed it.
+    Valid files, damaged copies, edited token streams, megapixel files: status and pixels of the default walk, file by file."""
+    import fpng_amd
+    rng = np.random.default_rng(6060)
+    files = []
+    for _ in range(60):
+        img, w, h, c = fuzz_image(rng) if rng.random() < 0.7 else fuzz_image(rng, force_dims=(int(rng.integers(100, 500)), int(rng.integers(3, 14))))
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 2)))
+        files.append(png)
+        files += [_damage(rng, png)[1] for _ in range(4)]
+    files += [f for _, f in edited_files(rng, 25)]
+    for (kind, w, h, c) in (("grad", 1500, 500, 4), ("grad", 1201, 333, 3), ("blocks", 900, 700, 3), ("solid", 2000, 300, 4)):
+        files.append(oracle().encode(fpng_amd.synth_image(kind, w, h, c), w, h, c, c & 1))
+    decided = 0
+    for f in files:
+        cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
+        for desired in (3, 4):
+            a = emul_decode(f, desired, cfg)
+            b = emul_decode(f, desired, cfg, variant="lean")
+            assert a[0] == b[0] and a[2:5] == b[2:5], (a[0], b[0], cfg)
+            assert a[0] != 0 or np.array_equal(a[1], b[1]), cfg
+            decided += a[0] == 0
+    assert decided >= 300
 
 
 # ---- the table's format, pinned by a decoder of a dozen lines ----

@@ -40,7 +40,7 @@ def emul(variant=""):
         so = os.path.join(lib_dir, f"libfpng_decode_emul{'_' + variant if variant else ''}.so")
         deps = [src, os.path.join(ROOT, "fpng_amd", "csrc", "decode_core.h"), os.path.join(lib_dir, "libfpng_amd.so")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            defs = ["-DFPNG_DEC_LEAN=1"] if variant == "lean" else []
+            defs = {"": [], "lean": ["-DFPNG_DEC_LEAN=1"], "stage": ["-DFPNG_DEC_STAGE=1"], "stage_lean": ["-DFPNG_DEC_STAGE=1", "-DFPNG_DEC_LEAN=1"]}[variant]
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + defs + ["-I", os.path.join(ROOT, "include"), "-I",
                                    os.path.join(ROOT, "fpng_amd", "csrc"), src, "-o", so, "-L", lib_dir, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
         L = C.CDLL(so)
@@ -338,10 +338,11 @@ def test_edited_token_streams_of_megapixel_images():
     assert len(seen) >= 7 and accepted >= 15 and left >= 2, (sorted(seen), accepted, left)
 
 
-def test_the_lean_variant_of_the_walk_gives_the_same_answers():
-    """FPNG_DEC_LEAN=1 (decode_core.h; fpng_amd/build.py --variant lean): the emit walk's straight-line part with fewer vector
-    instructions (tools/isa_loops.py: 92 instead of 102 per two-lookup iteration) -- not the default until a GPU has timed it.
-    Valid files, damaged copies, edited token streams, megapixel files: status and pixels of the default walk, file by file."""
+def test_the_variants_of_the_emit_walk_give_the_same_answers():
+    """Build variants of the emit walk that wait for a GPU to time them (decode_core.h; fpng_amd/build.py --variant ...):
+    FPNG_DEC_LEAN=1, the straight-line part with fewer vector instructions (tools/isa_loops.py: 92 instead of 102 per two-lookup
+    iteration); FPNG_DEC_STAGE=1, the 16-byte groups put together in a ring of bytes per thread (LDS) instead of in registers; both.
+    Valid files, damaged copies, edited token streams, megapixel files with long runs: status and pixels of the default walk."""
     import fpng_amd
     rng = np.random.default_rng(6060)
     files = []
@@ -351,16 +352,19 @@ def test_the_lean_variant_of_the_walk_gives_the_same_answers():
         files.append(png)
         files += [_damage(rng, png)[1] for _ in range(4)]
     files += [f for _, f in edited_files(rng, 25)]
-    for (kind, w, h, c) in (("grad", 1500, 500, 4), ("grad", 1201, 333, 3), ("blocks", 900, 700, 3), ("solid", 2000, 300, 4)):
+    for (kind, w, h, c) in (("grad", 1500, 500, 4), ("grad", 1201, 333, 3), ("blocks", 900, 700, 3), ("solid", 2000, 300, 4), ("solid", 1999, 40, 3), ("blocks", 777, 90, 4)):
         files.append(oracle().encode(fpng_amd.synth_image(kind, w, h, c), w, h, c, c & 1))
+    import ui_images
+    files += [oracle().encode(np.ascontiguousarray(g(900, 200, c, seed=3)).reshape(-1), 900, 200, c, 0) for g in (ui_images.glyphs, ui_images.panels) for c in (3, 4)]
     decided = 0
     for f in files:
         cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
         for desired in (3, 4):
             a = emul_decode(f, desired, cfg)
-            b = emul_decode(f, desired, cfg, variant="lean")
-            assert a[0] == b[0] and a[2:5] == b[2:5], (a[0], b[0], cfg)
-            assert a[0] != 0 or np.array_equal(a[1], b[1]), cfg
+            for variant in ("lean", "stage", "stage_lean"):
+                b = emul_decode(f, desired, cfg, variant=variant)
+                assert a[0] == b[0] and a[2:5] == b[2:5], (variant, a[0], b[0], cfg)
+                assert a[0] != 0 or np.array_equal(a[1], b[1]), (variant, cfg)
             decided += a[0] == 0
     assert decided >= 300
 

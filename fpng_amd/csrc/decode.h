@@ -7,7 +7,10 @@ namespace fpng_amd {
 
 constexpr uint32_t kSubBits = 512;      // token bits per subsequence (one thread each)
 constexpr uint32_t kDecSubBlock = 512;  // subsequences per workgroup of the synchronisation (a file's subsequences are padded to whole workgroups)
-constexpr uint32_t kDecLeadIn = 128;    // bits a subsequence's first decode starts early (decode_core.h: sub_first)
+#ifndef FPNG_DEC_LEADIN // (build variants lead96 / lead64: a shorter lead-in is less work for every thread and more threads to correct)
+#define FPNG_DEC_LEADIN 128
+#endif
+constexpr uint32_t kDecLeadIn = FPNG_DEC_LEADIN; // bits a subsequence's first decode starts early (decode_core.h: sub_first); a multiple of 32
 constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_emit_kernel (divides kDecSubBlock)
 #ifndef FPNG_DEC_UNF_ROWS
 #define FPNG_DEC_UNF_ROWS 48

@@ -275,6 +275,12 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
                 // flat content is runs of zero deltas
                 uint32_t px = 0;
                 if (fill > 1) memcpy(&px, o - 4, 4), px = SC == 4 ? px : px >> 8;
+#if defined(__SSE2__)
+                if (!px || SC == 4) { // 16 bytes a store, written in line (a run has 258 bytes at most; the row buffer has 16 bytes of slack)
+                    const __m128i v = _mm_set1_epi32((int)px);
+                    for (uint32_t i = 0; i < run; i += 16) _mm_storeu_si128((__m128i *)(o + i), v);
+                } else {
+#else
                 if (!px) {
                     if (run <= 16)
                         memset(o, 0, 16); // (two inline stores; the row buffer has 16 bytes of slack)
@@ -284,6 +290,7 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
                     const uint64_t p2 = (uint64_t)px << 32 | px;
                     for (uint32_t i = 0; i < run; i += 8) memcpy(o + i, &p2, 8); // (run is a multiple of 4; up to 4 bytes of slack behind the row)
                 } else {
+#endif
                     // 3-byte pixels: 12 bytes = 4 pixels at a time from three rotated words
                     const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
                     const uint32_t w0 = (uint32_t)wrap, w1 = (uint32_t)(wrap >> 8), w2 = (uint32_t)(wrap >> 16);

@@ -235,6 +235,7 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
     const uint8_t *up = zero_row.data();
     uint8_t *out = dst;
     size_t fill = 0; // bytes of the current row that are there (a group of literals may have run over the previous row's end)
+    size_t zero_run_bytes = 0; // ... of which runs of zero deltas (a row that is nothing else repeats the row above: flat content)
     for (uint32_t y = 0; y < h; y++) {
         while (fill < stride) {
             in.refill(); // >= 56 bits: three tokens (a match: 12 + 5 + 1 bits at most)
@@ -279,6 +280,7 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
                 if (!px || SC == 4) { // 16 bytes a store, written in line (a run has 258 bytes at most; the row buffer has 16 bytes of slack)
                     const __m128i v = _mm_set1_epi32((int)px);
                     for (uint32_t i = 0; i < run; i += 16) _mm_storeu_si128((__m128i *)(o + i), v);
+                    zero_run_bytes += (px || fill == 1) ? 0u : run; // (a run at the row's first pixel -- no fpng encoder writes one -- is left out: the test below looks at that pixel itself)
                 } else {
 #else
                 if (!px) {
@@ -304,7 +306,14 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
         if (over && y + 1 == h) return false;
         nb[0] = rb[stride], nb[1] = rb[stride + 1];
         // ---- Up filter undone (row 0: filter 0 = the bytes themselves; `up` is a row of zeros there), channels converted ----
-        unfilter_row<SC, DC>(rb + 1, up, out, w);
+        // (a flat row as fpng's encoders write it: the first pixel as literals -- no match stands there --, the rest runs of zero deltas)
+        uint32_t first_px;
+        memcpy(&first_px, rb + 1, 4);
+        if (y && zero_run_bytes + SC == bpl && !(SC == 4 ? first_px : first_px & 0xFFFFFFu))
+            memcpy(out, up, dst_bpl); // every delta of the row is zero (the reference's own short cut: src/fpng.cpp:2312-2316 copies the row above)
+        else
+            unfilter_row<SC, DC>(rb + 1, up, out, w);
+        zero_run_bytes = 0;
         up = out;
         out += dst_bpl;
         std::swap(rb, nb);

@@ -253,3 +253,32 @@ def test_cpu_decoder_under_the_sanitizers(tmp_path):
     assert q.returncode == 0 and "Sanitizer" not in q.stderr and "runtime error" not in q.stderr, q.stderr[-1500:]
     n, ok = int(q.stdout.split()[0]), int(q.stdout.split()[2])
     assert n == 2 * len(files) and 0.2 * n < ok < 0.9 * n, q.stdout
+
+
+@pytest.mark.skipif(not have_ref(), reason="the reference's decoder is the judge")
+def test_flat_rows_with_a_run_at_the_first_pixel():
+    """The CPU decoder copies the row above where a row is its first pixel of zero literals + runs of zero deltas.  Hand-made rows
+    that LOOK like that by their byte counts: a run of zeros that starts at the first pixel (the reference takes it: the pixel in
+    front of a row is zeros) followed by literal pixels that are not zero -- the short cut must not fire."""
+    import test_decode_model as M
+    import token_mutator as TM
+    for c in (3, 4):
+        w, h = 30, 6
+        img = np.full((h, w, c), 90, dtype=np.uint8)  # flat: every row after the first is [2][zero pixel][runs of zeros]
+        s = TM.Stream(oracle().encode(img.reshape(-1), w, h, c, 0), M.plan)  # (1-pass: the trained table has a code for every symbol)
+        pos = s.positions()
+        rows = [i for i, t in enumerate(s.tokens) if t[0] == "lit" and pos[i] % s.stride == 0]
+        T = list(s.tokens)
+        i = rows[3]  # the fourth row: filter literal, c zero literals, matches
+        assert all(T[i + 1 + k] == ("lit", 0) for k in range(c)) and T[i + 1 + c][0] == "match"
+        run = T[i + 1 + c][1]
+        # the first pixel's literals + the first run -> ONE run from the first pixel on, a pixel shorter; a literal pixel of 7s makes up for it
+        T[i + 1:i + 2 + c] = [("match", run, 0)] + [("lit", 7)] * c
+        f = s.write(T)
+        assert f is not None
+        for desired in (3, 4):
+            st_r, out_r, *_ = ref().decode(f, desired)
+            st_c, out_c, *_ = dropin.decode(f, desired)
+            assert st_r == 0 and st_c == 0 and np.array_equal(out_r, out_c)
+            px = np.asarray(out_c).reshape(h, w, desired)
+            assert (px[3, run // c, :3] == 97).all() and (px[2, :, :3] == 90).all()  # (the literal pixel's deltas arrived)

@@ -146,8 +146,8 @@ struct FastBits {
 };
 
 // ---- one final dynamic block: rows of (filter literal, pixels) ----
-// The rows are decoded as what they are to Deflate -- a stream of BYTES -- into a row buffer, then un-filtered with plain byte adds
-// the compiler vectorises: a lookup yields up to three literals at once (as many whole literal codes as fit the 12 index bits; the
+// The rows are decoded as what they are to Deflate -- a stream of BYTES -- into a row buffer, then un-filtered with packed byte adds
+// (unfilter_row): a lookup yields up to three literals at once (as many whole literal codes as fit the 12 index bits; the
 // GPU decoder's table idea, decode_core.h), stored with one unaligned 32-bit write; a match repeats the previous FILTERED pixel.  The
 // reference's rules, stated on byte positions (col = place in the row, 0 = the filter literal): a length symbol (or the end of the
 // block) may only stand where a pixel starts -- "a pixel is never split by a match" --, a match is whole pixels and ends inside its

@@ -78,17 +78,23 @@ def workload_tag(args):
     return tag
 
 
-def committed_traffic(kernel, tag):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS command (profiles/*_<tag>_pmc_traffic.txt,
-    produced by tools/gpu_profile_round.sh + tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    runs; files without a workload tag are the default 8k command).  PMC counters cannot be collected from inside the timed
-    process."""
-    import glob
+def _pmc_summaries(tag):
+    """profiles/rNN[x]_<tag>_pmc_traffic.txt, newest first -- the WHOLE basename is matched: `8k` must not pick up
+    `decode_8k` (round 4's driver line read the decoder's file for the encode chain and printed a rate above the HBM peak).
+    Round 1-2 files without a workload tag (rNN_x_pmc_traffic.txt) are the default 8k command."""
     import re
-    paths = glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}_pmc_traffic.txt"))
-    if tag == "8k":
-        paths += [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")) if re.fullmatch(r"r\d\d_[a-z]_pmc_traffic\.txt", os.path.basename(p))]
-    for path in sorted(paths, key=os.path.basename, reverse=True):
+    pat = re.compile(r"r\d\d[a-z]?_" + re.escape(tag) + r"_pmc_traffic\.txt")
+    old = re.compile(r"r\d\d_[a-z]_pmc_traffic\.txt")
+    d = os.path.join(ROOT, "profiles")
+    names = [n for n in (os.listdir(d) if os.path.isdir(d) else []) if pat.fullmatch(n) or (tag == "8k" and old.fullmatch(n))]
+    return [os.path.join(d, n) for n in sorted(names, reverse=True)]
+
+
+def committed_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS command (profiles/rNN_<tag>_pmc_traffic.txt,
+    produced by tools/gpu_profile_round.sh + tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs).  PMC counters cannot be collected from inside the timed process."""
+    for path in _pmc_summaries(tag):
         for line in open(path):
             f = line.split()
             if len(f) == 5 and f[0] == kernel:
@@ -100,13 +106,34 @@ def committed_traffic(kernel, tag):
 
 def committed_chain_traffic(tag):
     """HBM-side bytes of ALL kernels of one step, from the same committed PMC summary ("total HBM-side traffic per launch")."""
-    import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}_pmc_traffic.txt")), key=os.path.basename, reverse=True):
+    for path in _pmc_summaries(tag):
         m = re.search(r"total HBM-side traffic per launch:\s*([0-9.]+) MB", open(path).read())
         if m:
             return int(float(m.group(1)) * 1e6)
     return None
+
+
+def scope_name(world):
+    return "one GPU" if world == 1 else f"whole job, {world} GPUs"
+
+
+def check_rates(obj, path="line", errors=None):
+    """No rate this script prints may exceed the HBM peak of the GPUs it ran on: such a number is a reporting bug.  The field is
+    set to None and named in the returned list (the line then carries `reporting_errors`; tests/test_abi.py holds the rule)."""
+    errors = [] if errors is None else errors
+    if isinstance(obj, dict):
+        peak = obj.get("peak", HBM_PEAK_GBS) if obj.get("unit") == "GB/s" else HBM_PEAK_GBS
+        for k, v in list(obj.items()):
+            if isinstance(v, (dict, list)):
+                check_rates(v, f"{path}.{k}", errors)
+            elif isinstance(v, (int, float)) and (k == "achieved" or k.endswith("_GBs")) and obj.get("bound", "hbm") == "hbm" and v > peak:
+                errors.append(f"{path}.{k} = {v} GB/s is above the HBM peak ({peak} GB/s)")
+                obj[k] = None
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            check_rates(v, f"{path}[{i}]", errors)
+    return errors
 
 
 def verify_outputs(args, rank, w, h, c, outs, sizes):
@@ -367,7 +394,7 @@ def decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, 
     kernels_ms = sum(ph.values())
     value = world * B * w * h * K / elapsed / 1e6
     traffic, traffic_src = committed_traffic(f"dec_{dom}_kernel", "decode_" + workload_tag(args))
-    out = {"metric": "decode megapixels/sec (whole node), device-resident files -> device-resident pixels", "value": round(value, 1), "unit": "MP/s",
+    out = {"metric": f"decode megapixels/sec ({scope_name(world)}), device-resident files -> device-resident pixels", "value": round(value, 1), "unit": "MP/s",
            "steps": K, "ms_per_step": round(elapsed / K * 1e3, 4), "runs": [round(world * B * w * h * K / r / 1e6, 1) for r in runs],
            "parity_checked": True, "parity_images": B, "png_bytes_per_step_per_gpu": png_bytes,
            "roofline": {"bound": "hbm", "kernel": f"dec_{dom}_kernel", "achieved": round(alg / (ph[dom] / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -487,7 +514,7 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
         png_bytes = int(png.numel())
         alg = w * h * c + png_bytes
         _RESULT.append(json.dumps({
-            "metric": f"encode megapixels/sec (whole node), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
+            "metric": f"encode megapixels/sec ({scope_name(world)}), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident", "value": round(w * h * args.steps / elapsed / 1e6, 1),
             "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "prewarm": 0, "parity_checked": parity,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -623,7 +650,7 @@ def main():
         roofline["chain_traffic_rate_GBs"] = round(chain / (elapsed / args.steps) / 1e9, 1)
 
     line = {
-        "metric": f"encode megapixels/sec (whole node), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident",
+        "metric": f"encode megapixels/sec ({scope_name(world)}), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident",
         "value": round(value, 1), "unit": "MP/s", "value_MiPs": round(value * 1e6 / 2 ** 20, 1), "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "prewarm": args.prewarm, "parity_checked": bool(parity_checked) if parity_checked is not None else None,
         "parity_images": parity_checked, "runs": run_values,
@@ -666,6 +693,10 @@ def main():
         line["cpu_baseline"] = cpu_baseline(w, h, c, args.kind, args.flags, args.cpu_reps)
         line["speedup_vs_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 1)
     if rank == 0:
+        errs = check_rates(line)
+        if errs:
+            line["reporting_errors"] = errs
+            print("bench.py: " + "; ".join(errs), file=sys.stderr)
         _RESULT.append(json.dumps(line))
     enc.close()
     if distributed:

@@ -167,3 +167,25 @@ def test_container_from_band_crcs(built_lib):
                 begin = e
             crc = fpng_amd.idat_crc_from_bands(raw, ends, zlib_size, adler)
             assert fpng_amd.png_tail(adler, crc) == png[58 + zlib_size - 4:]
+
+
+def test_bench_reads_its_own_pmc_summary_and_prints_no_rate_above_the_peak():
+    """Round 4's driver line carried chain_traffic_rate_GBs = 13 244 GB/s: bench.py's glob for the encode command's PMC summary
+    (`*_8k_pmc_traffic.txt`) also matched the decoder's (`r04_decode_8k_pmc_traffic.txt`).  The finder matches whole basenames
+    now, and no HBM rate above the peak leaves the script."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    enc_files = [os.path.basename(p) for p in bench._pmc_summaries("8k")]
+    dec_files = [os.path.basename(p) for p in bench._pmc_summaries("decode_8k")]
+    assert enc_files and dec_files and not set(enc_files) & set(dec_files)
+    assert all("decode" not in n and "2pass" not in n and "noise" not in n for n in enc_files)
+    assert all(n.split("_", 1)[1].startswith("decode_8k_") for n in dec_files)
+    chain = bench.committed_chain_traffic("8k")
+    alg = 8 * 7680 * 4320 * 4 + 464_000_000
+    assert alg < chain < 2.5 * alg  # the encode chain's, not the decoder's 6.3 GB
+    line = {"roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": 4300.0, "chain_traffic_rate_GBs": 13244.0},
+            "decode": {"roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": 1600.0}}}
+    errs = bench.check_rates(line)
+    assert len(errs) == 1 and "chain_traffic_rate_GBs" in errs[0] and line["roofline"]["chain_traffic_rate_GBs"] is None
+    assert line["roofline"]["achieved"] == 4300.0 and bench.scope_name(1) == "one GPU"

@@ -49,6 +49,13 @@ def build_variant(name, defines, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if name in DROPIN_VARIANTS:  # options of png_parse.h / fpng_decode.cpp: the `namespace fpng` library is built against the variant too
+        dropin = os.path.join(LIB_DIR, f"libfpng_{name}.so")
+        cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + [f"-D{d}" for d in defines] + [
+            os.path.join(CSRC, "fpng_dropin.cpp"), os.path.join(CSRC, "fpng_decode.cpp"), "-o", dropin, "-L", LIB_DIR, f"-lfpng_amd_{name}", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return out
 
 
@@ -88,7 +95,9 @@ def build(force=False, verbose=False):
     return LIB
 
 
-VARIANTS = {"lead96": ["FPNG_DEC_LEADIN=96"], "lead64": ["FPNG_DEC_LEADIN=64"], "lean": ["FPNG_DEC_LEAN=1"], "stage": ["FPNG_DEC_STAGE=1"], "stage_lean": ["FPNG_DEC_STAGE=1", "FPNG_DEC_LEAN=1"], "timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"], "rows8": ["FPNG_ROW_WAVES=8"], "rows2": ["FPNG_ROW_WAVES=2"],
+DROPIN_VARIANTS = {"nocrc"}
+VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's fuzzing switch (src/fpng.cpp:50-53): libfpng_amd_nocrc.so + libfpng_nocrc.so
+            "lead96": ["FPNG_DEC_LEADIN=96"], "lead64": ["FPNG_DEC_LEADIN=64"], "lean": ["FPNG_DEC_LEAN=1"], "stage": ["FPNG_DEC_STAGE=1"], "stage_lean": ["FPNG_DEC_STAGE=1", "FPNG_DEC_LEAN=1"], "timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"], "rows8": ["FPNG_ROW_WAVES=8"], "rows2": ["FPNG_ROW_WAVES=2"],
             "emit_nostore": ["FPNG_DEC_EMIT_NOSTORE"], "emit_nt": ["FPNG_DEC_EMIT_NT"], "unf16": ["FPNG_DEC_UNF_ROWS=16"], "unf64": ["FPNG_DEC_UNF_ROWS=64"], "unf32": ["FPNG_DEC_UNF_ROWS=32"], "unf_w4": ["FPNG_DEC_UNF_WAVES=4"], "unf_w5": ["FPNG_DEC_UNF_WAVES=5"], "unf64_w4": ["FPNG_DEC_UNF_ROWS=64", "FPNG_DEC_UNF_WAVES=4"], "unf64_w5": ["FPNG_DEC_UNF_ROWS=64", "FPNG_DEC_UNF_WAVES=5"], "emit_l2store": ["FPNG_DEC_EMIT_L2STORE"],
             "dec_np": ["FPNG_DEC_PERSISTENT=0"], "dec_np6": ["FPNG_DEC_PERSISTENT=0", "FPNG_DEC_WGS=6"], "dec_npnv": ["FPNG_DEC_PERSISTENT=0", "FPNG_DEC_VOTE=0"],
             "dec_p6": ["FPNG_DEC_WGS=6"], "dec_nv": ["FPNG_DEC_VOTE=0"],

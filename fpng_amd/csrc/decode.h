@@ -113,7 +113,8 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
 // ONE file (jobs[0], a DEVICE pointer whose sub_base the caller knows: passed as first_block of the other launchers), blocks [blk_a, blk_b)
 void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_base_block, uint32_t blk_a, uint32_t blk_b, bool final_piece, uint32_t total_subs, DecSubArrays a,
                               const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry);
-void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch);
+// concurrent_status: kernels that may set the file's status bits run next to this launch (no workgroup may then skip its file: dec_unfilter_kernel)
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status);
 void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
                      const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored);

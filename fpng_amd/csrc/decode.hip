@@ -761,7 +761,7 @@ __device__ __forceinline__ void gstore_u8(gu8 *base, uint32_t off, uint32_t v) {
 #ifndef FPNG_DEC_UNF_WAVES
 #define FPNG_DEC_UNF_WAVES 4
 #endif
-__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch)
+__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
 {
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
@@ -796,8 +796,11 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
         job.segsum = (uint32_t *)uni64((uint64_t)(uintptr_t)job.segsum);
         job.w = uni32(job.w), job.h = uni32(job.h), job.bpl = uni32(job.bpl), job.src_c = uni32(job.src_c), job.dst_c = uni32(job.dst_c), job.nseg = uni32(job.nseg), job.mode = uni32(job.mode);
         // (only bits that the kernels in FRONT of this one set decide: every workgroup must come to the same conclusion about a
-        //  file, or a later segment would wait for an earlier one that was skipped -- the checks below have bits of their own)
-        if (job.mode != 0 || (status[ji] & (kDecNotConverged | kDecBadStream))) return;
+        //  file, or a later segment would wait for an earlier one that was skipped -- the checks below have bits of their own.
+        //  skip_mask = those bits; 0 where kernels that set them run NEXT to this launch -- the streamed form undoes a piece's rows
+        //  on a stream of its own while the next piece is decoded: there every workgroup runs and publishes, whatever the status
+        //  word says by then; a damaged file's rows are garbage either way and its status says so)
+        if (job.mode != 0 || (status[ji] & skip_mask)) return;
         const uint32_t ncol = (job.bpl + 3) / 4;
         const uint32_t sc = job.src_c, dc = job.dst_c, lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
         // Which dword column is this thread's?  Normally workgroup-thread t has column cb * 256 + t.  Where 3-channel rows become
@@ -1118,13 +1121,13 @@ void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint3
 }
 // jobs / status: of the group's first file; plan: device arrays (decode_api.cpp); epoch: this launch's (a new one every time; the
 // granules are never cleared)
-void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch)
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status)
 {
-    if (n_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, item0, status, epoch);
+    if (n_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, item0, status, epoch, concurrent_status ? 0u : (kDecNotConverged | kDecBadStream));
 }
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored)
 {
-    if (plan.total_items) launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch);
+    if (plan.total_items) launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch, false);
     if (!any_stored) return; // (a workgroup that finds its file is not a stored one leaves at once, but n_jobs x 512 of them is not free)
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) // (the y dimension of a grid holds at most 65535 workgroups)
         hipLaunchKernelGGL(dec_stored_kernel, dim3(512, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0, status + j0);

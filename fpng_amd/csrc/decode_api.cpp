@@ -106,8 +106,8 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
 // length code lengths, p.first_bit = the first row token).  z / avail: the stream's bytes in host memory, `complete`: all of them
 // (else only a head of the file: fpng::parse::kParseNeedMore asks for the rest).  Returns the reference's status code (0 or
 // FPNG_DECODE_NOT_FPNG) or FPNG_AMD_DECODE_UNDECIDED (a stored layout only the CPU decoder takes).
-// (memo: the last dynamic header read INTO `table` -- the files of a 1-pass batch all begin with the same one, and reading it
-//  means building two 4096-entry tables, 4 us a file; a header that is bit for bit the memo's is not read again)
+// (memo: the last dynamic header read -- the files of a 1-pass batch all begin with the same one, and reading it costs 4 us a
+//  file; a header that is bit for bit the memo's is not read again.  `table` may be nullptr: the code is then only checked)
 struct HeaderMemo {
     uint32_t bits = 0, chans = 0; // bits: the header's end = the first row token, from the stream's first byte (0: no memo)
     uint8_t bytes[320];
@@ -146,7 +146,7 @@ int plan_stream(const uint8_t *z, uint32_t avail, bool complete, Parsed &p, uint
         std::memcpy(sizes, memo->sizes, 288);
         p.first_bit = memo->bits;
     } else {
-        if (memo) memo->bits = 0; // (`table` is about to change)
+        if (memo) memo->bits = 0;
         const bool ok = read_dynamic_header(in, p.c, table, sizes);
         if (!complete && in.byte + 8 > avail) return kParseNeedMore; // (the header reader may have run off the head)
         if (!ok) return fpng::FPNG_DECODE_NOT_FPNG;
@@ -175,6 +175,14 @@ int parse_host(const uint8_t *png, uint32_t size, Parsed &p, uint32_t *table, ui
     return plan_stream(png + p.idat_ofs + 8, size - (p.idat_ofs + 8), true, p, table, sizes, memo);
 }
 
+// A new epoch for dec_unfilter_kernel's look-back granules (never cleared: the epoch tells launches apart).  0 is skipped: it is the
+// tag of granules that were zeroed and never written.
+uint32_t next_epoch(fpng_amd_encoder *e)
+{
+    if (!(++e->dec_epoch & 0x3FFFFFFFu)) ++e->dec_epoch;
+    return e->dec_epoch & 0x3FFFFFFFu;
+}
+
 int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uint32_t desired, fpng_amd_decode_result *results, bool device_data)
 {
     if (!e || !files || !n || !results) return fail(FPNG_AMD_ERR_INVALID_ARG, "null/empty batch");
@@ -192,6 +200,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     static const bool trace_t = getenv("FPNG_AMD_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::memset(results, 0, (size_t)n * sizeof *results); // (every entry is defined on every way out)
     std::vector<Parsed> ps(n);
     std::vector<uint8_t> lut_keys;                // the code lengths (288 each) of the unique lookup tables (1-pass files share two): ONE upload,
                                                   // the tables themselves are built on the GPU (dec_build_lut_kernel)
@@ -250,8 +259,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             r.status = fpng::FPNG_DECODE_FAILED_DIMENSIONS_TOO_LARGE;
             continue;
         }
-        if (!files[i].d_pixels || files[i].pixels_cap < need) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "d_pixels / pixels_cap < w * h * desired_chans");
         if (st) continue; // (reference :3131-3136: any stream problem is NOT_FPNG; or left to the CPU decoder)
+        if (!files[i].d_pixels || files[i].pixels_cap < need) return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "d_pixels / pixels_cap < w * h * desired_chans"); // (only files that will be written need room)
         if (!p.mode) {
             if (!max_rounds) {
                 r.status = FPNG_AMD_DECODE_UNDECIDED;
@@ -476,7 +485,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if ((pe = stamp(g, 3)) != hipSuccess) return pe;
         bool any_stored = false;
         for (uint32_t k = g.j0; k < g.j1; k++) any_stored |= jobs[k].mode != 0;
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, ++e->dec_epoch & 0x3FFFFFFFu, any_stored);
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, next_epoch(e), any_stored);
         if ((pe = stamp(g, 4)) != hipSuccess) return pe;
         if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
@@ -670,7 +679,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     HIP_TRY(hipMemcpyAsync(d_job, &j, sizeof j, hipMemcpyHostToDevice, s));
     DecUnfPlan plan;
     plan.pieces = d_piece, plan.cbpre = d_words, plan.order = d_words + 2, plan.n_pieces = 1, plan.total_items = j.nseg * (uint32_t)col_blocks;
-    const uint32_t epoch = ++e->dec_epoch & 0x3FFFFFFFu; // (one epoch for all of this file's unfilter launches: later segments look back at earlier launches' sums)
+    const uint32_t epoch = next_epoch(e); // (one epoch for all of this file's unfilter launches: later segments look back at earlier launches' sums)
     // ---- pieces: whole blocks of subsequences; a piece's kernels read up to 64 bytes behind its last block (a token's window, the pad) ----
     constexpr uint32_t kMaxPieces = 16;
     // (a piece costs ~100 us of launches and a host round trip: pieces of 6 MiB, but at least four of them -- measured on one box,
@@ -793,7 +802,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             if (q + 1 == np) segs = j.nseg, rows = p.h;
             else rows = segs * kDecUnfRows;
             if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s_unf, ev_carry[q], 0)); // (piece q's rows are in the filtered stream; the small words went up in front of piece 0)
-            if (segs > segs_done) launch_dec_unfilter(s_unf, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch);
+            if (segs > segs_done) launch_dec_unfilter(s_unf, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch, s_unf != s);
             segs_done = std::max(segs_done, segs);
             HIP_TRY(hipEventRecord(ev_rows[q], s_unf));
             {

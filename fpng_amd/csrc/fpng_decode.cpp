@@ -276,23 +276,30 @@ template <int SC, int DC> bool inflate_rows(const FastBits &in_, const uint32_t 
                 // flat content is runs of zero deltas
                 uint32_t px = 0;
                 if (fill > 1) memcpy(&px, o - 4, 4), px = SC == 4 ? px : px >> 8;
+                // (zero deltas, counted for the flat-row short cut below; a run at the row's first pixel -- no fpng encoder writes
+                //  one -- is left out: the test below looks at that pixel itself)
+                zero_run_bytes += (px || fill == 1) ? 0u : run;
+                bool filled = false;
 #if defined(__SSE2__)
                 if (!px || SC == 4) { // 16 bytes a store, written in line (a run has 258 bytes at most; the row buffer has 16 bytes of slack)
                     const __m128i v = _mm_set1_epi32((int)px);
                     for (uint32_t i = 0; i < run; i += 16) _mm_storeu_si128((__m128i *)(o + i), v);
-                    zero_run_bytes += (px || fill == 1) ? 0u : run; // (a run at the row's first pixel -- no fpng encoder writes one -- is left out: the test below looks at that pixel itself)
-                } else {
+                    filled = true;
+                }
 #else
                 if (!px) {
                     if (run <= 16)
                         memset(o, 0, 16); // (two inline stores; the row buffer has 16 bytes of slack)
                     else
                         memset(o, 0, run);
+                    filled = true;
                 } else if (SC == 4) {
                     const uint64_t p2 = (uint64_t)px << 32 | px;
                     for (uint32_t i = 0; i < run; i += 8) memcpy(o + i, &p2, 8); // (run is a multiple of 4; up to 4 bytes of slack behind the row)
-                } else {
+                    filled = true;
+                }
 #endif
+                if (!filled) {
                     // 3-byte pixels: 12 bytes = 4 pixels at a time from three rotated words
                     const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
                     const uint32_t w0 = (uint32_t)wrap, w1 = (uint32_t)(wrap >> 8), w2 = (uint32_t)(wrap >> 16);
@@ -367,9 +374,11 @@ int fpng_get_info(const void *pImage, uint32_t image_size, uint32_t &width, uint
 int fpng_decode_memory(const void *pImage, uint32_t image_size, std::vector<uint8_t> &out, uint32_t &width, uint32_t &height,
                        uint32_t &channels_in_file, uint32_t desired_channels)
 {
-    // (the reference empties `out` first and sizes it later, reference src/fpng.cpp:3087-3105: a vector reused from call to call
-    // is zero-filled every time.  Here it is emptied on the ways out that fail and otherwise resized once, so that a reused
-    // vector of the right size is only written by the pixels.)
+    // The reference empties `out` first and sizes it to width * height * desired_channels once the container is accepted
+    // (src/fpng.cpp:3087-3111): a call that fails before that point leaves an empty vector, one that fails in the stream
+    // (FPNG_DECODE_NOT_FPNG from the inflater, :3131-3136) leaves a vector of the image's size whose contents are unspecified.
+    // The same sizes leave here on every exit (tests/test_dropin_decode.py::test_vector_size_on_every_exit); what is not
+    // repeated is the zero fill of a reused vector on every call (resize(0) + resize(n) writes n zeros: 133 MB for an 8K frame).
     width = height = channels_in_file = 0;
     if (!pImage || !image_size || (desired_channels != 3 && desired_channels != 4)) {
         out.resize(0);
@@ -405,11 +414,10 @@ int fpng_decode_memory(const void *pImage, uint32_t image_size, std::vector<uint
                                                 },
                                                 &out, &r);
             if (rc == FPNG_AMD_OK && r.status != FPNG_AMD_DECODE_UNDECIDED) {
-                if (r.status) out.resize(0);
+                out.resize((size_t)need); // (a stream that fails leaves the sized vector, like the reference)
                 g_gpu_decodes.fetch_add(1, std::memory_order_relaxed);
                 return r.status;
             }
-            out.resize(0);
         }
     }
     out.resize((size_t)need);
@@ -417,8 +425,7 @@ int fpng_decode_memory(const void *pImage, uint32_t image_size, std::vector<uint
     const uint32_t avail = image_size - (idat_ofs + 8);
     // a 4-channel file whose alpha deltas are dropped still needs them for the run logic: handled inside
     if (!inflate_pixels(z, avail, idat_len, out.data(), width, height, channels_in_file, desired_channels)) {
-        out.resize(0); // (the reference leaves whatever was decoded so far; callers must not look at it)
-        return FPNG_DECODE_NOT_FPNG;
+        return FPNG_DECODE_NOT_FPNG; // (`out` keeps the image's size, its contents are whatever was decoded so far: src/fpng.cpp:3131-3136)
     }
     return FPNG_DECODE_SUCCESS;
 }

@@ -10,6 +10,13 @@
 
 #include <string.h>
 
+// Set to 1 to skip the CRC-32 test of the chunks behind IHDR, for decoder fuzzing (zzuf and friends would otherwise be stopped
+// by the first chunk CRC): the reference's compile-time switch of the same name, src/fpng.cpp:10, :50-53, used at :3016-3023
+// (IHDR's own CRC is still checked there, :2960, and here).  Build both libraries with it: python -m fpng_amd.build --variant nocrc.
+#ifndef FPNG_DISABLE_DECODE_CRC32_CHECKS
+#define FPNG_DISABLE_DECODE_CRC32_CHECKS (0)
+#endif
+
 namespace fpng {
 namespace parse {
 
@@ -76,7 +83,9 @@ inline int parse_container_view(const View &v, uint32_t &w, uint32_t &h, uint32_
         if (!is_idat) { // (the reference skips the CRC of the IDAT as well: src/fpng.cpp:3016-3026)
             ck = v.at(ofs, 8 + (size_t)len + 4);
             if (!ck) return kParseNeedMore;
+#if !FPNG_DISABLE_DECODE_CRC32_CHECKS
             if (fpng_amd_crc32(ck + 4, 4 + len, 0) != be32(ck + 8 + len)) return FPNG_DECODE_FAILED_HEADER_CRC32;
+#endif
         }
         const uint8_t *data = ck + 8;
         if (memcmp(ck + 4, "IEND", 4) == 0) break;

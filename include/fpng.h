@@ -11,8 +11,11 @@
 //   * fpng_cpu_supports_sse41() answers "is the accelerator usable";
 //   * if no GPU is usable the encode functions return false (there is no silent CPU path); the decode functions then use
 //     their CPU decoder for every image;
-//   * fpng_decode_memory() empties `out` only on the ways out that fail: a vector reused from call to call is not zero-filled
-//     again (the reference resizes it to 0 and back on every call).
+//   * fpng_decode_memory() leaves `out` with the reference's size() on every exit (empty after a container-level failure, width *
+//     height * desired_channels after success or a failure inside the stream: src/fpng.cpp:3087-3136), but a vector reused from call
+//     to call is not zero-filled again (the reference resizes it to 0 and back on every call);
+//   * FPNG_DISABLE_DECODE_CRC32_CHECKS (src/fpng.cpp:50-53) is honoured when the libraries are built with it
+//     (python -m fpng_amd.build --variant nocrc -> libfpng_nocrc.so + libfpng_amd_nocrc.so).
 #pragma once
 
 #include <stdint.h>

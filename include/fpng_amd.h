@@ -366,9 +366,12 @@ int fpng_amd_decode_batch(fpng_amd_encoder *enc, const fpng_amd_png *files, uint
 int fpng_amd_decode_batch_device(fpng_amd_encoder *enc, const fpng_amd_png *files, uint32_t n, uint32_t desired_chans,
                                  fpng_amd_decode_result *results);
 /* One HOST-resident file to HOST pixels (reference src/fpng.h:108 fpng_decode_memory; the fpng:: drop-in routes images of
- * 256K pixels and more through it): container checks, upload, GPU decode, one download into memory obtained from `reserve`
- * (called at most once, with w * h * desired_chans, only when the file decodes).  result->status as in fpng_amd_decode_batch():
- * FPNG_AMD_DECODE_UNDECIDED = decode it on the CPU. */
+ * 256K pixels and more through it): container checks, upload, GPU decode, download into memory obtained from `reserve`.
+ * `reserve` is called with w * h * desired_chans once the container and the block header are accepted -- BEFORE the stream is known
+ * to decode when the file is streamed (8 MiB of IDAT and more: rows go down while later pieces come up), and possibly a second
+ * time with the same size when such a file needs more synchronisation rounds; it must return the same or equally good memory
+ * every time.  When result->status is not 0 the memory's contents are undefined (rows decoded before the damage may be there).
+ * result->status as in fpng_amd_decode_batch(): FPNG_AMD_DECODE_UNDECIDED = decode it on the CPU. */
 int fpng_amd_decode_host(fpng_amd_encoder *enc, const void *png, uint32_t size, uint32_t desired_chans, fpng_amd_reserve_fn reserve,
                          void *user, fpng_amd_decode_result *result);
 /* What fpng_amd_decode_batch() settles on the HOST about one file before the GPU sees it (no GPU needed; tests/ run the decode

@@ -48,6 +48,16 @@ int ref_decode(const void *png, uint32_t size, uint8_t *out, size_t out_cap, uin
     return st;
 }
 
+// size() of a vector that held `prefill` bytes before the call, after fpng_decode_memory() returned *status (what a caller who
+// reuses one vector observes on every exit: src/fpng.cpp:3087 empties it, :3111 sizes it)
+size_t ref_decode_vector_size(const void *png, uint32_t size, uint32_t desired, size_t prefill, int *status)
+{
+    std::vector<uint8_t> v(prefill, 0xAB);
+    uint32_t w, h, c;
+    *status = fpng::fpng_decode_memory(png, size, v, w, h, c, desired);
+    return v.size();
+}
+
 // Timed loop for the decoder's CPU baseline: `reps` decodes of the same file into one reused vector (as
 // src/fpng_test.cpp:1236-1273 does), returns best seconds per decode (negative: the decoder's status code).
 double ref_time_decode(const void *png, uint32_t size, uint32_t desired, int reps)

@@ -48,6 +48,14 @@ int shim_decode(const void *png, uint32_t size, uint8_t *out, size_t cap, uint32
     }
     return st;
 }
+// size() of a vector that held `prefill` bytes before the call, after fpng_decode_memory() returned *status
+size_t shim_decode_vector_size(const void *png, uint32_t size, uint32_t desired, size_t prefill, int *status)
+{
+    std::vector<uint8_t> v(prefill, 0xAB);
+    uint32_t w, h, c;
+    *status = fpng::fpng_decode_memory(png, size, v, w, h, c, desired);
+    return v.size();
+}
 // best seconds per fpng::fpng_decode_memory() call into one reused std::vector (like shim_time_encode)
 double shim_time_decode(const void *png, uint32_t size, uint32_t desired, int reps)
 {

@@ -282,3 +282,117 @@ def test_flat_rows_with_a_run_at_the_first_pixel():
             assert st_r == 0 and st_c == 0 and np.array_equal(out_r, out_c)
             px = np.asarray(out_c).reshape(h, w, desired)
             assert (px[3, run // c, :3] == 97).all() and (px[2, :, :3] == 90).all()  # (the literal pixel's deltas arrived)
+
+
+def _vector_size_fn(lib, name):
+    import ctypes as C
+    f = getattr(lib, name)
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(C.c_int)]
+
+    def call(png, desired, prefill):
+        b = np.frombuffer(bytes(png), dtype=np.uint8)
+        st = C.c_int(0)
+        n = f(b.ctypes.data if b.size else None, b.size, desired, prefill, C.byref(st))
+        return st.value, n
+    return call
+
+
+@pytest.mark.skipif(not have_ref(), reason="the reference's decoder is the judge")
+def test_vector_size_on_every_exit():
+    """fpng_decode_memory empties `out` on entry and sizes it once the container is accepted (src/fpng.cpp:3087-3111): a caller who
+    reuses one vector sees size 0 after a container-level failure and width*height*desired after a failure inside the stream.
+    Same sizes out of the drop-in on every exit: bad arguments, every container status, stream failures, success."""
+    import container_mutator as CM
+    mine = _vector_size_fn(dropin.shim(), "shim_decode_vector_size")
+    theirs = _vector_size_fn(ref().L, "ref_decode_vector_size")
+    rng = np.random.default_rng(909)
+    files = [b"", b"x", b"\x89PNG\r\n\x1a\n" + bytes(60)]
+    for _ in range(60):
+        img, w, h, c = fuzz_image(rng)
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 3)))
+        files.append(png)
+        files.append(png[: int(rng.integers(1, len(png)))])
+        for _ in range(4):
+            bad = bytearray(png)
+            bad[int(rng.integers(58, len(bad) - 16))] ^= 1 << int(rng.integers(0, 8))  # the stream: no CRC guards it
+            files.append(bytes(bad))
+        for _ in range(6):
+            files.append(CM.mutate(png, rng)[1])
+    seen = {}
+    for f in files:
+        for desired in (3, 4, 5):
+            if not f and desired != 5:
+                continue
+            for prefill in (0, 1000):
+                a, b = theirs(f, desired, prefill), mine(f, desired, prefill)
+                assert a == b, (len(f), desired, prefill, a, b)
+                seen[(a[0], a[1] > 0)] = seen.get((a[0], a[1] > 0), 0) + 1
+    # success, stream failure with a sized vector, container failures with an empty one
+    assert seen.get((0, True), 0) > 50 and seen.get((1, True), 0) > 50 and sum(v for (st, sized), v in seen.items() if st > 1 and not sized) > 50, seen
+    assert not any(sized for (st, sized) in seen if st > 1), seen
+
+
+@pytest.mark.skipif(not have_ref() or not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libfpng_ref_nocrc.so")),
+                    reason="the reference built with FPNG_DISABLE_DECODE_CRC32_CHECKS=1 is the judge")
+def test_disable_decode_crc32_checks_build():
+    """FPNG_DISABLE_DECODE_CRC32_CHECKS (src/fpng.cpp:10, :50-53, :3016-3023): the reference's compile-time switch for fuzzing
+    skips the CRC-32 of every chunk behind IHDR (IHDR's own is still checked, :2960).  fpng_amd/csrc/png_parse.h carries the
+    same switch; the drop-in's decoder built with it against the reference built with it, on files whose chunk CRCs are wrong:
+    same status, same geometry, same pixels -- and the default builds still reject those files."""
+    import ctypes as C
+    import subprocess
+    import container_mutator as CM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "fpng_amd", "lib")
+    dropin.shim()  # (builds the product libraries)
+    so = os.path.join(lib_dir, "libfpng_test_nocrc.so")
+    srcs = [os.path.join(root, "fpng_amd", "csrc", n) for n in ("fpng_dropin.cpp", "fpng_decode.cpp")] + [os.path.join(root, "tests", "cpp", "dropin_shim.cpp")]
+    deps = srcs + [os.path.join(root, "fpng_amd", "csrc", "png_parse.h"), os.path.join(lib_dir, "libfpng_amd.so")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        # the CPU decoder + container walk with the switch on (in a process with a GPU, `python -m fpng_amd.build --variant nocrc`
+        # builds libfpng_amd_nocrc.so + libfpng_nocrc.so so that the GPU tier's host side skips the CRCs as well)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DFPNG_DISABLE_DECODE_CRC32_CHECKS=1", "-I", os.path.join(root, "include"),
+                               "-I", os.path.join(root, "fpng_amd", "csrc")] + srcs + ["-o", so, "-L", lib_dir, "-lfpng_amd", "-pthread", "-Wl,-rpath,$ORIGIN"])
+    mine = C.CDLL(so)
+    theirs = C.CDLL(os.path.join(root, "oracle", "_ref", "libfpng_ref_nocrc.so"))
+    theirs.ref_init()
+
+    def run(lib, prefix, f, desired):
+        b = np.frombuffer(f, dtype=np.uint8)
+        w, h, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        gst = getattr(lib, prefix + "_get_info")(C.c_void_p(b.ctypes.data), C.c_uint32(b.size), C.byref(w), C.byref(h), C.byref(c))
+        if gst:
+            return gst, None
+        out = np.zeros(w.value * h.value * desired, dtype=np.uint8)
+        st = getattr(lib, prefix + "_decode")(C.c_void_p(b.ctypes.data), C.c_uint32(b.size), C.c_void_p(out.ctypes.data), C.c_size_t(out.size),
+                                              C.byref(w), C.byref(h), C.byref(c), C.c_uint32(desired))
+        return st, (w.value, h.value, c.value, out.tobytes() if st == 0 else None)
+    rng = np.random.default_rng(1212)
+    accepted_only_without_checks = ihdr_still_checked = 0
+    for _ in range(80):
+        img, w, h, c = fuzz_image(rng)
+        png = oracle().encode(img, w, h, c, int(rng.integers(0, 3)))
+        chunks = CM.chunks_of(png)
+        files = []
+        for k in range(len(chunks)):  # one chunk's CRC damaged at a time (IHDR, fdEC, IDAT, IEND)
+            ofs = 8 + sum(12 + len(body) for _, body in chunks[: k + 1]) - 1
+            bad = bytearray(png)
+            bad[ofs] ^= 0x5A
+            files.append((chunks[k][0], bytes(bad)))
+        for _ in range(6):  # flipped bits anywhere: with the checks off they reach the parser and the inflater
+            bad = bytearray(png)
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(8, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            files.append((b"bits", bytes(bad)))
+        for name, f in files:
+            desired = int(rng.choice([3, 4]))
+            a, b = run(theirs, "ref", f, desired), run(mine, "shim", f, desired)
+            assert a == b, (name, a[0], b[0])
+            if name in (b"fdEC", b"IEND"):
+                assert a[0] == 0 and ref().decode(f, desired)[0] == 4 and dropin.decode(f, desired)[0] == 4  # FPNG_DECODE_FAILED_HEADER_CRC32 by default
+                accepted_only_without_checks += 1
+            if name == b"IHDR":
+                assert a[0] == 4
+                ihdr_still_checked += 1
+    assert accepted_only_without_checks >= 150 and ihdr_still_checked >= 80

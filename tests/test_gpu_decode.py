@@ -591,3 +591,96 @@ def test_other_huffman_tables_and_the_reserved_length_symbols(enc, device):
                 accepted += 1
                 assert cf == c and np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
         assert accepted >= 50 and left >= 10, (accepted, left)
+
+
+@pytest.mark.skipif(not have_ref(), reason="the reference's decoder is the judge")
+@pytest.mark.parametrize("case", ["4k_rgba_streamed", "1080p_rgb_glyphs_2pass", "blocks_rgb"])
+def test_token_edited_megapixel_files(enc, case):
+    """tests/token_mutator.py on MEGAPIXEL files (LargeStream / mutate_large: one local edit at a random place of a token stream that
+    spans hundreds of workgroups -- a match lengthened over a row's end, off a pixel boundary, an end-of-block symbol moved, a
+    filter literal changed ...), through fpng_amd_decode_batch, fpng_amd_decode_batch_device and fpng::fpng_decode_memory (which
+    STREAMS the 4K file: more than 8 MiB of IDAT; semantics src/fpng.cpp:2587-2901).  Status and pixels of the reference's decoder
+    at both channel counts; UNDECIDED only where the drop-in's CPU decoder then gives the reference's answer."""
+    import struct
+    import fpng_amd
+    import test_decode_model as M
+    import token_mutator as TM
+    import ui_images
+    img, w, h, c, flags = {
+        "4k_rgba_streamed": lambda: (np.asarray(fpng_amd.synth_image("grad", 3840, 2160, 4)).reshape(-1), 3840, 2160, 4, 0),
+        "1080p_rgb_glyphs_2pass": lambda: (np.ascontiguousarray(ui_images.glyphs(1920, 1080, 3, seed=5)).reshape(-1), 1920, 1080, 3, 1),
+        "blocks_rgb": lambda: (np.asarray(fpng_amd.synth_image("blocks", 2048, 1500, 3)).reshape(-1), 2048, 1500, 3, 0),
+    }[case]()
+    rng = np.random.default_rng({"4k_rgba_streamed": 1, "1080p_rgb_glyphs_2pass": 2, "blocks_rgb": 3}[case])
+    base = ref().encode(img, w, h, c, flags)
+    if case == "4k_rgba_streamed":
+        assert len(base) > (8 << 20) + 100
+    s = TM.LargeStream(base, M.plan, M.emul())
+    files = [(name, f) for name, f in (TM.mutate_large(s, rng) for _ in range(20)) if f is not None]
+    assert len(files) >= 6
+    rejected = 0
+    for desired in (3, 4):
+        judged = [ref().decode(f, desired) for _, f in files]
+        dims = [struct.unpack(">II", bytes(f[16:24])) for _, f in files]
+        for got in (enc.decode_batch([f for _, f in files], desired), enc.decode_device(_device_files([f for _, f in files], shift=2), desired, dims)):
+            for (name, f), (cst, cpx, *_), (st, px, _) in zip(files, judged, got):
+                if st == UNDECIDED:
+                    os.environ["FPNG_AMD_DECODE_CPU"] = "1"
+                    try:
+                        st, dpx, *_ = dropin.decode(f, desired)
+                    finally:
+                        del os.environ["FPNG_AMD_DECODE_CPU"]
+                    assert st == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])), name
+                else:
+                    assert st == cst, (name, st, cst)
+                    assert cst != 0 or np.array_equal(px.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * desired]), name
+        before = dropin.shim().shim_gpu_decodes()
+        for (name, f), (cst, cpx, *_) in zip(files, judged):  # the drop-in itself (GPU tier; streamed where the IDAT is large)
+            st, dpx, *_ = dropin.decode(f, desired)
+            assert st == cst and (cst != 0 or np.array_equal(np.asarray(dpx)[: w * h * desired], np.asarray(cpx)[: w * h * desired])), name
+            rejected += cst != 0
+        assert dropin.shim().shim_gpu_decodes() > before
+    assert rejected >= 2
+
+
+@pytest.mark.skipif(not have_ref(), reason="the reference's decoder is the judge")
+def test_damaged_8k_files_through_the_streamed_host_path(enc):
+    """fpng_amd_decode_host / fpng::fpng_decode_memory STREAM a file from 8 MiB of IDAT on: a piece's rows are un-filtered on a
+    stream of their own while the next piece is synchronised and decoded, and those kernels may set the file's status bits at any
+    moment.  dec_unfilter_kernel must not let such a bit split one launch's workgroups into some that publish their look-back sums
+    and some that leave (the others would spin up to the limit: a multi-second stall, found by review in round 4) -- in the streamed
+    form no workgroup skips.  Damaged 8K files (flipped bits stratified over 58 MB, bursts, a damaged header): the reference's
+    status, its pixels where it succeeds, and no call takes long."""
+    import time
+    import torch
+    import fpng_amd
+    rng = np.random.default_rng(4242)
+    (base,), _ = enc.encode_tensors([torch.from_numpy(fpng_amd.synth_image("grad", 7680, 4320, 4)).cuda()], 0)
+    L = len(base)
+    files = []
+    for k in range(10):
+        d = bytearray(base)
+        if k % 3 == 0:
+            d[60 + (L - 80) * k // 10 + int(rng.integers(0, 1000))] ^= 1 << int(rng.integers(0, 8))
+        elif k % 3 == 1:
+            i = int(rng.integers(200, L - 30))
+            d[i:i + 4] = bytes(int(v) for v in rng.integers(0, 256, 4))
+        else:
+            for _ in range(3):
+                d[int(rng.integers(L // 2, L - 30))] ^= 0xFF
+        files.append(bytes(d))
+    dropin.decode(base, 4)  # (warm: buffers, streams)
+    n_bad = 0
+    slowest = 0.0
+    for f in files:
+        cst, cpx, w, h, c = ref().decode(f, 4)
+        t0 = time.perf_counter()
+        st, px, *_ = dropin.decode(f, 4)
+        slowest = max(slowest, time.perf_counter() - t0)
+        assert st == cst
+        if cst == 0:
+            assert np.array_equal(np.asarray(px), np.asarray(cpx)[: w * h * 4])
+        n_bad += cst != 0
+    assert n_bad >= 5
+    # (dropin.decode() allocates and copies ~270 MB around the call: ~0.15 s; a stalled look-back costs seconds)
+    assert slowest < 1.0, slowest

@@ -596,20 +596,28 @@ def main():
     # of pinned slots) between a barrier + synchronize on both sides; per region the max over ranks counts.  The reported
     # value is the MEDIAN region; all of them are in `runs` (boxes and clocks wander by a few per cent within a run).
     runs = []
+    own_runs = []  # per region: every rank's OWN time to its last result (before the closing barrier): a straggler shows here
     for _ in range(max(1, args.regions)):
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             enc.submit(batches[i & 3], None, args.flags)
         res = enc.finish(B)
+        own = time.perf_counter() - t0
         barrier()
         el = time.perf_counter() - t0
         if distributed:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+            g = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(g, torch.tensor([own], dtype=torch.float64, device=dev))
+            own_runs.append([float(v.item()) for v in g])
+        else:
+            own_runs.append([own])
         runs.append(el)
     elapsed = sorted(runs)[len(runs) // 2]
+    per_rank_ms = [round(v / args.steps * 1e3, 4) for v in own_runs[runs.index(elapsed)]]
 
     png_bytes = sum(r[0] for r in res)
     assert all(r[2] == 0 for r in res)
@@ -655,7 +663,7 @@ def main():
         "warmup": args.warmup, "prewarm": args.prewarm, "parity_checked": bool(parity_checked) if parity_checked is not None else None,
         "parity_images": parity_checked, "runs": run_values,
         "spread": round((max(run_values) - min(run_values)) / value, 4) if len(run_values) > 1 else None,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{B} x {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' frames per GPU per step, "
                                f"flags={args.flags}, bit-exact fpng PNG output", "batch_per_gpu": B,

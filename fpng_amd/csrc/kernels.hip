@@ -50,7 +50,13 @@ constexpr int kScanBlock = kWave * kScanWaves;
 constexpr int kHistWaves = 8;              // hist_kernel: one LDS histogram (36 KiB) and one round of global atomics per block
 constexpr int kHistBlock = kWave * kHistWaves;
 constexpr int kRowBlock = kWave * kRowWaves;
-constexpr int kStageDwords = 1024;         // per-wave LDS staging window of the output bit stream
+#ifndef FPNG_STAGE_DWORDS
+#define FPNG_STAGE_DWORDS 1024
+#endif
+#ifndef FPNG_ROWS_WPE // waves per SIMD the row kernels are compiled for (build variants: occupancy against window size)
+#define FPNG_ROWS_WPE 8
+#endif
+constexpr int kStageDwords = FPNG_STAGE_DWORDS; // per-wave LDS staging window of the output bit stream
 // Local-stream stores carry the non-temporal hint (build with -DFPNG_LOCAL_NT=0 to A/B it: the hint decides whether the
 // streams are kept in L2 / Infinity Cache for assemble_kernel)
 #ifndef FPNG_LOCAL_NT
@@ -1205,7 +1211,7 @@ __device__ __forceinline__ void xcd_block_order(uint32_t &bx, uint32_t &by)
 }
 
 template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(FPNG_ROWS_WPE, FPNG_ROWS_WPE))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
                                                                                                       JobState *states, uint32_t *local)
 {
     uint32_t bx, by;
@@ -1217,7 +1223,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // upload in front of the chain (a blit kernel + a dispatch gap: ~7 us of a single frame's ~90); workgroup 0 leaves it in
 // device memory for scan / assemble / finalize, which start after this kernel has ended.
 template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void encode_rows_first_kernel(const JobArg arg, Job *job_out,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(FPNG_ROWS_WPE, FPNG_ROWS_WPE))) void encode_rows_first_kernel(const JobArg arg, Job *job_out,
                                                                                                             RowInfo *rows_out, JobState *states,
                                                                                                             uint32_t *local)
 {

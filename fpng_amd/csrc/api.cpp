@@ -370,6 +370,8 @@ constexpr uint64_t kLocalFrontPad = 32; // dwords (one 128-byte line)
 
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
+    bool direct = false;       // direct placement (kernels.h: Job::piece_px): total_rows counts CHUNKS then
+    uint32_t total_blocks = 0; // ... workgroups of encode_direct_kernel
     uint64_t total_rows = 0;
     uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
@@ -413,6 +415,14 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     sub = Submission();
     sub.n = n;
+    // Direct placement (FPNG_AMD_DIRECT=0: the two-kernel chain with local streams, kept for A/B runs and used by the row
+    // bands): rows are cut into pieces of FPNG_AMD_PIECE_PX pixels (a multiple of 256) whose token bits fit a wave's LDS window --
+    // 1536 RGBA / 2048 RGB pixels hold up to ~12.5 / ~9.4 bits per pixel without a spill (the synthetic gradient: 14.1 / 10.6 ...).
+    // (read at every call: tests and A/B runs switch them inside one process)
+    const char *de = getenv("FPNG_AMD_DIRECT"), *pe = getenv("FPNG_AMD_PIECE_PX");
+    const bool direct_env = !de || de[0] != '0';
+    const uint32_t piece_env = pe ? (((uint32_t)atoi(pe) + 255u) & ~255u) : 0u;
+    sub.direct = direct_env && !force_stored;
     for (uint32_t i = 0; i < n; i++) {
         const fpng_amd_image &im = images[i];
         if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
@@ -421,7 +431,6 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
             return fail(FPNG_AMD_ERR_INVALID_ARG, "d_out must be 16-byte aligned, RGBA d_pixels 4-byte aligned");
         if (im.out_cap < fpng_amd_max_encoded_size(im.w, im.h, im.num_chans))
             return fail(FPNG_AMD_ERR_BUFFER_TOO_SMALL, "out_cap < fpng_amd_max_encoded_size()");
-        if (sub.total_rows + im.h > 0xFFFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many rows in one batch");
         Job &j = slot.jobs.p[i];
         std::memset(&j, 0, sizeof j);
         j.rows = (const uint8_t *)im.d_pixels;
@@ -449,14 +458,30 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 31) & ~31ull); // whole 128-byte lines
         j.local_base = sub.local_dwords;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
-        sub.local_dwords += (uint64_t)j.local_stride * im.h;
-        sub.total_rows += im.h;
+        uint64_t units = im.h; // records of the job: rows, or chunks
+        if (sub.direct) {
+            j.flags |= kJobDirect;
+            j.piece_px = piece_env ? piece_env : (im.num_chans == 4 ? kDirectPiecePx4 : kDirectPiecePx3);
+            j.n_pieces = (im.w + j.piece_px - 1) / j.piece_px;
+            units = (uint64_t)im.h * j.n_pieces;
+            if (units > 0xFFFFFFFFull || sub.total_blocks + (units + 3) / 4 > 0x7FFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many chunks in one batch");
+            j.n_chunks = (uint32_t)units;
+            j.block_base = sub.total_blocks;
+            sub.total_blocks += (uint32_t)((units + 3) / 4);
+            // a chunk's spill area: its pixels' worst case (+ the filter literal, the end-of-block symbol, slack for the 16-byte flush and the zeros behind the stream)
+            const uint64_t px = std::min<uint64_t>(j.piece_px, im.w);
+            j.local_stride = (uint32_t)((((px * im.num_chans + 1) * bits_per_byte + 64 + 31) / 32 + 12 + 31) & ~31ull);
+        }
+        sub.local_dwords += (uint64_t)j.local_stride * units;
+        if (sub.total_rows + units > 0xFFFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many rows in one batch");
+        sub.total_rows += units;
         sub.max_rows = std::max(sub.max_rows, im.h);
         sub.max_crc_blocks = std::max(sub.max_crc_blocks, j.crc_blocks);
     }
     if ((rc = sc.d_jobs.ensure(n))) return rc;
     if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
-    if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
+    if ((rc = sc.d_row_off.ensure(sub.direct ? 16 : sub.total_rows))) return rc;
+    if (sub.direct && (rc = sc.d_look.ensure(2 * (size_t)sub.total_rows))) return rc;
     if ((rc = sc.d_states.ensure(n))) return rc;
     if ((rc = sc.d_results.ensure(n))) return rc;
     if ((rc = sc.d_partials.ensure(3 * (size_t)n * sub.max_crc_blocks))) return rc; // CRC partials + two Adler words per range (stored images)
@@ -552,7 +577,17 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const char *v = getenv("FPNG_AMD_JOB_IN_ARGS");
         return !v || v[0] != '0';
     }();
-    const bool job_in_args = job_in_args_env && n == 1 && !force_stored;
+    const bool job_in_args = job_in_args_env && n == 1 && !force_stored && !sub.direct;
+    if (sub.direct) { // granules and status words the kernels expect to find zero (they leave them so)
+        if (sc.d_look.fresh) {
+            HIP_TRY(hipMemsetAsync(sc.d_look.p, 0, sc.d_look.cap * sizeof(unsigned long long), s));
+            sc.d_look.fresh = false;
+        }
+        if (sc.d_states.fresh) {
+            HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, sc.d_states.cap * sizeof(JobState), s));
+            sc.d_states.fresh = false;
+        }
+    }
     const Job *d_jobs = sc.d_jobs.p;
     if (!job_in_args) HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
@@ -594,6 +629,8 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
     if (job_in_args)
         launch_encode_rows_first(s, two_pass ? slot.jobs2.p[0] : slot.jobs.p[0], sc.d_jobs.p, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    else if (sub.direct)
+        launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_look.p);
     else if (!force_stored)
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;
@@ -610,7 +647,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
             e->prev_walked = slot.walked;
         }
     }
-    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
+    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p, sub.direct ? sc.d_look.p : nullptr, sub.direct ? sc.d_local.p : nullptr);
     if ((rc = mark(e, s, ++ph))) return rc;
     uint32_t *adler_parts = sc.d_partials.p + (size_t)n * sub.max_crc_blocks;
     launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, adler_parts);
@@ -622,6 +659,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, s));
     sc.last_done = slot.done;
+    sc.last_n = n, sc.last_chunks = sub.direct ? (uint32_t)sub.total_rows : 0u;
     e->submitted++;
     slot.ticket = e->submitted;
     slot.n = n;
@@ -1242,6 +1280,15 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
     if (!e || lane < 0 || lane >= fpng_amd_encoder::kLanes || !dst) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (n_words == 4) { // direct placement, the lane's last submission: chunks deferred to scan_kernel, chunks that overflowed their window, jobs
+        const uint32_t n = e->sc[lane].last_n;
+        std::vector<JobState> st(n);
+        if (n) HIP_TRY(hipMemcpy(st.data(), e->sc[lane].d_states.p, n * sizeof(JobState), hipMemcpyDeviceToHost));
+        uint64_t deferred = 0, spilled = 0;
+        for (const JobState &q : st) deferred += q.reserved[0], spilled += q.reserved[1];
+        dst[0] = (uint32_t)deferred, dst[1] = (uint32_t)spilled, dst[2] = n, dst[3] = e->sc[lane].last_chunks;
+        return FPNG_AMD_OK;
+    }
     if (n_words == 8) { // the timing build's cycle counts of build_dynamic_kernel (head of the histogram scratch)
         if (!e->sc[lane].d_hist.p) return fail(FPNG_AMD_ERR_INVALID_ARG, "no 2-pass submission yet");
         const uint32_t page = (dst[7] == 0xFEEDu) ? 8u : 0u; // (second page: the table builder's inner phases)

@@ -30,8 +30,20 @@ struct Job {
     uint64_t local_base;      // dwords
     uint32_t local_stride;    // dwords per row (worst-case token bits of a row + slack)
     uint32_t local_pad;
+    // DIRECT PLACEMENT (whole images, flag kJobDirect): a row is cut into n_pieces pieces of piece_px pixels (a
+    // multiple of 256; the last one takes what is left), a wave encodes one piece ("chunk") into its LDS window, learns the
+    // chunk's bit offset by a decoupled look-back over the chunks in front of it and writes its bits straight into the file:
+    // no local streams, no second kernel that shifts them into place.  Per-chunk arrays (RowInfo records, look-back granules,
+    // spill areas) are indexed row_base + row * n_pieces + piece; local_stride is then a CHUNK's spill area.
+    uint32_t piece_px, n_pieces;
+    uint32_t n_chunks;        // nrows * n_pieces
+    uint32_t block_base;      // the job's first workgroup in the linear order of encode_direct_kernel (kRowWaves chunks each)
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
+
+constexpr uint32_t kJobDirect = 0x800u; // Job::flags: direct placement (above)
+constexpr uint32_t kDirectPiecePx4 = 1536, kDirectPiecePx3 = 2048; // default piece lengths (FPNG_AMD_PIECE_PX overrides)
+constexpr uint32_t kDirectGroupBlocks = 64; // encode_direct_kernel: workgroups handed to one XCD in a row (see direct_block_order)
 
 struct RowInfo {
     uint32_t bits; // token bits of the row
@@ -73,10 +85,16 @@ struct CrcDeviceTables {
 void build_crc_device_tables(CrcDeviceTables *t);
 
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
-void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
+// look / local: the look-back granules of direct jobs (cleared again here, for the scratch set's next submission) and the chunks' spill
+// areas (chunks that encode_direct_kernel deferred are placed here), or NULL
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look = nullptr,
+                 const uint32_t *local = nullptr);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);
+// direct placement: total_blocks = workgroups of all jobs (Job::block_base); look = two 64-bit granules per chunk, all zero
+void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t chan_mask, RowInfo *rows, JobState *states,
+                          uint32_t *local, unsigned long long *look);
 // one job per submission: the record travels in the kernel arguments and is left at d_job for the kernels that follow
 void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local);
 void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist);

@@ -505,9 +505,15 @@ struct RowResult {
     uint32_t s1, s2;         // Adler raw sums of the filtered row, mod 65521
 };
 
-// Walks row r of the job.
-template <int C, Pass PASS>
-__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink)
+// Walks row r of the job -- or, PIECE = true (direct placement), the pixels [xb, xe) of it: xb a multiple of 256 (0: the row's first piece,
+// which carries the filter literal), xe a multiple of 256 or the row's width (its last piece).  A piece that starts inside the row
+// needs what the walk carries from window to window -- the filtered pixel in front of it and where the greedy cutting of a run
+// stands there (Rle::carry): both are found by looking back over the pixels in front of it, 64 at a time, as far as the run that
+// reaches the piece's first pixel goes (usually one window).  Its Adler sums are relative to the ROW's end, like a row's, so that
+// the pieces of a row simply add up.
+template <int C, Pass PASS, bool PIECE = false>
+__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink, uint32_t xb_in = 0,
+                                              uint32_t xe_in = 0)
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
@@ -523,11 +529,35 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     const uint64_t lane_le_mask = (2ull << lane) - 1ull;
     const uint32_t nwin = (w + 63) >> 6;
     const uint32_t n_interior = (w >= 128) ? (w >> 6) - 1 : 0; // windows k with (k+2)*64 <= w
+    const uint32_t xb = PIECE ? uniform(xb_in) : 0u, xe = PIECE ? uniform(xe_in) : w;
+    const bool first_piece = !PIECE || xb == 0, last_piece = !PIECE || xe == w;
+    const uint32_t k_end = last_piece ? nwin : (xe >> 6); // windows [xb / 64, k_end) are this walk's
 
     RowWindows<C> px;
     px.init(row, up_row, bpl, lane);
 
     Rle<C> rle;
+    uint32_t piece_prev_f = 0; // PIECE, xb > 0: the filtered pixel in front of the piece
+    if (PIECE && xb) {
+        uint32_t x0 = xb - 64, t = 0;
+        uint32_t f = px.filtered_at(x0);
+        piece_prev_f = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+        for (;;) {
+            uint32_t fp = 0, prev = 0;
+            if (x0) { // (wave-uniform)
+                fp = px.filtered_at(x0 - 64);
+                prev = (uint32_t)__builtin_amdgcn_readlane((int)fp, 63);
+            }
+            uint64_t m = __ballot(f == lane_prev(f, prev));
+            if (!x0) m &= ~1ull; // (the row's first pixel repeats nothing)
+            if (m != ~0ull) {
+                t += (uint32_t)__builtin_clzll(~m); // pixels at the window's end that repeat their left neighbour
+                break;
+            }
+            t += 64, x0 -= 64, f = fp; // (x0 was not 0: the mask of the row's first window is never full)
+        }
+        rle.carry = t % Rle<C>::CAP;
+    }
     uint32_t row_bits = 0, last_unit = 0;
     // Adler per-lane accumulators: byte sum, sum of (bytes from the pixel's first byte to the row end) x
     // (pixel byte sum), sum of (byte index inside the pixel) x byte.  s2(row) = acc_w - acc_j.
@@ -535,7 +565,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     uint64_t acc_w = 0;
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
     const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
-    if (kEmit) {
+    if (kEmit && first_piece) {
         if (lane == 0) {
             const uint64_t v = (uint64_t)plit_code(fl) << (sink->fill & 31);
             atomicOr(&sink->stage[sink->fill >> 5], (uint32_t)v);
@@ -693,8 +723,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // ~all of photographic content); any other super-window is replayed through the per-pixel walk
     // below with ds_bpermute gathers.  Super-windows S with 256*(S+1) < w qualify.
     // =====================================================================================
-    uint32_t k0 = 0;      // first 64-pixel window left for phase B
-    uint32_t carry_f = 0; // filtered value of the pixel just before window k0
+    uint32_t k0 = xb >> 6;           // first 64-pixel window left for phase B
+    uint32_t carry_f = piece_prev_f; // filtered value of the pixel just before window k0
     {
         constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
         constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
@@ -704,8 +734,10 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         // super-window here as well -- lanes past the row end masked -- was measured and dropped: 256 x 1080p RGBA 1.15
         // instead of 1.10 ms, and three spilled VGPRs in the 3-channel walk.)
         const uint32_t NS = (w - 1) >> 8;
-        const uint32_t NSX = NS + (((w & 255u) == 0) ? 1u : 0u);
-        if (NSX > 0) {
+        const uint32_t NSX_row = NS + (((w & 255u) == 0) ? 1u : 0u);
+        const uint32_t S0 = xb >> 8;                                      // the walk's first super-window
+        const uint32_t NSX = (PIECE && !last_piece) ? (xe >> 8) : NSX_row; // ... and the one it stops in front of (a piece that ends inside the row: every one of its super-windows is followed by pixels)
+        if (NSX > S0) {
             const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
                 // RGB: 16 aligned bytes that contain the lane's 12 (the resources start on a dword, the row begins
@@ -742,14 +774,14 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             };
             constexpr int PF4 = 1; // super-windows in flight ahead of the look-ahead one
             u32x4 c_first, u_first, rc[PF4], ru[PF4];
-            load4(0, c_first, u_first);
+            load4(S0, c_first, u_first);
 #pragma unroll
-            for (int j = 0; j < PF4; j++) load4((uint32_t)j + 1, rc[j], ru[j]);
+            for (int j = 0; j < PF4; j++) load4(S0 + (uint32_t)j + 1, rc[j], ru[j]);
             uint32_t fd[4];
             filt(c_first, u_first, fd);
             // pixel just before the super-window; in front of pixel 0: a value pixel 0 cannot equal (it has no left neighbour)
-            uint32_t last_f = ~uniform(fd[0]);
-            uint32_t wgt = bpl - kLaneBytes * lane; // bytes from this lane's first byte to the row end
+            uint32_t last_f = (PIECE && xb) ? piece_prev_f : ~uniform(fd[0]);
+            uint32_t wgt = bpl - kLaneBytes * lane - S0 * kSuperBytes; // bytes from this lane's first byte to the row end
             const uint32_t c1_bits = chunk1 & 0xFF;
             // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
             auto gather = [&](uint32_t jw, const uint32_t (&src)[4]) {
@@ -761,8 +793,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
                 const uint32_t comp = lane & 3;
                 return comp == 0 ? t0 : (comp == 1 ? t1 : (comp == 2 ? t2 : t3));
             };
-            uint32_t gen_streak = 1, done = 0, limit = NSX; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
-            for (uint32_t Sb = 0; Sb < limit; Sb += PF4) {
+            uint32_t gen_streak = 1, done = S0, limit = NSX; // streak starts at 1: a row whose FIRST super-window is general is handed over at once
+            for (uint32_t Sb = S0; Sb < limit; Sb += PF4) {
 #pragma unroll
                 for (int js = 0; js < PF4; js++) {
                     const uint32_t S = Sb + (uint32_t)js;
@@ -887,7 +919,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // =====================================================================================
     // Phase B: per-pixel walk (lane = pixel) of windows k0 .. nwin-1: everything for RGB, the row tail for RGBA
     // =====================================================================================
-    if (k0 < nwin) { // (phase A may have taken the whole row)
+    if (k0 < k_end) { // (phase A may have taken the whole row)
         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
         Raw ring[PF];
         const Raw raw0 = px.load_raw(k0 << 6);
@@ -897,7 +929,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         m_cur = __ballot(f_cur == lane_prev(f_cur, carry_f)) & valid_mask(k0 << 6, w);
         if (k0 == 0) m_cur &= ~1ull;
         // interior windows: ring-fed, unmasked
-        const uint32_t lim_int = n_interior;
+        const uint32_t lim_int = n_interior < k_end ? n_interior : k_end;
         for (uint32_t kb = k0; kb < lim_int; kb += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
@@ -909,7 +941,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             }
         }
         // the last one or two windows of the row: masked body, look-ahead loaded directly
-        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
+        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < k_end; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
     }
 
     RowResult res;
@@ -917,7 +949,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
     if (kSums) {
-        const uint32_t fl_bits = plit_len(fl);
+        const uint32_t fl_bits = first_piece ? plit_len(fl) : 0u;
         res.bits = row_bits + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
@@ -925,7 +957,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         const uint32_t la = acc_a % kAdlerMod;
         const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod); // every byte weight is positive
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
-        const uint32_t fb = filter_byte;
+        const uint32_t fb = first_piece ? filter_byte : 0u; // (the filter byte is the first piece's)
         res.s1 = (wave_sum(la) + fb) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * fb) % kAdlerMod;
     }
@@ -1011,9 +1043,55 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
     p[3] = (uint8_t)v;
 }
 
-__device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
-                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */)
+// ---- direct placement: look-back granules (encode_direct_kernel, further down; scan_kernel places the chunks that kernel deferred) ----
+constexpr unsigned long long kLookReady = 1ull << 63;
+#ifndef FPNG_DIRECT_SPIN_LIMIT
+#define FPNG_DIRECT_SPIN_LIMIT 256
+#endif
+constexpr uint32_t kDirectSpinLimit = FPNG_DIRECT_SPIN_LIMIT; // polls (~0.1 us each) a chunk waits for the chunks in front of it before it is deferred
+__device__ __forceinline__ unsigned long long look_load(const unsigned long long *p)
 {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void look_store(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The sh (1..31) stream bits in front of chunk `id`, top-aligned in the returned word: the last bits of the chunk(s) in front of it
+// (their records; every one of them has been published when this is called), or of the block header.
+__device__ __forceinline__ uint32_t direct_bits_in_front(const Job &job, const unsigned long long *agg, uint32_t id, uint32_t sh, uint32_t first_bit)
+{
+    uint32_t W = 0, have = 0;
+    int64_t j = (int64_t)id - 1;
+    while (have < sh && j >= 0) {
+        unsigned long long a = look_load(&agg[2 * j]);
+        for (uint32_t spins = 0; !(a & kLookReady) && spins < (1u << 16); spins++) a = look_load(&agg[2 * j]); // (published long ago: see the callers; bounded all the same)
+        const uint32_t b = (uint32_t)(a & 0xFFFFFFu), t = (uint32_t)(a >> 24) & 0x7FFFFFFFu;
+        W |= (t << 1) >> have;
+        have += b < 31u ? b : 31u;
+        j--;
+    }
+    if (have < sh) { // the block header's last bits (zlib bits [first_bit - 31, first_bit))
+        const FPNG_GLOBAL uint8_t *hb = (const FPNG_GLOBAL uint8_t *)(uintptr_t)job.table->header;
+        const uint32_t k = first_bit - 31u, b0 = k >> 3;
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < 5; i++) v |= (uint64_t)hb[b0 + i] << (8 * i);
+        const uint32_t t = (uint32_t)(v >> (k & 7u)) & 0x7FFFFFFFu;
+        W |= (t << 1) >> have;
+    }
+    return W;
+}
+
+
+__device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
+                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */, unsigned long long *look, const uint32_t *spill)
+{
+    // direct placement (encode_direct_kernel): the records are CHUNKS' (n_pieces per row), the bits are in the file already --
+    // what is left is the sums, the decision, the head of the file in front of the first chunk's first dword, and the look-back
+    // granules' clearing for the scratch set's next submission
+    const bool direct = (job.flags & kJobDirect) != 0;
+    const uint32_t n_rec = direct ? job.n_chunks : job.nrows, rec_per_row = direct ? job.n_pieces : 1u;
     const uint32_t t = threadIdx.x, lane = t & 63, wv = uniform(t >> 6);
     const TokenTable *tab = job.table;
     const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
@@ -1028,9 +1106,10 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     if (!force_stored) {
         // every thread owns a contiguous chunk of rows: local sums, one scan of the 256 chunk totals (per wave, then across
         // the four waves through LDS), then the chunk is walked again to hand out the row offsets
-        const uint32_t per = (job.nrows + kScanBlock - 1) / kScanBlock;
-        const uint32_t r0 = t * per < job.nrows ? t * per : job.nrows, r1 = (r0 + per < job.nrows) ? r0 + per : job.nrows;
+        const uint32_t per = (n_rec + kScanBlock - 1) / kScanBlock;
+        const uint32_t r0 = t * per < n_rec ? t * per : n_rec, r1 = (r0 + per < n_rec) ? r0 + per : n_rec;
         uint64_t local = 0;
+        uint32_t n_deferred = 0, n_spilled = 0; // direct placement: chunks of this thread's range that encode_direct_kernel left in their spill areas / that overflowed the window
         for (uint32_t rb = r0; rb < r1; rb += 8) { // eight records in flight per round trip
             u32x4 ri[8];
 #pragma unroll
@@ -1041,9 +1120,11 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
                 if (r >= r1) break;
                 const uint32_t s1 = ri[k].y, s2 = ri[k].z; // < 65521
                 local += ri[k].x;
+                n_deferred += ri[k].w & 1u;
+                n_spilled += (ri[k].w >> 1) & 1u;
                 // S2 of the concatenation: every byte of this row is followed by the later rows.  All factors are below
                 // 65521, so the products (and 65520^2 + 65520) fit 32 bits
-                const uint32_t after = ((job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
+                const uint32_t after = ((job.nrows - 1 - r / rec_per_row) % kAdlerMod) * n_row_mod % kAdlerMod; // (a chunk's sums are relative to its ROW's end)
                 a_s1 += s1;
                 a_s2 += (s2 + after * s1) % kAdlerMod;
             }
@@ -1051,6 +1132,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         uint64_t wave_total;
         const uint64_t excl = wave_exclusive_sum_u64(local, lane, wave_total);
         if (lane == 0) wsum[0][wv] = wave_total;
+        if (t == 0) st.reserved[0] = st.reserved[1] = 0;
         __syncthreads();
         uint64_t before = 0, total = 0;
 #pragma unroll
@@ -1060,7 +1142,62 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
             total += v;
         }
         uint64_t pos = first_bit + before + excl;
-        for (uint32_t rb = r0; rb < r1; rb += 4) {
+        if (direct) { // (statistics: fpng_amd_debug_peek; thread 0 cleared them in front of the barrier above)
+            if (n_deferred) atomicAdd((unsigned long long *)&st.reserved[0], (unsigned long long)n_deferred);
+            if (n_spilled) atomicAdd((unsigned long long *)&st.reserved[1], (unsigned long long)n_spilled);
+        }
+        if (direct && look && spill) {
+            // ---- deferred chunks (rare: a chunk that did not learn its offset in time, encode_direct_kernel): their offsets are known
+            //      here.  Per round every thread names the next deferred chunk of its range; the workgroup places them one by one, all
+            //      threads on one chunk's dwords.  (Nothing else of the file is touched: the dword a chunk's last bits end in is its
+            //      successor's, which took those bits from the chunk's record.) ----
+            __shared__ uint32_t def_rec[kScanBlock], def_w;
+            __shared__ uint64_t def_pos[kScanBlock];
+            __shared__ uint32_t def_any;
+            const unsigned long long *agg = look + 2 * (size_t)job.row_base;
+            gptr_u32 out32 = to_global<gptr_u32>(job.out);
+            const uint64_t cap_dw = job.out_cap >> 2;
+            const uint32_t eob_len_d = tab->lit[256] >> 16;
+            for (uint32_t round = 0;; round++) {
+                if (t == 0) def_any = 0;
+                __syncthreads();
+                def_rec[t] = 0xFFFFFFFFu;
+                if (round < n_deferred) { // this thread's round-th deferred chunk and its offset
+                    uint64_t q = pos;
+                    uint32_t seen = 0;
+                    for (uint32_t r = r0; r < r1; r++) {
+                        const u32x4 ri = rg[r];
+                        if ((ri.w & 1u) && seen++ == round) {
+                            def_rec[t] = r, def_pos[t] = q;
+                            break;
+                        }
+                        q += ri.x;
+                    }
+                    def_any = 1;
+                }
+                __syncthreads();
+                if (!def_any) break;
+                for (uint32_t e = 0; e < kScanBlock; e++) {
+                    const uint32_t rec = def_rec[e];
+                    if (rec == 0xFFFFFFFFu) continue; // (uniform: LDS value)
+                    const bool last = rec + 1 == n_rec;
+                    const uint32_t nbits = rg[rec].x + (last ? eob_len_d : 0u);
+                    const uint64_t P = (uint64_t)job.bit_bias + def_pos[e];
+                    const uint32_t sh = (uint32_t)P & 31u;
+                    const uint64_t D0 = P >> 5, D1 = last ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5);
+                    if (t == 0) def_w = sh ? direct_bits_in_front(job, agg, rec, sh, (uint32_t)first_bit) : 0u;
+                    __syncthreads();
+                    const uint32_t W = def_w;
+                    gptr_cu32 loc = to_global<gptr_cu32>(spill) + job.local_base + (uint64_t)rec * job.local_stride;
+                    for (uint32_t m = t; m < (uint32_t)(D1 - D0); m += kScanBlock) {
+                        const uint32_t hi = loc[m], lo = m ? loc[m - 1] : W;
+                        if (D0 + m < cap_dw) out32[D0 + m] = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        for (uint32_t rb = r0; rb < r1 && !direct; rb += 4) {
             uint32_t bits[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) bits[k] = rg[rb + k < r1 ? rb + k : r1 - 1].x;
@@ -1102,7 +1239,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     if (t == 0) {
         st.token_end_bit = s_last;
         st.mode = stored ? 1u : 0u;
-        st.status = 0;
+        st.status = direct ? (st.status & 0x40u) : 0u; // (0x40: a chunk of encode_direct_kernel gave up waiting; finalize_kernel reports and clears it)
         st.zlib_size = zlib_size;
         st.s1 = (uint32_t)S1;
         st.s2 = (uint32_t)S2;
@@ -1130,20 +1267,29 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         for (uint32_t i = t; i < kPngHeaderBytes; i += kScanBlock)
             if (i < 50 || i >= 54) out[i] = job.png_header[i];
     gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
-    if (!stored && job.is_first) {
+    if (!stored && job.is_first && direct) {
+        // (the first chunk wrote the dword its first bit lies in, with the header's last bits: the head ends in front of it)
+        const uint32_t head_bytes = (uint32_t)((((uint64_t)job.bit_bias + tab->first_token_bit) >> 5) * 4u) - kPngHeaderBytes;
+        for (uint32_t i = t; i < head_bytes; i += kScanBlock) zl[i] = tab->header[i];
+    } else if (!stored && job.is_first) {
         const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
         for (uint32_t i = t; i < head_bytes; i += kScanBlock) zl[i] = tab->header[i];
         const uint32_t head_end = kPngHeaderBytes + head_bytes;
         for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kScanBlock) out[i] = 0;
     }
+    if (direct && look) { // the chain's last reader of the granules leaves them zeroed
+        unsigned long long *g = look + 2 * (size_t)job.row_base;
+        for (uint32_t i = t; i < 2 * n_rec; i += kScanBlock) g[i] = 0ull;
+    }
     if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
 // scan_kernel: one block per job (whole images; row bands: counting phase and placement phase)
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look,
+                                                             const uint32_t *local)
 {
     __shared__ uint64_t wsum[3][kScanWaves];
-    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum);
+    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum, look, local);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,6 +1377,198 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     uint32_t bx, by;
     xcd_block_order(bx, by);
     encode_rows_block<C>(arg.job, 0, bx, rows_out, states, local);
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode_direct_kernel (round 5): ONE kernel walks the pixels and writes the file's bits where they belong.
+//
+// encode_rows + assemble move the compressed bytes through HBM three times (local streams out, back in, file out: 1.68 x the
+// step's algorithmic bytes).  What forces the detour is that a row's bit offset is the sum of all earlier rows' bit counts.  Here a
+// row is cut into PIECES whose token bits fit the wave's LDS window (a "chunk" = one piece of one row, one wave): the wave encodes its
+// chunk into the window, publishes the bit count, finds its offset by a DECOUPLED LOOK-BACK over the chunks in front of it (every
+// chunk publishes {bits, its last 31 bits} as soon as it is encoded and {bits up to its end} once it knows them; a chunk waits
+// for lower numbers only, and the hardware starts the workgroups of a grid in rising order -- the argument of dec_unfilter_kernel),
+// and then writes the window, shifted, straight to the file: whole dwords, the first one completed with the last bits of the
+// chunk in front (which it knows from that chunk's record), the one its last bits end in left to the next chunk.  A chunk whose
+// bits do not fit the window spills to its scratch area as the rows of encode_rows do and copies from there (noisy content: no
+// gain, no loss).  What is left for other kernels: scan (totals, Adler, the stored-or-compressed decision, the file's head),
+// the CRC over the finished file (assemble_kernel's direct branch = crc_kernel's arithmetic), finalize.
+// ---------------------------------------------------------------------------------------------
+// Workgroup order: the hardware deals a grid's workgroups round-robin to the 8 XCDs (each with its own L2).  Runs of
+// kDirectGroupBlocks consecutive workgroups (= chunks in file order) go to ONE XCD, so that the rows above a chunk's are L2 hits
+// (all but the first of a run), and the runs go round the XCDs, so that chunks that wait for each other run at about the same time.
+// lin -> logical; the grid is padded to whole rounds of 8 runs (logical numbers past the end leave at once).
+__device__ __forceinline__ uint32_t direct_block_order()
+{
+    const uint32_t lin = blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+    return ((slot / kDirectGroupBlocks) * 8u + xcd) * kDirectGroupBlocks + slot % kDirectGroupBlocks;
+}
+
+template <int C>
+__device__ __forceinline__ void encode_direct_block(const Job &job, JobState &state, uint32_t jb, RowInfo *rows_out, uint32_t *local, unsigned long long *look)
+{
+    __shared__ PackedTables T;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
+    stage_packed_tables<kRowBlock>(T, job.table);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), id = jb * kRowWaves + wv;
+    const uint32_t n_chunks = uniform(job.n_chunks), np = uniform(job.n_pieces), w = uniform(job.w);
+    if (id >= n_chunks) return;
+    const uint32_t r = id / np, piece = id - r * np;
+    const uint32_t xb = piece * uniform(job.piece_px), xe = (piece + 1 == np) ? w : xb + uniform(job.piece_px);
+    const bool last_chunk = id + 1 == n_chunks;
+    const size_t slot = (size_t)job.row_base + id;
+
+    EmitSink sink;
+    sink.stage = stage[wv];
+    gptr_u32 loc = to_global<gptr_u32>(local + job.local_base + (uint64_t)id * job.local_stride); // the chunk's spill area
+    sink.out32 = loc;
+    const uint32_t zero = uniform(job.local_pad); // (a zero the compiler cannot see: encode_rows_block)
+    sink.base_dw = zero;
+    sink.fill = zero;
+    sink.wide = (C == 4);
+    sink_zero_window(sink, lane);
+    wave_lds_fence();
+
+    const RowResult res = walk_row<C, Pass::Encode, true>(job, T, nullptr, r, lane, &sink, xb, xe);
+    if (last_chunk) { // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of the record's bits
+        const uint32_t eob = T.lit[256];
+        sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
+        sink.fill += plit_len(eob);
+    }
+    wave_lds_fence();
+    // ---- the chunk's stream: dword k of it is stage[k] -- or, if the window overflowed on the way, loc[k] ----
+    const bool spilled = uniform((uint32_t)sink.base_dw) != 0u;
+    const uint32_t nbits = (uint32_t)sink.base_dw * 32u + sink.fill; // (with the end-of-block symbol, if it is here)
+    if (spilled) {
+        sink_flush(sink, lane, true);
+        if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u; // (the dwords behind the last one are read as zeros below; the final flush may or may not have covered them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the wave reads its own non-temporal stores back)
+    }
+    auto sdw = [&](uint32_t k) -> uint32_t { return spilled ? loc[k] : sink.stage[k]; }; // (spilled is wave-uniform)
+    // its last 31 bits, the last one in bit 30 (a chunk of fewer bits: what there is, at the top)
+    uint32_t tail31;
+    if (nbits >= 32) {
+        const uint32_t k = nbits - 31, q = k >> 5, o = k & 31u;
+        const uint32_t lo = uniform(sdw(q)), hi = uniform(sdw(q + 1)); // (q + 1 may lie behind the last dword: zeros there -- the window is cleared, a spill area's slack is written as zeros by the final flush)
+        tail31 = (o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo) & 0x7FFFFFFFu;
+    } else
+        tail31 = nbits ? ((uniform(sdw(0)) << (31u - nbits)) & 0x7FFFFFFFu) : 0u;
+    unsigned long long *agg = look + 2 * (size_t)job.row_base, *pre = agg + 1; // granule pair of chunk i: agg[2 i], pre[2 i]
+    if (lane == 0) look_store(&agg[2 * (size_t)id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
+    // ---- look-back: bits of all chunks in front of this one ----
+    uint64_t excl = 0;
+    bool deferred = false;
+    {
+        int64_t base = (int64_t)id - 1; // the nearest chunk not yet accounted for
+        uint32_t width = 16;            // chunks looked at per round: the nearest ones nearly always do
+        bool first_round = true;
+        for (uint32_t spins = 0; base >= 0;) {
+            const int64_t j = base - lane;
+            const bool look_at = lane < width && j >= 0;
+            unsigned long long a = kLookReady, q = 0; // (in front of chunk 0: nothing, and it is "known")
+            if (look_at) {
+                q = look_load(&pre[2 * j]);
+                a = look_load(&agg[2 * j]);
+            } else if (j < 0)
+                q = kLookReady;
+            const uint64_t live = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+            const uint64_t qmask = __ballot((q & kLookReady) != 0) & live, amask = __ballot((a & kLookReady) != 0) & live;
+            bool progress = false;
+            if (qmask) {
+                const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest chunk whose inclusive prefix is known
+                const uint64_t need = ((1ull << L) - 1ull) | (first_round ? 1ull : 0ull); // (the chunk right in front: its last bits are wanted below)
+                if ((amask & need) == need) {
+                    const uint64_t part = (lane < L) ? (uint64_t)(a & 0xFFFFFFu) : (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
+                    uint64_t total;
+                    (void)wave_exclusive_sum_u64(part, lane, total);
+                    excl += total;
+                    base = -1;
+                    progress = true;
+                }
+            } else if (amask == live) { // only aggregates so far: take them, look further back
+                uint64_t total;
+                (void)wave_exclusive_sum_u64((lane < width) ? (uint64_t)(a & 0xFFFFFFu) : 0ull, lane, total);
+                excl += total;
+                base -= width;
+                width = 64;
+                first_round = false;
+                progress = true;
+            }
+            if (!progress) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kDirectSpinLimit) { // see below
+                    deferred = true;
+                    break;
+                }
+            }
+        }
+    }
+    if (deferred) {
+        // The chunks in front have not all reported in time.  A wave that waits holds its place on the compute unit, and with several
+        // such kernels on one GPU (two lanes, several encoders, several processes) waves that wait for each other's unstarted
+        // predecessors could fill it: so nobody waits long.  The chunk goes to its spill area like a row of encode_rows, its record
+        // says so, and scan_kernel -- which knows every offset -- places it (its bit count is published: nobody behind it is held up).
+        if (!spilled) {
+            sink_flush(sink, lane, true);
+            if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u;
+        }
+        if (lane == 0) {
+            RowInfo ri;
+            ri.bits = res.bits, ri.s1 = res.s1, ri.s2 = res.s2, ri.pad = 1u | (spilled ? 2u : 0u);
+            rows_out[slot] = ri;
+            if (last_chunk) state.last_unit_bits = res.last_unit_bits;
+        }
+        return;
+    }
+    if (lane == 0) look_store(&pre[2 * (size_t)id], kLookReady | (excl + res.bits));
+    // ---- place the bits.  File bit of the chunk's first bit: ----
+    const uint64_t first_bit = job.table->first_token_bit;
+    const uint64_t P = (uint64_t)job.bit_bias + first_bit + excl;
+    const uint32_t sh = (uint32_t)P & 31u;
+    const uint64_t D0 = P >> 5;
+    const uint64_t D1 = last_chunk ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5); // dwords [D0, D1) are this chunk's
+    const uint32_t W = sh ? uniform(direct_bits_in_front(job, agg, id, sh, (uint32_t)first_bit)) : 0u;
+    gptr_u32 out32 = to_global<gptr_u32>(job.out);
+    const uint64_t cap_dw = job.out_cap >> 2; // (a stream that outgrows the file's buffer ends as stored blocks: scan_kernel decides, assemble_kernel writes them)
+    const uint32_t nD = (uint32_t)(D1 - D0);
+    for (uint32_t m = lane; m < nD; m += kWave) {
+        const uint32_t hi = sdw(m), lo = m ? sdw(m - 1) : W;
+        const uint32_t v = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+        if (D0 + m < cap_dw) out32[D0 + m] = v;
+    }
+    if (lane == 0) {
+        RowInfo ri;
+        ri.bits = res.bits;
+        ri.s1 = res.s1;
+        ri.s2 = res.s2;
+        ri.pad = spilled ? 2u : 0u; // (bit 0: deferred, bit 1: the window overflowed -- statistics)
+        rows_out[slot] = ri;
+        if (last_chunk) state.last_unit_bits = res.last_unit_bits;
+    }
+}
+
+#ifndef FPNG_DIRECT_WPE
+#define FPNG_DIRECT_WPE 6
+#endif
+template <int C>
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DIRECT_WPE, FPNG_DIRECT_WPE))) void encode_direct_kernel(const Job *jobs, uint32_t n_jobs, uint32_t total_blocks,
+                                                                                                                          RowInfo *rows_out, JobState *states, uint32_t *local,
+                                                                                                                          unsigned long long *look)
+{
+    const uint32_t b = direct_block_order();
+    if (b >= total_blocks) return;
+    // the job this workgroup belongs to: the last one whose block_base is <= b
+    uint32_t lo = 0, hi = n_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].block_base <= b) lo = mid; else hi = mid;
+    }
+    const uint32_t ji = uniform(lo);
+    const Job &job = jobs[ji];
+    if (job.c != C || !(job.flags & kJobDirect)) return;
+    encode_direct_block<C>(job, states[ji], b - job.block_base, rows_out, local, look);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1447,6 +1785,7 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
         result.png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes;
         result.mode = st.mode;
         result.status = st.status;
+        st.status = 0;
     }
 }
 
@@ -1637,8 +1976,11 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
     const int32_t db = sat(data_begin - range_begin), de = sat(data_end - range_begin); // bytes
     gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
 
-    const bool gather = uniform(st.mode) == 0u;
-    if (!gather && job.whole_png && adler_parts) { // the image fell back to stored blocks: this workgroup writes its range of them
+    // direct placement (encode_direct_kernel): a compressed image's bits are in the file already -- this kernel reads them back for the
+    // CRC (crc_kernel's arithmetic: every piece of the data comes from the file, nothing is gathered); stored outcomes as always
+    const bool compressed = uniform(st.mode) == 0u;
+    const bool gather = compressed && !(job.flags & kJobDirect);
+    if (!compressed && job.whole_png && adler_parts) { // the image fell back to stored blocks: this workgroup writes its range of them
         const size_t slot = (size_t)blockIdx.y * max_crc_blocks + blockIdx.x;
         assemble_stored(job, st, range_begin, range_bytes, db, de, tab, red, tabs, &partials[slot], &adler_parts[2 * slot]);
         return;
@@ -2261,9 +2603,19 @@ void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist
     arg.job = job;
     hipLaunchKernelGGL(hist_first_kernel, dim3((job.nrows + kHistWaves - 1) / kHistWaves, 1, 1), dim3(kHistBlock), 0, s, arg, d_job, hist);
 }
-void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look, const uint32_t *local)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states, look, local);
+}
+void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t chan_mask, RowInfo *rows, JobState *states,
+                          uint32_t *local, unsigned long long *look)
+{
+    // whole rounds of 8 runs of kDirectGroupBlocks workgroups (direct_block_order)
+    const uint32_t round = 8u * kDirectGroupBlocks, grid = (total_blocks + round - 1) / round * round;
+    if (chan_mask & 1u)
+        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, rows, states, local, look);
+    if (chan_mask & 2u)
+        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, rows, states, local, look);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero)
 {

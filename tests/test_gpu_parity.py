@@ -729,3 +729,104 @@ def test_length_limited_tables_from_the_device_builder(enc):
                 if res.status == 0 and mode == 0:  # (the literals' code lengths lie behind the 4096 lookup entries)
                     deep += int(lut[4096:4096 + 64].view(np.uint8).max() == 12)
     assert deep >= 10, deep  # (files whose literal codes reach the 12-bit limit)
+
+
+def _direct_cases(rng):
+    """Images that put row-piece seams where they hurt: widths just over / under / on multiples of 256, runs that cross seams or end
+    on them, flat rows (one run over the whole row: the look back over the pixels in front of a piece walks to the row's start),
+    64-pixel tiles, noise (chunks that overflow the wave's window and spill), gradients."""
+    import fpng_amd
+    cases = []
+    for w in (257, 300, 511, 512, 513, 768, 1025, 1280, 1537, 2049, 2304):
+        for c in (3, 4):
+            h = int(rng.integers(3, 12))
+            for kind in ("grad", "blocks", "solid"):
+                cases.append((fpng_amd.synth_image(kind, w, h, c, seed=int(rng.integers(1, 1 << 30))), w, h, c))
+            # runs of random lengths (1..700 pixels) of random colours, rows repeated now and then (Up-filtered: all-zero rows)
+            img = np.zeros((h, w, c), dtype=np.uint8)
+            for y in range(h):
+                if y and rng.random() < 0.3:
+                    img[y] = img[y - 1]
+                    continue
+                x = 0
+                while x < w:
+                    n = int(rng.integers(1, 700)) if rng.random() < 0.5 else int(rng.integers(1, 6))
+                    img[y, x:x + n] = rng.integers(0, 256, c, dtype=np.uint8)
+                    x += n
+            cases.append((img, w, h, c))
+            # a run that ends exactly on / one pixel after / one before every multiple of 256
+            img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+            for y in range(h):
+                for s0 in range(256, w, 256):
+                    e = s0 + int(rng.integers(-1, 2))
+                    b = max(0, e - int(rng.integers(2, 200)))
+                    img[y, b:e] = img[y, b]
+            cases.append((img, w, h, c))
+    cases.append((fpng_amd.synth_image("noise", 2048, 5, 4), 2048, 5, 4))
+    cases.append((fpng_amd.synth_image("noise", 3000, 4, 3), 3000, 4, 3))
+    return cases
+
+
+@pytest.mark.parametrize("piece_px", [256, 512, 0])
+def test_direct_placement_seams(enc, piece_px):
+    """encode_direct_kernel: rows cut into pieces, every piece's bits placed by the wave that encoded it.  The seams
+    between pieces are where it can go wrong -- the RLE state carried into a piece, the dword two chunks share, tiny last pieces
+    whose bits do not fill the shared dword, chunks that spill.  Small piece sizes (FPNG_AMD_PIECE_PX) put many seams into small
+    images; 0 = the product's sizes.  Byte-identical to the checker, both passes; and the same images through the two-kernel chain
+    (FPNG_AMD_DIRECT=0), which the row bands still use."""
+    rng = np.random.default_rng(5150 + piece_px)
+    cases = _direct_cases(rng)
+    judge = ref() if have_ref() else oracle()
+    old = {k: os.environ.get(k) for k in ("FPNG_AMD_PIECE_PX", "FPNG_AMD_DIRECT")}
+    try:
+        if piece_px:
+            os.environ["FPNG_AMD_PIECE_PX"] = str(piece_px)
+        for direct in ("1", "0") if piece_px == 0 else ("1",):
+            os.environ["FPNG_AMD_DIRECT"] = direct
+            for flags in (0, 1):
+                for k in range(0, len(cases), 24):
+                    part = cases[k:k + 24]
+                    pngs, _ = _gpu_encode(enc, [i for i, *_ in part], flags)
+                    for p, (img, w, h, c) in zip(pngs, part):
+                        _assert_same(bytes(p), judge.encode(img, w, h, c, flags), f"direct={direct} piece {piece_px}: {w}x{h}x{c} flags {flags}")
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_direct_placement_deferred_chunks(built_lib):
+    """A chunk that does not learn its offset in time is DEFERRED: it goes to its spill area and scan_kernel places it (no wave waits
+    long while it holds a place on a compute unit).  The build with FPNG_DIRECT_SPIN_LIMIT=0 defers every chunk that has to wait at
+    all -- thousands per image -- and must still write the reference's bytes (fresh process: the library is chosen at load time)."""
+    import subprocess
+    import sys
+    from fpng_amd import build as B
+    lib = os.path.join(B.LIB_DIR, "libfpng_amd_direct_defer.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(B.CSRC, "kernels.hip")):
+        B.build_variant("direct_defer", B.VARIANTS["direct_defer"])
+    code = r"""
+import os, sys, json, hashlib, numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import fpng_amd
+from cpu_ref import oracle, ref, have_ref
+judge = ref() if have_ref() else oracle()
+enc = fpng_amd.Encoder(device=0)
+bad = 0
+cases = [("grad", 3840, 2160, 4), ("grad", 1920, 1080, 3), ("blocks", 2048, 600, 4), ("solid", 4000, 300, 3), ("noise", 1024, 256, 4)]
+for flags in (0, 1):
+    imgs = [fpng_amd.synth_image(k, w, h, c) for k, w, h, c in cases]
+    for rep in range(2):
+        pngs, _ = enc.encode_tensors([torch.from_numpy(i).cuda() for i in imgs], flags)
+        for p, i, (k, w, h, c) in zip(pngs, imgs, cases):
+            ok = bytes(p) == judge.encode(i, w, h, c, flags)
+            bad += not ok
+            if not ok: print("DIFFERS", k, w, h, c, flags, rep)
+enc.close()
+sys.exit(1 if bad else 0)
+"""
+    env = dict(os.environ, FPNG_AMD_LIB=lib, FPNG_AMD_DIRECT="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

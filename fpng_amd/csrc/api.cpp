@@ -372,6 +372,7 @@ struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
     bool direct = false;       // direct placement (kernels.h: Job::piece_px): total_rows counts CHUNKS then
     uint32_t total_blocks = 0; // ... workgroups of encode_direct_kernel
+    uint32_t blocks_per_job = 0; // ... of every job if they all have the same number, else 0
     uint64_t total_rows = 0;
     uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
@@ -467,7 +468,9 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
             if (units > 0xFFFFFFFFull || sub.total_blocks + (units + 3) / 4 > 0x7FFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many chunks in one batch");
             j.n_chunks = (uint32_t)units;
             j.block_base = sub.total_blocks;
-            sub.total_blocks += (uint32_t)((units + 3) / 4);
+            const uint32_t nb = (uint32_t)((units + 3) / 4);
+            sub.blocks_per_job = (i == 0 || sub.blocks_per_job == nb) ? nb : 0xFFFFFFFFu; // (0xFFFFFFFF: they differ)
+            sub.total_blocks += nb;
             // a chunk's spill area: its pixels' worst case (+ the filter literal, the end-of-block symbol, slack for the 16-byte flush and the zeros behind the stream)
             const uint64_t px = std::min<uint64_t>(j.piece_px, im.w);
             j.local_stride = (uint32_t)((((px * im.num_chans + 1) * bits_per_byte + 64 + 31) / 32 + 12 + 31) & ~31ull);
@@ -630,7 +633,8 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     if (job_in_args)
         launch_encode_rows_first(s, two_pass ? slot.jobs2.p[0] : slot.jobs.p[0], sc.d_jobs.p, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     else if (sub.direct)
-        launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, sc.d_look.p);
+        launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.blocks_per_job == 0xFFFFFFFFu ? 0u : sub.blocks_per_job, sub.chan_mask, sc.d_rows.p, sc.d_states.p,
+                             sc.d_local.p, sc.d_look.p);
     else if (!force_stored)
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;

@@ -92,8 +92,9 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);
-// direct placement: total_blocks = workgroups of all jobs (Job::block_base); look = two 64-bit granules per chunk, all zero
-void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t chan_mask, RowInfo *rows, JobState *states,
+// direct placement: total_blocks = workgroups of all jobs (Job::block_base), blocks_per_job = every job's count if they are all equal, else 0;
+// look = two 64-bit granules per chunk, all zero
+void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
                           uint32_t *local, unsigned long long *look);
 // one job per submission: the record travels in the kernel arguments and is left at d_job for the kernels that follow
 void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local);

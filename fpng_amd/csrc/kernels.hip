@@ -505,6 +505,31 @@ struct RowResult {
     uint32_t s1, s2;         // Adler raw sums of the filtered row, mod 65521
 };
 
+// What a piece that starts inside a row (pixel xb > 0, a multiple of 256) needs from the pixels in front of it: the filtered pixel
+// xb - 1 and t(xb - 1) mod CAP, t = how many pixels in a row, ending there, repeat their left neighbour (Rle::carry).  ra / rb: the
+// raw windows [xb - 64, xb) and [xb - 128, xb - 64), loaded by the caller early (the loads travel with the table staging); a run that
+// covers all of the first window is followed further back, window by window (flat rows only).
+template <int C>
+__device__ __forceinline__ void piece_look_behind(const RowWindows<C> &px, const typename RowWindows<C>::Raw &ra, const typename RowWindows<C>::Raw &rb, uint32_t xb, uint32_t lane,
+                                                  uint32_t &prev_f, uint32_t &carry)
+{
+    uint32_t x0 = xb - 64, t = 0;
+    uint32_t f = px.filter(ra), fp = px.filter(rb);
+    prev_f = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+    for (;;) {
+        const uint32_t prev = x0 ? (uint32_t)__builtin_amdgcn_readlane((int)fp, 63) : 0u;
+        uint64_t m = __ballot(f == lane_prev(f, prev));
+        if (!x0) m &= ~1ull; // (the row's first pixel repeats nothing)
+        if (m != ~0ull) {
+            t += (uint32_t)__builtin_clzll(~m); // pixels at the window's end that repeat their left neighbour
+            break;
+        }
+        t += 64, x0 -= 64, f = fp; // (x0 was not 0: the mask of the row's first window is never full)
+        fp = x0 ? px.filtered_at(x0 - 64) : 0u;
+    }
+    carry = t % Rle<C>::CAP;
+}
+
 // Walks row r of the job -- or, PIECE = true (direct placement), the pixels [xb, xe) of it: xb a multiple of 256 (0: the row's first piece,
 // which carries the filter literal), xe a multiple of 256 or the row's width (its last piece).  A piece that starts inside the row
 // needs what the walk carries from window to window -- the filtered pixel in front of it and where the greedy cutting of a run
@@ -513,7 +538,7 @@ struct RowResult {
 // the pieces of a row simply add up.
 template <int C, Pass PASS, bool PIECE = false>
 __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink, uint32_t xb_in = 0,
-                                              uint32_t xe_in = 0)
+                                              uint32_t xe_in = 0, uint32_t piece_prev_f = 0, uint32_t piece_carry = 0)
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
@@ -537,27 +562,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     px.init(row, up_row, bpl, lane);
 
     Rle<C> rle;
-    uint32_t piece_prev_f = 0; // PIECE, xb > 0: the filtered pixel in front of the piece
-    if (PIECE && xb) {
-        uint32_t x0 = xb - 64, t = 0;
-        uint32_t f = px.filtered_at(x0);
-        piece_prev_f = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
-        for (;;) {
-            uint32_t fp = 0, prev = 0;
-            if (x0) { // (wave-uniform)
-                fp = px.filtered_at(x0 - 64);
-                prev = (uint32_t)__builtin_amdgcn_readlane((int)fp, 63);
-            }
-            uint64_t m = __ballot(f == lane_prev(f, prev));
-            if (!x0) m &= ~1ull; // (the row's first pixel repeats nothing)
-            if (m != ~0ull) {
-                t += (uint32_t)__builtin_clzll(~m); // pixels at the window's end that repeat their left neighbour
-                break;
-            }
-            t += 64, x0 -= 64, f = fp; // (x0 was not 0: the mask of the row's first window is never full)
-        }
-        rle.carry = t % Rle<C>::CAP;
-    }
+    if (PIECE && xb) rle.carry = piece_carry; // (piece_prev_f / piece_carry: piece_look_behind(), called by the kernel in front of its first barrier)
     uint32_t row_bits = 0, last_unit = 0;
     // Adler per-lane accumulators: byte sum, sum of (bytes from the pixel's first byte to the row end) x
     // (pixel byte sum), sum of (byte index inside the pixel) x byte.  s2(row) = acc_w - acc_j.
@@ -1044,6 +1049,9 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
 }
 
 // ---- direct placement: look-back granules (encode_direct_kernel, further down; scan_kernel places the chunks that kernel deferred) ----
+#ifndef FPNG_DIRECT_ABL // timing-only builds (wrong files!): bit 0 no look-back, bit 1 no placement stores, bit 2 no look behind a piece's first pixel
+#define FPNG_DIRECT_ABL 0
+#endif
 constexpr unsigned long long kLookReady = 1ull << 63;
 #ifndef FPNG_DIRECT_SPIN_LIMIT
 #define FPNG_DIRECT_SPIN_LIMIT 256
@@ -1409,15 +1417,35 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
 {
     __shared__ PackedTables T;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
-    stage_packed_tables<kRowBlock>(T, job.table);
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), id = jb * kRowWaves + wv;
     const uint32_t n_chunks = uniform(job.n_chunks), np = uniform(job.n_pieces), w = uniform(job.w);
-    if (id >= n_chunks) return;
-    const uint32_t r = id / np, piece = id - r * np;
+    const bool have_chunk = id < n_chunks;
+    const uint32_t r = have_chunk ? id / np : 0u, piece = have_chunk ? id - r * np : 0u;
     const uint32_t xb = piece * uniform(job.piece_px), xe = (piece + 1 == np) ? w : xb + uniform(job.piece_px);
+    // Everything a chunk must fetch before it can start is asked for at once, in front of the barrier: the tables, the two pixel
+    // windows in front of a piece that starts inside its row, the first token bit.  (A wave's time per chunk is a dozen
+    // microseconds: every dependent round trip to memory that is not hidden costs a fifth of it.)
+    RowWindows<C> pw;
+    typename RowWindows<C>::Raw ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+    {
+        const uint32_t bpl = uniform(job.bpl);
+        const uint8_t *row = job.rows + (size_t)r * bpl;
+        const bool filter_up = (uniform(job.y0) + r) != 0;
+        pw.init(row, filter_up ? (r ? row - bpl : job.row_above) : nullptr, bpl, lane);
+#if !(FPNG_DIRECT_ABL & 4)
+        if (xb) ra = pw.load_raw(xb - 64), rb = pw.load_raw(xb - 128);
+#endif
+    }
+    const uint64_t first_bit = job.table->first_token_bit;
+    stage_packed_tables<kRowBlock>(T, job.table);
+    __syncthreads();
+    if (!have_chunk) return;
     const bool last_chunk = id + 1 == n_chunks;
     const size_t slot = (size_t)job.row_base + id;
+    uint32_t piece_prev_f = 0, piece_carry = 0;
+#if !(FPNG_DIRECT_ABL & 4)
+    if (xb) piece_look_behind<C>(pw, ra, rb, xb, lane, piece_prev_f, piece_carry);
+#endif
 
     EmitSink sink;
     sink.stage = stage[wv];
@@ -1430,7 +1458,7 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     sink_zero_window(sink, lane);
     wave_lds_fence();
 
-    const RowResult res = walk_row<C, Pass::Encode, true>(job, T, nullptr, r, lane, &sink, xb, xe);
+    const RowResult res = walk_row<C, Pass::Encode, true>(job, T, nullptr, r, lane, &sink, xb, xe, piece_prev_f, piece_carry);
     if (last_chunk) { // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of the record's bits
         const uint32_t eob = T.lit[256];
         sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
@@ -1460,6 +1488,10 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     // ---- look-back: bits of all chunks in front of this one ----
     uint64_t excl = 0;
     bool deferred = false;
+    unsigned long long front = 0; // the record of the chunk right in front (its last bits are wanted below)
+#if FPNG_DIRECT_ABL & 1
+    excl = (uint64_t)id * 21000u; // (timing only: no look-back, chunks at made-up offsets)
+#else
     {
         int64_t base = (int64_t)id - 1; // the nearest chunk not yet accounted for
         uint32_t width = 16;            // chunks looked at per round: the nearest ones nearly always do
@@ -1475,6 +1507,7 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
                 q = kLookReady;
             const uint64_t live = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
             const uint64_t qmask = __ballot((q & kLookReady) != 0) & live, amask = __ballot((a & kLookReady) != 0) & live;
+            if (first_round) front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, 0);
             bool progress = false;
             if (qmask) {
                 const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest chunk whose inclusive prefix is known
@@ -1505,6 +1538,7 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
             }
         }
     }
+#endif
     if (deferred) {
         // The chunks in front have not all reported in time.  A wave that waits holds its place on the compute unit, and with several
         // such kernels on one GPU (two lanes, several encoders, several processes) waves that wait for each other's unstarted
@@ -1524,20 +1558,32 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     }
     if (lane == 0) look_store(&pre[2 * (size_t)id], kLookReady | (excl + res.bits));
     // ---- place the bits.  File bit of the chunk's first bit: ----
-    const uint64_t first_bit = job.table->first_token_bit;
     const uint64_t P = (uint64_t)job.bit_bias + first_bit + excl;
     const uint32_t sh = (uint32_t)P & 31u;
     const uint64_t D0 = P >> 5;
     const uint64_t D1 = last_chunk ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5); // dwords [D0, D1) are this chunk's
-    const uint32_t W = sh ? uniform(direct_bits_in_front(job, agg, id, sh, (uint32_t)first_bit)) : 0u;
+    // the sh bits in front of the chunk, top-aligned: nearly always the last bits of the chunk right in front, whose record the first
+    // look-back round fetched (fewer than sh bits there, or no chunk in front: direct_bits_in_front() collects them)
+    uint32_t W = 0;
+    if (sh) {
+        const uint32_t fb = (uint32_t)(front & 0xFFFFFFu);
+        if (id && (front & kLookReady) && (fb >= 31u || fb >= sh))
+            W = ((uint32_t)(front >> 24) & 0x7FFFFFFFu) << 1;
+#if !(FPNG_DIRECT_ABL & 1)
+        else
+            W = uniform(direct_bits_in_front(job, agg, id, sh, (uint32_t)first_bit));
+#endif
+    }
     gptr_u32 out32 = to_global<gptr_u32>(job.out);
     const uint64_t cap_dw = job.out_cap >> 2; // (a stream that outgrows the file's buffer ends as stored blocks: scan_kernel decides, assemble_kernel writes them)
     const uint32_t nD = (uint32_t)(D1 - D0);
+#if !(FPNG_DIRECT_ABL & 2)
     for (uint32_t m = lane; m < nD; m += kWave) {
         const uint32_t hi = sdw(m), lo = m ? sdw(m - 1) : W;
         const uint32_t v = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
         if (D0 + m < cap_dw) out32[D0 + m] = v;
     }
+#endif
     if (lane == 0) {
         RowInfo ri;
         ri.bits = res.bits;
@@ -1553,18 +1599,22 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
 #define FPNG_DIRECT_WPE 6
 #endif
 template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DIRECT_WPE, FPNG_DIRECT_WPE))) void encode_direct_kernel(const Job *jobs, uint32_t n_jobs, uint32_t total_blocks,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DIRECT_WPE, FPNG_DIRECT_WPE))) void encode_direct_kernel(const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job,
                                                                                                                           RowInfo *rows_out, JobState *states, uint32_t *local,
                                                                                                                           unsigned long long *look)
 {
     const uint32_t b = direct_block_order();
     if (b >= total_blocks) return;
-    // the job this workgroup belongs to: the last one whose block_base is <= b
+    // the job this workgroup belongs to: the last one whose block_base is <= b (blocks_per_job != 0: all jobs have that many -- the
+    // usual batch of equal frames -- and no search's round trips stand in front of the chunk)
     uint32_t lo = 0, hi = n_jobs;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (jobs[mid].block_base <= b) lo = mid; else hi = mid;
-    }
+    if (blocks_per_job)
+        lo = b / blocks_per_job;
+    else
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (jobs[mid].block_base <= b) lo = mid; else hi = mid;
+        }
     const uint32_t ji = uniform(lo);
     const Job &job = jobs[ji];
     if (job.c != C || !(job.flags & kJobDirect)) return;
@@ -2607,15 +2657,15 @@ void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo 
 {
     hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states, look, local);
 }
-void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t chan_mask, RowInfo *rows, JobState *states,
+void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
                           uint32_t *local, unsigned long long *look)
 {
     // whole rounds of 8 runs of kDirectGroupBlocks workgroups (direct_block_order)
     const uint32_t round = 8u * kDirectGroupBlocks, grid = (total_blocks + round - 1) / round * round;
     if (chan_mask & 1u)
-        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, rows, states, local, look);
+        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look);
     if (chan_mask & 2u)
-        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, rows, states, local, look);
+        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero)
 {

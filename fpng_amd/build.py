@@ -99,6 +99,7 @@ DROPIN_VARIANTS = {"nocrc"}
 VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's fuzzing switch (src/fpng.cpp:50-53): libfpng_amd_nocrc.so + libfpng_nocrc.so
             "direct_defer": ["FPNG_DIRECT_SPIN_LIMIT=0"],  # every chunk that has to wait at all is deferred to scan_kernel (tests)
             "abl_nolook": ["FPNG_DIRECT_ABL=1"], "abl_nostore": ["FPNG_DIRECT_ABL=2"], "abl_nobehind": ["FPNG_DIRECT_ABL=4"], "abl_all": ["FPNG_DIRECT_ABL=7"],  # timing only: wrong files
+            "direct_sleep4": ["FPNG_DIRECT_SLEEP=4"], "direct_sleep64": ["FPNG_DIRECT_SLEEP=64"],
             "direct_w8": ["FPNG_DIRECT_WPE=8"], "direct_w5_win1536": ["FPNG_DIRECT_WPE=5", "FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "direct_win1280": ["FPNG_STAGE_DWORDS=1280", "FPNG_ROWS_WPE=6"],
             "win1536_w5": ["FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "win2048_w4": ["FPNG_STAGE_DWORDS=2048", "FPNG_ROWS_WPE=4"], "win1024_w6": ["FPNG_ROWS_WPE=6"], "win1024_w4": ["FPNG_ROWS_WPE=4"],
             "lead96": ["FPNG_DEC_LEADIN=96"], "lead64": ["FPNG_DEC_LEADIN=64"], "lean": ["FPNG_DEC_LEAN=1"], "stage": ["FPNG_DEC_STAGE=1"], "stage_lean": ["FPNG_DEC_STAGE=1", "FPNG_DEC_LEAN=1"], "timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"], "rows8": ["FPNG_ROW_WAVES=8"], "rows2": ["FPNG_ROW_WAVES=2"],

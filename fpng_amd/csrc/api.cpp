@@ -373,6 +373,7 @@ struct Submission {
     bool direct = false;       // direct placement (kernels.h: Job::piece_px): total_rows counts CHUNKS then
     uint32_t total_blocks = 0; // ... workgroups of encode_direct_kernel
     uint32_t blocks_per_job = 0; // ... of every job if they all have the same number, else 0
+    uint32_t total_groups = 0;   // ... groups of 64 chunks (look-back granules)
     uint64_t total_rows = 0;
     uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
@@ -416,12 +417,14 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     sub = Submission();
     sub.n = n;
-    // Direct placement (FPNG_AMD_DIRECT=0: the two-kernel chain with local streams, kept for A/B runs and used by the row
-    // bands): rows are cut into pieces of FPNG_AMD_PIECE_PX pixels (a multiple of 256) whose token bits fit a wave's LDS window --
-    // 1536 RGBA / 2048 RGB pixels hold up to ~12.5 / ~9.4 bits per pixel without a spill (the synthetic gradient: 14.1 / 10.6 ...).
+    // Direct placement (profiles/r05_encode_onchip_ab.txt): FPNG_AMD_DIRECT=1 replaces the two-kernel chain (row walk into
+    // local streams, assemble) by encode_direct_kernel -- rows cut into pieces of FPNG_AMD_PIECE_PX pixels (a multiple of 256) whose
+    // token bits fit a wave's LDS window, every chunk placed by the wave that encoded it.  Bit-exact and tested, and 3 x SLOWER on
+    // this hardware (a chunk's offset arrives through agent-scope memory: ~50 us per chunk against 2 us of work), so it is OFF
+    // unless asked for; the measurements and the ablations that bound what it could ever gain (+12 %) are in that file.
     // (read at every call: tests and A/B runs switch them inside one process)
     const char *de = getenv("FPNG_AMD_DIRECT"), *pe = getenv("FPNG_AMD_PIECE_PX");
-    const bool direct_env = !de || de[0] != '0';
+    const bool direct_env = de && de[0] == '1';
     const uint32_t piece_env = pe ? (((uint32_t)atoi(pe) + 255u) & ~255u) : 0u;
     sub.direct = direct_env && !force_stored;
     for (uint32_t i = 0; i < n; i++) {
@@ -468,6 +471,8 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
             if (units > 0xFFFFFFFFull || sub.total_blocks + (units + 3) / 4 > 0x7FFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many chunks in one batch");
             j.n_chunks = (uint32_t)units;
             j.block_base = sub.total_blocks;
+            j.group_base = sub.total_groups;
+            sub.total_groups += (uint32_t)((units + 63) / 64);
             const uint32_t nb = (uint32_t)((units + 3) / 4);
             sub.blocks_per_job = (i == 0 || sub.blocks_per_job == nb) ? nb : 0xFFFFFFFFu; // (0xFFFFFFFF: they differ)
             sub.total_blocks += nb;
@@ -484,7 +489,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     if ((rc = sc.d_jobs.ensure(n))) return rc;
     if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
     if ((rc = sc.d_row_off.ensure(sub.direct ? 16 : sub.total_rows))) return rc;
-    if (sub.direct && (rc = sc.d_look.ensure(2 * (size_t)sub.total_rows))) return rc;
+    if (sub.direct && (rc = sc.d_look.ensure(((size_t)sub.total_rows + 15) / 16 * 16 + 16 * (size_t)sub.total_groups))) return rc;
     if ((rc = sc.d_states.ensure(n))) return rc;
     if ((rc = sc.d_results.ensure(n))) return rc;
     if ((rc = sc.d_partials.ensure(3 * (size_t)n * sub.max_crc_blocks))) return rc; // CRC partials + two Adler words per range (stored images)
@@ -634,7 +639,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         launch_encode_rows_first(s, two_pass ? slot.jobs2.p[0] : slot.jobs.p[0], sc.d_jobs.p, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     else if (sub.direct)
         launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.blocks_per_job == 0xFFFFFFFFu ? 0u : sub.blocks_per_job, sub.chan_mask, sc.d_rows.p, sc.d_states.p,
-                             sc.d_local.p, sc.d_look.p);
+                             sc.d_local.p, sc.d_look.p, sc.d_look.p + (sub.total_rows + 15) / 16 * 16);
     else if (!force_stored)
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
     if ((rc = mark(e, s, ++ph))) return rc;
@@ -651,7 +656,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
             e->prev_walked = slot.walked;
         }
     }
-    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p, sub.direct ? sc.d_look.p : nullptr, sub.direct ? sc.d_local.p : nullptr);
+    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p, sub.direct ? sc.d_look.p : nullptr, sub.direct ? sc.d_look.p + (sub.total_rows + 15) / 16 * 16 : nullptr, sub.direct ? sc.d_local.p : nullptr);
     if ((rc = mark(e, s, ++ph))) return rc;
     uint32_t *adler_parts = sc.d_partials.p + (size_t)n * sub.max_crc_blocks;
     launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, adler_parts);

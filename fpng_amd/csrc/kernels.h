@@ -38,6 +38,8 @@ struct Job {
     uint32_t piece_px, n_pieces;
     uint32_t n_chunks;        // nrows * n_pieces
     uint32_t block_base;      // the job's first workgroup in the linear order of encode_direct_kernel (kRowWaves chunks each)
+    uint32_t group_base;      // ... and its first group of 64 chunks in the look-back's group granules
+    uint32_t direct_pad;
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
 
@@ -88,14 +90,14 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 // look / local: the look-back granules of direct jobs (cleared again here, for the scratch set's next submission) and the chunks' spill
 // areas (chunks that encode_direct_kernel deferred are placed here), or NULL
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look = nullptr,
-                 const uint32_t *local = nullptr);
+                 unsigned long long *look_grp = nullptr, const uint32_t *local = nullptr);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local);
 // direct placement: total_blocks = workgroups of all jobs (Job::block_base), blocks_per_job = every job's count if they are all equal, else 0;
-// look = two 64-bit granules per chunk, all zero
+// look / look_grp = one 64-bit granule per chunk / two per group of 64 chunks (Job::group_base), all zero
 void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
-                          uint32_t *local, unsigned long long *look);
+                          uint32_t *local, unsigned long long *look, unsigned long long *look_grp);
 // one job per submission: the record travels in the kernel arguments and is left at d_job for the kernels that follow
 void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local);
 void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist);

@@ -1053,8 +1053,12 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
 #define FPNG_DIRECT_ABL 0
 #endif
 constexpr unsigned long long kLookReady = 1ull << 63;
+constexpr uint32_t kGrpStride = 16; // granules per group record (128 bytes)
 #ifndef FPNG_DIRECT_SPIN_LIMIT
 #define FPNG_DIRECT_SPIN_LIMIT 256
+#endif
+#ifndef FPNG_DIRECT_SLEEP // s_sleep argument between two polls (units of 64 cycles)
+#define FPNG_DIRECT_SLEEP 24
 #endif
 constexpr uint32_t kDirectSpinLimit = FPNG_DIRECT_SPIN_LIMIT; // polls (~0.1 us each) a chunk waits for the chunks in front of it before it is deferred
 __device__ __forceinline__ unsigned long long look_load(const unsigned long long *p)
@@ -1073,8 +1077,8 @@ __device__ __forceinline__ uint32_t direct_bits_in_front(const Job &job, const u
     uint32_t W = 0, have = 0;
     int64_t j = (int64_t)id - 1;
     while (have < sh && j >= 0) {
-        unsigned long long a = look_load(&agg[2 * j]);
-        for (uint32_t spins = 0; !(a & kLookReady) && spins < (1u << 16); spins++) a = look_load(&agg[2 * j]); // (published long ago: see the callers; bounded all the same)
+        unsigned long long a = look_load(&agg[j]);
+        for (uint32_t spins = 0; !(a & kLookReady) && spins < (1u << 16); spins++) a = look_load(&agg[j]); // (published long ago: see the callers; bounded all the same)
         const uint32_t b = (uint32_t)(a & 0xFFFFFFu), t = (uint32_t)(a >> 24) & 0x7FFFFFFFu;
         W |= (t << 1) >> have;
         have += b < 31u ? b : 31u;
@@ -1093,7 +1097,7 @@ __device__ __forceinline__ uint32_t direct_bits_in_front(const Job &job, const u
 
 
 __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
-                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */, unsigned long long *look, const uint32_t *spill)
+                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */, unsigned long long *look, unsigned long long *look_grp, const uint32_t *spill)
 {
     // direct placement (encode_direct_kernel): the records are CHUNKS' (n_pieces per row), the bits are in the file already --
     // what is left is the sums, the decision, the head of the file in front of the first chunk's first dword, and the look-back
@@ -1162,7 +1166,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
             __shared__ uint32_t def_rec[kScanBlock], def_w;
             __shared__ uint64_t def_pos[kScanBlock];
             __shared__ uint32_t def_any;
-            const unsigned long long *agg = look + 2 * (size_t)job.row_base;
+            const unsigned long long *agg = look + (size_t)job.row_base;
             gptr_u32 out32 = to_global<gptr_u32>(job.out);
             const uint64_t cap_dw = job.out_cap >> 2;
             const uint32_t eob_len_d = tab->lit[256] >> 16;
@@ -1286,18 +1290,19 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kScanBlock) out[i] = 0;
     }
     if (direct && look) { // the chain's last reader of the granules leaves them zeroed
-        unsigned long long *g = look + 2 * (size_t)job.row_base;
-        for (uint32_t i = t; i < 2 * n_rec; i += kScanBlock) g[i] = 0ull;
+        unsigned long long *g = look + (size_t)job.row_base, *gg = look_grp + kGrpStride * (size_t)job.group_base;
+        for (uint32_t i = t; i < n_rec; i += kScanBlock) g[i] = 0ull;
+        for (uint32_t i = t; i < ((n_rec + 63u) >> 6); i += kScanBlock) gg[kGrpStride * (size_t)i] = 0ull, gg[kGrpStride * (size_t)i + 8] = 0ull;
     }
     if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
 // scan_kernel: one block per job (whole images; row bands: counting phase and placement phase)
 __global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look,
-                                                             const uint32_t *local)
+                                                             unsigned long long *look_grp, const uint32_t *local)
 {
     __shared__ uint64_t wsum[3][kScanWaves];
-    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum, look, local);
+    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum, look, look_grp, local);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1413,7 +1418,8 @@ __device__ __forceinline__ uint32_t direct_block_order()
 }
 
 template <int C>
-__device__ __forceinline__ void encode_direct_block(const Job &job, JobState &state, uint32_t jb, RowInfo *rows_out, uint32_t *local, unsigned long long *look)
+__device__ __forceinline__ void encode_direct_block(const Job &job, JobState &state, uint32_t jb, RowInfo *rows_out, uint32_t *local, unsigned long long *look,
+                                                    unsigned long long *look_grp)
 {
     __shared__ PackedTables T;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
@@ -1471,21 +1477,31 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     if (spilled) {
         sink_flush(sink, lane, true);
         if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u; // (the dwords behind the last one are read as zeros below; the final flush may or may not have covered them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the wave reads its own non-temporal stores back)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the wave reads its own stores back: they have left the wave; the loads below go past the caches)
     }
-    auto sdw = [&](uint32_t k) -> uint32_t { return spilled ? loc[k] : sink.stage[k]; }; // (spilled is wave-uniform)
+    // (spilled is wave-uniform; a spilled stream is read back past the caches -- the rare path)
+    auto sdw = [&](uint32_t k) -> uint32_t { return spilled ? __hip_atomic_load((const uint32_t *)(local + job.local_base + (uint64_t)id * job.local_stride) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sink.stage[k]; };
     // its last 31 bits, the last one in bit 30 (a chunk of fewer bits: what there is, at the top)
     uint32_t tail31;
     if (nbits >= 32) {
         const uint32_t k = nbits - 31, q = k >> 5, o = k & 31u;
-        const uint32_t lo = uniform(sdw(q)), hi = uniform(sdw(q + 1)); // (q + 1 may lie behind the last dword: zeros there -- the window is cleared, a spill area's slack is written as zeros by the final flush)
+        const uint32_t lo = uniform(sdw(q)), hi = uniform(sdw(q + 1)); // (q + 1 may lie behind the last dword: zeros there -- the window is cleared, a spill area's slack is written as zeros above)
         tail31 = (o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo) & 0x7FFFFFFFu;
     } else
         tail31 = nbits ? ((uniform(sdw(0)) << (31u - nbits)) & 0x7FFFFFFFu) : 0u;
-    unsigned long long *agg = look + 2 * (size_t)job.row_base, *pre = agg + 1; // granule pair of chunk i: agg[2 i], pre[2 i]
-    if (lane == 0) look_store(&agg[2 * (size_t)id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
-    // ---- look-back: bits of all chunks in front of this one ----
+    // ---- look-back, two levels.  Per chunk one granule {ready, its last 31 bits, its bits}; per GROUP of 64 chunks two: {chunks that
+    //      have reported << 44 | their bits' sum} (atomic adds) and {ready | bits in front of the group} (written by the group's
+    //      first chunk).  A chunk needs the records of the chunks of its own group in front of it (one load per lane) and its
+    //      group's prefix; a group's first chunk finds that prefix by looking back over the GROUPS in front (64 of them per round
+    //      trip = 4096 chunks: with chunks alone the front of known offsets moved 64 chunks per round trip and job -- the first
+    //      version's 0.74 ms, profiles/r05_direct_v1.txt). ----
+    unsigned long long *agg = look + (size_t)job.row_base;
+    unsigned long long *grp = look_grp + kGrpStride * (size_t)job.group_base; // a group's record: its own 128-byte line, the counter the chunks add to and the prefix the chunks poll 64 bytes apart
+    const uint32_t g = id >> 6, k = id & 63u;
+    if (lane == 0) {
+        look_store(&agg[id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
+        (void)__hip_atomic_fetch_add(&grp[kGrpStride * (size_t)g], (1ull << 44) | (unsigned long long)res.bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     uint64_t excl = 0;
     bool deferred = false;
     unsigned long long front = 0; // the record of the chunk right in front (its last bits are wanted below)
@@ -1493,48 +1509,79 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     excl = (uint64_t)id * 21000u; // (timing only: no look-back, chunks at made-up offsets)
 #else
     {
-        int64_t base = (int64_t)id - 1; // the nearest chunk not yet accounted for
-        uint32_t width = 16;            // chunks looked at per round: the nearest ones nearly always do
-        bool first_round = true;
-        for (uint32_t spins = 0; base >= 0;) {
-            const int64_t j = base - lane;
-            const bool look_at = lane < width && j >= 0;
-            unsigned long long a = kLookReady, q = 0; // (in front of chunk 0: nothing, and it is "known")
-            if (look_at) {
-                q = look_load(&pre[2 * j]);
-                a = look_load(&agg[2 * j]);
-            } else if (j < 0)
-                q = kLookReady;
-            const uint64_t live = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
-            const uint64_t qmask = __ballot((q & kLookReady) != 0) & live, amask = __ballot((a & kLookReady) != 0) & live;
-            if (first_round) front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, 0);
-            bool progress = false;
-            if (qmask) {
-                const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest chunk whose inclusive prefix is known
-                const uint64_t need = ((1ull << L) - 1ull) | (first_round ? 1ull : 0ull); // (the chunk right in front: its last bits are wanted below)
-                if ((amask & need) == need) {
-                    const uint64_t part = (lane < L) ? (uint64_t)(a & 0xFFFFFFu) : (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
-                    uint64_t total;
-                    (void)wave_exclusive_sum_u64(part, lane, total);
-                    excl += total;
-                    base = -1;
-                    progress = true;
-                }
-            } else if (amask == live) { // only aggregates so far: take them, look further back
-                uint64_t total;
-                (void)wave_exclusive_sum_u64((lane < width) ? (uint64_t)(a & 0xFFFFFFu) : 0ull, lane, total);
-                excl += total;
-                base -= width;
-                width = 64;
-                first_round = false;
-                progress = true;
+        // Polling discipline (the second version hammered: 6000 waves re-reading 64 granules each past the caches made every round
+        // trip slower for everybody -- 3.9 ms): a wave re-reads only what it is still missing, ONE granule while it waits for its
+        // group's prefix, and sleeps about a microsecond between polls.
+        bool g_known = g == 0; // the group's prefix (gval) is known
+        bool intra_ok = k == 0 && id == 0;
+        uint64_t gval = 0, gacc = 0, intra = 0;
+        int64_t gbase = (int64_t)g - 1; // (leading) the nearest group not yet accounted for
+        for (uint32_t spins = 0;;) {
+            // (a chunk that has waited long for its group's prefix looks for it itself, like the group's first chunk: that one may
+            //  have been deferred)
+            const bool lead = k == 0 || spins >= 48;
+            unsigned long long a = kLookReady, q = 0, ga = 0;
+            if (!intra_ok) {
+                if (lane < k)
+                    a = look_load(&agg[(size_t)g * 64u + lane]);
+                else if (k == 0 && lane == 0)
+                    a = look_load(&agg[id - 1]); // (the chunk right in front, of the group in front: only its last bits are wanted)
             }
-            if (!progress) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kDirectSpinLimit) { // see below
-                    deferred = true;
-                    break;
+            if (!g_known) {
+                if (!lead)
+                    q = look_load(&grp[kGrpStride * (size_t)g + 8]);
+                else {
+                    const int64_t j = gbase - lane;
+                    if (j >= 0) {
+                        ga = look_load(&grp[kGrpStride * j]);
+                        q = look_load(&grp[kGrpStride * j + 8]);
+                    } else
+                        ga = 64ull << 44, q = kLookReady; // (in front of the first group: nothing, and known)
                 }
+            }
+            if (!intra_ok && __ballot((a & kLookReady) != 0) == ~0ull) {
+                uint64_t total;
+                (void)wave_exclusive_sum_u64(lane < k ? (uint64_t)(a & 0xFFFFFFu) : 0ull, lane, total);
+                intra = total;
+                const int fl = k ? (int)k - 1 : 0;
+                front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), fl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, fl);
+                intra_ok = true;
+            }
+            if (!g_known) {
+                if (!lead) {
+                    const unsigned long long q0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
+                    if (q0 & kLookReady) g_known = true, gval = q0 & ~kLookReady;
+                } else {
+                    const uint64_t qmask = __ballot((q & kLookReady) != 0), cmask = __ballot((ga >> 44) == 64u);
+                    if (qmask) {
+                        const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest group whose prefix is known
+                        const uint64_t need = L >= 63 ? ~0ull : ((2ull << L) - 1ull); // ... it and the groups behind it must be complete
+                        if ((cmask & need) == need) {
+                            const uint64_t part = (lane <= L ? (uint64_t)(ga & ((1ull << 44) - 1ull)) : 0ull) + (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
+                            uint64_t total;
+                            (void)wave_exclusive_sum_u64(part, lane, total);
+                            gval = gacc + total;
+                            g_known = true;
+                            if (lane == 0) look_store(&grp[kGrpStride * (size_t)g + 8], kLookReady | gval);
+                        }
+                    } else if (cmask == ~0ull) { // 64 complete groups, no prefix among them: take them, look further back
+                        uint64_t total;
+                        (void)wave_exclusive_sum_u64((uint64_t)(ga & ((1ull << 44) - 1ull)), lane, total);
+                        gacc += total;
+                        gbase -= 64;
+                        continue;
+                    }
+                }
+            }
+            if (g_known && intra_ok) {
+                excl = gval + intra;
+                if (!id) front = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(FPNG_DIRECT_SLEEP);
+            if (++spins > kDirectSpinLimit) { // see below
+                deferred = true;
+                break;
             }
         }
     }
@@ -1543,7 +1590,8 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
         // The chunks in front have not all reported in time.  A wave that waits holds its place on the compute unit, and with several
         // such kernels on one GPU (two lanes, several encoders, several processes) waves that wait for each other's unstarted
         // predecessors could fill it: so nobody waits long.  The chunk goes to its spill area like a row of encode_rows, its record
-        // says so, and scan_kernel -- which knows every offset -- places it (its bit count is published: nobody behind it is held up).
+        // says so, and scan_kernel -- which knows every offset -- places it (its bit count is published: nobody behind it is held up;
+        // a group whose first chunk is deferred has no prefix written: its other chunks end here too, later groups look past it).
         if (!spilled) {
             sink_flush(sink, lane, true);
             if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u;
@@ -1556,32 +1604,51 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
         }
         return;
     }
-    if (lane == 0) look_store(&pre[2 * (size_t)id], kLookReady | (excl + res.bits));
     // ---- place the bits.  File bit of the chunk's first bit: ----
     const uint64_t P = (uint64_t)job.bit_bias + first_bit + excl;
     const uint32_t sh = (uint32_t)P & 31u;
     const uint64_t D0 = P >> 5;
     const uint64_t D1 = last_chunk ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5); // dwords [D0, D1) are this chunk's
-    // the sh bits in front of the chunk, top-aligned: nearly always the last bits of the chunk right in front, whose record the first
-    // look-back round fetched (fewer than sh bits there, or no chunk in front: direct_bits_in_front() collects them)
+    // the sh bits in front of the chunk, top-aligned: nearly always the last bits of the chunk right in front, whose record the
+    // look-back fetched (fewer than sh bits there, or no chunk in front: direct_bits_in_front() collects them)
     uint32_t W = 0;
     if (sh) {
         const uint32_t fb = (uint32_t)(front & 0xFFFFFFu);
-        if (id && (front & kLookReady) && (fb >= 31u || fb >= sh))
+        if (id && (front & kLookReady) && fb >= sh)
             W = ((uint32_t)(front >> 24) & 0x7FFFFFFFu) << 1;
 #if !(FPNG_DIRECT_ABL & 1)
         else
             W = uniform(direct_bits_in_front(job, agg, id, sh, (uint32_t)first_bit));
 #endif
     }
-    gptr_u32 out32 = to_global<gptr_u32>(job.out);
-    const uint64_t cap_dw = job.out_cap >> 2; // (a stream that outgrows the file's buffer ends as stored blocks: scan_kernel decides, assemble_kernel writes them)
-    const uint32_t nD = (uint32_t)(D1 - D0);
 #if !(FPNG_DIRECT_ABL & 2)
-    for (uint32_t m = lane; m < nD; m += kWave) {
-        const uint32_t hi = sdw(m), lo = m ? sdw(m - 1) : W;
-        const uint32_t v = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-        if (D0 + m < cap_dw) out32[D0 + m] = v;
+    {
+        // file dword D0 + m = stream dwords m - 1 (its top sh bits) and m (the rest); stream dword -1 = W.  Up to three dwords to the
+        // next 16-byte boundary of the file, then 16 bytes per lane, then what is left.
+        gptr_u32 out32 = to_global<gptr_u32>(job.out);
+        const uint64_t cap_dw = job.out_cap >> 2; // (a stream that outgrows the file's buffer ends as stored blocks: scan_kernel decides, assemble_kernel writes them)
+        const uint32_t nD = (uint32_t)(D1 - D0);
+        auto fdw = [&](uint32_t m, uint32_t lo) -> uint32_t { // lo = stream dword m - 1
+            const uint32_t hi = sdw(m);
+            return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+        };
+        uint32_t head = (4u - ((uint32_t)D0 & 3u)) & 3u;
+        head = head < nD ? head : nD;
+        if (lane < head && D0 + lane < cap_dw) out32[D0 + lane] = fdw(lane, lane ? sdw(lane - 1) : W);
+        const uint32_t nq = (nD - head) >> 2;
+        for (uint32_t q = lane; q < nq; q += kWave) {
+            const uint32_t m0 = head + 4u * q;
+            const uint32_t s0 = m0 ? sdw(m0 - 1) : W, s1 = sdw(m0), s2 = sdw(m0 + 1), s3 = sdw(m0 + 2), s4 = sdw(m0 + 3);
+            u32x4 v;
+            if (sh) {
+                v.x = __builtin_amdgcn_alignbit(s1, s0, 32u - sh), v.y = __builtin_amdgcn_alignbit(s2, s1, 32u - sh);
+                v.z = __builtin_amdgcn_alignbit(s3, s2, 32u - sh), v.w = __builtin_amdgcn_alignbit(s4, s3, 32u - sh);
+            } else
+                v.x = s1, v.y = s2, v.z = s3, v.w = s4;
+            if (D0 + m0 + 4 <= cap_dw) *(gptr_u128)(uintptr_t)(out32 + D0 + m0) = v;
+        }
+        const uint32_t mt = head + 4u * nq + lane;
+        if (mt < nD && D0 + mt < cap_dw) out32[D0 + mt] = fdw(mt, mt ? sdw(mt - 1) : W);
     }
 #endif
     if (lane == 0) {
@@ -1601,7 +1668,7 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
 template <int C>
 __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DIRECT_WPE, FPNG_DIRECT_WPE))) void encode_direct_kernel(const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job,
                                                                                                                           RowInfo *rows_out, JobState *states, uint32_t *local,
-                                                                                                                          unsigned long long *look)
+                                                                                                                          unsigned long long *look, unsigned long long *look_grp)
 {
     const uint32_t b = direct_block_order();
     if (b >= total_blocks) return;
@@ -1618,7 +1685,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
     const uint32_t ji = uniform(lo);
     const Job &job = jobs[ji];
     if (job.c != C || !(job.flags & kJobDirect)) return;
-    encode_direct_block<C>(job, states[ji], b - job.block_base, rows_out, local, look);
+    encode_direct_block<C>(job, states[ji], b - job.block_base, rows_out, local, look, look_grp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2653,19 +2720,20 @@ void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist
     arg.job = job;
     hipLaunchKernelGGL(hist_first_kernel, dim3((job.nrows + kHistWaves - 1) / kHistWaves, 1, 1), dim3(kHistBlock), 0, s, arg, d_job, hist);
 }
-void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look, const uint32_t *local)
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look,
+                 unsigned long long *look_grp, const uint32_t *local)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states, look, local);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states, look, look_grp, local);
 }
 void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
-                          uint32_t *local, unsigned long long *look)
+                          uint32_t *local, unsigned long long *look, unsigned long long *look_grp)
 {
     // whole rounds of 8 runs of kDirectGroupBlocks workgroups (direct_block_order)
     const uint32_t round = 8u * kDirectGroupBlocks, grid = (total_blocks + round - 1) / round * round;
     if (chan_mask & 1u)
-        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look);
+        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look, look_grp);
     if (chan_mask & 2u)
-        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look);
+        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look, look_grp);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero)
 {

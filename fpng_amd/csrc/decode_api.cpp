@@ -374,9 +374,19 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     std::vector<Group> groups;
     {
         // (file k goes to the group its middle byte falls into when the batch's bytes are cut into `want` equal parts)
-        const uint32_t want = (!device_data && z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : 1u;
+        // Files in device memory CAN be cut into groups as well (FPNG_AMD_DECODE_DEVICE_GROUPS=2..4; round 5): the groups' kernels
+        // alternate between two streams, so that one group's un-filter pass -- memory-bound -- could run under the next group's
+        // synchronisation and emit passes, which are bound by vector instruction issue.  Measured: no gain (8 x 8K 2.33 -> 2.39 /
+        // 2.45 / 2.46 ms with 2 / 3 / 4 groups, profiles/r05_decode_groups.txt: the persistent sync / emit workgroups hold the compute
+        // units' LDS and registers until their kernel ends, the other stream's kernels queue behind them), so the default is one group.
         uint64_t total = 0, run = 0;
         for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
+        static const uint32_t dev_groups = [] {
+            const char *v = getenv("FPNG_AMD_DECODE_DEVICE_GROUPS");
+            return v ? (uint32_t)std::min(std::max(atoi(v), 1), (int)kMaxGroups) : 1u;
+        }();
+        const bool split_device = device_data && !e->profiling && nj > 1 && total >= (8u << 20) && e->lane_stream[0] && e->lane_stream[1];
+        const uint32_t want = (!device_data && z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : (split_device ? std::min<uint32_t>(dev_groups, nj) : 1u);
         auto close = [&](uint32_t j0, uint32_t j1) {
             Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, {}};
             groups.push_back(g);
@@ -410,7 +420,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             if (w) w->wait();
         }
     } joiner;
-    if (ng > 1) {
+    const bool uploads = !device_data && ng > 1; // groups of host-resident files: their bytes go up on a stream of their own
+    const bool split = device_data && ng > 1;    // groups of device-resident files: their kernels alternate between two streams
+    if (uploads) {
         if (!e->dec_up) HIP_TRY(create_copy_stream(&e->dec_up));
         for (uint32_t g = 0; g < ng; g++)
             if (!e->dec_ev[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[g], hipEventDisableTiming));
@@ -472,7 +484,18 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         for (hipEvent_t &ev : e->dec_prof_ev)
             if (!ev) HIP_TRY(hipEventCreate(&ev));
     auto stamp = [&](const Group &g, int k) -> hipError_t { return (prof && &g == groups.data()) ? hipEventRecord(e->dec_prof_ev[k], s) : hipSuccess; };
-    auto finish_group = [&](const Group &g) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
+    hipStream_t gstream[2] = {s, split ? e->lane_stream[1] : s};
+    if (split) {
+        for (uint32_t g = 0; g < ng; g++) {
+            if (!e->dec_ev2[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev2[g], hipEventDisableTiming));
+            if (!e->dec_ev3[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev3[g], hipEventDisableTiming));
+        }
+        if (!e->dec_ev[15]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[15], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e->dec_ev[15], s)); // tables, job records, plans, cleared status words: every stream starts behind them
+        HIP_TRY(hipStreamWaitEvent(gstream[1], e->dec_ev[15], 0));
+    }
+    // gi: the group's number (>= ng: a later pass over it, after everything has been joined: no neighbours to order against)
+    auto finish_group = [&](const Group &g, hipStream_t s, uint32_t gi) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
         const uint32_t nblk = g.blk1 - g.blk0;
         hipError_t pe = stamp(g, 1);
         if (pe != hipSuccess) return pe;
@@ -485,16 +508,21 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if ((pe = stamp(g, 3)) != hipSuccess) return pe;
         bool any_stored = false;
         for (uint32_t k = g.j0; k < g.j1; k++) any_stored |= jobs[k].mode != 0;
+        // (two un-filter kernels never run at once: each one's workgroups wait for lower-numbered ones of their own launch, and two
+        //  sets of waiting workgroups could keep each other's predecessors off the compute units)
+        if (split && gi && gi < ng && (pe = hipStreamWaitEvent(s, e->dec_ev2[gi - 1], 0)) != hipSuccess) return pe;
         launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, next_epoch(e), any_stored);
+        if (split && gi < ng && (pe = hipEventRecord(e->dec_ev2[gi], s)) != hipSuccess) return pe;
         if ((pe = stamp(g, 4)) != hipSuccess) return pe;
         if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
     };
     for (uint32_t gi = 0; gi < ng; gi++) {
         const Group &g = groups[gi];
+        hipStream_t s = gstream[gi & 1]; // (shadows the call's stream inside the loop)
         if (ng == 1) {
             if (!device_data) HIP_TRY(upload_group(g, s));
-        } else {
+        } else if (uploads) {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return issued > gi; });
             if (up_err != hipSuccess) return fail(FPNG_AMD_ERR_HIP, "upload of the files", up_err);
@@ -507,9 +535,12 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
         for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi, d_multi + gi);
-        HIP_TRY(finish_group(g));
+        HIP_TRY(finish_group(g, s, gi));
+        if (split) HIP_TRY(hipEventRecord(e->dec_ev3[gi], s));
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
+    if (split)
+        for (uint32_t gi = 1; gi < ng; gi += 2) HIP_TRY(hipStreamWaitEvent(s, e->dec_ev3[gi], 0)); // (the call's stream collects the other one's groups)
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> status(nj);
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, nj * 4, hipMemcpyDeviceToHost, s));
@@ -539,7 +570,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u needed %u rounds\n", since(), gi, r + 1);
         HIP_TRY(hipMemsetAsync(d_status + g.j0, 0, (g.j1 - g.j0) * 4, s));
-        HIP_TRY(finish_group(g));
+        HIP_TRY(finish_group(g, s, ng));
     }
     if (again) {
         HIP_TRY(hipGetLastError());

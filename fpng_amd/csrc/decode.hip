@@ -58,15 +58,11 @@ struct LdsBits {
     const uint32_t *l;
     __device__ __forceinline__ uint32_t window(uint32_t pos) const
     {
-#if FPNG_DEC_LEAN
         // (the dword index hidden from the optimiser, which otherwise spreads the "* 4" of the address over both shifts: five vector
         //  instructions for the slot's byte address instead of shift, shift, add-shift)
         uint32_t d = pos >> 5;
         asm("" : "+v"(d));
         const uint32_t s = d + (d >> 5);
-#else
-        const uint32_t s = slice_slot(pos >> 5);
-#endif
         return __builtin_amdgcn_alignbit(l[s + 1], l[s], pos & 31u);
     }
 };
@@ -621,11 +617,6 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) u32_any_t lds_u32_any;
 struct StreamSink {
     __attribute__((address_space(1))) uint32_t *f; // the file's filtered stream (global_store, not flat_store: a flat store also counts as an LDS operation in flight)
-#if FPNG_DEC_STAGE
-    lds_u8 *ring; // this thread's 44 bytes of LDS (decode_core.h: StagedWriter); gfx950 takes unaligned DS accesses
-    __device__ __forceinline__ void stage_w32(uint32_t pos, uint32_t v) { *(lds_u32_any *)(ring + pos) = v; }
-    __device__ __forceinline__ uint32_t stage_r32(uint32_t pos) const { return *(const lds_u32_any *)(ring + pos); }
-#endif
     uint32_t fill_g0 = 0, fill_n = 0, fill_d0 = 0, fill_d1 = 0, fill_d2 = 0; // this thread's long run, waiting for the wave (StreamWriter::run4 / run3)
     __device__ __forceinline__ void fill(uint32_t g0, uint32_t groups, uint32_t d0, uint32_t d1, uint32_t d2) { fill_g0 = g0, fill_n = groups, fill_d0 = d0, fill_d1 = d1, fill_d2 = d2; }
     static __device__ __forceinline__ bool any(bool x) { return __ballot(x) != 0; }
@@ -673,9 +664,6 @@ __global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(cons
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kEmitDwords)];
-#if FPNG_DEC_STAGE
-    __shared__ uint32_t rings[kEmitBlock * 11]; // 44 bytes a thread: 11 dwords, so that the lanes of a wave meet in different banks
-#endif
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // (workgroups are persistent: the table is staged when the file's differs from the one in LDS)
     LdsBits in = {bits};
@@ -705,9 +693,6 @@ __global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(cons
         const uint32_t pad = (is_last || !active) ? 0u : (0u - ((uint32_t)off + own)) & 15u; // bytes of the following subsequences that complete the last 16-byte group
         StreamSink sink;
         sink.f = (__attribute__((address_space(1))) uint32_t *)(uintptr_t)job.filt;
-#if FPNG_DEC_STAGE
-        sink.ring = (lds_u8 *)(rings + 11 * threadIdx.x);
-#endif
         uint32_t eob_end = 0;
         const uint32_t p0 = nominal + (active ? info_start(a.info[g]) : 0u), lastpx = active ? a.lastpx[g] : 0u;
         uint32_t err = job.src_c == 4 ? walk_emit<4>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end)

@@ -24,18 +24,6 @@
 namespace fpng_amd {
 namespace dec {
 
-// FPNG_DEC_LEAN = 1: a build variant for the next GPU session (fpng_amd/build.py --variant lean; default 0 = the measured tree): the
-// same walk with fewer vector instructions where tools/isa_loops.py shows them -- the literal mask as a bit-field extract, the row
-// bookkeeping as subtract / add / minimum, the staged bits' slot address as shift + add-shift.  Same results (the CPU emulation runs
-// both: tests/test_decode_model.py).
-#ifndef FPNG_DEC_LEAN
-#define FPNG_DEC_LEAN 0
-#endif
-// FPNG_DEC_STAGE = 1: another variant for the next GPU session (--variant stage): the 16-byte groups of the filtered stream are put
-// together in a 44-byte ring per thread (LDS on the GPU: unaligned ds_write_b32) instead of in registers -- StagedWriter below.
-#ifndef FPNG_DEC_STAGE
-#define FPNG_DEC_STAGE 0
-#endif
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
@@ -413,7 +401,6 @@ template <class Sink> struct StreamWriter {
         }
         for (uint32_t k = 0; k < left; k++) put(px, 3);
     }
-    FPNG_DEC_HD void flush() {} // (StagedWriter's: this one stores as it goes)
     // Only where the stream ends inside a group: its whole dwords, and the pending bytes (zeros behind them: the buffer is padded).
     FPNG_DEC_HD void finish()
     {
@@ -423,91 +410,6 @@ template <class Sink> struct StreamWriter {
         if (m >= 3) sink.store32(dw - 3, q1);
         if (m >= 2) sink.store32(dw - 2, q2);
         if (m >= 1) sink.store32(dw - 1, q3);
-    }
-};
-
-// The same writer with the group under construction kept in a RING of bytes per thread instead of in registers (on the GPU: LDS,
-// 44 bytes a thread, written with unaligned 32-bit stores; Sink::stage_w32 / stage_r32).  In registers a lookup's bytes cost a shift
-// and OR into the pending dword, the rotation of four dwords and a predicated store -- about twenty vector instructions; here one
-// store and one add, and ONE check per iteration of the walk (flush(): two lookups write at most 8 bytes + 3 of slack, a group has
-// 16).  Ring: the group being filled at [cur, cur + 16), cur = 0 or 16; what runs over byte 32 lands in [32, 44) and moves to the
-// ring's start when the upper group is stored.  Bytes behind p are never valid yet: a store may always write four.
-template <class Sink> struct StagedWriter {
-    Sink &sink;
-    uint32_t p;   // the next byte's place in the ring
-    uint32_t cur; // 0 or 16
-    uint32_t g;   // stream index of the group at `cur`
-    bool skip;    // the group the output starts in belongs to the thread in front
-    FPNG_DEC_HD StagedWriter(Sink &s, uint64_t off) : sink(s), p((uint32_t)off & 15u), cur(0), g((uint32_t)(off >> 4)), skip(((uint32_t)off & 15u) != 0) {}
-    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 4 bytes, the first one lowest
-    {
-        sink.stage_w32(p, bytes);
-        p += n;
-    }
-    FPNG_DEC_HD void flush()
-    {
-        while (p >= cur + 16u) {
-            if (!skip) sink.store128(g, sink.stage_r32(cur), sink.stage_r32(cur + 4u), sink.stage_r32(cur + 8u), sink.stage_r32(cur + 12u));
-            skip = false;
-            g++;
-            if (cur) {
-                sink.stage_w32(0u, sink.stage_r32(32u)), sink.stage_w32(4u, sink.stage_r32(36u)), sink.stage_w32(8u, sink.stage_r32(40u));
-                p -= 32u, cur = 0u;
-            } else
-                cur = 16u;
-        }
-    }
-    FPNG_DEC_HD void run4(uint32_t px, uint32_t npix)
-    {
-        uint32_t left = npix;
-        if (npix - 1u >= kFillMinDwords) { // a long run: up to the end of the group being filled, then whole groups by the wave
-            const uint32_t k = (cur + 16u - p + 3u) >> 2;
-            for (uint32_t i = 0; i < k; i++) put(px, 4);
-            flush();
-            left -= k;
-            const uint32_t e = p - cur; // bytes of the run in the new group already: its dwords are the pixel rotated by e bytes
-            const uint32_t r = e ? (px << (8u * e)) | (px >> (32u - 8u * e)) : px;
-            const uint32_t bytes = e + 4u * left, groups = bytes >> 4;
-            sink.fill(g, groups, r, r, r);
-            g += groups;
-            sink.stage_w32(cur, r), sink.stage_w32(cur + 4u, r), sink.stage_w32(cur + 8u, r), sink.stage_w32(cur + 12u, r);
-            p = cur + (bytes & 15u);
-            return;
-        }
-        for (uint32_t i = 0; i < left; i++) put(px, 4), flush();
-    }
-    FPNG_DEC_HD void run3(uint32_t px, uint32_t npix)
-    {
-        uint32_t left = npix;
-        if (npix >= kFillMinPixels3) {
-            const uint32_t k = (cur + 16u - p + 2u) / 3u;
-            for (uint32_t i = 0; i < k; i++) put(px, 3);
-            flush();
-            left -= k;
-            const uint32_t e = p - cur, ph = (3u - e) % 3u; // byte j of the group is the pixel's byte (j + ph) % 3
-            const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
-            const uint32_t d[3] = {(uint32_t)(wrap >> (8 * ph)), (uint32_t)(wrap >> (8 * ((ph + 1) % 3u))), (uint32_t)(wrap >> (8 * ((ph + 2) % 3u)))};
-            const uint32_t bytes = e + 3u * left, groups = bytes >> 4;
-            sink.fill(g, groups, d[0], d[1], d[2]);
-            g += groups;
-            const uint32_t m = (4u * groups) % 3u; // the dwords go on d[m], d[m + 1], ...
-            sink.stage_w32(cur, d[m]), sink.stage_w32(cur + 4u, d[(m + 1) % 3u]), sink.stage_w32(cur + 8u, d[(m + 2) % 3u]), sink.stage_w32(cur + 12u, d[m]);
-            p = cur + (bytes & 15u);
-            return;
-        }
-        for (uint32_t i = 0; i < left; i++) put(px, 3), flush();
-    }
-    // Only where the stream ends inside a group: its whole dwords, and the pending bytes (zeros behind them: the buffer is padded).
-    FPNG_DEC_HD void finish()
-    {
-        flush();
-        if (skip) return;
-        const uint32_t n = p - cur;
-        for (uint32_t k = 0; 4u * k < n; k++) {
-            uint32_t v = sink.stage_r32(cur + 4u * k);
-            if (n - 4u * k < 4u) v &= (1u << (8u * (n - 4u * k))) - 1u;
-            sink.store32(4u * g + k, v);
-        }
     }
 };
 
@@ -525,17 +427,12 @@ template <int C, class Bits, class Sink>
 FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t own, uint32_t pad, bool last, uint64_t off, uint32_t col,
                                uint32_t lastpx, uint32_t stride, Sink &sink, uint32_t &eob_end)
 {
-#if FPNG_DEC_STAGE
-    StagedWriter<Sink> out(sink, off);
-#else
     StreamWriter<Sink> out(sink, off);
-#endif
     const uint32_t bpl = stride - 1;
     uint32_t todo = own + pad;
     uint32_t rowleft = stride - col; // bytes up to the end of the row, the next one included (== stride: the next byte is a filter byte)
     uint32_t err = 0;
     // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one, or nothing left to do)
-#if FPNG_DEC_LEAN
     // (the straight-line part keeps rl = rowleft - 1, 0 .. stride - 1: "wrap at the row's end" is then min(t, t + stride) of
     //  t = rl - bytes taken -- the unsigned difference is huge exactly when the row ended; the match branch below works on rowleft)
     uint32_t rl = rowleft - 1;
@@ -551,30 +448,13 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
         todo -= nb;
         return nb ? L + (m1 ? 1u : 0u) : 0u;
     };
-#else
-    auto take = [&](uint32_t wk) -> uint32_t {
-        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
-        const bool m1 = (e & 0x0FFFFFFFu) == (kEntMatch | (uint32_t)C) && rowleft % C == 0 && rowleft != bpl && todo >= (uint32_t)C;
-        const uint32_t nl = n < todo ? n : todo, nb = m1 ? (uint32_t)C : nl;
-        const uint32_t lits = e & (0xFFFFFFu >> (8 * (3 - nl))); // (nl = 0: no byte)
-        out.put(m1 ? (C == 4 ? lastpx : lastpx >> 8) : lits, nb);
-        lastpx = funnel(lits, lastpx, m1 ? 0u : 8 * nl);
-        rowleft -= nb;
-        rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
-        todo -= nb;
-        return nb ? L + (m1 ? 1u : 0u) : 0u;
-    };
-#endif
     while (sink.any(todo != 0)) { // (the whole wave stays until its last thread is done: Sink::cooperate() needs them all)
         const uint32_t w = in.window(pos);
         const uint32_t ba = take(w);
         const uint32_t bb = take(w >> ba); // (a first token that was not plain is looked at again, to no effect)
-        out.flush();
         pos += ba + bb;
         if (todo && !bb) { // the token at pos is not a plain one: a match (or the stream ends, or derails, with bytes still owed)
-#if FPNG_DEC_LEAN
             rowleft = rl + 1;
-#endif
             // Matches that follow one another repeat the same pixel (no literal in between, and none of them may leave its row):
             // they are written as ONE run -- a flat row of a screenshot is a few dozen maximal matches.
             const uint32_t px = C == 4 ? lastpx : lastpx >> 8;
@@ -611,15 +491,13 @@ FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_
                 else { // the match reaches into (or lies in) the pad: byte by byte
                     if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
                     whole = 0;
-                    for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1), out.flush();
+                    for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1);
                     break;
                 }
                 if (!todo || rowleft == stride) break; // (a row ended: a filter literal must follow)
             }
             if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
-#if FPNG_DEC_LEAN
             rl = rowleft - 1;
-#endif
             if (stop) break;
         }
         sink.cooperate();

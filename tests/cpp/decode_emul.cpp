@@ -48,20 +48,6 @@ struct HostSink { // the filtered stream; every dword may be stored once
     }
     static bool any(bool x) { return x; }
     static void cooperate() {}
-    // (FPNG_DEC_STAGE: the per-thread ring of StagedWriter -- LDS on the GPU)
-    uint8_t ring[48] = {};
-    void stage_w32(uint32_t pos, uint32_t v)
-    {
-        if (pos + 4 > 44) *fault = true;
-        else memcpy(ring + pos, &v, 4);
-    }
-    uint32_t stage_r32(uint32_t pos)
-    {
-        uint32_t v = 0;
-        if ((pos & 3) || pos + 4 > 44) *fault = true;
-        else memcpy(&v, ring + pos, 4);
-        return v;
-    }
 };
 
 } // namespace

@@ -31,7 +31,7 @@ _emul = {}
 
 
 def emul(variant=""):
-    """the emulator library; variant "lean": decode_core.h compiled with FPNG_DEC_LEAN=1 (the build variant of the same name)"""
+    """the emulator library (variant: extra -D options by name, none at present)"""
     if variant not in _emul:
         from fpng_amd import build
         build.build()
@@ -40,7 +40,7 @@ def emul(variant=""):
         so = os.path.join(lib_dir, f"libfpng_decode_emul{'_' + variant if variant else ''}.so")
         deps = [src, os.path.join(ROOT, "fpng_amd", "csrc", "decode_core.h"), os.path.join(lib_dir, "libfpng_amd.so")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            defs = {"": [], "lean": ["-DFPNG_DEC_LEAN=1"], "stage": ["-DFPNG_DEC_STAGE=1"], "stage_lean": ["-DFPNG_DEC_STAGE=1", "-DFPNG_DEC_LEAN=1"]}[variant]
+            defs = {"": []}[variant]
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + defs + ["-I", os.path.join(ROOT, "include"), "-I",
                                    os.path.join(ROOT, "fpng_amd", "csrc"), src, "-o", so, "-L", lib_dir, "-lfpng_amd", "-Wl,-rpath,$ORIGIN"])
         L = C.CDLL(so)
@@ -336,37 +336,6 @@ def test_edited_token_streams_of_megapixel_images():
             seen.add(name)
             accepted += st_r == 0
     assert len(seen) >= 7 and accepted >= 15 and left >= 2, (sorted(seen), accepted, left)
-
-
-def test_the_variants_of_the_emit_walk_give_the_same_answers():
-    """Build variants of the emit walk that wait for a GPU to time them (decode_core.h; fpng_amd/build.py --variant ...):
-    FPNG_DEC_LEAN=1, the straight-line part with fewer vector instructions (tools/isa_loops.py: 92 instead of 102 per two-lookup
-    iteration); FPNG_DEC_STAGE=1, the 16-byte groups put together in a ring of bytes per thread (LDS) instead of in registers; both.
-    Valid files, damaged copies, edited token streams, megapixel files with long runs: status and pixels of the default walk."""
-    import fpng_amd
-    rng = np.random.default_rng(6060)
-    files = []
-    for _ in range(60):
-        img, w, h, c = fuzz_image(rng) if rng.random() < 0.7 else fuzz_image(rng, force_dims=(int(rng.integers(100, 500)), int(rng.integers(3, 14))))
-        png = oracle().encode(img, w, h, c, int(rng.integers(0, 2)))
-        files.append(png)
-        files += [_damage(rng, png)[1] for _ in range(4)]
-    files += [f for _, f in edited_files(rng, 25)]
-    for (kind, w, h, c) in (("grad", 1500, 500, 4), ("grad", 1201, 333, 3), ("blocks", 900, 700, 3), ("solid", 2000, 300, 4), ("solid", 1999, 40, 3), ("blocks", 777, 90, 4)):
-        files.append(oracle().encode(fpng_amd.synth_image(kind, w, h, c), w, h, c, c & 1))
-    import ui_images
-    files += [oracle().encode(np.ascontiguousarray(g(900, 200, c, seed=3)).reshape(-1), 900, 200, c, 0) for g in (ui_images.glyphs, ui_images.panels) for c in (3, 4)]
-    decided = 0
-    for f in files:
-        cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
-        for desired in (3, 4):
-            a = emul_decode(f, desired, cfg)
-            for variant in ("lean", "stage", "stage_lean"):
-                b = emul_decode(f, desired, cfg, variant=variant)
-                assert a[0] == b[0] and a[2:5] == b[2:5], (variant, a[0], b[0], cfg)
-                assert a[0] != 0 or np.array_equal(a[1], b[1]), (variant, cfg)
-            decided += a[0] == 0
-    assert decided >= 300
 
 
 # ---- the table's format, pinned by a decoder of a dozen lines ----

@@ -111,6 +111,7 @@ SIGNATURES = {
     "fpng_amd_rccl_transport_create": (_int, [C.POINTER(C.POINTER(Transport)), _vp, _int, _int, _int]),
     "fpng_amd_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
     "fpng_amd_encode_image_sharded": (_int, [_vp, C.POINTER(Transport), C.POINTER(Band), _u32, _int, _vp, _sz, C.POINTER(_sz)]),
+    "fpng_amd_sharded_last_report": (_int, [_vp, _vp]),
     "fpng_amd_encoder_last_host_bands": (_int, [_vp]),
     "fpng_amd_pin_host_memory": (_int, [_vp, _sz]),
     "fpng_amd_unpin_host_memory": (_int, [_vp]),

@@ -189,6 +189,7 @@ struct fpng_amd_encoder {
     hipEvent_t dec_ev[16] = {};
     hipEvent_t dec_ev2[16] = {}, dec_ev3[16] = {}; // the streamed fpng_amd_decode_host: a piece's byte count is known / its finished rows are pixels
     PinnedBuf<uint8_t> h_dec_fetch; // fpng_amd_decode_batch_device(): the files' first and last bytes on their way to the host parser
+    fpng_amd_sharded_report sharded_report = {}; // fpng_amd_encode_image_sharded(): where the last call's bytes went
     DeviceBuf<uint8_t> d_xchg;    // fpng_amd_encode_image_sharded(): the records it exchanges, and their pinned mirror
     PinnedBuf<uint8_t> h_xchg;
     struct HostWorkers *workers = nullptr; // fpng_amd_encode_host_to(): the uploader and downloader threads (pipeline.cpp)

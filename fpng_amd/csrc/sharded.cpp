@@ -64,6 +64,8 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const size_t bpl = (size_t)w * c;
+    fpng_amd_sharded_report &rep = e->sharded_report;
+    std::memset(&rep, 0, sizeof rep);
     // FPNG_AMD_TRACE=1: where a call's time goes, on stderr (microseconds from its start)
     static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
@@ -87,6 +89,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
         } else
             HIP_TRY(hipMemsetAsync(d_hist, 0, 288 * 4, s));
         T_TRY(t->all_reduce_sum_u32(t->ctx, d_hist, 288, s));
+        rep.collectives++;
     }
     fpng_amd_band_stats st;
     std::memset(&st, 0, sizeof st);
@@ -102,6 +105,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
     mine->y0 = band->y0, mine->y1 = band->y1;
     HIP_TRY(hipMemcpyAsync(dx + o_rec, mine, sizeof(Record), hipMemcpyHostToDevice, s));
     T_TRY(t->all_gather(t->ctx, dx + o_rec, dx + o_recs, sizeof(Record), s));
+    rep.collectives++;
     HIP_TRY(hipMemcpyAsync(hx + o_recs, dx + o_recs, sizeof(Record) * world, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     lap("records gathered");
@@ -131,6 +135,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
     }
     const uint32_t eob_bits = stats[first_pos].eob_bits;
 
+    rep.stored = plan.stored ? 1u : 0u;
     if (plan.stored) {
         // ---- the reference's stored-block outcome (incompressible image): no bit seams; the rows go to the root, which
         //      encodes the image whole (the stored kernels) ----
@@ -141,6 +146,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
                 const Record &q = recs[r];
                 if (q.y1 <= q.y0) continue;
                 uint8_t *dst = e->d_stage_in.p + (size_t)q.y0 * bpl;
+                rep.root_staged_bytes += (size_t)(q.y1 - q.y0) * bpl; // (the rows meet in a staging buffer: the stored kernels then write the file)
                 if (r == rank)
                     HIP_TRY(hipMemcpyAsync(dst, band->d_rows, (size_t)(q.y1 - q.y0) * bpl, hipMemcpyDeviceToDevice, s));
                 else
@@ -156,6 +162,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
         } else {
             T_TRY(t->group_begin(t->ctx));
             if (have_rows) T_TRY(t->send(t->ctx, band->d_rows, (size_t)(band->y1 - band->y0) * bpl, root, s));
+            if (have_rows) rep.sent_bytes += (size_t)(band->y1 - band->y0) * bpl;
             T_TRY(t->group_end(t->ctx));
             HIP_TRY(hipStreamSynchronize(s));
         }
@@ -187,6 +194,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
         size_t nbytes = 0;
         if ((rc = fpng_amd_band_place(e, band, start_bits[my_pos], 0, d_window, is_root ? png_cap - g.off : e->d_stage_out.cap, &off, &nbytes))) return rc;
         if (off != g.off || nbytes != g.bytes) return fail(FPNG_AMD_ERR_HIP, "band window differs from the plan");
+        rep.own_window_bytes = nbytes;
         lap("placement enqueued");
         if ((rc = fpng_amd_band_crc(e, &my_crc->raw_crc, &my_crc->end_offset))) return rc;
         lap("placed, band CRC here");
@@ -195,6 +203,7 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
     }
     HIP_TRY(hipMemcpyAsync(dx + o_crc, my_crc, sizeof(CrcRecord), hipMemcpyHostToDevice, s));
     T_TRY(t->all_gather(t->ctx, dx + o_crc, dx + o_crcs, sizeof(CrcRecord), s));
+    rep.collectives++;
 
     // ---- 4: windows to the root ----
     T_TRY(t->group_begin(t->ctx));
@@ -204,11 +213,14 @@ extern "C" int fpng_amd_encode_image_sharded(fpng_amd_encoder *e, const fpng_amd
             if (r == rank || !geo[k].bytes) continue;
             if (geo[k].head) T_TRY(t->recv(t->ctx, dx + o_heads + 16 * (size_t)k, 16, r, s));
             if (geo[k].bytes > geo[k].head) T_TRY(t->recv(t->ctx, d_png + geo[k].off + geo[k].head, geo[k].bytes - geo[k].head, r, s));
+            rep.received_in_place += geo[k].bytes - geo[k].head; // (straight to its file offset: nothing is copied again)
+            rep.shared_pieces += geo[k].head ? 1u : 0u;
         }
     } else if (have_rows) {
         const Geo &g = geo[my_pos];
         if (g.head) T_TRY(t->send(t->ctx, dx + o_heads + 16 * (size_t)my_pos, 16, root, s));
         if (g.bytes > g.head) T_TRY(t->send(t->ctx, d_window + g.head, g.bytes - g.head, root, s));
+        rep.sent_bytes += g.bytes;
     }
     T_TRY(t->group_end(t->ctx));
     lap("windows enqueued");
@@ -311,6 +323,13 @@ int r_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream)
 } // namespace
 
 extern "C" {
+
+int fpng_amd_sharded_last_report(fpng_amd_encoder *e, fpng_amd_sharded_report *report)
+{
+    if (!e || !report) return fail(FPNG_AMD_ERR_INVALID_ARG, "null argument");
+    *report = e->sharded_report;
+    return FPNG_AMD_OK;
+}
 
 int fpng_amd_rccl_unique_id(uint8_t id[128])
 {

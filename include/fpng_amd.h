@@ -329,6 +329,21 @@ void fpng_amd_rccl_transport_destroy(fpng_amd_transport *t);
 int fpng_amd_encode_image_sharded(fpng_amd_encoder *enc, const fpng_amd_transport *t, const fpng_amd_band *band, uint32_t flags,
                                   int root, uint8_t *d_png, size_t png_cap, size_t *png_size);
 
+/* Where the bytes of this rank's last fpng_amd_encode_image_sharded() call went (what a scaling run is held against: DESIGN.md 5):
+ * every window travels ONCE, from its rank straight into its place in the root's file buffer -- there is no staging copy on the
+ * root for a compressed image (root_staged_bytes stays 0; only the stored outcome, where the rows themselves go to the root, stages). */
+typedef struct fpng_amd_sharded_report {
+    uint64_t sent_bytes;          /* this rank -> root (its window, or its rows for the stored outcome) */
+    uint64_t received_in_place;   /* root: bytes received straight into d_png at their file offset */
+    uint64_t root_staged_bytes;   /* root: bytes that went through a staging buffer and were copied again (stored outcome: the rows) */
+    uint64_t own_window_bytes;    /* this rank's band placed by its own kernels (root: directly in the file) */
+    uint32_t shared_pieces;       /* root: 16-byte pieces two windows share, OR-ed in afterwards */
+    uint32_t collectives;         /* all-gathers / all-reduces of the call (2 or 3) */
+    uint32_t stored;              /* 1: the image ended as stored blocks */
+    uint32_t reserved;
+} fpng_amd_sharded_report;
+int fpng_amd_sharded_last_report(fpng_amd_encoder *enc, fpng_amd_sharded_report *report);
+
 /* First token bit of the 1-pass stream (490 for 4 channels, 503 for 3; reference src/fpng.cpp:535,:551)
  * and the EOB length (12) -- what a host needs to evaluate the failure rule without a GPU. */
 int fpng_amd_1pass_layout(uint32_t num_chans, uint32_t *first_token_bit, uint32_t *eob_bits, uint32_t *prefix_bytes);

@@ -150,8 +150,16 @@ int l_group_end(void *ctx) { return l_group_end_s((Rank *)ctx, t_stream); }
 
 // Encodes img (host, w x h x c) as `world` row bands cut at cuts[0..world] (cuts[0] = 0, cuts[world] = h; equal neighbours =
 // a rank without rows) by `world` threads; the file comes back from rank `root`.  Returns 0 or the first failing rank's code.
+// reports (optional): `world` records, every rank's fpng_amd_sharded_last_report() of this call
+extern "C" int shim_sharded_local2(int world, const uint32_t *cuts, const uint8_t *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int root,
+                                   uint8_t *out, size_t cap, size_t *size, char *err, size_t err_cap, fpng_amd_sharded_report *reports);
 extern "C" int shim_sharded_local(int world, const uint32_t *cuts, const uint8_t *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int root,
                                   uint8_t *out, size_t cap, size_t *size, char *err, size_t err_cap)
+{
+    return shim_sharded_local2(world, cuts, img, w, h, c, flags, root, out, cap, size, err, err_cap, nullptr);
+}
+extern "C" int shim_sharded_local2(int world, const uint32_t *cuts, const uint8_t *img, uint32_t w, uint32_t h, uint32_t c, uint32_t flags, int root,
+                                   uint8_t *out, size_t cap, size_t *size, char *err, size_t err_cap, fpng_amd_sharded_report *reports)
 {
     Hub hub;
     hub.world = world;
@@ -187,6 +195,7 @@ extern "C" int shim_sharded_local(int world, const uint32_t *cuts, const uint8_t
                     snprintf(err, err_cap, "rank %d: %s", r, fpng_amd_last_error());
                 }
             }
+            if (!rc && reports) rc = fpng_amd_sharded_last_report(enc, &reports[r]);
             if (!rc && r == root) {
                 *size = n;
                 rc = (n > cap) ? -101 : (hipMemcpy(out, d_png, n, hipMemcpyDeviceToHost) != hipSuccess);

@@ -179,12 +179,19 @@ def sharded_local():
     L = C.CDLL(so)
     L.shim_sharded_local.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.shim_sharded_local2.argtypes = L.shim_sharded_local.argtypes + [C.c_void_p]
     _sharded = L
     return L
 
 
-def encode_sharded_local(img, cuts, flags=0, root=0):
-    """img: uint8 (h, w, c); cuts: row boundaries [0, ..., h] (one band per rank) -> PNG bytes from rank `root`."""
+class ShardedReport(C.Structure):  # include/fpng_amd.h: fpng_amd_sharded_report
+    _fields_ = [("sent_bytes", C.c_uint64), ("received_in_place", C.c_uint64), ("root_staged_bytes", C.c_uint64), ("own_window_bytes", C.c_uint64),
+                ("shared_pieces", C.c_uint32), ("collectives", C.c_uint32), ("stored", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def encode_sharded_local(img, cuts, flags=0, root=0, reports=None):
+    """img: uint8 (h, w, c); cuts: row boundaries [0, ..., h] (one band per rank) -> PNG bytes from rank `root`.
+    reports: a list that receives every rank's data-movement report (ShardedReport)."""
     L = sharded_local()
     a = np.ascontiguousarray(img, dtype=np.uint8)
     h, w, c = a.shape
@@ -194,7 +201,10 @@ def encode_sharded_local(img, cuts, flags=0, root=0):
     out = np.zeros(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     err = C.create_string_buffer(512)
-    rc = L.shim_sharded_local(world, (C.c_uint32 * (world + 1))(*cuts), a.ctypes.data, w, h, c, flags, root, out.ctypes.data, cap, C.byref(n), err, 512)
+    rep = (ShardedReport * world)()
+    rc = L.shim_sharded_local2(world, (C.c_uint32 * (world + 1))(*cuts), a.ctypes.data, w, h, c, flags, root, out.ctypes.data, cap, C.byref(n), err, 512, C.byref(rep))
     if rc:
         raise RuntimeError(f"sharded_local rc={rc}: {err.value.decode(errors='replace')}")
+    if reports is not None:
+        reports.extend(rep)
     return out[: n.value].tobytes()

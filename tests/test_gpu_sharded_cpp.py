@@ -68,8 +68,19 @@ def test_4k_frame_eight_ranks_vs_reference(built_lib):
         e = kat[(kind, 3840, 2160, 4)]
         img = fpng_amd.synth_image(kind, 3840, 2160, 4)
         for flags in (0, 1):
-            png = dropin.encode_sharded_local(img, _cuts(2160, 8), flags, root=0)
+            reports = []
+            png = dropin.encode_sharded_local(img, _cuts(2160, 8), flags, root=0, reports=reports)
             assert hashlib.sha256(png).hexdigest() == e["flags"][str(flags)]["sha256"], (kind, flags)
+            # where the bytes went (fpng_amd_sharded_last_report): a compressed image's windows travel ONCE, from their ranks straight
+            # into the root's file buffer -- no staging copy on the root; the stored outcome (noise) moves the rows instead
+            root, others = reports[0], reports[1:]
+            if kind == "noise":
+                assert root.stored == 1 and root.root_staged_bytes == 3840 * 2160 * 4 and sum(r.sent_bytes for r in others) == 3840 * 2160 * 4 // 8 * 7
+            else:
+                assert root.stored == 0 and root.root_staged_bytes == 0 and all(r.root_staged_bytes == 0 for r in others)
+                assert root.received_in_place + 16 * root.shared_pieces == sum(r.sent_bytes for r in others) and root.sent_bytes == 0
+                assert root.own_window_bytes + sum(r.sent_bytes for r in others) >= len(png) - 58 - 20 - 16 * 8  # (the windows are the file's zlib bytes)
+                assert root.collectives == (3 if flags else 2)
 
 
 def test_rccl_transport_one_rank(built_lib):

@@ -419,8 +419,8 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     sub.n = n;
     // Direct placement (profiles/r05_encode_onchip_ab.txt): FPNG_AMD_DIRECT=1 replaces the two-kernel chain (row walk into
     // local streams, assemble) by encode_direct_kernel -- rows cut into pieces of FPNG_AMD_PIECE_PX pixels (a multiple of 256) whose
-    // token bits fit a wave's LDS window, every chunk placed by the wave that encoded it.  Bit-exact and tested, and 3 x SLOWER on
-    // this hardware (a chunk's offset arrives through agent-scope memory: ~50 us per chunk against 2 us of work), so it is OFF
+    // token bits fit a wave's LDS window, every chunk placed by the wave that encoded it.  Bit-exact and tested, and 2.3 x SLOWER on
+    // this hardware (a chunk's offset arrives through agent-scope memory: ~20 us per chunk against 2 us of work), so it is OFF
     // unless asked for; the measurements and the ablations that bound what it could ever gain (+12 %) are in that file.
     // (read at every call: tests and A/B runs switch them inside one process)
     const char *de = getenv("FPNG_AMD_DIRECT"), *pe = getenv("FPNG_AMD_PIECE_PX");

@@ -1489,19 +1489,17 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
         tail31 = (o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo) & 0x7FFFFFFFu;
     } else
         tail31 = nbits ? ((uniform(sdw(0)) << (31u - nbits)) & 0x7FFFFFFFu) : 0u;
-    // ---- look-back, two levels.  Per chunk one granule {ready, its last 31 bits, its bits}; per GROUP of 64 chunks two: {chunks that
-    //      have reported << 44 | their bits' sum} (atomic adds) and {ready | bits in front of the group} (written by the group's
-    //      first chunk).  A chunk needs the records of the chunks of its own group in front of it (one load per lane) and its
-    //      group's prefix; a group's first chunk finds that prefix by looking back over the GROUPS in front (64 of them per round
-    //      trip = 4096 chunks: with chunks alone the front of known offsets moved 64 chunks per round trip and job -- the first
-    //      version's 0.74 ms, profiles/r05_direct_v1.txt). ----
+    // ---- look-back, two levels, no read-modify-write anywhere.  Per chunk one granule {ready, its last 31 bits, its bits}; per GROUP
+    //      of 64 chunks a 128-byte record with two: the group's bit SUM (written by the NEXT group's first chunk -- its "leader" --
+    //      once it has seen all 64 records) and the bits in FRONT of the group (written by the group's own leader).  A chunk needs
+    //      the records of the chunks of its group in front of it (one load per lane) and its group's prefix; a leader finds that
+    //      prefix by looking back over the groups in front, 64 per round trip = 4096 chunks.  (History, profiles/
+    //      r05_encode_onchip_ab.txt: with chunk granules alone the front of known offsets moved 64 chunks per round trip and job;
+    //      a group counter kept with atomic adds serialised 64 agent-scope atomics per group on one address.) ----
     unsigned long long *agg = look + (size_t)job.row_base;
-    unsigned long long *grp = look_grp + kGrpStride * (size_t)job.group_base; // a group's record: its own 128-byte line, the counter the chunks add to and the prefix the chunks poll 64 bytes apart
+    unsigned long long *grp = look_grp + kGrpStride * (size_t)job.group_base; // group j: grp[16 j] = sum, grp[16 j + 8] = prefix
     const uint32_t g = id >> 6, k = id & 63u;
-    if (lane == 0) {
-        look_store(&agg[id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
-        (void)__hip_atomic_fetch_add(&grp[kGrpStride * (size_t)g], (1ull << 44) | (unsigned long long)res.bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) look_store(&agg[id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
     uint64_t excl = 0;
     bool deferred = false;
     unsigned long long front = 0; // the record of the chunk right in front (its last bits are wanted below)
@@ -1509,64 +1507,79 @@ __device__ __forceinline__ void encode_direct_block(const Job &job, JobState &st
     excl = (uint64_t)id * 21000u; // (timing only: no look-back, chunks at made-up offsets)
 #else
     {
-        // Polling discipline (the second version hammered: 6000 waves re-reading 64 granules each past the caches made every round
-        // trip slower for everybody -- 3.9 ms): a wave re-reads only what it is still missing, ONE granule while it waits for its
-        // group's prefix, and sleeps about a microsecond between polls.
-        bool g_known = g == 0; // the group's prefix (gval) is known
-        bool intra_ok = k == 0 && id == 0;
-        uint64_t gval = 0, gacc = 0, intra = 0;
-        int64_t gbase = (int64_t)g - 1; // (leading) the nearest group not yet accounted for
+        // Polling discipline: a wave re-reads only what it is still missing -- ONE granule while it waits for its group's prefix --
+        // and sleeps about a microsecond between polls.
+        bool g_known = g == 0;            // the group's prefix (gval) is known
+        bool intra_ok = id == 0;          // the records in front, inside the group (k == 0: just the chunk right in front), are in
+        bool prev_sum_ok = g == 0;        // (leading) the group in front is complete and its sum (prev_sum) is known
+        uint64_t gval = 0, gacc = 0, intra = 0, prev_sum = 0;
+        int64_t gbase = (int64_t)g - 2;   // (leading) the nearest group whose record is not yet accounted for (g - 1 comes from its chunks' records)
         for (uint32_t spins = 0;;) {
-            // (a chunk that has waited long for its group's prefix looks for it itself, like the group's first chunk: that one may
-            //  have been deferred)
-            const bool lead = k == 0 || spins >= 48;
-            unsigned long long a = kLookReady, q = 0, ga = 0;
-            if (!intra_ok) {
-                if (lane < k)
-                    a = look_load(&agg[(size_t)g * 64u + lane]);
-                else if (k == 0 && lane == 0)
-                    a = look_load(&agg[id - 1]); // (the chunk right in front, of the group in front: only its last bits are wanted)
-            }
+            // (a chunk that has waited long for its group's prefix looks for it itself, like the group's leader: that one may have been deferred)
+            const bool lead = !g_known && (k == 0 || spins >= 48);
+            unsigned long long a = kLookReady, pa = kLookReady, q = 0, gs = 0;
+            if (!intra_ok && lane < k) a = look_load(&agg[(size_t)g * 64u + lane]);
+            if (lead && !prev_sum_ok) pa = look_load(&agg[(size_t)(g - 1) * 64u + lane]); // the 64 records of the group in front
             if (!g_known) {
                 if (!lead)
                     q = look_load(&grp[kGrpStride * (size_t)g + 8]);
                 else {
                     const int64_t j = gbase - lane;
                     if (j >= 0) {
-                        ga = look_load(&grp[kGrpStride * j]);
+                        gs = look_load(&grp[kGrpStride * j]);
                         q = look_load(&grp[kGrpStride * j + 8]);
                     } else
-                        ga = 64ull << 44, q = kLookReady; // (in front of the first group: nothing, and known)
+                        gs = kLookReady, q = kLookReady; // (in front of the first group: nothing, and known)
                 }
             }
-            if (!intra_ok && __ballot((a & kLookReady) != 0) == ~0ull) {
+            if (lead && !prev_sum_ok && __ballot((pa & kLookReady) != 0) == ~0ull) {
+                uint64_t total;
+                (void)wave_exclusive_sum_u64((uint64_t)(pa & 0xFFFFFFu), lane, total);
+                prev_sum = total;
+                prev_sum_ok = true;
+                if (lane == 0) look_store(&grp[kGrpStride * (size_t)(g - 1)], kLookReady | prev_sum); // for the leaders further on
+                if (k == 0) { // the chunk right in front is the group's last one
+                    front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pa >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pa, 63);
+                    intra_ok = true;
+                }
+            }
+            if (!intra_ok && k && __ballot((a & kLookReady) != 0) == ~0ull) {
                 uint64_t total;
                 (void)wave_exclusive_sum_u64(lane < k ? (uint64_t)(a & 0xFFFFFFu) : 0ull, lane, total);
                 intra = total;
-                const int fl = k ? (int)k - 1 : 0;
-                front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), fl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, fl);
+                front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), (int)k - 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, (int)k - 1);
                 intra_ok = true;
             }
             if (!g_known) {
                 if (!lead) {
                     const unsigned long long q0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
                     if (q0 & kLookReady) g_known = true, gval = q0 & ~kLookReady;
-                } else {
-                    const uint64_t qmask = __ballot((q & kLookReady) != 0), cmask = __ballot((ga >> 44) == 64u);
+                } else if (prev_sum_ok) {
+                    const uint64_t qmask = __ballot((q & kLookReady) != 0), smask = __ballot((gs & kLookReady) != 0);
                     if (qmask) {
                         const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest group whose prefix is known
-                        const uint64_t need = L >= 63 ? ~0ull : ((2ull << L) - 1ull); // ... it and the groups behind it must be complete
-                        if ((cmask & need) == need) {
-                            const uint64_t part = (lane <= L ? (uint64_t)(ga & ((1ull << 44) - 1ull)) : 0ull) + (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
+                        const uint64_t need = L >= 63 ? ~0ull : ((2ull << L) - 1ull); // ... its sum and those of the groups behind it must be known
+                        if ((smask & need) == need) {
+                            const uint64_t part = (lane <= L ? (uint64_t)(gs & ~kLookReady) : 0ull) + (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
                             uint64_t total;
                             (void)wave_exclusive_sum_u64(part, lane, total);
-                            gval = gacc + total;
+                            gval = gacc + total + prev_sum;
                             g_known = true;
                             if (lane == 0) look_store(&grp[kGrpStride * (size_t)g + 8], kLookReady | gval);
+                        } else if (spins >= 48) {
+                            // a sum is missing although its group must be complete (its leader-to-be was deferred?): make it from the records
+                            const uint32_t m = (uint32_t)__builtin_ctzll(~smask & need);
+                            const int64_t jm = gbase - (int64_t)m;
+                            const unsigned long long ra = look_load(&agg[(size_t)jm * 64u + lane]);
+                            if (__ballot((ra & kLookReady) != 0) == ~0ull) {
+                                uint64_t total;
+                                (void)wave_exclusive_sum_u64((uint64_t)(ra & 0xFFFFFFu), lane, total);
+                                if (lane == 0) look_store(&grp[kGrpStride * (size_t)jm], kLookReady | total);
+                            }
                         }
-                    } else if (cmask == ~0ull) { // 64 complete groups, no prefix among them: take them, look further back
+                    } else if (smask == ~0ull) { // 64 sums, no prefix among them: take them, look further back
                         uint64_t total;
-                        (void)wave_exclusive_sum_u64((uint64_t)(ga & ((1ull << 44) - 1ull)), lane, total);
+                        (void)wave_exclusive_sum_u64((uint64_t)(gs & ~kLookReady), lane, total);
                         gacc += total;
                         gbase -= 64;
                         continue;

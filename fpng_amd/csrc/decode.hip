@@ -190,6 +190,11 @@ __device__ __forceinline__ PhaseMap rec_map(const DecBlockRec &r)
 // ---- synchronisation ----
 constexpr uint32_t kGatherMin = 4; // threads of a workgroup to correct from which on they are gathered into one wave (dec_sync_kernel<true>)
 enum : uint32_t { kLeftMany = 1, kLeftCrawling = 2 }; // DecBlockRec::left: why round 0 left the workgroup unsettled
+#ifndef FPNG_DEC_PAD_LDS
+#define FPNG_DEC_PAD_LDS 0
+#endif
+// (keeps the probe's padding alive: the compiler cannot tell that the condition in front of it never holds)
+__device__ __noinline__ void status_touch(uint32_t *p) { asm volatile("" ::"v"(p[0]) : "memory"); }
 constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 + 1 + 3;
 
 // CAND = false: round 0, the kernel nearly every subsequence of nearly every file is settled by -- kept lean: a workgroup whose
@@ -205,6 +210,10 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
     __shared__ uint32_t s_end[kSubBlock];
     __shared__ uint32_t red3[3 * (kSubBlock / kWave)];
     __shared__ PhaseMap wtail[kSubBlock / kWave + 1];
+#if FPNG_DEC_PAD_LDS // occupancy probe (build variant): LDS nobody uses, so that fewer workgroups share a compute unit
+    __shared__ uint32_t pad_lds[FPNG_DEC_PAD_LDS / 4];
+    if (total_subs == 0xFFFFFFFFu) pad_lds[threadIdx.x] = round, status_touch(pad_lds);
+#endif
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
@@ -664,6 +673,10 @@ __global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(cons
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kEmitDwords)];
+#if FPNG_DEC_PAD_LDS
+    __shared__ uint32_t pad_lds[FPNG_DEC_PAD_LDS / 4];
+    if (total_subs == 0xFFFFFFFFu) pad_lds[threadIdx.x] = n_jobs, status_touch(pad_lds);
+#endif
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // (workgroups are persistent: the table is staged when the file's differs from the one in LDS)
     LdsBits in = {bits};

@@ -453,6 +453,13 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.bit_bias = (int64_t)kPngHeaderBytes * 8;
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
+        if (const char *rl_env = getenv("FPNG_AMD_ASSEMBLE_RL")) { // (A/B runs: the bytes of the file one assemble workgroup owns, as a power of two)
+            const int rl = atoi(rl_env);
+            if (rl >= 12 && rl <= 16) {
+                j.force_range_log2 = (uint32_t)rl;
+                j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + (1u << rl) - 1) >> rl) + 1;
+            }
+        }
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
         // a row's local stream: at most L bits per filtered byte, L = the longest literal code of the table in use
         // (12 for the per-image tables of 2-pass, reference fpng.cpp:1111; run tokens need less per byte they

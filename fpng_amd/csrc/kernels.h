@@ -39,7 +39,7 @@ struct Job {
     uint32_t n_chunks;        // nrows * n_pieces
     uint32_t block_base;      // the job's first workgroup in the linear order of encode_direct_kernel (kRowWaves chunks each)
     uint32_t group_base;      // ... and its first group of 64 chunks in the look-back's group granules
-    uint32_t direct_pad;
+    uint32_t force_range_log2; // 0, or the range size (12..16) scan_kernel is to hand assemble_kernel / crc_kernel whatever the batch (A/B runs: FPNG_AMD_ASSEMBLE_RL)
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
 

@@ -1266,6 +1266,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         want = want < 4u ? 4u : want;
         uint32_t rl = 12;
         while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
+        if (job.force_range_log2 && ((span >> job.force_range_log2) + 1 <= job.crc_blocks)) rl = job.force_range_log2;
         if (!job.whole_png) rl = 16; // row bands: every rank must cut the file into the same ranges (their CRC partials are XOR-ed)
         st.range_log2 = rl;
     }

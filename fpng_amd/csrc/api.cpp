@@ -593,14 +593,10 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         return !v || v[0] != '0';
     }();
     const bool job_in_args = job_in_args_env && n == 1 && !force_stored && !sub.direct;
-    if (sub.direct) { // granules and status words the kernels expect to find zero (they leave them so)
+    if (sub.direct) { // the look-back granules must be zero when the kernel starts (scan_kernel leaves them so)
         if (sc.d_look.fresh) {
             HIP_TRY(hipMemsetAsync(sc.d_look.p, 0, sc.d_look.cap * sizeof(unsigned long long), s));
             sc.d_look.fresh = false;
-        }
-        if (sc.d_states.fresh) {
-            HIP_TRY(hipMemsetAsync(sc.d_states.p, 0, sc.d_states.cap * sizeof(JobState), s));
-            sc.d_states.fresh = false;
         }
     }
     const Job *d_jobs = sc.d_jobs.p;

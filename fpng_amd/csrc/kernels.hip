@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
     if (t == 0) {
         st.token_end_bit = s_last;
         st.mode = stored ? 1u : 0u;
-        st.status = direct ? (st.status & 0x40u) : 0u; // (0x40: a chunk of encode_direct_kernel gave up waiting; finalize_kernel reports and clears it)
+        st.status = 0;
         st.zlib_size = zlib_size;
         st.s1 = (uint32_t)S1;
         st.s2 = (uint32_t)S2;
@@ -1916,7 +1916,6 @@ __device__ __forceinline__ void finalize_job(const Job &job, const RowInfo *rows
         result.png_size = kPngHeaderBytes + zlib_size + kPngTrailerBytes;
         result.mode = st.mode;
         result.status = st.status;
-        st.status = 0;
     }
 }
 

@@ -830,3 +830,28 @@ sys.exit(1 if bad else 0)
     env = dict(os.environ, FPNG_AMD_LIB=lib, FPNG_AMD_DIRECT="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_direct_placement_from_many_encoders_at_once(built_lib):
+    """Several encoders (one per thread, each with its own streams) run encode_direct_kernel on one GPU at the same time: chunks
+    of different kernels compete for the compute units while they wait for their predecessors -- the situation the deferral
+    exists for (no wave waits long while it holds its place).  Eight threads, frames of 4-14 MB of pixels (below the size from
+    which the drop-in streams row bands: these take the one-submission path the switch applies to), five calls each, through
+    fpng::fpng_encode_image_to_memory: every file equals the checker's, every repetition the same bytes."""
+    import dropin
+    import fpng_amd
+    specs = [("grad", 1920, 1080, 4, 0), ("blocks", 1920, 1080, 3, 1), ("grad", 1600, 1200, 3, 0), ("noise", 800, 600, 4, 0),
+             ("grad", 2048, 1536, 4, 1), ("solid", 1920, 1080, 4, 0), ("grad", 1280, 720, 3, 0), ("blocks", 1999, 1111, 4, 0)]
+    imgs = [fpng_amd.synth_image(k, w, h, c, seed=500 + i) for i, (k, w, h, c, _) in enumerate(specs)]
+    old = os.environ.get("FPNG_AMD_DIRECT")
+    os.environ["FPNG_AMD_DIRECT"] = "1"
+    try:
+        pngs, agree = dropin.encode_threads(imgs, [s[4] for s in specs], reps=5)
+    finally:
+        if old is None:
+            del os.environ["FPNG_AMD_DIRECT"]
+        else:
+            os.environ["FPNG_AMD_DIRECT"] = old
+    assert agree
+    for (k, w, h, c, fl), im, png in zip(specs, imgs, pngs):
+        _assert_same(png, oracle().encode(im, w, h, c, fl), f"direct placement, thread frame {k} {w}x{h}x{c} flags {fl}")

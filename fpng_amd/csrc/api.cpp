@@ -377,6 +377,7 @@ struct Submission {
     uint64_t total_rows = 0;
     uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
+    uint64_t px4 = 0, px4_wide = 0; // pixels of the 4-channel jobs, and of those with rows of kWideRowPixels and more
 };
 
 int mark(fpng_amd_encoder *e, hipStream_t s, uint32_t idx)
@@ -427,6 +428,8 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     const bool direct_env = de && de[0] == '1';
     const uint32_t piece_env = pe ? (((uint32_t)atoi(pe) + 255u) & ~255u) : 0u;
     sub.direct = direct_env && !force_stored;
+    const char *rl_env = getenv("FPNG_AMD_ASSEMBLE_RL");
+    const int force_rl = rl_env ? atoi(rl_env) : 0;
     for (uint32_t i = 0; i < n; i++) {
         const fpng_amd_image &im = images[i];
         if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
@@ -453,8 +456,8 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.bit_bias = (int64_t)kPngHeaderBytes * 8;
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
-        if (const char *rl_env = getenv("FPNG_AMD_ASSEMBLE_RL")) { // (A/B runs: the bytes of the file one assemble workgroup owns, as a power of two)
-            const int rl = atoi(rl_env);
+        if (force_rl) { // (A/B runs: the bytes of the file one assemble workgroup owns, as a power of two)
+            const int rl = force_rl;
             if (rl >= 12 && rl <= 16) {
                 j.force_range_log2 = (uint32_t)rl;
                 j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + (1u << rl) - 1) >> rl) + 1;
@@ -469,6 +472,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.local_stride = (uint32_t)(((((uint64_t)j.bpl + 1) * bits_per_byte + 64 + 31) / 32 + 4 + 31) & ~31ull); // whole 128-byte lines
         j.local_base = sub.local_dwords;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
+        if (im.num_chans == 4) sub.px4 += (uint64_t)im.w * im.h, sub.px4_wide += im.w >= kWideRowPixels ? (uint64_t)im.w * im.h : 0u;
         uint64_t units = im.h; // records of the job: rows, or chunks
         if (sub.direct) {
             j.flags |= kJobDirect;
@@ -644,7 +648,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.blocks_per_job == 0xFFFFFFFFu ? 0u : sub.blocks_per_job, sub.chan_mask, sc.d_rows.p, sc.d_states.p,
                              sc.d_local.p, sc.d_look.p, sc.d_look.p + (sub.total_rows + 15) / 16 * 16);
     else if (!force_stored)
-        launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+        launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, 2 * sub.px4_wide >= sub.px4);
     if ((rc = mark(e, s, ++ph))) return rc;
     if (two_pass || stagger_env == 1) { // (only the staggered 2-pass walks wait for it)
         // ... and only a submission that follows while this one runs: with every other lane idle (one frame at a time) the marker
@@ -1068,7 +1072,7 @@ int fpng_amd_band_encode(fpng_amd_encoder *e, const fpng_amd_band *b, uint32_t f
         launch_build_dynamic(s, sc.d_jobs.p + 1, 1, d_hist288, sc.d_dyn.p, 0);
     }
     HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, &j, sizeof(Job), hipMemcpyHostToDevice, s));
-    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
+    launch_encode_rows(s, sc.d_jobs.p, 1, j.nrows, b->num_chans == 3 ? 1u : 2u, sc.d_rows.p, sc.d_states.p, sc.d_local.p, b->w >= kWideRowPixels);
     launch_scan(s, sc.d_jobs.p, 1, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p); // band count: sums only
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_states.p, sc.d_states.p, sizeof(JobState), hipMemcpyDeviceToHost, s));

@@ -56,6 +56,14 @@ constexpr int kRowBlock = kWave * kRowWaves;
 #ifndef FPNG_ROWS_WPE // waves per SIMD the row kernels are compiled for (build variants: occupancy against window size)
 #define FPNG_ROWS_WPE 8
 #endif
+// ... and the 4-channel one on WIDE rows (launch_encode_rows' `wide4`: most of the batch's pixels lie in rows of kWideRowPixels and more):
+// SIX.  Same-box A/B (profiles/r05_rows_w6.txt): on long rows the 4-channel walk is as fast with six waves per SIMD as with eight (no
+// register spills), and the two waves' worth of registers and LDS it leaves free let the other lane's kernels -- the next submission's
+// histogram pass, the previous one's assemble -- run NEXT to it instead of behind it: 8 x 8K 2-pass + 4.4 %, 1-pass + 1.7 %, 16 x 4K
+// + 0.8 % / + 4.6 %.  Short rows need their eight waves (256 x 1080p RGBA - 5.5 % with six), and so does the 3-channel walk (- 10 %).
+#ifndef FPNG_ROWS_WPE4
+#define FPNG_ROWS_WPE4 6
+#endif
 constexpr int kStageDwords = FPNG_STAGE_DWORDS; // per-wave LDS staging window of the output bit stream
 // Local-stream stores carry the non-temporal hint (build with -DFPNG_LOCAL_NT=0 to A/B it: the hint decides whether the
 // streams are kept in L2 / Infinity Cache for assemble_kernel)
@@ -1370,8 +1378,8 @@ __device__ __forceinline__ void xcd_block_order(uint32_t &bx, uint32_t &by)
     bx = logical - by * gridDim.x;
 }
 
-template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(FPNG_ROWS_WPE, FPNG_ROWS_WPE))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
+template <int C, int WPE>
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(WPE, WPE))) void encode_rows_kernel(const Job *jobs, RowInfo *rows_out,
                                                                                                       JobState *states, uint32_t *local)
 {
     uint32_t bx, by;
@@ -1382,8 +1390,8 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // One image per submission, first kernel of its chain: the job record comes IN THE KERNEL ARGUMENTS instead of through an
 // upload in front of the chain (a blit kernel + a dispatch gap: ~7 us of a single frame's ~90); workgroup 0 leaves it in
 // device memory for scan / assemble / finalize, which start after this kernel has ended.
-template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(FPNG_ROWS_WPE, FPNG_ROWS_WPE))) void encode_rows_first_kernel(const JobArg arg, Job *job_out,
+template <int C, int WPE>
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(WPE, WPE))) void encode_rows_first_kernel(const JobArg arg, Job *job_out,
                                                                                                             RowInfo *rows_out, JobState *states,
                                                                                                             uint32_t *local)
 {
@@ -2753,21 +2761,25 @@ void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const
     hipLaunchKernelGGL(build_dynamic_kernel, dim3(n_jobs), dim3(kWave), 0, s, jobs, (uint32_t *)hist, tables, rezero);
 }
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
-                        JobState *states, uint32_t *local)
+                        JobState *states, uint32_t *local, bool wide4)
 {
     if (chan_mask & 1u)
-        hipLaunchKernelGGL(encode_rows_kernel<3>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
-    if (chan_mask & 2u)
-        hipLaunchKernelGGL(encode_rows_kernel<4>, row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+        hipLaunchKernelGGL((encode_rows_kernel<3, FPNG_ROWS_WPE>), row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+    if ((chan_mask & 2u) && wide4)
+        hipLaunchKernelGGL((encode_rows_kernel<4, FPNG_ROWS_WPE4>), row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
+    else if (chan_mask & 2u)
+        hipLaunchKernelGGL((encode_rows_kernel<4, FPNG_ROWS_WPE>), row_grid(max_rows, n_jobs), dim3(kRowBlock), 0, s, jobs, rows, states, local);
 }
 void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local)
 {
     JobArg arg;
     arg.job = job;
     if (job.c == 3)
-        hipLaunchKernelGGL(encode_rows_first_kernel<3>, row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
+        hipLaunchKernelGGL((encode_rows_first_kernel<3, FPNG_ROWS_WPE>), row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
+    else if (job.w >= kWideRowPixels)
+        hipLaunchKernelGGL((encode_rows_first_kernel<4, FPNG_ROWS_WPE4>), row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
     else
-        hipLaunchKernelGGL(encode_rows_first_kernel<4>, row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
+        hipLaunchKernelGGL((encode_rows_first_kernel<4, FPNG_ROWS_WPE>), row_grid(job.nrows, 1), dim3(kRowBlock), 0, s, arg, d_job, rows, states, local);
 }
 void launch_assemble(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_crc_blocks, JobState *states,
                      const uint64_t *row_off, const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials, uint32_t *adler_parts)

@@ -92,7 +92,7 @@ void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_r
 void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look = nullptr,
                  unsigned long long *look_grp = nullptr, const uint32_t *local = nullptr);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
-// wide4: the 4-channel jobs' pixels lie mostly in rows of kWideRowPixels and more (their walk then runs with six waves per SIMD: kernels.hip)
+// wide4: the 4-channel jobs' pixels lie mostly in rows of kWideRowPixels and more (their walk then runs with seven waves per SIMD instead of eight: kernels.hip)
 constexpr uint32_t kWideRowPixels = 3584; // (same-box A/B: 3840-pixel rows gain with six waves, 3072-pixel rows lose 1 % in 1-pass)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local, bool wide4 = false);

@@ -57,12 +57,13 @@ constexpr int kRowBlock = kWave * kRowWaves;
 #define FPNG_ROWS_WPE 8
 #endif
 // ... and the 4-channel one on WIDE rows (launch_encode_rows' `wide4`: most of the batch's pixels lie in rows of kWideRowPixels and more):
-// SIX.  Same-box A/B (profiles/r05_rows_w6.txt): on long rows the 4-channel walk is as fast with six waves per SIMD as with eight (no
-// register spills), and the two waves' worth of registers and LDS it leaves free let the other lane's kernels -- the next submission's
-// histogram pass, the previous one's assemble -- run NEXT to it instead of behind it: 8 x 8K 2-pass + 4.4 %, 1-pass + 1.7 %, 16 x 4K
-// + 0.8 % / + 4.6 %.  Short rows need their eight waves (256 x 1080p RGBA - 5.5 % with six), and so does the 3-channel walk (- 10 %).
+// SEVEN.  Same-box A/Bs on two boxes (profiles/r05_rows_w6.txt): on long rows the 4-channel walk is as fast with six or seven waves per SIMD
+// as with eight (no register spills), and the registers and LDS it leaves free let the other lane's kernels -- the next submission's
+// histogram pass, the previous one's assemble -- run NEXT to it instead of behind it: 8 x 8K 2-pass + 2.5 ... 4.4 % with six or seven,
+// 1-pass + 1.7 % / - 0.5 % with six (by box), + 0.8 % with seven; five waves lose 2 %.  Short rows need their eight waves (256 x 1080p
+// RGBA - 5.5 % with six), and so does the 3-channel walk (- 10 %).
 #ifndef FPNG_ROWS_WPE4
-#define FPNG_ROWS_WPE4 6
+#define FPNG_ROWS_WPE4 7
 #endif
 constexpr int kStageDwords = FPNG_STAGE_DWORDS; // per-wave LDS staging window of the output bit stream
 // Local-stream stores carry the non-temporal hint (build with -DFPNG_LOCAL_NT=0 to A/B it: the hint decides whether the

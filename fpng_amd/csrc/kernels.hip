@@ -2079,6 +2079,8 @@ __device__ __forceinline__ void assemble_stored(const Job &job, const JobState &
     }
 }
 
+// (measured and dropped, round 5: assemble_kernel capped at 4 / 2 waves per SIMD so that the other lane's row walk finds room next to it --
+//  8 x 8K 0.49 -> 0.54 / 0.69 ms per step, profiles/r05_rows_w6.txt block 5)
 __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobState *states, const uint64_t *row_off,
                                                          const uint32_t *local, const CrcDeviceTables *tabs, uint32_t *partials,
                                                          uint32_t *adler_parts, uint32_t max_crc_blocks)

@@ -102,6 +102,7 @@ VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's 
             "direct_sleep4": ["FPNG_DIRECT_SLEEP=4"], "direct_sleep64": ["FPNG_DIRECT_SLEEP=64"],
             "dec_pad27k": ["FPNG_DEC_PAD_LDS=27648"],  # decoder occupancy probe: two workgroups per compute unit instead of three
             "direct_w8": ["FPNG_DIRECT_WPE=8"], "direct_w5_win1536": ["FPNG_DIRECT_WPE=5", "FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "direct_win1280": ["FPNG_STAGE_DWORDS=1280", "FPNG_ROWS_WPE=6"],
+            "rows_w7": ["FPNG_ROWS_WPE=7"],  # the 3-channel and the narrow 4-channel walk at seven waves per SIMD too
             "rows4_w6": ["FPNG_ROWS_WPE4=6"],
             "rows4_w5": ["FPNG_ROWS_WPE4=5"], "rows4_w7": ["FPNG_ROWS_WPE4=7"],
             "rows4_w8": ["FPNG_ROWS_WPE4=8"],  # the 4-channel row kernel at eight waves per SIMD on wide rows too (the product: six there)

@@ -316,6 +316,7 @@ void fpng_amd_encoder_destroy(fpng_amd_encoder *e)
     e->d_stream_partials.release();
     e->d_decode.release();
     e->d_dec_gran.release();
+    e->d_lut_cache.release();
     for (hipEvent_t ev : e->dec_prof_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->dec_ev2)

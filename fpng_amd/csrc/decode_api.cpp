@@ -354,6 +354,27 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
     uint32_t *d_eob = d_status + nj + kMaxGroups;
     uint32_t *d_multi = d_status + 2 * nj + kMaxGroups + 1; // (one word per group: launch_dec_sync)
+    // the tables: from the encoder's cache when every one of this batch's is there; a batch of few distinct tables that are not
+    // refills the cache (its tables are built in place); a batch of many (2-pass files: one each) builds them in the call's scratch
+    const uint32_t n_luts = (uint32_t)(lut_keys.size() / 288);
+    bool luts_cached = false;
+    std::vector<uint32_t> lut_slot(n_luts, 0);
+    if (n_luts && n_luts <= fpng_amd_encoder::kDecLutCache) {
+        if ((rc = e->d_lut_cache.ensure((size_t)fpng_amd_encoder::kDecLutCache * dec::kLutDwords))) return rc;
+        if (e->d_lut_cache.fresh) e->lut_cache_n = 0, e->d_lut_cache.fresh = false;
+        luts_cached = true;
+        for (uint32_t q = 0; q < n_luts && luts_cached; q++) {
+            bool hit = false;
+            for (uint32_t c = 0; c < e->lut_cache_n && !hit; c++)
+                if (!std::memcmp(e->lut_cache_keys[c], lut_keys.data() + (size_t)q * 288, 288)) lut_slot[q] = c, hit = true;
+            luts_cached = hit;
+        }
+        if (!luts_cached) { // (re)fill: this batch's tables become the cache
+            for (uint32_t q = 0; q < n_luts; q++) std::memcpy(e->lut_cache_keys[q], lut_keys.data() + (size_t)q * 288, 288), lut_slot[q] = q;
+            e->lut_cache_n = n_luts;
+            d_luts = e->d_lut_cache.p; // (built below, in place)
+        }
+    }
     for (uint32_t k = 0; k < nj; k++) {
         DecJob &j = jobs[k];
         const Parsed &p = ps[job_file[k]];
@@ -361,7 +382,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (!j.mode) {
             j.filt = d_filt + (size_t)(uintptr_t)j.filt;
             j.segsum = (uint32_t *)(d_seg + (size_t)(uintptr_t)j.segsum);
-            j.lut = d_luts + (size_t)p.lut * dec::kLutDwords;
+            j.lut = (n_luts <= fpng_amd_encoder::kDecLutCache ? e->d_lut_cache.p + (size_t)lut_slot[p.lut] * dec::kLutDwords : d_luts + (size_t)p.lut * dec::kLutDwords);
         }
     }
     // ---- groups of files: while one group is decoded the next one's bytes are on their way (its own stream; from pageable
@@ -441,7 +462,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             }
         });
     }
-    if (!lut_keys.empty()) {
+    if (!lut_keys.empty() && !luts_cached) {
         HIP_TRY(hipMemcpyAsync(d_keys, lut_keys.data(), lut_keys.size(), hipMemcpyHostToDevice, s));
         launch_dec_build_luts(s, d_keys, (uint32_t)(lut_keys.size() / 288), d_luts);
     }

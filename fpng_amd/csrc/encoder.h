@@ -183,6 +183,12 @@ struct fpng_amd_encoder {
     DeviceBuf<uint8_t> d_decode;  // fpng_amd_decode_batch(): all of its device scratch
     DeviceBuf<unsigned long long> d_dec_gran; // ... the look-back granules of dec_unfilter_kernel: zeroed when allocated, then told apart by epochs
     uint32_t dec_epoch = 0;
+    // the decoder's lookup tables of the last batch that had at most kDecLutCache distinct ones (1-pass files: always the same two):
+    // a batch whose tables are all here neither uploads code lengths nor builds tables (dec_build_lut_kernel: 34 us in front of everything)
+    static constexpr uint32_t kDecLutCache = 4;
+    DeviceBuf<uint32_t> d_lut_cache;
+    uint8_t lut_cache_keys[kDecLutCache][288] = {};
+    uint32_t lut_cache_n = 0;
     hipEvent_t dec_prof_ev[5] = {}; // profiling: around the decode kernels of the last call's first group of files
     bool dec_prof_recorded = false;
     hipStream_t dec_up = nullptr; // ... the stream the files' bytes are uploaded on, one event per group of files

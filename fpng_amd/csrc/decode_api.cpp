@@ -359,7 +359,12 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     const uint32_t n_luts = (uint32_t)(lut_keys.size() / 288);
     bool luts_cached = false;
     std::vector<uint32_t> lut_slot(n_luts, 0);
-    if (n_luts && n_luts <= fpng_amd_encoder::kDecLutCache) {
+    static const bool lut_cache_on = [] {
+        const char *v = getenv("FPNG_AMD_DECODE_LUT_CACHE");
+        return !(v && v[0] == '0');
+    }();
+    const bool few_luts = lut_cache_on && n_luts && n_luts <= fpng_amd_encoder::kDecLutCache;
+    if (few_luts) {
         if ((rc = e->d_lut_cache.ensure((size_t)fpng_amd_encoder::kDecLutCache * dec::kLutDwords))) return rc;
         if (e->d_lut_cache.fresh) e->lut_cache_n = 0, e->d_lut_cache.fresh = false;
         luts_cached = true;
@@ -382,7 +387,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (!j.mode) {
             j.filt = d_filt + (size_t)(uintptr_t)j.filt;
             j.segsum = (uint32_t *)(d_seg + (size_t)(uintptr_t)j.segsum);
-            j.lut = (n_luts <= fpng_amd_encoder::kDecLutCache ? e->d_lut_cache.p + (size_t)lut_slot[p.lut] * dec::kLutDwords : d_luts + (size_t)p.lut * dec::kLutDwords);
+            j.lut = (few_luts ? e->d_lut_cache.p + (size_t)lut_slot[p.lut] * dec::kLutDwords : d_luts + (size_t)p.lut * dec::kLutDwords);
         }
     }
     // ---- groups of files: while one group is decoded the next one's bytes are on their way (its own stream; from pageable

@@ -100,6 +100,7 @@ VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's 
             "direct_defer": ["FPNG_DIRECT_SPIN_LIMIT=0"],  # every chunk that has to wait at all is deferred to scan_kernel (tests)
             "abl_nolook": ["FPNG_DIRECT_ABL=1"], "abl_nostore": ["FPNG_DIRECT_ABL=2"], "abl_nobehind": ["FPNG_DIRECT_ABL=4"], "abl_all": ["FPNG_DIRECT_ABL=7"],  # timing only: wrong files
             "direct_sleep4": ["FPNG_DIRECT_SLEEP=4"], "direct_sleep64": ["FPNG_DIRECT_SLEEP=64"],
+            "dec_noprefilter": ["FPNG_DEC_PREFILTER=0"],
             "dec_pad27k": ["FPNG_DEC_PAD_LDS=27648"],  # decoder occupancy probe: two workgroups per compute unit instead of three
             "direct_w8": ["FPNG_DIRECT_WPE=8"], "direct_w5_win1536": ["FPNG_DIRECT_WPE=5", "FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "direct_win1280": ["FPNG_STAGE_DWORDS=1280", "FPNG_ROWS_WPE=6"],
             "rows_w7": ["FPNG_ROWS_WPE=7"],  # the 3-channel and the narrow 4-channel walk at seven waves per SIMD too

@@ -190,6 +190,9 @@ __device__ __forceinline__ PhaseMap rec_map(const DecBlockRec &r)
 // ---- synchronisation ----
 constexpr uint32_t kGatherMin = 4; // threads of a workgroup to correct from which on they are gathered into one wave (dec_sync_kernel<true>)
 enum : uint32_t { kLeftMany = 1, kLeftCrawling = 2 }; // DecBlockRec::left: why round 0 left the workgroup unsettled
+#ifndef FPNG_DEC_PREFILTER // 0: the border rounds walk over their blocks one check after the other (A/B builds)
+#define FPNG_DEC_PREFILTER 1
+#endif
 #ifndef FPNG_DEC_PAD_LDS
 #define FPNG_DEC_PAD_LDS 0
 #endif
@@ -217,7 +220,31 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
+    // Border rounds: nearly every block's border holds, and finding that out costs a chain of dependent loads per block (its file,
+    // its record, its neighbour's) -- a persistent workgroup walking over its ten blocks one after the other spent 47 us per round on
+    // nothing else.  The threads look at the workgroup's first kSubBlock blocks AT ONCE (thread t at the t-th); the walk below then
+    // stops only at the blocks that are open.  (A record that another workgroup changes meanwhile is seen a round later, as before.)
+    __shared__ uint32_t open_bits[CAND ? kSubBlock / 32 : 1];
+    if (CAND && round && FPNG_DEC_PREFILTER) {
+        const uint32_t bi = blockIdx.x + t * gridDim.x;
+        bool open = false;
+        if (bi < n_blocks && (first_block + bi) * kSubBlock < total_subs) {
+            const uint32_t blk = first_block + bi;
+            uint32_t local0;
+            (void)job_of_sub(jobs, n_jobs, blk * kSubBlock, local0);
+            const DecBlockRec mine = recs[blk];
+            const uint32_t prev = !local0 ? mine.entry_rel : (mine.want_rel != kDecWantUnknown ? mine.want_rel : recs[blk - 1].exit_rel);
+            open = !(mine.entry_rel == prev && pm_count(rec_map(mine)));
+        }
+        const uint64_t m = __ballot(open);
+        if ((t & 63) == 0) open_bits[(t >> 6) * 2] = (uint32_t)m, open_bits[(t >> 6) * 2 + 1] = (uint32_t)(m >> 32);
+        __syncthreads();
+    }
     for (uint32_t bi = blockIdx.x; bi < n_blocks; bi += gridDim.x) {
+        if (CAND && round && FPNG_DEC_PREFILTER) {
+            const uint32_t k = (bi - blockIdx.x) / gridDim.x;
+            if (k < (uint32_t)kSubBlock && !((open_bits[k >> 5] >> (k & 31u)) & 1u)) continue; // (blocks behind the kSubBlock-th are looked at the old way)
+        }
         const uint32_t blk = first_block + bi, g0 = blk * kSubBlock;
         if (g0 >= total_subs) break;
         // all subsequences of a workgroup's block belong to one file (sub_base is padded to kSubBlock by the host)

@@ -224,6 +224,8 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
     // its record, its neighbour's) -- a persistent workgroup walking over its ten blocks one after the other spent 47 us per round on
     // nothing else.  The threads look at the workgroup's first kSubBlock blocks AT ONCE (thread t at the t-th); the walk below then
     // stops only at the blocks that are open.  (A record that another workgroup changes meanwhile is seen a round later, as before.)
+    // (round 2 is launched blind behind round 1: when round 1 rewrote no record there is nothing for it to find)
+    if (CAND && round == 2 && !*changed) return;
     __shared__ uint32_t open_bits[CAND ? kSubBlock / 32 : 1];
     if (CAND && round && FPNG_DEC_PREFILTER) {
         const uint32_t bi = blockIdx.x + t * gridDim.x;

@@ -323,6 +323,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     DecJob *d_jobs;
     uint8_t *d_plan;
     const size_t subs = std::max<size_t>(sub_total, 1), blocks = (subs + kDecSubBlock - 1) / kDecSubBlock;
+    size_t setup_ofs = 0, setup_len = 0, setup_plan = 0; // job records, un-filter plans and the (zero) status words: adjacent in the scratch, ONE upload
     {
         size_t need = 0;
         auto carve = [&](size_t bytes) {
@@ -350,6 +351,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
         d_luts = (uint32_t *)(base + o_luts), d_keys = base + o_keys, d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
         d_plan = base + o_plan;
+        setup_ofs = o_jobs, setup_plan = o_plan - o_jobs, setup_len = o_status + (2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4 - o_jobs;
     }
     d_changed = d_status + nj; // (one word per group of files; 2 * nj + 1 + 2 * kMaxGroups words were carved out)
     uint32_t *d_eob = d_status + nj + kMaxGroups;
@@ -471,7 +473,11 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         HIP_TRY(hipMemcpyAsync(d_keys, lut_keys.data(), lut_keys.size(), hipMemcpyHostToDevice, s));
         launch_dec_build_luts(s, d_keys, (uint32_t)(lut_keys.size() / 288), d_luts);
     }
-    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(DecJob), hipMemcpyHostToDevice, s));
+    // (four small uploads -- job records, plan pieces, plan words, cleared status words -- were four blit kernels with their dispatch
+    //  gaps in front of the first decode kernel, ~7 us each: they go up as one block from pinned memory)
+    if ((rc = e->h_dec_fetch.ensure(setup_len))) return rc;
+    uint8_t *const h_setup = e->h_dec_fetch.p; // (the fetched heads and tails that lived here have been parsed)
+    std::memset(h_setup, 0, setup_len);
     {   // dec_unfilter_kernel's work items per group of files, numbered segment by segment (decode.h: DecUnfPlan)
         DecUnfPiece *d_pieces = (DecUnfPiece *)d_plan;
         uint32_t *d_words = (uint32_t *)(d_pieces + nj + kMaxGroups);
@@ -499,10 +505,11 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             g.plan.pieces = d_pieces + p0, g.plan.n_pieces = (uint32_t)(pieces.size() - p0), g.plan.total_items = item;
             g.plan.cbpre = d_words + w0, g.plan.order = d_words + w0 + m + 1;
         }
-        if (!pieces.empty()) HIP_TRY(hipMemcpyAsync(d_pieces, pieces.data(), pieces.size() * sizeof(DecUnfPiece), hipMemcpyHostToDevice, s));
-        if (!words.empty()) HIP_TRY(hipMemcpyAsync(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice, s));
+        if (!pieces.empty()) std::memcpy(h_setup + setup_plan, pieces.data(), pieces.size() * sizeof(DecUnfPiece));
+        if (!words.empty()) std::memcpy(h_setup + setup_plan + ((size_t)nj + kMaxGroups) * sizeof(DecUnfPiece), words.data(), words.size() * 4);
     }
-    HIP_TRY(hipMemsetAsync(d_status, 0, (2 * nj + 1 + 2 * kMaxGroups) * 4, s));
+    std::memcpy(h_setup, jobs.data(), nj * sizeof(DecJob));
+    HIP_TRY(hipMemcpyAsync(e->d_decode.p + setup_ofs, h_setup, setup_len, hipMemcpyHostToDevice, s));
     // profiling (fpng_amd_encoder_set_profiling): events around the kernels of the first group of files
     const bool prof = e->profiling;
     e->dec_prof_recorded = false;

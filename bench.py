@@ -538,6 +538,7 @@ def main():
     args = parse()
     if args.end_to_end_only:
         w, h, c = (int(v) for v in args.workload.split("x"))
+        import fpng_amd  # noqa: F401  (as below: before the first HIP call)
         torch.cuda.set_device(args.device)
         print(json.dumps(end_to_end_here(args.device, w, h, c, args.kind, args.flags, args.end_to_end_only)), flush=True)
         return
@@ -547,6 +548,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = "RANK" in os.environ  # launched by torch.distributed.run (also exercised with one rank)
+    import fpng_amd  # (before the first HIP call of the process: loading the library sets the runtime's hardware queues, csrc/api.cpp runtime_defaults())
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
@@ -559,7 +561,6 @@ def main():
         torch.cuda.synchronize()
     dev = torch.device("cuda", local_rank)
 
-    import fpng_amd
     w, h, c = WORKLOADS[args.workload] if args.workload in WORKLOADS else tuple(int(v) for v in args.workload.split("x"))  # (a name, or WxHxC)
     if args.mode == "rowband":
         return rowband(args, rank, local_rank, world, distributed, dev, w, h, c)

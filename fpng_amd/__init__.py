@@ -3,6 +3,14 @@
 The product is libfpng_amd.so (hand-written HIP kernels behind a C ABI, include/fpng_amd.h) plus
 the `fpng::` C++ drop-in; this package is the Python door to the same C ABI.
 """
+import os as _os
+
+from . import _lib
+if _os.path.exists(_lib.LIB_PATH):
+    # The library is loaded NOW, not at the first call: loading it asks the HIP runtime for eight hardware queues
+    # (GPU_MAX_HW_QUEUES, csrc/api.cpp runtime_defaults()), which only counts before the process's first HIP call --
+    # import fpng_amd before the first torch.cuda call.
+    _lib.load()
 from .api import (FPNG_ADLER32_INIT, FPNG_CRC32_INIT, FPNG_ENCODE_SLOWER, FPNG_FORCE_UNCOMPRESSED, MODE_COMPRESSED,  # noqa: F401
                   MODE_STORED, Encoder, FpngAmdError, adler32_combine, crc32_combine, fpng_adler32,
                   fpng_cpu_supports_sse41, fpng_crc32, fpng_encode_image_to_file, fpng_encode_image_to_memory,

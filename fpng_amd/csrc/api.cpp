@@ -15,9 +15,52 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <dirent.h>
+#include <unistd.h>
 
 namespace {
 thread_local std::string g_last_error;
+
+// HARDWARE QUEUES.  The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, four by default: with the
+// caller's stream, the encoder's stream and the lanes (one stream + scratch set each, whole chains alternate between them) two chains
+// land in ONE queue and run one behind the other.  With eight queues and four lanes (same box, alternating; profiles/r05_hw_queues.txt)
+// one 8K frame per submission + 29 %, 8 x 8K + 3 ... 4 % (2-pass + 6 %), 256 x 1080p RGB + 12 %, 1024 x 512^2 + 5 %; four lanes over
+// four queues lose 7 % in 2-pass, so the lanes follow what the library can tell about the queues.  The runtime reads the variable
+// when it initialises (the first HIP call of the process): the library asks for eight when it is loaded, unless the variable is set
+// already, FPNG_AMD_KEEP_HW_QUEUES=1 says hands off, or the process has the GPU driver open already (too late: two lanes then).
+int g_hw_queues = 4;
+
+bool gpu_driver_open()
+{
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool found = false;
+    char path[64], target[256];
+    while (const dirent *ent = readdir(d)) {
+        if (ent->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/fd/%s", ent->d_name);
+        const ssize_t len = readlink(path, target, sizeof target - 1);
+        if (len <= 0) continue;
+        target[len] = 0;
+        if (!strcmp(target, "/dev/kfd")) {
+            found = true;
+            break;
+        }
+    }
+    closedir(d);
+    return found;
+}
+
+__attribute__((constructor)) void runtime_defaults()
+{
+    const char *keep = getenv("FPNG_AMD_KEEP_HW_QUEUES");
+    if (const char *cur = getenv("GPU_MAX_HW_QUEUES")) {
+        g_hw_queues = atoi(cur);
+    } else if (!(keep && keep[0] == '1') && !gpu_driver_open()) {
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        g_hw_queues = 8;
+    }
+}
 }
 
 int fpng_amd::fail(int code, const char *what, hipError_t e)
@@ -233,6 +276,13 @@ int fpng_amd_1pass_layout(uint32_t c, uint32_t *first_token_bit, uint32_t *eob_b
     return FPNG_AMD_OK;
 }
 
+static uint32_t default_lanes()
+{
+    const char *v = getenv("FPNG_AMD_LANES");
+    const int n = v ? atoi(v) : (g_hw_queues >= 8 ? 4 : 2);
+    return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
+}
+
 static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, bool use_given_stream)
 {
     if (!out) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder pointer");
@@ -254,8 +304,9 @@ static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, 
         }
         e->own_stream = true;
     }
-    for (auto &ls : e->lane_stream) {
-        hipError_t err = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
+    const uint32_t n_streams = std::max(default_lanes(), 2u); // (the decoder uses the first two)
+    for (uint32_t l = 0; l < n_streams; l++) {
+        hipError_t err = hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking);
         if (err != hipSuccess) {
             fpng_amd_encoder_destroy(e);
             return fail(FPNG_AMD_ERR_HIP, "hipStreamCreate (lane)", err);
@@ -526,12 +577,8 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
     }
-    static const uint32_t n_lanes = [] {
-        const char *v = getenv("FPNG_AMD_LANES");
-        const int n = v ? atoi(v) : 2;
-        return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
-    }();
-    // lane = internal stream + scratch set; whole chains alternate between FPNG_AMD_LANES (default 2) of them, so that the
+    static const uint32_t n_lanes = default_lanes();
+    // lane = internal stream + scratch set; whole chains alternate between FPNG_AMD_LANES (default: four over eight hardware queues, else two) of them, so that the
     // latency-bound tail of one submission (scan, stored fallback, finalize) and its memory-bound assemble run next to the
     // row walk of the next one.  Per-kernel profiling stays on lane 0, which serialises it.
     // (Measured on one box and dropped: the three stages of a submission on three streams linked by events -- prep, walk,
@@ -1304,6 +1351,10 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
         uint64_t deferred = 0, spilled = 0;
         for (const JobState &q : st) deferred += q.reserved[0], spilled += q.reserved[1];
         dst[0] = (uint32_t)deferred, dst[1] = (uint32_t)spilled, dst[2] = n, dst[3] = e->sc[lane].last_chunks;
+        return FPNG_AMD_OK;
+    }
+    if (n_words == 2) { // what the library assumes about the runtime's hardware queues, and the lanes that take submissions
+        dst[0] = (uint32_t)g_hw_queues, dst[1] = default_lanes();
         return FPNG_AMD_OK;
     }
     if (n_words == 8) { // the timing build's cycle counts of build_dynamic_kernel (head of the histogram scratch)

@@ -144,7 +144,7 @@ struct fpng_amd_encoder {
             d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release(), d_look.release();
         }
     };
-    static constexpr int kLanes = 4; // streams created; FPNG_AMD_LANES (default 2) of them take submissions
+    static constexpr int kLanes = 8; // streams created; FPNG_AMD_LANES of them take submissions (default: api.cpp, default_lanes())
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)

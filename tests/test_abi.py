@@ -189,3 +189,24 @@ def test_bench_reads_its_own_pmc_summary_and_prints_no_rate_above_the_peak():
     errs = bench.check_rates(line)
     assert len(errs) == 1 and "chain_traffic_rate_GBs" in errs[0] and line["roofline"]["chain_traffic_rate_GBs"] is None
     assert line["roofline"]["achieved"] == 4300.0 and bench.scope_name(1) == "one GPU"
+
+
+def test_loading_the_library_asks_for_eight_hardware_queues_unless_told_otherwise(built_lib):
+    """csrc/api.cpp runtime_defaults(): GPU_MAX_HW_QUEUES=8 is put into the process environment when the library is loaded
+    (the HIP runtime reads it at its first call), never over a value that is there, never with FPNG_AMD_KEEP_HW_QUEUES=1."""
+    import subprocess
+    import sys
+    prog = ("import ctypes, fpng_amd; libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print('Q=%s' % (libc.getenv(b'GPU_MAX_HW_QUEUES') or b'-').decode())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FPNG_AMD_KEEP_HW_QUEUES")}
+        env.update(extra, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [ln for ln in out.stdout.splitlines() if ln.startswith("Q=")][-1]
+
+    assert run({}) == "Q=8"
+    assert run({"GPU_MAX_HW_QUEUES": "4"}) == "Q=4"
+    assert run({"FPNG_AMD_KEEP_HW_QUEUES": "1"}) == "Q=-"

@@ -855,3 +855,18 @@ def test_direct_placement_from_many_encoders_at_once(built_lib):
     assert agree
     for (k, w, h, c, fl), im, png in zip(specs, imgs, pngs):
         _assert_same(png, oracle().encode(im, w, h, c, fl), f"direct placement, thread frame {k} {w}x{h}x{c} flags {fl}")
+
+
+@pytest.mark.parametrize("case,env,expect", [("early", {}, "OK 8 4"), ("early", {"FPNG_AMD_KEEP_HW_QUEUES": "1"}, "OK 4 2"),
+                                             ("late", {}, "OK 4 2"), ("early", {"GPU_MAX_HW_QUEUES": "16", "FPNG_AMD_LANES": "8"}, "OK 16 8")])
+def test_lanes_follow_the_hardware_queues(built_lib, case, env, expect):
+    """csrc/api.cpp runtime_defaults() / default_lanes(): a process that loads the library before its first HIP call gets eight
+    hardware queues and four lanes, one that comes too late (or says hands off) keeps the runtime's four queues and two lanes;
+    in every case seven submissions in flight at once give the checker's files (tests/lanes_check.py)."""
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FPNG_AMD_KEEP_HW_QUEUES", "FPNG_AMD_LANES")}
+    e.update(env, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lanes_check.py"), case], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert [ln for ln in out.stdout.splitlines() if ln.startswith("OK")][-1] == expect

@@ -684,7 +684,9 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         const char *v = getenv("FPNG_AMD_STAGGER");
         return v ? (v[0] == '1' ? 1 : 0) : -1;
     }();
-    const bool stagger = stagger_env < 0 ? two_pass : stagger_env == 1;
+    // (With four lanes over eight hardware queues the rule turns into a loss -- 8 x 8K 2-pass 0.622 -> 0.591 ms per step without it,
+    // profiles/r05_hw_queues.txt -- so it stays with the two-lane case it was measured for.)
+    const bool stagger = stagger_env < 0 ? (two_pass && n_lanes <= 2) : stagger_env == 1;
     if (stagger && e->prev_walked && !e->profiling) HIP_TRY(hipStreamWaitEvent(s, e->prev_walked, 0));
     // four launches: rows, row scan (sizes, offsets, stored-or-compressed decision, stream head), assemble (rows into place or,
     // for an image that fell back, the stored blocks; + CRC partials), finalize (CRC fold, Adler, trailer, result record).  Folding the scan into the last row block and
@@ -698,7 +700,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     else if (!force_stored)
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, 2 * sub.px4_wide >= sub.px4);
     if ((rc = mark(e, s, ++ph))) return rc;
-    if (two_pass || stagger_env == 1) { // (only the staggered 2-pass walks wait for it)
+    if (stagger) { // (only staggered walks wait for it)
         // ... and only a submission that follows while this one runs: with every other lane idle (one frame at a time) the marker
         // packet between the walk and the scan would only lengthen the chain
         bool others_busy = always_order;

@@ -570,8 +570,9 @@ def main():
     # B distinct frames per rank (seed varies per image and per rank)
     imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]
     cap = fpng_amd.max_encoded_size(w, h, c) + 64
-    # consecutive submissions overlap on the GPU (two encoder lanes): each gets its own set of output buffers
-    out_sets = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(4)]
+    # consecutive submissions overlap on the GPU (up to eight encoder lanes, four by default): each one in flight has its own set of output buffers
+    n_sets = 8
+    out_sets = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(n_sets)]
     outs = out_sets[0]
     enc = fpng_amd.Encoder(device=local_rank, stream="own")
 
@@ -590,7 +591,7 @@ def main():
     # warmup: W steps enqueued back to back like the timed ones (the first time two submissions overlap on the GPU
     # costs several ms once per process; with one finish per warmup step that would land in the timed region)
     for i in range(args.prewarm + args.warmup):
-        enc.submit(batches[i & 3], None, args.flags)
+        enc.submit(batches[i % n_sets], None, args.flags)
     if args.prewarm + args.warmup:
         res = enc.finish(B)
     # `regions` timed regions, each EXACTLY K steps enqueued back to back (the encoder pipelines submissions through a ring
@@ -602,7 +603,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            enc.submit(batches[i & 3], None, args.flags)
+            enc.submit(batches[i % n_sets], None, args.flags)
         res = enc.finish(B)
         own = time.perf_counter() - t0
         barrier()
@@ -624,7 +625,7 @@ def main():
     assert all(r[2] == 0 for r in res)
     # self-check: EVERY image of the last timed submission's output set against the reference's bytes
     # (tests/golden/batches.json / kat.json: sha256 of the unmodified reference encoder's file for this input)
-    parity_checked = verify_outputs(args, rank, w, h, c, out_sets[(args.steps - 1) & 3], [r[0] for r in res])
+    parity_checked = verify_outputs(args, rank, w, h, c, out_sets[(args.steps - 1) % n_sets], [r[0] for r in res])
     pixels_per_step = B * w * h
     value = world * pixels_per_step * args.steps / elapsed / 1e6
     run_values = [round(world * pixels_per_step * args.steps / r / 1e6, 1) for r in runs]
@@ -680,7 +681,7 @@ def main():
             el = float(t.item())
         return el
 
-    last_set = out_sets[(args.steps - 1) & 3]
+    last_set = out_sets[(args.steps - 1) % n_sets]
     pngs = [o[: r[0]] for o, r in zip(last_set, res)]
     dec = decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, rank == 0 and world == 1 and not args.no_cpu_baseline)
     if True:

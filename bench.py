@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="8k")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--out-sets", type=int, default=8, help="sets of output buffers the submissions cycle through (one per submission that can be in flight)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--kind", default="grad")
     ap.add_argument("--prewarm", type=int, default=60,
@@ -571,7 +572,7 @@ def main():
     imgs = [torch.from_numpy(fpng_amd.synth_image(args.kind, w, h, c, seed=12345 + rank * 1000 + i)).to(dev) for i in range(B)]
     cap = fpng_amd.max_encoded_size(w, h, c) + 64
     # consecutive submissions overlap on the GPU (up to eight encoder lanes, four by default): each one in flight has its own set of output buffers
-    n_sets = 8
+    n_sets = max(1, args.out_sets)
     out_sets = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(n_sets)]
     outs = out_sets[0]
     enc = fpng_amd.Encoder(device=local_rank, stream="own")
@@ -590,9 +591,20 @@ def main():
 
     # warmup: W steps enqueued back to back like the timed ones (the first time two submissions overlap on the GPU
     # costs several ms once per process; with one finish per warmup step that would land in the timed region)
-    for i in range(args.prewarm + args.warmup):
+    # ... in TWO bursts with a finish in between: the burst after the first one that ran the lanes at full overlap is slow once more
+    # (short rows, four lanes: one slot wait of 7-12 ms instead of 3.8; tools/region_diag.py) -- the timed regions are to be the third and later
+    n_warm = args.prewarm + args.warmup
+    for i in range(n_warm):
         enc.submit(batches[i % n_sets], None, args.flags)
-    if args.prewarm + args.warmup:
+        if i + 1 == n_warm // 2:
+            res = enc.finish(B)
+    if n_warm:
+        res = enc.finish(B)
+        # ... and one more untimed burst shaped like a timed region (barrier, K steps, finish): the first one of a process still runs 10-20 %
+        # slow on the short-row workloads whatever the length of the warm-up in front of it (profiles/r05_hw_queues.txt, section 5)
+        barrier()
+        for i in range(args.steps):
+            enc.submit(batches[i % n_sets], None, args.flags)
         res = enc.finish(B)
     # `regions` timed regions, each EXACTLY K steps enqueued back to back (the encoder pipelines submissions through a ring
     # of pinned slots) between a barrier + synchronize on both sides; per region the max over ranks counts.  The reported

@@ -300,12 +300,24 @@ class Encoder:
         self._keep = {}
         return [(r.png_size, r.mode, r.status) for r in res]
 
-    def encode_tensors(self, images, flags=0):
-        """Convenience: allocate outputs, encode, return list of PNG byte strings."""
+    def encode_tensors(self, images, flags=0, submissions=1):
+        """Convenience: allocate outputs, encode, return list of PNG byte strings.  submissions: the batch goes to the GPU in that
+        many submissions (at most one per image).  With frames in hand and nothing in flight, four submissions beat one -- their
+        chains run on different lanes, one's assemble next to the next one's row walk: 8 x 8K 0.66 -> 0.56 ms, 64 x 1080p RGB
+        0.34 -> 0.31 ms (tools/oneshot_split.py, profiles/r05_hw_queues.txt section 6); a caller that keeps submissions in flight
+        anyway gains nothing from smaller ones."""
         outs = [torch.empty(max_encoded_size(im.shape[1], im.shape[0], im.shape[2]) + 64, dtype=torch.uint8,
                             device=im.device) for im in images]
-        n = self.submit(images, outs, flags)
-        res = self.finish(n)
+        n = len(images)
+        subs = min(max(1, submissions), 8)  # (the C side keeps the records of the last eight submissions)
+        k = max(1, (n + subs - 1) // subs)
+        parts = []
+        for i in range(0, n, k):
+            self.submit(images[i:i + k], outs[i:i + k], flags)
+            parts.append((self.last_ticket, len(images[i:i + k])))
+        res = []
+        for ticket, m in parts:
+            res += self.wait(ticket, m)
         pngs = []
         for out, (size, mode, status) in zip(outs, res):
             if status:

@@ -870,3 +870,19 @@ def test_lanes_follow_the_hardware_queues(built_lib, case, env, expect):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lanes_check.py"), case], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert [ln for ln in out.stdout.splitlines() if ln.startswith("OK")][-1] == expect
+
+
+@pytest.mark.parametrize("submissions", [2, 4, 8, 100])
+def test_a_batch_in_several_submissions(enc, submissions):
+    """Encoder.encode_tensors(..., submissions=k): the batch cut into k submissions whose chains overlap on the lanes (what a caller
+    with frames in hand and an idle GPU should do: INTEGRATION.md) -- same files as one submission, both modes, mixed shapes."""
+    import torch
+    import fpng_amd
+    specs = [("grad", 1920, 1080, 4), ("blocks", 640, 480, 3), ("noise", 333, 77, 4), ("grad", 2048, 1536, 3), ("solid", 800, 600, 4),
+             ("grad", 4096, 16, 3), ("blocks", 1280, 720, 4), ("grad", 1, 1, 3), ("noise", 64, 64, 3), ("grad", 3840, 2160, 4), ("blocks", 97, 1031, 3)]
+    imgs = [fpng_amd.synth_image(k, w, h, c, seed=700 + i) for i, (k, w, h, c) in enumerate(specs)]
+    ts = [torch.from_numpy(im).cuda() for im in imgs]
+    for flags in (0, 1):
+        pngs, _ = enc.encode_tensors(ts, flags, submissions=submissions)
+        for (k, w, h, c), im, png in zip(specs, imgs, pngs):
+            _assert_same(png, oracle().encode(im, w, h, c, flags), f"{submissions} submissions, {k} {w}x{h}x{c} flags {flags}")

@@ -2363,37 +2363,71 @@ __device__ __forceinline__ void dev_build_table(BuilderLds &L, uint32_t n, uint3
     if (used == 1) {
         if (lane == 0) L.num_codes[1] = 1;
     } else if (used >= 2) {
-        if (lane == 0) {
-            // two-queue merge: leaves ascending, internal nodes in creation order; an internal node is
-            // taken only when strictly lighter than the next leaf (reference fpng.cpp:645-651).
-            // The heads of both queues and their successors are kept in registers: an LDS load issued when a queue
-            // advances is needed only after its NEXT advance, so the loop does not wait for LDS; weights of internal
-            // nodes made just now are forwarded instead of read back.  (Measured alternatives, both slower: the same
-            // loop on scalar registers with readfirstlane after every load, and both queues held in vector registers
-            // with v_readlane / v_writelane: a lone wave issues an instruction every ~8 cycles whatever it is.)
+        {
+            // Two-queue merge: leaves ascending, internal nodes in creation order; an internal node is taken only when strictly
+            // lighter than the next leaf (reference fpng.cpp:645-651).  The reference takes its 2 * (used - 1) picks one after the
+            // other; here the WAVE takes a run of picks at once wherever the choices of the run do not depend on what the run makes:
+            //   * leaves: while the queue of internal nodes does not move, its head H is fixed -- every leaf of the run with
+            //     !(H < key) is taken, two by two, lane l making node made + l (with the queue empty the first pair only: it
+            //     becomes the head the next picks are compared with);
+            //   * internal nodes that exist already: while no leaf is taken, the next leaf K is fixed -- every node of the run with
+            //     weight < K (all of them once the leaves are used up) is taken, two by two;
+            //   * anything else (a leaf and a node, a run of one): one step as the reference does it.
+            // Histograms of images begin with runs of symbols that occur a few times (the 8K `grad` frame: 262 symbols, 13 steps
+            // of the wave + 8 single ones instead of 261; a photograph: 85 + 102) -- tests/cpp/merge_model.cpp holds the two forms
+            // against each other (keys whose sums wrap at 16 bits included: every comparison is the reference's own).
             uint32_t leaf = 0, root = 0, made = 0;
-            uint32_t key_head = L.skey[0], key_next = (used > 1) ? L.skey[1] : 0u;
-            uint32_t iw_head = 0, iw_next = 0; // iw[root], iw[root + 1] (meaningful when the index is below `made`)
-            while (made < used - 1) {
-                uint32_t wsum = 0;
-                for (int k = 0; k < 2; k++) {
-                    if (leaf >= used || (root < made && iw_head < key_head)) {
-                        wsum += iw_head;
-                        L.iparent[root++] = (int)made;
-                        iw_head = iw_next;
-                        if (root + 1 < made) iw_next = L.iw[root + 1];
-                    } else {
-                        wsum += key_head;
-                        L.lparent[leaf++] = (int)made;
-                        key_head = key_next;
-                        if (leaf + 1 < used) key_next = L.skey[leaf + 1];
+            while (made + 1 < used) {
+                const bool q = root < made, have_leaf = leaf < used;
+                const uint32_t H = uniform(q ? L.iw[root] : 0u), K = uniform(have_leaf ? L.skey[leaf] : 0u);
+                uint32_t pairs = 0;
+                if (have_leaf && !(q && H < K)) {
+                    const uint32_t li = leaf + lane;
+                    const bool c = li < used && !(q && H < L.skey[li < used ? li : leaf]);
+                    const uint64_t stop = ~__ballot(c);
+                    uint32_t run = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                    if (!q && run > 2) run = 2;
+                    pairs = run >> 1;
+                    if (lane < pairs) {
+                        const uint32_t node = made + lane;
+                        L.iw[node] = (L.skey[leaf + 2 * lane] + L.skey[leaf + 2 * lane + 1]) & 0xFFFFu;
+                        L.lparent[leaf + 2 * lane] = (int)node;
+                        L.lparent[leaf + 2 * lane + 1] = (int)node;
                     }
+                    leaf += 2 * pairs;
+                } else {
+                    const uint32_t ri = root + lane;
+                    const bool c = ri < made && (!have_leaf || L.iw[ri < made ? ri : root] < K);
+                    const uint64_t stop = ~__ballot(c);
+                    const uint32_t run = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                    pairs = run >> 1;
+                    if (lane < pairs) {
+                        const uint32_t node = made + lane;
+                        L.iw[node] = (L.iw[root + 2 * lane] + L.iw[root + 2 * lane + 1]) & 0xFFFFu;
+                        L.iparent[root + 2 * lane] = (int)node;
+                        L.iparent[root + 2 * lane + 1] = (int)node;
+                    }
+                    root += 2 * pairs;
                 }
-                wsum &= 0xFFFFu;
-                L.iw[made] = wsum;
-                if (made == root) iw_head = wsum;          // the queue was empty: the new node is its head
-                else if (made == root + 1) iw_next = wsum; // ... or the head's successor
-                made++;
+                made += pairs;
+                if (!pairs) { // one step of the reference's loop (all lanes walk through it; lane 0 writes)
+                    uint32_t wsum = 0;
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t iw_head = uniform(root < made ? L.iw[root] : 0u), key_head = uniform(leaf < used ? L.skey[leaf] : 0u);
+                        if (leaf >= used || (root < made && iw_head < key_head)) {
+                            wsum += iw_head;
+                            if (lane == 0) L.iparent[root] = (int)made;
+                            root++;
+                        } else {
+                            wsum += key_head;
+                            if (lane == 0) L.lparent[leaf] = (int)made;
+                            leaf++;
+                        }
+                    }
+                    if (lane == 0) L.iw[made] = wsum & 0xFFFFu;
+                    made++;
+                }
+                wave_lds_fence();
             }
         }
         wave_lds_fence();
@@ -2418,15 +2452,32 @@ __device__ __forceinline__ void dev_build_table(BuilderLds &L, uint32_t n, uint3
             if (lane == max_len) nc += (int)over;
             if (lane > max_len) nc = 0;
             uint32_t total = wave_sum((lane >= 1 && lane <= max_len) ? ((uint32_t)nc << (max_len - lane)) : 0u);
+            // The reference's loop moves one code per iteration, depth-first: a code taken from level l (the largest level below max_len
+            // that has codes) is split down to max_len -- 2^(max_len - l) - 1 iterations, after which the levels between are empty again
+            // and level max_len has gained one code -- before the next code of level l is touched.  As many whole walks as the sum is
+            // still too large by are applied in one go; what is left over takes single iterations, at most one per level (`grad`: 13
+            // passes through this loop instead of 256).  tests/cpp/merge_model.cpp holds this form against the reference's.
             while (total != (1u << max_len)) {
                 const uint64_t have = __ballot(nc != 0 && lane >= 1 && lane < max_len);
-                if (lane == max_len) nc--;
+                const uint32_t excess = total - (1u << max_len);
                 if (have) {
                     const uint32_t l = 63u - (uint32_t)__builtin_clzll(have);
-                    if (lane == l) nc--;
-                    if (lane == l + 1) nc += 2;
+                    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane(nc, (int)l), cost = (1u << (max_len - l)) - 1u;
+                    const uint32_t afford = excess / cost, k = cnt < afford ? cnt : afford;
+                    if (k) {
+                        if (lane == l) nc -= (int)k;
+                        if (lane == max_len) nc += (int)k;
+                        total -= k * cost;
+                    } else {
+                        if (lane == max_len) nc--;
+                        if (lane == l) nc--;
+                        if (lane == l + 1) nc += 2;
+                        total--;
+                    }
+                } else {
+                    if (lane == max_len) nc--;
+                    total--;
                 }
-                total--;
             }
             if (lane < 40) L.num_codes[lane] = nc;
         }

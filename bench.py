@@ -674,7 +674,8 @@ def main():
     line = {
         "metric": f"encode megapixels/sec ({scope_name(world)}), {PASS_NAME.get(args.flags, 'flags=%d' % args.flags)}, device-resident",
         "value": round(value, 1), "unit": "MP/s", "value_MiPs": round(value * 1e6 / 2 ** 20, 1), "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "prewarm": args.prewarm, "parity_checked": bool(parity_checked) if parity_checked is not None else None,
+        "warmup": args.warmup, "prewarm": args.prewarm, "prewarm_bursts": 1 if (args.prewarm + args.warmup) else 0,  # (+ one untimed burst of `steps` submissions shaped like a timed region)
+        "parity_checked": bool(parity_checked) if parity_checked is not None else None,
         "parity_images": parity_checked, "runs": run_values,
         "spread": round((max(run_values) - min(run_values)) / value, 4) if len(run_values) > 1 else None,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": "weak",

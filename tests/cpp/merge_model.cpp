@@ -122,7 +122,9 @@ int main(int argc, char **argv)
         if (k.size() >= 2) {
             g_kraft_serial_it = g_kraft_batched_it = 0;
             const std::vector<int> nc = depth_counts(a, (uint32_t)k.size());
-            if (!kraft_both(nc, k.size() <= 19 ? 7 : 12)) { printf("KRAFT MISMATCH %s n=%zu\n", what, k.size()); exit(1); }
+            // (the kernel builds the 19-symbol table with max_len 7 and the 288-symbol one with 12; both limits on every tree with enough leaves)
+            if (k.size() <= 128 && !kraft_both(nc, 7)) { printf("KRAFT MISMATCH (7) %s n=%zu\n", what, k.size()); exit(1); }
+            if (!kraft_both(nc, 12)) { printf("KRAFT MISMATCH (12) %s n=%zu\n", what, k.size()); exit(1); }
             if (report) printf("   length limiter: %ld iterations serial, %ld with whole depth-first walks in one go\n", g_kraft_serial_it, g_kraft_batched_it);
         }
         trials++;
@@ -140,6 +142,24 @@ int main(int argc, char **argv)
     for (int a = 2; a < argc; a++) {
         FILE *f = fopen(argv[a], "r"); std::vector<uint32_t> k; unsigned v; while (f && fscanf(f, "%u", &v) == 1) k.push_back(v); if (f) fclose(f);
         check(k, argv[a], true);
+    }
+    // exhaustive: every multiset of up to 9 keys from a small set (ties everywhere, sums that wrap at 16 bits)
+    {
+        const uint32_t vals[] = {1, 2, 3, 5, 30000, 40000, 65535};
+        const int nv = sizeof vals / sizeof vals[0];
+        for (int n = 2; n <= 9; n++) {
+            std::vector<int> idx(n, 0);
+            for (;;) {
+                std::vector<uint32_t> k(n);
+                for (int i = 0; i < n; i++) k[i] = vals[idx[i]];
+                check(k, "exhaustive", false);
+                int p = n - 1; // next non-decreasing index vector
+                while (p >= 0 && idx[p] == nv - 1) p--;
+                if (p < 0) break;
+                const int v = idx[p] + 1;
+                for (int i = p; i < n; i++) idx[i] = v;
+            }
+        }
     }
     // random: sizes, value ranges (incl. keys whose sums wrap at 16 bits)
     for (int t = 0; t < 150000; t++) {

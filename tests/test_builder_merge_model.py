@@ -1,7 +1,8 @@
 """CPU check of the Huffman builder's two-queue merge as build_dynamic_kernel runs it since round 5 (fpng_amd/csrc/kernels.hip,
 dev_build_table): the reference takes its picks one after the other (src/fpng.cpp:645-651); the kernel's wave takes runs of picks at
-once.  tests/cpp/merge_model.cpp holds both forms and compares parents and weights on shapes of real histograms and on 150 000 random
-key sets (sums that wrap at 16 bits included); the kernel itself is held against the reference's files by the 2-pass GPU parity tests."""
+once, and the length limiter behind it (:663-674) whole depth-first walks in one go.  tests/cpp/merge_model.cpp holds both forms of both
+loops and compares parents, weights and the limited length counts (limits 7 and 12) on shapes of real histograms, on every multiset of
+up to nine keys from a small set and on 150 000 random key sets (sums that wrap at 16 bits included); the kernel itself is held against the reference's files by the 2-pass GPU parity tests."""
 import os
 import subprocess
 

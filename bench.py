@@ -65,7 +65,58 @@ def parse():
     ap.add_argument("--end-to-end-only", default=None, choices=["cabi", "dropin"], help="(internal) print that part of the end_to_end object for --workload WxHxC and exit")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch check without a GPU: the ranks --gpus N asks for are started (gloo), meet at the barriers of a timed region "
+                         "that holds no kernels, and rank 0 prints the one JSON line with n_gpus = the ranks that actually ran (tests/test_bench_launch.py)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become N ranks (one per GPU) under torch.distributed.run, the
+    command line unchanged.  The parent makes no HIP call and prints nothing of its own: the one JSON line is rank 0's."""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); a run over fewer GPUs than asked for would not be the run asked for")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def dry_launch(args, rank, world):
+    """The launch path of a scaling run with everything GPU-side left out: rendezvous (gloo), the barriers of one timed region, the
+    max over ranks, one line from rank 0.  What it shows: `--gpus N` really is N processes, and `n_gpus` counts processes, not flags."""
+    import torch.distributed as dist
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass  # (a step of the real run: enc.submit(...))
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.ones(1, dtype=torch.int64)
+    if dist.is_initialized():
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        _RESULT.append(json.dumps({"metric": "launch check only (--dry-launch): no kernels ran", "value": None, "unit": "MP/s", "n_gpus": int(ranks.item()),
+                                   "gpus_asked_for": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry_launch": True,
+                                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                                   "config": {"workload": "none", "mode": args.mode, "backend": "gloo" if dist.is_initialized() else "none"}}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def workload_tag(args):
@@ -414,13 +465,18 @@ def decode_bench(args, enc, imgs, pngs, w, h, c, rank, world, barrier, all_max, 
 def nodeimage(args, w, h, c):
     """--mode nodeimage: ONE host-resident image through fpng_amd_node_encode_host_image (row bands dealt to the node's devices, every
     device moving its band up and its window down over its own link).  PCIe inclusive -- a host path, never the headline `value`
-    of the default mode.  One process drives all devices; on a one-GPU box the same device is listed --pipelines times."""
+    of the default mode.  ONE process drives the first --gpus devices (n_gpus = that count; fewer visible devices is an error); --pipelines
+    bands are dealt to them in turn (default: one per device, eight through the one link of a one-GPU run).
+    This is BASELINE config 4's scaling line: the file must end up in ONE memory, and a host-resident image reaches N GPUs over N PCIe
+    links (model: 28 ms on one link -> 3.9 ms on eight), whereas --mode rowband (rows already in the GPUs' memories,
+    windows gathered over xGMI into rank 0's) is by the same model SLOWER on eight GPUs than on one (1.3 vs 0.50 ms)."""
     import hashlib
     import fpng_amd
     ngpu = torch.cuda.device_count()
-    devices = list(range(ngpu)) if ngpu > 1 and not args.pipelines else [0] * max(1, args.pipelines or 8)
-    if ngpu > 1 and args.pipelines:
-        devices = [i % ngpu for i in range(args.pipelines)]
+    if ngpu < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {ngpu} GPU(s)")
+    n_pipes = max(1, args.pipelines or (args.gpus if args.gpus > 1 else 8))
+    devices = [i % args.gpus for i in range(n_pipes)]
     img = fpng_amd.synth_image(args.kind, w, h, c, seed=777 if args.workload == "16k" else 12345)
     node = fpng_amd.Node(devices)
     out = np.empty(fpng_amd.max_encoded_size(w, h, c), dtype=np.uint8)  # (reused from call to call, like the harness's vector)
@@ -452,7 +508,9 @@ def nodeimage(args, w, h, c):
         "data": "synthetic", "parity_checked": parity,
         "config": {"workload": f"ONE {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' image in host memory -> one fpng file in host memory, flags={args.flags}",
                    "devices": devices, "png_bytes": len(png), "host_bytes_moved": bytes_moved,
-                   "parallelism": "row bands, one per listed device; band up / window down over the device's own PCIe link; 64-byte records meet on the host"},
+                   "parallelism": "row bands, one per listed device; band up / window down over the device's own PCIe link; 64-byte records meet on the host",
+                   "baseline_config": "4 (one 16384x16384 image over the node): the line to scale with --gpus; --mode rowband gathers the windows over xGMI "
+                                      "into one GPU's memory and is slower on 8 GPUs than on 1 by its own cost model (DESIGN.md section 5)"},
         "roofline": {"bound": "pcie", "note": "host path: bytes over the links / time", "achieved": round(bytes_moved / med / 1e9, 1), "unit": "GB/s",
                      "peak": None, "frac": None, "traffic": None}}))
 
@@ -523,7 +581,9 @@ def rowband(args, rank, local_rank, world, distributed, dev, w, h, c):
                                    f"flags={args.flags}, windows gathered to rank 0, bit-exact fpng PNG output", "width": w, "height": h,
                        "channels": c, "png_bytes": png_bytes, "parallelism": f"rows sharded over {world} GPU(s) behind the C ABI "
                        "(fpng_amd_encode_image_sharded, RCCL transport): all_gather of a 64-byte and a 16-byte record per rank "
-                       "(+ all_reduce of 288 counters for 2-pass), windows sent to rank 0"},
+                       "(+ all_reduce of 288 counters for 2-pass), windows sent to rank 0",
+                       "expectation": "for rows that already live on several GPUs; by the cost model (DESIGN.md section 5) 8 ranks take ~1.3 ms where one GPU takes 0.50 ms, "
+                                      "because 7 windows of 58.6 MB converge on rank 0 over one xGMI link each: BASELINE config 4's scaling line is --mode nodeimage"},
             "roofline": {"bound": "hbm", "kernel": "whole step (band encode + exchange + place + gather + wrap)",
                          "achieved": round(alg / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(alg / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
@@ -545,10 +605,18 @@ def main():
         return
     if args.workload not in WORKLOADS and not re.fullmatch(r"\d+x\d+x[34]", args.workload):
         raise SystemExit(f"--workload: one of {sorted(WORKLOADS)}, or WxHxC")
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also exercised with one rank)
+    if args.gpus < 1:
+        raise SystemExit("--gpus: at least 1")
+    if args.gpus > 1 and not distributed and args.mode != "nodeimage":  # (nodeimage: ONE process drives --gpus devices)
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also exercised with one rank)
+    if distributed and world != args.gpus and args.mode != "nodeimage":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): n_gpus would not be what the command says")
+    if args.dry_launch:
+        return dry_launch(args, rank, world)
     import fpng_amd  # (before the first HIP call of the process: loading the library sets the runtime's hardware queues, csrc/api.cpp runtime_defaults())
     torch.cuda.set_device(local_rank)
     if distributed:
@@ -576,6 +644,7 @@ def main():
     out_sets = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(n_sets)]
     outs = out_sets[0]
     enc = fpng_amd.Encoder(device=local_rank, stream="own")
+    rt = fpng_amd.runtime_info()
 
     batches = [enc.make_batch(imgs, o) for o in out_sets]  # descriptor arrays built once, like a capture pipeline would
 
@@ -663,7 +732,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": phase_ms[dom],
                 "all_kernels_ms": round(kernels_s * 1e3, 4),
-                "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": phase_ms}
+                "pipeline_frac": round(alg_bytes / kernels_s / 1e9 / HBM_PEAK_GBS, 4),
+                "step_frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),  # the timed, pipelined step against the same peak
+                "phase_ms": phase_ms}
     # what the whole chain moves per step (all kernels, PMC) and the rate it moves it at in the timed, pipelined regions: the
     # number to hold against what plain streaming kernels reach on the same read/write mix (profiles/r03_mix_probe.txt: 5.1 TB/s)
     chain = committed_chain_traffic(workload_tag(args))
@@ -683,7 +754,10 @@ def main():
         "config": {"workload": f"{B} x {w}x{h} {'RGBA' if c == 4 else 'RGB'} '{args.kind}' frames per GPU per step, "
                                f"flags={args.flags}, bit-exact fpng PNG output", "batch_per_gpu": B,
                    "width": w, "height": h, "channels": c, "png_bytes_per_step_per_gpu": png_bytes,
-                   "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+                   "parallelism": f"images sharded over {world} GPU(s), no data-path collective",
+                   # how the submissions' chains share the GPU (fpng_amd_runtime_info(): the library asks the HIP runtime for eight hardware
+                   # queues when it is loaded before the process's first HIP call; a process that comes too late runs two lanes over four)
+                   "lanes": enc.lanes, "hw_queues": rt["hw_queues"], "hw_queue_source": rt["hw_queue_source"]},
         "roofline": roofline,
     }
     # ---- the way back: the files of the last submission, still in device memory, decoded to pixels in device memory ----

@@ -68,6 +68,13 @@ class Transport(C.Structure):
 
 # every symbol include/fpng_amd.h declares: (restype, argtypes)
 _u32, _u64, _sz, _vp, _int = C.c_uint32, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int
+
+
+class RuntimeInfo(C.Structure):
+    """fpng_amd_runtime (include/fpng_amd.h)"""
+    _fields_ = [("hw_queues", _u32), ("hw_queue_source", _u32), ("lanes", _u32), ("reserved", _u32 * 5)]
+
+
 SIGNATURES = {
     "fpng_amd_init": (_int, [_int]),
     "fpng_amd_device_available": (_int, []),
@@ -131,6 +138,8 @@ SIGNATURES = {
     "fpng_amd_encoder_set_profiling": (_int, [_vp, _int]),
     "fpng_amd_encoder_last_phase_ms": (_int, [_vp, C.POINTER(C.c_float * NUM_PHASES)]),
     "fpng_amd_debug_peek": (_int, [_vp, _int, C.POINTER(_u32), _u32]),
+    "fpng_amd_runtime_info": (_int, [C.POINTER(RuntimeInfo)]),
+    "fpng_amd_encoder_lanes": (_u32, [_vp]),
     "fpng_amd_calibration_stream": (_int, [_vp, _int, _u32, _vp, _sz]),
     "fpng_amd_release_cached_memory": (_int, []),
 }

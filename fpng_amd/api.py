@@ -72,6 +72,17 @@ def layout_1pass(num_chans):
     return a.value, b.value, c.value
 
 
+HW_QUEUE_SOURCES = ("library_set", "caller_set", "driver_open", "hands_off")  # FPNG_AMD_HWQ_* (include/fpng_amd.h)
+
+
+def runtime_info():
+    """fpng_amd_runtime_info(): {"hw_queues", "hw_queue_source", "lanes"} -- the hardware queues the library believes the HIP runtime
+    uses, why (it asks for eight when it is loaded before the process's first HIP call), and the lanes a new encoder would get."""
+    info = _lib.RuntimeInfo()
+    check(_lib.load().fpng_amd_runtime_info(C.byref(info)))
+    return {"hw_queues": int(info.hw_queues), "hw_queue_source": HW_QUEUE_SOURCES[info.hw_queue_source], "lanes": int(info.lanes)}
+
+
 def release_cached_memory():
     """Free the device buffers that destroyed encoders left with the library (fpng_amd_release_cached_memory)."""
     check(_lib.load().fpng_amd_release_cached_memory())
@@ -220,6 +231,11 @@ class Encoder:
             check(self.lib.fpng_amd_encoder_create_on_stream(C.byref(h), device, C.c_void_p(int(stream))))
         self.h = h
         self._keep = {}  # ticket -> buffers of that submission (at most 8 are in flight: the C side's slot ring)
+
+    @property
+    def lanes(self):
+        """Lanes (stream + scratch set each) this encoder's submissions take turns over: fixed when it was created."""
+        return int(self.lib.fpng_amd_encoder_lanes(self.h))
 
     def _sync_stream(self):
         if self._follow_torch:

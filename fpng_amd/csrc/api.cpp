@@ -29,6 +29,7 @@ thread_local std::string g_last_error;
 // when it initialises (the first HIP call of the process): the library asks for eight when it is loaded, unless the variable is set
 // already, FPNG_AMD_KEEP_HW_QUEUES=1 says hands off, or the process has the GPU driver open already (too late: two lanes then).
 int g_hw_queues = 4;
+int g_hw_queue_source = FPNG_AMD_HWQ_DRIVER_OPEN; // fpng_amd_runtime_info(): why g_hw_queues is what it is
 
 bool gpu_driver_open()
 {
@@ -55,10 +56,16 @@ __attribute__((constructor)) void runtime_defaults()
 {
     const char *keep = getenv("FPNG_AMD_KEEP_HW_QUEUES");
     if (const char *cur = getenv("GPU_MAX_HW_QUEUES")) {
-        g_hw_queues = atoi(cur);
-    } else if (!(keep && keep[0] == '1') && !gpu_driver_open()) {
+        g_hw_queues = std::max(1, atoi(cur));
+        g_hw_queue_source = FPNG_AMD_HWQ_CALLER_SET;
+    } else if (keep && keep[0] == '1') {
+        g_hw_queue_source = FPNG_AMD_HWQ_HANDS_OFF;
+    } else if (gpu_driver_open()) {
+        g_hw_queue_source = FPNG_AMD_HWQ_DRIVER_OPEN; // the runtime has read its settings: its default of four stands
+    } else {
         setenv("GPU_MAX_HW_QUEUES", "8", 0);
         g_hw_queues = 8;
+        g_hw_queue_source = FPNG_AMD_HWQ_LIBRARY_SET;
     }
 }
 }
@@ -283,6 +290,18 @@ static uint32_t default_lanes()
     return (uint32_t)std::min(std::max(n, 1), fpng_amd_encoder::kLanes);
 }
 
+int fpng_amd_runtime_info(fpng_amd_runtime *info)
+{
+    if (!info) return fail(FPNG_AMD_ERR_INVALID_ARG, "null runtime info");
+    std::memset(info, 0, sizeof *info);
+    info->hw_queues = (uint32_t)g_hw_queues;
+    info->hw_queue_source = (uint32_t)g_hw_queue_source;
+    info->lanes = default_lanes();
+    return FPNG_AMD_OK;
+}
+
+uint32_t fpng_amd_encoder_lanes(const fpng_amd_encoder *e) { return e ? e->n_lanes : 0u; }
+
 static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, bool use_given_stream)
 {
     if (!out) return fail(FPNG_AMD_ERR_INVALID_ARG, "null encoder pointer");
@@ -304,7 +323,8 @@ static int encoder_create(fpng_amd_encoder **out, int device, void *hip_stream, 
         }
         e->own_stream = true;
     }
-    const uint32_t n_streams = std::max(default_lanes(), 2u); // (the decoder uses the first two)
+    e->n_lanes = default_lanes(); // fixed for the encoder's life: submit() takes turns over exactly the streams made here
+    const uint32_t n_streams = std::max(e->n_lanes, 2u); // (the decoder uses the first two)
     for (uint32_t l = 0; l < n_streams; l++) {
         hipError_t err = hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking);
         if (err != hipSuccess) {
@@ -577,7 +597,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
         HIP_TRY(hipEventSynchronize(slot.done));
         slot.in_flight = false;
     }
-    static const uint32_t n_lanes = default_lanes();
+    const uint32_t n_lanes = e->n_lanes;
     // lane = internal stream + scratch set; whole chains alternate between FPNG_AMD_LANES (default: four over eight hardware queues, else two) of them, so that the
     // latency-bound tail of one submission (scan, stored fallback, finalize) and its memory-bound assemble run next to the
     // row walk of the next one.  Per-kernel profiling stays on lane 0, which serialises it.
@@ -1353,10 +1373,6 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
         uint64_t deferred = 0, spilled = 0;
         for (const JobState &q : st) deferred += q.reserved[0], spilled += q.reserved[1];
         dst[0] = (uint32_t)deferred, dst[1] = (uint32_t)spilled, dst[2] = n, dst[3] = e->sc[lane].last_chunks;
-        return FPNG_AMD_OK;
-    }
-    if (n_words == 2) { // what the library assumes about the runtime's hardware queues, and the lanes that take submissions
-        dst[0] = (uint32_t)g_hw_queues, dst[1] = default_lanes();
         return FPNG_AMD_OK;
     }
     if (n_words == 8) { // the timing build's cycle counts of build_dynamic_kernel (head of the histogram scratch)

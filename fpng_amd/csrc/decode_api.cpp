@@ -377,8 +377,10 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             luts_cached = hit;
         }
         if (!luts_cached) { // (re)fill: this batch's tables become the cache
+            // The cache holds NOTHING until launch_dec_build_luts has been enqueued (further down): every error return between here
+            // and there leaves it empty instead of naming tables that were never built.
+            e->lut_cache_n = 0;
             for (uint32_t q = 0; q < n_luts; q++) std::memcpy(e->lut_cache_keys[q], lut_keys.data() + (size_t)q * 288, 288), lut_slot[q] = q;
-            e->lut_cache_n = n_luts;
             d_luts = e->d_lut_cache.p; // (built below, in place)
         }
     }
@@ -472,6 +474,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     if (!lut_keys.empty() && !luts_cached) {
         HIP_TRY(hipMemcpyAsync(d_keys, lut_keys.data(), lut_keys.size(), hipMemcpyHostToDevice, s));
         launch_dec_build_luts(s, d_keys, (uint32_t)(lut_keys.size() / 288), d_luts);
+        if (few_luts) e->lut_cache_n = n_luts; // (the build is in the stream, in front of everything that will read the tables: now the cache names them)
     }
     // (four small uploads -- job records, plan pieces, plan words, cleared status words -- were four blit kernels with their dispatch
     //  gaps in front of the first decode kernel, ~7 us each: they go up as one block from pinned memory)

@@ -144,7 +144,8 @@ struct fpng_amd_encoder {
             d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release(), d_look.release();
         }
     };
-    static constexpr int kLanes = 8; // streams created; FPNG_AMD_LANES of them take submissions (default: api.cpp, default_lanes())
+    static constexpr int kLanes = 8; // most lanes an encoder can have; n_lanes of them exist and take submissions in turn
+    uint32_t n_lanes = 2;            // FPNG_AMD_LANES, or by the hardware queues the process got (api.cpp, default_lanes()), read when the encoder is made
     Scratch sc[kLanes];
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t prev_walked = nullptr; // `walked` event of the previous submission (owned by its slot)

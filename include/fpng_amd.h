@@ -67,6 +67,33 @@ int fpng_amd_device_count(void);
 const char *fpng_amd_last_error(void);
 int fpng_amd_abi_version(void);
 
+/* What the library got from the HIP runtime, and what it does with it.  SIDE EFFECT OF LOADING THIS LIBRARY: its constructor sets
+ * GPU_MAX_HW_QUEUES=8 in the process environment (the runtime spreads a process's streams over that many hardware queues, four by
+ * default; with four the encoder's chains share queues and run one behind the other) -- unless the variable is set already,
+ * FPNG_AMD_KEEP_HW_QUEUES=1 says hands off, or the process has /dev/kfd open (the runtime has read its settings: too late).  The
+ * setting counts only before the process's first HIP call, is inherited by child processes and applies to every HIP user of the
+ * process.  hw_queues = what the library believes the runtime uses (no HIP call reports it); source says why:
+ *   LIBRARY_SET  the constructor set 8 (loaded before the first HIP call) -> four lanes
+ *   CALLER_SET   the variable was there: its value is taken
+ *   DRIVER_OPEN  loaded after the process's first HIP call (e.g. after `import torch; torch.cuda.init()`): four queues, two lanes --
+ *                every batch result is the same, 8 x 8K encode throughput reads 3-5 % lower, one-frame submissions 25 % lower
+ *   HANDS_OFF    FPNG_AMD_KEEP_HW_QUEUES=1
+ * lanes = the lanes an encoder created NOW would have (FPNG_AMD_LANES overrides: 1..8); an encoder keeps the count it was made with. */
+#define FPNG_AMD_HWQ_LIBRARY_SET 0
+#define FPNG_AMD_HWQ_CALLER_SET 1
+#define FPNG_AMD_HWQ_DRIVER_OPEN 2
+#define FPNG_AMD_HWQ_HANDS_OFF 3
+typedef struct fpng_amd_encoder fpng_amd_encoder;
+typedef struct fpng_amd_runtime {
+    uint32_t hw_queues;
+    uint32_t hw_queue_source; /* FPNG_AMD_HWQ_* */
+    uint32_t lanes;
+    uint32_t reserved[5];
+} fpng_amd_runtime;
+int fpng_amd_runtime_info(fpng_amd_runtime *info);
+/* ... and the lanes of a live encoder */
+uint32_t fpng_amd_encoder_lanes(const fpng_amd_encoder *enc);
+
 /* fpng_crc32 / fpng_adler32 (reference src/fpng.h:26-31), host buffers, same calling convention
  * (prev = finished checksum of the preceding bytes; init 0 / 1). */
 uint32_t fpng_amd_crc32(const void *data, size_t size, uint32_t prev_crc32);

@@ -2,8 +2,7 @@
 seven submissions in flight at once (1- and 2-pass alternating, three frames each, every submission its own output buffers) --
 so every lane the library uses has a chain running next to the others' -- then every file against the checker's.
     python tests/lanes_check.py early|late      (late: the process has made HIP calls before the library is loaded)
-prints "OK <hardware queues the library assumes> <lanes>"."""
-import ctypes as C
+prints "OK <hardware queues the library assumes> <lanes> <why: fpng_amd_runtime_info()'s source>"."""
 import os
 import sys
 
@@ -17,8 +16,8 @@ import fpng_amd
 from cpu_ref import oracle
 
 enc = fpng_amd.Encoder(device=0)
-info = (C.c_uint32 * 2)()
-assert enc.lib.fpng_amd_debug_peek(enc.h, 0, info, 2) == 0
+info = fpng_amd.runtime_info()
+assert enc.lanes == info["lanes"]
 specs = [("grad", 1920, 1080, 4), ("blocks", 1280, 720, 3), ("noise", 640, 480, 4)]
 imgs = [fpng_amd.synth_image(k, w, h, c, seed=900 + i) for i, (k, w, h, c) in enumerate(specs)]
 dev = [torch.from_numpy(im).cuda() for im in imgs]
@@ -33,4 +32,4 @@ for ticket, outs, fl in subs:
         assert status == 0
         assert bytes(out[:size].cpu().numpy()) == exp, f"submission {ticket} flags {fl}: file differs from the checker's"
 enc.close()
-print("OK", info[0], info[1], flush=True)
+print("OK", info["hw_queues"], info["lanes"], info["hw_queue_source"], flush=True)

@@ -857,11 +857,12 @@ def test_direct_placement_from_many_encoders_at_once(built_lib):
         _assert_same(png, oracle().encode(im, w, h, c, fl), f"direct placement, thread frame {k} {w}x{h}x{c} flags {fl}")
 
 
-@pytest.mark.parametrize("case,env,expect", [("early", {}, "OK 8 4"), ("early", {"FPNG_AMD_KEEP_HW_QUEUES": "1"}, "OK 4 2"),
-                                             ("late", {}, "OK 4 2"), ("early", {"GPU_MAX_HW_QUEUES": "16", "FPNG_AMD_LANES": "8"}, "OK 16 8")])
+@pytest.mark.parametrize("case,env,expect", [("early", {}, "OK 8 4 library_set"), ("early", {"FPNG_AMD_KEEP_HW_QUEUES": "1"}, "OK 4 2 hands_off"),
+                                             ("late", {}, "OK 4 2 driver_open"), ("early", {"GPU_MAX_HW_QUEUES": "16", "FPNG_AMD_LANES": "8"}, "OK 16 8 caller_set")])
 def test_lanes_follow_the_hardware_queues(built_lib, case, env, expect):
-    """csrc/api.cpp runtime_defaults() / default_lanes(): a process that loads the library before its first HIP call gets eight
-    hardware queues and four lanes, one that comes too late (or says hands off) keeps the runtime's four queues and two lanes;
+    """csrc/api.cpp runtime_defaults() / default_lanes(), reported by fpng_amd_runtime_info(): a process that loads the library before
+    its first HIP call gets eight hardware queues and four lanes, one that comes too late (a HIP call first: "driver_open") or says
+    hands off keeps the runtime's four queues and two lanes;
     in every case seven submissions in flight at once give the checker's files (tests/lanes_check.py)."""
     import subprocess
     import sys

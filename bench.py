@@ -149,7 +149,7 @@ def committed_traffic(kernel, tag):
     for path in _pmc_summaries(tag):
         for line in open(path):
             f = line.split()
-            if len(f) == 5 and f[0] == kernel:
+            if len(f) in (5, 7) and f[0] == kernel:  # (round 6 on: + launches per step, megabytes per step; the first five columns are ONE launch's)
                 import hashlib
                 # (the file's content hash goes along: a summary from another tree cannot pass for this one's unnoticed)
                 return int((float(f[2]) + float(f[4])) * 1e6), os.path.relpath(path, ROOT) + "#sha256=" + hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]

@@ -140,7 +140,6 @@ SIGNATURES = {
     "fpng_amd_debug_peek": (_int, [_vp, _int, C.POINTER(_u32), _u32]),
     "fpng_amd_runtime_info": (_int, [C.POINTER(RuntimeInfo)]),
     "fpng_amd_encoder_lanes": (_u32, [_vp]),
-    "fpng_amd_calibration_stream": (_int, [_vp, _int, _u32, _vp, _sz]),
     "fpng_amd_release_cached_memory": (_int, []),
 }
 

@@ -554,10 +554,6 @@ class Encoder:
         return n.value
 
     # ---- instrumentation ----
-    def calibration_stream(self, buf, write, lane_bytes):
-        self._sync_stream()
-        check(self.lib.fpng_amd_calibration_stream(self.h, int(write), lane_bytes, buf.data_ptr(), buf.numel()))
-
     def set_profiling(self, on=True):
         check(self.lib.fpng_amd_encoder_set_profiling(self.h, int(on)))
 

@@ -96,23 +96,13 @@ def build(force=False, verbose=False):
 
 
 DROPIN_VARIANTS = {"nocrc"}
+# Build variants next to the product: the reference's own build switch, and the diagnostic builds a committed profile was made with
+# (the A/B variants of rounds 3-5 whose outcome is settled are gone from the sources; `git log -S<define>` finds them).
 VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's fuzzing switch (src/fpng.cpp:50-53): libfpng_amd_nocrc.so + libfpng_nocrc.so
-            "direct_defer": ["FPNG_DIRECT_SPIN_LIMIT=0"],  # every chunk that has to wait at all is deferred to scan_kernel (tests)
-            "abl_nolook": ["FPNG_DIRECT_ABL=1"], "abl_nostore": ["FPNG_DIRECT_ABL=2"], "abl_nobehind": ["FPNG_DIRECT_ABL=4"], "abl_all": ["FPNG_DIRECT_ABL=7"],  # timing only: wrong files
-            "direct_sleep4": ["FPNG_DIRECT_SLEEP=4"], "direct_sleep64": ["FPNG_DIRECT_SLEEP=64"],
-            "dec_noprefilter": ["FPNG_DEC_PREFILTER=0"],
-            "dec_pad27k": ["FPNG_DEC_PAD_LDS=27648"],  # decoder occupancy probe: two workgroups per compute unit instead of three
-            "direct_w8": ["FPNG_DIRECT_WPE=8"], "direct_w5_win1536": ["FPNG_DIRECT_WPE=5", "FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "direct_win1280": ["FPNG_STAGE_DWORDS=1280", "FPNG_ROWS_WPE=6"],
-            "rows_w7": ["FPNG_ROWS_WPE=7"],  # the 3-channel and the narrow 4-channel walk at seven waves per SIMD too
-            "rows4_w6": ["FPNG_ROWS_WPE4=6"],
-            "rows4_w5": ["FPNG_ROWS_WPE4=5"], "rows4_w7": ["FPNG_ROWS_WPE4=7"],
-            "rows4_w8": ["FPNG_ROWS_WPE4=8"],  # the 4-channel row kernel at eight waves per SIMD on wide rows too (the product: six there)
-            "win1536_w5": ["FPNG_STAGE_DWORDS=1536", "FPNG_ROWS_WPE=5"], "win2048_w4": ["FPNG_STAGE_DWORDS=2048", "FPNG_ROWS_WPE=4"], "win1024_w6": ["FPNG_ROWS_WPE=6"], "win1024_w4": ["FPNG_ROWS_WPE=4"],
-            "lead96": ["FPNG_DEC_LEADIN=96"], "lead64": ["FPNG_DEC_LEADIN=64"], "timing": ["FPNG_BUILD_TIMING"], "nont": ["FPNG_LOCAL_NT=0"], "rows8": ["FPNG_ROW_WAVES=8"], "rows2": ["FPNG_ROW_WAVES=2"],
-            "emit_nostore": ["FPNG_DEC_EMIT_NOSTORE"], "emit_nt": ["FPNG_DEC_EMIT_NT"], "unf16": ["FPNG_DEC_UNF_ROWS=16"], "unf64": ["FPNG_DEC_UNF_ROWS=64"], "unf32": ["FPNG_DEC_UNF_ROWS=32"], "unf_w4": ["FPNG_DEC_UNF_WAVES=4"], "unf_w5": ["FPNG_DEC_UNF_WAVES=5"], "unf64_w4": ["FPNG_DEC_UNF_ROWS=64", "FPNG_DEC_UNF_WAVES=4"], "unf64_w5": ["FPNG_DEC_UNF_ROWS=64", "FPNG_DEC_UNF_WAVES=5"], "emit_l2store": ["FPNG_DEC_EMIT_L2STORE"],
-            "dec_np": ["FPNG_DEC_PERSISTENT=0"], "dec_np6": ["FPNG_DEC_PERSISTENT=0", "FPNG_DEC_WGS=6"], "dec_npnv": ["FPNG_DEC_PERSISTENT=0", "FPNG_DEC_VOTE=0"],
-            "dec_p6": ["FPNG_DEC_WGS=6"], "dec_nv": ["FPNG_DEC_VOTE=0"],
-            "refix1": ["FPNG_DEC_REFIX_ROUNDS=1"], "refix2": ["FPNG_DEC_REFIX_ROUNDS=2"], "refix3": ["FPNG_DEC_REFIX_ROUNDS=3"], "refix5": ["FPNG_DEC_REFIX_ROUNDS=5"]}
+            "timing": ["FPNG_BUILD_TIMING"],  # cycle counters inside build_dynamic_kernel (tools/build_timing.py, profiles/r05_table_builder.txt)
+            "emit_nostore": ["FPNG_DEC_EMIT_NOSTORE"],  # dec_emit_kernel without its stores: what the stores cost (wrong pixels)
+            "dec_pad27k": ["FPNG_DEC_PAD_LDS=27648"],  # decoder occupancy probe: two workgroups per compute unit instead of three (profiles/r05_decode_occupancy.txt)
+            "rows4_w8": ["FPNG_ROWS_WPE4=8"]}  # the 4-channel row walk at eight waves per SIMD on wide rows too (profiles/r05_rows_w6.txt; the product: seven)
 
 if __name__ == "__main__":
     if "--variant" in sys.argv:

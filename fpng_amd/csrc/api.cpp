@@ -442,10 +442,6 @@ constexpr uint64_t kLocalFrontPad = 32; // dwords (one 128-byte line)
 
 struct Submission {
     uint32_t n = 0, max_rows = 0, max_crc_blocks = 0;
-    bool direct = false;       // direct placement (kernels.h: Job::piece_px): total_rows counts CHUNKS then
-    uint32_t total_blocks = 0; // ... workgroups of encode_direct_kernel
-    uint32_t blocks_per_job = 0; // ... of every job if they all have the same number, else 0
-    uint32_t total_groups = 0;   // ... groups of 64 chunks (look-back granules)
     uint64_t total_rows = 0;
     uint64_t local_dwords = kLocalFrontPad; // scratch for the rows' local streams (assemble_kernel may read up to four dwords in front of a stream)
     uint32_t chan_mask = 0;    // bit 0: 3-channel jobs present, bit 1: 4-channel jobs
@@ -490,18 +486,6 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     const bool two_pass = (flags & FPNG_AMD_ENCODE_SLOWER) && !force_stored;
     sub = Submission();
     sub.n = n;
-    // Direct placement (profiles/r05_encode_onchip_ab.txt): FPNG_AMD_DIRECT=1 replaces the two-kernel chain (row walk into
-    // local streams, assemble) by encode_direct_kernel -- rows cut into pieces of FPNG_AMD_PIECE_PX pixels (a multiple of 256) whose
-    // token bits fit a wave's LDS window, every chunk placed by the wave that encoded it.  Bit-exact and tested, and 2.3 x SLOWER on
-    // this hardware (a chunk's offset arrives through agent-scope memory: ~20 us per chunk against 2 us of work), so it is OFF
-    // unless asked for; the measurements and the ablations that bound what it could ever gain (+12 %) are in that file.
-    // (read at every call: tests and A/B runs switch them inside one process)
-    const char *de = getenv("FPNG_AMD_DIRECT"), *pe = getenv("FPNG_AMD_PIECE_PX");
-    const bool direct_env = de && de[0] == '1';
-    const uint32_t piece_env = pe ? (((uint32_t)atoi(pe) + 255u) & ~255u) : 0u;
-    sub.direct = direct_env && !force_stored;
-    const char *rl_env = getenv("FPNG_AMD_ASSEMBLE_RL");
-    const int force_rl = rl_env ? atoi(rl_env) : 0;
     for (uint32_t i = 0; i < n; i++) {
         const fpng_amd_image &im = images[i];
         if ((rc = check_dims(im.w, im.h, im.num_chans))) return rc;
@@ -528,13 +512,6 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.bit_bias = (int64_t)kPngHeaderBytes * 8;
         j.table = two_pass ? nullptr /* patched below */ : dt.one_pass[im.num_chans];
         j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + kCrcRangeBytes - 1) / kCrcRangeBytes) + 1;
-        if (force_rl) { // (A/B runs: the bytes of the file one assemble workgroup owns, as a power of two)
-            const int rl = force_rl;
-            if (rl >= 12 && rl <= 16) {
-                j.force_range_log2 = (uint32_t)rl;
-                j.crc_blocks = (uint32_t)((fpng_amd_max_encoded_size(im.w, im.h, im.num_chans) + (1u << rl) - 1) >> rl) + 1;
-            }
-        }
         make_png_header(j.png_header, im.w, im.h, im.num_chans);
         // a row's local stream: at most L bits per filtered byte, L = the longest literal code of the table in use
         // (12 for the per-image tables of 2-pass, reference fpng.cpp:1111; run tokens need less per byte they
@@ -545,24 +522,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
         j.local_base = sub.local_dwords;
         sub.chan_mask |= (im.num_chans == 3) ? 1u : 2u;
         if (im.num_chans == 4) sub.px4 += (uint64_t)im.w * im.h, sub.px4_wide += im.w >= kWideRowPixels ? (uint64_t)im.w * im.h : 0u;
-        uint64_t units = im.h; // records of the job: rows, or chunks
-        if (sub.direct) {
-            j.flags |= kJobDirect;
-            j.piece_px = piece_env ? piece_env : (im.num_chans == 4 ? kDirectPiecePx4 : kDirectPiecePx3);
-            j.n_pieces = (im.w + j.piece_px - 1) / j.piece_px;
-            units = (uint64_t)im.h * j.n_pieces;
-            if (units > 0xFFFFFFFFull || sub.total_blocks + (units + 3) / 4 > 0x7FFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many chunks in one batch");
-            j.n_chunks = (uint32_t)units;
-            j.block_base = sub.total_blocks;
-            j.group_base = sub.total_groups;
-            sub.total_groups += (uint32_t)((units + 63) / 64);
-            const uint32_t nb = (uint32_t)((units + 3) / 4);
-            sub.blocks_per_job = (i == 0 || sub.blocks_per_job == nb) ? nb : 0xFFFFFFFFu; // (0xFFFFFFFF: they differ)
-            sub.total_blocks += nb;
-            // a chunk's spill area: its pixels' worst case (+ the filter literal, the end-of-block symbol, slack for the 16-byte flush and the zeros behind the stream)
-            const uint64_t px = std::min<uint64_t>(j.piece_px, im.w);
-            j.local_stride = (uint32_t)((((px * im.num_chans + 1) * bits_per_byte + 64 + 31) / 32 + 12 + 31) & ~31ull);
-        }
+        const uint64_t units = im.h; // records of the job: one per row
         sub.local_dwords += (uint64_t)j.local_stride * units;
         if (sub.total_rows + units > 0xFFFFFFFFull) return fail(FPNG_AMD_ERR_UNSUPPORTED, "too many rows in one batch");
         sub.total_rows += units;
@@ -571,8 +531,7 @@ int prepare_jobs(fpng_amd_encoder *e, fpng_amd_encoder::Slot &slot, fpng_amd_enc
     }
     if ((rc = sc.d_jobs.ensure(n))) return rc;
     if ((rc = sc.d_rows.ensure(sub.total_rows))) return rc;
-    if ((rc = sc.d_row_off.ensure(sub.direct ? 16 : sub.total_rows))) return rc;
-    if (sub.direct && (rc = sc.d_look.ensure(((size_t)sub.total_rows + 15) / 16 * 16 + 16 * (size_t)sub.total_groups))) return rc;
+    if ((rc = sc.d_row_off.ensure(sub.total_rows))) return rc;
     if ((rc = sc.d_states.ensure(n))) return rc;
     if ((rc = sc.d_results.ensure(n))) return rc;
     if ((rc = sc.d_partials.ensure(3 * (size_t)n * sub.max_crc_blocks))) return rc; // CRC partials + two Adler words per range (stored images)
@@ -642,16 +601,12 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // everything the caller enqueued on the encoder's stream so far (e.g. the producer of the pixels)
     // (when that stream has nothing pending there is nothing to order against: no marker + barrier packet in front of the chain;
     // the same for the scratch set's previous user when it is done already)
-    static const bool always_order = [] {
-        const char *v = getenv("FPNG_AMD_ALWAYS_ORDER");
-        return v && v[0] == '1';
-    }();
-    if (always_order || hipStreamQuery(e->stream) != hipSuccess) {
+    if (hipStreamQuery(e->stream) != hipSuccess) {
         (void)hipGetLastError(); // ("not ready" is not an error)
         HIP_TRY(hipEventRecord(slot.in, e->stream));
         HIP_TRY(hipStreamWaitEvent(s, slot.in, 0));
     }
-    if (sc.last_done && (always_order || hipEventQuery(sc.last_done) != hipSuccess)) {
+    if (sc.last_done && hipEventQuery(sc.last_done) != hipSuccess) {
         (void)hipGetLastError();
         HIP_TRY(hipStreamWaitEvent(s, sc.last_done, 0)); // the scratch set's previous user
     }
@@ -659,18 +614,8 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // the slot's pinned host memory instead of uploading them -- the upload is a blit kernel + a dispatch gap, ~7 us -- costs
     // 7 us MORE per chain: every kernel's first touch of the record goes over PCIe.)
     // One image: its record travels in the arguments of the chain's first kernel, which leaves it in d_jobs for the others
-    // (encode_rows_first_kernel): no blit kernel + dispatch gap in front of the chain.  FPNG_AMD_JOB_IN_ARGS=0 uploads as always.
-    static const bool job_in_args_env = [] {
-        const char *v = getenv("FPNG_AMD_JOB_IN_ARGS");
-        return !v || v[0] != '0';
-    }();
-    const bool job_in_args = job_in_args_env && n == 1 && !force_stored && !sub.direct;
-    if (sub.direct) { // the look-back granules must be zero when the kernel starts (scan_kernel leaves them so)
-        if (sc.d_look.fresh) {
-            HIP_TRY(hipMemsetAsync(sc.d_look.p, 0, sc.d_look.cap * sizeof(unsigned long long), s));
-            sc.d_look.fresh = false;
-        }
-    }
+    // (encode_rows_first_kernel): no blit kernel + dispatch gap in front of the chain.
+    const bool job_in_args = n == 1 && !force_stored;
     const Job *d_jobs = sc.d_jobs.p;
     if (!job_in_args) HIP_TRY(hipMemcpyAsync(sc.d_jobs.p, slot.jobs.p, n * sizeof(Job), hipMemcpyHostToDevice, s));
     if ((rc = mark(e, s, 0))) return rc;
@@ -714,16 +659,13 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     // (both kernels get slower by more than the two small launches cost) and 5-19 % MORE single-frame latency.
     if (job_in_args)
         launch_encode_rows_first(s, two_pass ? slot.jobs2.p[0] : slot.jobs.p[0], sc.d_jobs.p, sc.d_rows.p, sc.d_states.p, sc.d_local.p);
-    else if (sub.direct)
-        launch_encode_direct(s, d_jobs, n, sub.total_blocks, sub.blocks_per_job == 0xFFFFFFFFu ? 0u : sub.blocks_per_job, sub.chan_mask, sc.d_rows.p, sc.d_states.p,
-                             sc.d_local.p, sc.d_look.p, sc.d_look.p + (sub.total_rows + 15) / 16 * 16);
     else if (!force_stored)
         launch_encode_rows(s, d_jobs, n, sub.max_rows, sub.chan_mask, sc.d_rows.p, sc.d_states.p, sc.d_local.p, 2 * sub.px4_wide >= sub.px4);
     if ((rc = mark(e, s, ++ph))) return rc;
     if (stagger) { // (only staggered walks wait for it)
         // ... and only a submission that follows while this one runs: with every other lane idle (one frame at a time) the marker
         // packet between the walk and the scan would only lengthen the chain
-        bool others_busy = always_order;
+        bool others_busy = false;
         for (uint32_t l = 0; l < n_lanes && !others_busy; l++)
             if ((int)l != lane && e->sc[l].last_done && hipEventQuery(e->sc[l].last_done) != hipSuccess) others_busy = true;
         (void)hipGetLastError();
@@ -733,7 +675,7 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
             e->prev_walked = slot.walked;
         }
     }
-    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p, sub.direct ? sc.d_look.p : nullptr, sub.direct ? sc.d_look.p + (sub.total_rows + 15) / 16 * 16 : nullptr, sub.direct ? sc.d_local.p : nullptr);
+    launch_scan(s, d_jobs, n, sc.d_rows.p, sc.d_row_off.p, sc.d_states.p);
     if ((rc = mark(e, s, ++ph))) return rc;
     uint32_t *adler_parts = sc.d_partials.p + (size_t)n * sub.max_crc_blocks;
     launch_assemble(s, d_jobs, n, sub.max_crc_blocks, sc.d_states.p, sc.d_row_off.p, sc.d_local.p, dt.crc, sc.d_partials.p, adler_parts);
@@ -745,7 +687,6 @@ int submit(fpng_amd_encoder *e, const fpng_amd_image *images, uint32_t n, uint32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(slot.done, s));
     sc.last_done = slot.done;
-    sc.last_n = n, sc.last_chunks = sub.direct ? (uint32_t)sub.total_rows : 0u;
     e->submitted++;
     slot.ticket = e->submitted;
     slot.n = n;
@@ -1366,15 +1307,6 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
     if (!e || lane < 0 || lane >= fpng_amd_encoder::kLanes || !dst) return fail(FPNG_AMD_ERR_INVALID_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (n_words == 4) { // direct placement, the lane's last submission: chunks deferred to scan_kernel, chunks that overflowed their window, jobs
-        const uint32_t n = e->sc[lane].last_n;
-        std::vector<JobState> st(n);
-        if (n) HIP_TRY(hipMemcpy(st.data(), e->sc[lane].d_states.p, n * sizeof(JobState), hipMemcpyDeviceToHost));
-        uint64_t deferred = 0, spilled = 0;
-        for (const JobState &q : st) deferred += q.reserved[0], spilled += q.reserved[1];
-        dst[0] = (uint32_t)deferred, dst[1] = (uint32_t)spilled, dst[2] = n, dst[3] = e->sc[lane].last_chunks;
-        return FPNG_AMD_OK;
-    }
     if (n_words == 8) { // the timing build's cycle counts of build_dynamic_kernel (head of the histogram scratch)
         if (!e->sc[lane].d_hist.p) return fail(FPNG_AMD_ERR_INVALID_ARG, "no 2-pass submission yet");
         const uint32_t page = (dst[7] == 0xFEEDu) ? 8u : 0u; // (second page: the table builder's inner phases)
@@ -1382,20 +1314,6 @@ int fpng_amd_debug_peek(fpng_amd_encoder *e, int lane, uint32_t *dst, uint32_t n
         return FPNG_AMD_OK;
     }
     return fail(FPNG_AMD_ERR_INVALID_ARG, "unknown debug page");
-}
-
-int fpng_amd_calibration_stream(fpng_amd_encoder *e, int write, uint32_t lane_bytes, void *d_buf, size_t bytes)
-{
-    if (!e || !d_buf || (lane_bytes != 4 && lane_bytes != 16) || ((uintptr_t)d_buf & 15))
-        return fail(FPNG_AMD_ERR_INVALID_ARG, "bad calibration arguments");
-    HIP_TRY(hipSetDevice(e->device));
-    int rc;
-    if ((rc = e->sc[0].d_hist.ensure(288))) return rc;
-    e->sc[0].hist_zero = 0;
-    launch_calibration(e->stream, write, lane_bytes, d_buf, bytes, e->sc[0].d_hist.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return FPNG_AMD_OK;
 }
 
 } // extern "C"

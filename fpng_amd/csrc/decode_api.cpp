@@ -361,11 +361,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     const uint32_t n_luts = (uint32_t)(lut_keys.size() / 288);
     bool luts_cached = false;
     std::vector<uint32_t> lut_slot(n_luts, 0);
-    static const bool lut_cache_on = [] {
-        const char *v = getenv("FPNG_AMD_DECODE_LUT_CACHE");
-        return !(v && v[0] == '0');
-    }();
-    const bool few_luts = lut_cache_on && n_luts && n_luts <= fpng_amd_encoder::kDecLutCache;
+    const bool few_luts = n_luts && n_luts <= fpng_amd_encoder::kDecLutCache;
     if (few_luts) {
         if ((rc = e->d_lut_cache.ensure((size_t)fpng_amd_encoder::kDecLutCache * dec::kLutDwords))) return rc;
         if (e->d_lut_cache.fresh) e->lut_cache_n = 0, e->d_lut_cache.fresh = false;
@@ -404,19 +400,12 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     std::vector<Group> groups;
     {
         // (file k goes to the group its middle byte falls into when the batch's bytes are cut into `want` equal parts)
-        // Files in device memory CAN be cut into groups as well (FPNG_AMD_DECODE_DEVICE_GROUPS=2..4; round 5): the groups' kernels
-        // alternate between two streams, so that one group's un-filter pass -- memory-bound -- could run under the next group's
-        // synchronisation and emit passes, which are bound by vector instruction issue.  Measured: no gain (8 x 8K 2.33 -> 2.39 /
-        // 2.45 / 2.46 ms with 2 / 3 / 4 groups, profiles/r05_decode_groups.txt: the persistent sync / emit workgroups hold the compute
-        // units' LDS and registers until their kernel ends, the other stream's kernels queue behind them), so the default is one group.
+        // Files in device memory are ONE group.  (Cutting them into 2..4 groups whose kernels alternate between two streams -- one
+        // group's un-filter pass, memory-bound, under the next group's synchronisation and emit passes -- was measured in round 5: no
+        // gain, 8 x 8K 2.33 -> 2.39 / 2.45 / 2.46 ms, profiles/r05_decode_groups.txt.)
         uint64_t total = 0, run = 0;
         for (uint32_t k = 0; k < nj; k++) total += jobs[k].z_bytes;
-        static const uint32_t dev_groups = [] {
-            const char *v = getenv("FPNG_AMD_DECODE_DEVICE_GROUPS");
-            return v ? (uint32_t)std::min(std::max(atoi(v), 1), (int)kMaxGroups) : 1u;
-        }();
-        const bool split_device = device_data && !e->profiling && nj > 1 && total >= (8u << 20) && e->lane_stream[0] && e->lane_stream[1];
-        const uint32_t want = (!device_data && z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : (split_device ? std::min<uint32_t>(dev_groups, nj) : 1u);
+        const uint32_t want = (!device_data && z_total >= (8u << 20) && nj > 1) ? std::min<uint32_t>(kMaxGroups, nj) : 1u;
         auto close = [&](uint32_t j0, uint32_t j1) {
             Group g = {j0, j1, jobs[j0].sub_base / kDecSubBlock, (j1 < nj ? jobs[j1].sub_base : sub_total) / kDecSubBlock, {}};
             groups.push_back(g);
@@ -451,7 +440,6 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
     } joiner;
     const bool uploads = !device_data && ng > 1; // groups of host-resident files: their bytes go up on a stream of their own
-    const bool split = device_data && ng > 1;    // groups of device-resident files: their kernels alternate between two streams
     if (uploads) {
         if (!e->dec_up) HIP_TRY(create_copy_stream(&e->dec_up));
         for (uint32_t g = 0; g < ng; g++)
@@ -520,18 +508,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         for (hipEvent_t &ev : e->dec_prof_ev)
             if (!ev) HIP_TRY(hipEventCreate(&ev));
     auto stamp = [&](const Group &g, int k) -> hipError_t { return (prof && &g == groups.data()) ? hipEventRecord(e->dec_prof_ev[k], s) : hipSuccess; };
-    hipStream_t gstream[2] = {s, split ? e->lane_stream[1] : s};
-    if (split) {
-        for (uint32_t g = 0; g < ng; g++) {
-            if (!e->dec_ev2[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev2[g], hipEventDisableTiming));
-            if (!e->dec_ev3[g]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev3[g], hipEventDisableTiming));
-        }
-        if (!e->dec_ev[15]) HIP_TRY(hipEventCreateWithFlags(&e->dec_ev[15], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(e->dec_ev[15], s)); // tables, job records, plans, cleared status words: every stream starts behind them
-        HIP_TRY(hipStreamWaitEvent(gstream[1], e->dec_ev[15], 0));
-    }
-    // gi: the group's number (>= ng: a later pass over it, after everything has been joined: no neighbours to order against)
-    auto finish_group = [&](const Group &g, hipStream_t s, uint32_t gi) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
+    auto finish_group = [&](const Group &g, hipStream_t s) -> hipError_t { // everything behind the synchronisation (every step of it is idempotent)
         const uint32_t nblk = g.blk1 - g.blk0;
         hipError_t pe = stamp(g, 1);
         if (pe != hipSuccess) return pe;
@@ -544,18 +521,15 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if ((pe = stamp(g, 3)) != hipSuccess) return pe;
         bool any_stored = false;
         for (uint32_t k = g.j0; k < g.j1; k++) any_stored |= jobs[k].mode != 0;
-        // (two un-filter kernels never run at once: each one's workgroups wait for lower-numbered ones of their own launch, and two
-        //  sets of waiting workgroups could keep each other's predecessors off the compute units)
-        if (split && gi && gi < ng && (pe = hipStreamWaitEvent(s, e->dec_ev2[gi - 1], 0)) != hipSuccess) return pe;
+        // (all groups run on one stream: two un-filter kernels never run at once -- each one's workgroups wait for lower-numbered ones
+        //  of their own launch, and two sets of waiting workgroups could keep each other's predecessors off the compute units)
         launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, next_epoch(e), any_stored);
-        if (split && gi < ng && (pe = hipEventRecord(e->dec_ev2[gi], s)) != hipSuccess) return pe;
         if ((pe = stamp(g, 4)) != hipSuccess) return pe;
         if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
     };
     for (uint32_t gi = 0; gi < ng; gi++) {
         const Group &g = groups[gi];
-        hipStream_t s = gstream[gi & 1]; // (shadows the call's stream inside the loop)
         if (ng == 1) {
             if (!device_data) HIP_TRY(upload_group(g, s));
         } else if (uploads) {
@@ -571,12 +545,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         // round 0 settles every workgroup in itself; the borders between workgroups get kBorderRounds rounds launched blind (a
         // workgroup whose border holds leaves at once), and the chain check of dec_offsets_kernel says whether that was enough
         for (uint32_t r = 0; nblk && r <= std::min(kBorderRounds, max_rounds - 1); r++) launch_dec_sync(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, r, d_sub, d_recs, d_changed + gi, d_multi + gi);
-        HIP_TRY(finish_group(g, s, gi));
-        if (split) HIP_TRY(hipEventRecord(e->dec_ev3[gi], s));
+        HIP_TRY(finish_group(g, s));
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u enqueued\n", since(), gi);
     }
-    if (split)
-        for (uint32_t gi = 1; gi < ng; gi += 2) HIP_TRY(hipStreamWaitEvent(s, e->dec_ev3[gi], 0)); // (the call's stream collects the other one's groups)
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> status(nj);
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, nj * 4, hipMemcpyDeviceToHost, s));
@@ -606,7 +577,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         if (trace_t) fprintf(stderr, "[decode] +%.0f us: group %u needed %u rounds\n", since(), gi, r + 1);
         HIP_TRY(hipMemsetAsync(d_status + g.j0, 0, (g.j1 - g.j0) * 4, s));
-        HIP_TRY(finish_group(g, s, ng));
+        HIP_TRY(finish_group(g, s));
     }
     if (again) {
         HIP_TRY(hipGetLastError());
@@ -614,7 +585,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (trace_t) fprintf(stderr, "[decode] +%.0f us: done\n", since());
-    static const bool trace = getenv("FPNG_AMD_TRACE_FILES") != nullptr;
+    static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)
             fprintf(stderr, "[decode] file %u: %ux%ux%u mode %u, %u subsequences, first bit %llu, device status 0x%x\n", job_file[k], jobs[k].w, jobs[k].h,
@@ -681,11 +652,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     hipStream_t s = e->stream, s_up = e->host.up, s_down = e->host.down;
     // The Up filter's undoing of a piece's rows runs on a stream of its own (a lane's: the lanes are drained), next to the following
     // piece's synchronisation and decode instead of behind them: the rows go down one piece earlier.
-    static const bool unf_aside = [] {
-        const char *v = getenv("FPNG_AMD_DECODE_UNF_STREAM");
-        return !(v && v[0] == '0');
-    }();
-    hipStream_t s_unf = (unf_aside && e->lane_stream[0]) ? e->lane_stream[0] : s;
+    hipStream_t s_unf = e->lane_stream[0] ? e->lane_stream[0] : s;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
     const uint32_t resident = (uint32_t)std::max(cus, 1) * 3;
@@ -751,18 +718,11 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     constexpr uint32_t kMaxPieces = 16;
     // (a piece costs ~100 us of launches and a host round trip: pieces of 6 MiB, but at least four of them -- measured on one box,
     //  2 / 3 / 4 / 6 MiB pieces: 8K RGBA 3.06 / 3.05 / 3.01 / 2.99 ms, an 11 MP photograph 2.46 / 1.90 / 1.53 / 1.38, 4K RGBA 1.03 / 0.95 / 1.02 / 1.06)
-    static const uint32_t piece_mb = [] {
-        const char *v = getenv("FPNG_AMD_DECODE_PIECE_MB");
-        return v ? (uint32_t)std::max(1, atoi(v)) : 0u;
-    }();
-    const uint32_t np_want = piece_mb ? p.idat_len / (piece_mb << 20) : std::max(4u, p.idat_len / (6u << 20));
+    const uint32_t np_want = std::max(4u, p.idat_len / (6u << 20));
     const uint32_t np = std::max(1u, std::min<uint32_t>({kMaxPieces, n_blocks, np_want}));
     // The first pieces are small -- a quarter, then half a share: the first rows are on their way down after 1 MiB instead of 4,
     // and the download, which takes longer than everything else together, starts that much earlier.
-    static const bool ramp = [] {
-        const char *v = getenv("FPNG_AMD_DECODE_RAMP");
-        return !(v && v[0] == '0');
-    }();
+    constexpr bool ramp = true;
     uint32_t blk_end[kMaxPieces], byte_end[kMaxPieces];
     for (uint32_t k = 0; k < np; k++) {
         // shares: 1/4, 1/2, 1, 1, ... of (np - 1.25) equal ones

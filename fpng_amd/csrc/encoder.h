@@ -135,13 +135,11 @@ struct fpng_amd_encoder {
         size_t hist_zero = 0; // leading counters of d_hist that are zero when the lane's stream gets there (the table builder re-zeroes what it read)
         DeviceBuf<TokenTable> d_dyn;
         DeviceBuf<uint32_t> d_local; // rows pipeline: the rows' local streams (Job::local_base / local_stride)
-        DeviceBuf<unsigned long long> d_look; // direct placement: two look-back granules per chunk; zero between submissions (scan_kernel clears what it read)
         hipEvent_t last_done = nullptr; // `done` event (owned by a slot) of the last submission that used this set
-        uint32_t last_n = 0, last_chunks = 0; // its jobs, and (direct placement) its chunks: fpng_amd_debug_peek
         void release()
         {
             d_jobs.release(), d_rows.release(), d_row_off.release(), d_states.release(), d_results.release();
-            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release(), d_look.release();
+            d_partials.release(), d_hist.release(), d_dyn.release(), d_local.release();
         }
     };
     static constexpr int kLanes = 8; // most lanes an encoder can have; n_lanes of them exist and take submissions in turn

@@ -30,22 +30,10 @@ struct Job {
     uint64_t local_base;      // dwords
     uint32_t local_stride;    // dwords per row (worst-case token bits of a row + slack)
     uint32_t local_pad;
-    // DIRECT PLACEMENT (whole images, flag kJobDirect): a row is cut into n_pieces pieces of piece_px pixels (a
-    // multiple of 256; the last one takes what is left), a wave encodes one piece ("chunk") into its LDS window, learns the
-    // chunk's bit offset by a decoupled look-back over the chunks in front of it and writes its bits straight into the file:
-    // no local streams, no second kernel that shifts them into place.  Per-chunk arrays (RowInfo records, look-back granules,
-    // spill areas) are indexed row_base + row * n_pieces + piece; local_stride is then a CHUNK's spill area.
-    uint32_t piece_px, n_pieces;
-    uint32_t n_chunks;        // nrows * n_pieces
-    uint32_t block_base;      // the job's first workgroup in the linear order of encode_direct_kernel (kRowWaves chunks each)
-    uint32_t group_base;      // ... and its first group of 64 chunks in the look-back's group granules
-    uint32_t force_range_log2; // 0, or the range size (12..16) scan_kernel is to hand assemble_kernel / crc_kernel whatever the batch (A/B runs: FPNG_AMD_ASSEMBLE_RL)
+    uint32_t reserved[6];     // (keeps the record at 224 bytes and png_header where it was: the row walk's and the histogram pass's code is, instruction for
+                              //  instruction, the build round 5's profiles were measured on -- tools/isa_diff.py)
     uint8_t png_header[60];   // 58 bytes used (reference fpng.cpp:1767-1791), IDAT length patched on device
 };
-
-constexpr uint32_t kJobDirect = 0x800u; // Job::flags: direct placement (above)
-constexpr uint32_t kDirectPiecePx4 = 1536, kDirectPiecePx3 = 2048; // default piece lengths (FPNG_AMD_PIECE_PX overrides)
-constexpr uint32_t kDirectGroupBlocks = 64; // encode_direct_kernel: workgroups handed to one XCD in a row (see direct_block_order)
 
 struct RowInfo {
     uint32_t bits; // token bits of the row
@@ -87,19 +75,12 @@ struct CrcDeviceTables {
 void build_crc_device_tables(CrcDeviceTables *t);
 
 void launch_hist(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t *hist);
-// look / local: the look-back granules of direct jobs (cleared again here, for the scratch set's next submission) and the chunks' spill
-// areas (chunks that encode_direct_kernel deferred are placed here), or NULL
-void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look = nullptr,
-                 unsigned long long *look_grp = nullptr, const uint32_t *local = nullptr);
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states);
 // chan_mask: bit 0 = the batch has 3-channel jobs, bit 1 = 4-channel jobs (one kernel instantiation each)
 // wide4: the 4-channel jobs' pixels lie mostly in rows of kWideRowPixels and more (their walk then runs with seven waves per SIMD instead of eight: kernels.hip)
 constexpr uint32_t kWideRowPixels = 3584; // (same-box A/B: 3840-pixel rows gain with six waves, 3072-pixel rows lose 1 % in 1-pass)
 void launch_encode_rows(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t max_rows, uint32_t chan_mask, RowInfo *rows,
                         JobState *states, uint32_t *local, bool wide4 = false);
-// direct placement: total_blocks = workgroups of all jobs (Job::block_base), blocks_per_job = every job's count if they are all equal, else 0;
-// look / look_grp = one 64-bit granule per chunk / two per group of 64 chunks (Job::group_base), all zero
-void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
-                          uint32_t *local, unsigned long long *look, unsigned long long *look_grp);
 // one job per submission: the record travels in the kernel arguments and is left at d_job for the kernels that follow
 void launch_encode_rows_first(hipStream_t s, const Job &job, Job *d_job, RowInfo *rows, JobState *states, uint32_t *local);
 void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist);
@@ -115,7 +96,6 @@ void launch_finalize(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t m
 void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n_images, uint64_t *sums);
 // dst[0..16) |= src[0..16): the 16-byte piece two neighbouring band windows share (each holds zeros where the other's bits are)
 void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src);
-void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink);
 // rezero: leave the counters that were read zeroed (the next 2-pass submission's histogram pass needs no clearing in front of it)
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero);
 

@@ -514,40 +514,9 @@ struct RowResult {
     uint32_t s1, s2;         // Adler raw sums of the filtered row, mod 65521
 };
 
-// What a piece that starts inside a row (pixel xb > 0, a multiple of 256) needs from the pixels in front of it: the filtered pixel
-// xb - 1 and t(xb - 1) mod CAP, t = how many pixels in a row, ending there, repeat their left neighbour (Rle::carry).  ra / rb: the
-// raw windows [xb - 64, xb) and [xb - 128, xb - 64), loaded by the caller early (the loads travel with the table staging); a run that
-// covers all of the first window is followed further back, window by window (flat rows only).
-template <int C>
-__device__ __forceinline__ void piece_look_behind(const RowWindows<C> &px, const typename RowWindows<C>::Raw &ra, const typename RowWindows<C>::Raw &rb, uint32_t xb, uint32_t lane,
-                                                  uint32_t &prev_f, uint32_t &carry)
-{
-    uint32_t x0 = xb - 64, t = 0;
-    uint32_t f = px.filter(ra), fp = px.filter(rb);
-    prev_f = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
-    for (;;) {
-        const uint32_t prev = x0 ? (uint32_t)__builtin_amdgcn_readlane((int)fp, 63) : 0u;
-        uint64_t m = __ballot(f == lane_prev(f, prev));
-        if (!x0) m &= ~1ull; // (the row's first pixel repeats nothing)
-        if (m != ~0ull) {
-            t += (uint32_t)__builtin_clzll(~m); // pixels at the window's end that repeat their left neighbour
-            break;
-        }
-        t += 64, x0 -= 64, f = fp; // (x0 was not 0: the mask of the row's first window is never full)
-        fp = x0 ? px.filtered_at(x0 - 64) : 0u;
-    }
-    carry = t % Rle<C>::CAP;
-}
-
-// Walks row r of the job -- or, PIECE = true (direct placement), the pixels [xb, xe) of it: xb a multiple of 256 (0: the row's first piece,
-// which carries the filter literal), xe a multiple of 256 or the row's width (its last piece).  A piece that starts inside the row
-// needs what the walk carries from window to window -- the filtered pixel in front of it and where the greedy cutting of a run
-// stands there (Rle::carry): both are found by looking back over the pixels in front of it, 64 at a time, as far as the run that
-// reaches the piece's first pixel goes (usually one window).  Its Adler sums are relative to the ROW's end, like a row's, so that
-// the pieces of a row simply add up.
-template <int C, Pass PASS, bool PIECE = false>
-__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink, uint32_t xb_in = 0,
-                                              uint32_t xe_in = 0, uint32_t piece_prev_f = 0, uint32_t piece_carry = 0)
+// Walks row r of the job.
+template <int C, Pass PASS>
+__device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables &T, uint32_t *hist, uint32_t r, uint32_t lane, EmitSink *sink)
 {
     using Raw = typename RowWindows<C>::Raw;
     constexpr int PF = 4; // windows in flight ahead of the one being processed
@@ -563,15 +532,11 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     const uint64_t lane_le_mask = (2ull << lane) - 1ull;
     const uint32_t nwin = (w + 63) >> 6;
     const uint32_t n_interior = (w >= 128) ? (w >> 6) - 1 : 0; // windows k with (k+2)*64 <= w
-    const uint32_t xb = PIECE ? uniform(xb_in) : 0u, xe = PIECE ? uniform(xe_in) : w;
-    const bool first_piece = !PIECE || xb == 0, last_piece = !PIECE || xe == w;
-    const uint32_t k_end = last_piece ? nwin : (xe >> 6); // windows [xb / 64, k_end) are this walk's
 
     RowWindows<C> px;
     px.init(row, up_row, bpl, lane);
 
     Rle<C> rle;
-    if (PIECE && xb) rle.carry = piece_carry; // (piece_prev_f / piece_carry: piece_look_behind(), called by the kernel in front of its first barrier)
     uint32_t row_bits = 0, last_unit = 0;
     // Adler per-lane accumulators: byte sum, sum of (bytes from the pixel's first byte to the row end) x
     // (pixel byte sum), sum of (byte index inside the pixel) x byte.  s2(row) = acc_w - acc_j.
@@ -579,7 +544,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     uint64_t acc_w = 0;
     const uint32_t fl = T.lit[filter_byte]; // filter-type literal in front of pixel 0 (reference fpng.cpp:1473-1475)
     const uint32_t chunk1 = uniform(T.chunk[1]); // token of a 1-pixel chunk (sparse tier)
-    if (kEmit && first_piece) {
+    if (kEmit) {
         if (lane == 0) {
             const uint64_t v = (uint64_t)plit_code(fl) << (sink->fill & 31);
             atomicOr(&sink->stage[sink->fill >> 5], (uint32_t)v);
@@ -737,8 +702,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // ~all of photographic content); any other super-window is replayed through the per-pixel walk
     // below with ds_bpermute gathers.  Super-windows S with 256*(S+1) < w qualify.
     // =====================================================================================
-    uint32_t k0 = xb >> 6;           // first 64-pixel window left for phase B
-    uint32_t carry_f = piece_prev_f; // filtered value of the pixel just before window k0
+    uint32_t k0 = 0;      // first 64-pixel window left for phase B
+    uint32_t carry_f = 0; // filtered value of the pixel just before window k0
     {
         constexpr int ND = C;                         // filtered dwords per lane: 4 pixels x C bytes
         constexpr uint32_t kLaneBytes = 4u * C, kSuperBytes = 256u * C;
@@ -748,9 +713,8 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         // super-window here as well -- lanes past the row end masked -- was measured and dropped: 256 x 1080p RGBA 1.15
         // instead of 1.10 ms, and three spilled VGPRs in the 3-channel walk.)
         const uint32_t NS = (w - 1) >> 8;
-        const uint32_t NSX_row = NS + (((w & 255u) == 0) ? 1u : 0u);
-        const uint32_t S0 = xb >> 8;                                      // the walk's first super-window
-        const uint32_t NSX = (PIECE && !last_piece) ? (xe >> 8) : NSX_row; // ... and the one it stops in front of (a piece that ends inside the row: every one of its super-windows is followed by pixels)
+        const uint32_t NSX = NS + (((w & 255u) == 0) ? 1u : 0u);
+        constexpr uint32_t S0 = 0; // the walk's first super-window
         if (NSX > S0) {
             const uint32_t voff4 = lane * kLaneBytes;
             auto load4 = [&](uint32_t S, u32x4 &c4, u32x4 &u4) {
@@ -794,7 +758,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             uint32_t fd[4];
             filt(c_first, u_first, fd);
             // pixel just before the super-window; in front of pixel 0: a value pixel 0 cannot equal (it has no left neighbour)
-            uint32_t last_f = (PIECE && xb) ? piece_prev_f : ~uniform(fd[0]);
+            uint32_t last_f = ~uniform(fd[0]);
             uint32_t wgt = bpl - kLaneBytes * lane - S0 * kSuperBytes; // bytes from this lane's first byte to the row end
             const uint32_t c1_bits = chunk1 & 0xFF;
             // gather the per-pixel view of 64-pixel window jw of the current super-window (lane i <- pixel 64*jw+i)
@@ -933,7 +897,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     // =====================================================================================
     // Phase B: per-pixel walk (lane = pixel) of windows k0 .. nwin-1: everything for RGB, the row tail for RGBA
     // =====================================================================================
-    if (k0 < k_end) { // (phase A may have taken the whole row)
+    if (k0 < nwin) { // (phase A may have taken the whole row)
         if (kEmit && sink->fill > (uint32_t)kStageFlushAt * 32u) sink_flush(*sink, lane, false); // room for a 64-pixel window
         Raw ring[PF];
         const Raw raw0 = px.load_raw(k0 << 6);
@@ -943,7 +907,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         m_cur = __ballot(f_cur == lane_prev(f_cur, carry_f)) & valid_mask(k0 << 6, w);
         if (k0 == 0) m_cur &= ~1ull;
         // interior windows: ring-fed, unmasked
-        const uint32_t lim_int = n_interior < k_end ? n_interior : k_end;
+        const uint32_t lim_int = n_interior < nwin ? n_interior : nwin;
         for (uint32_t kb = k0; kb < lim_int; kb += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
@@ -955,7 +919,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
             }
         }
         // the last one or two windows of the row: masked body, look-ahead loaded directly
-        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < k_end; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
+        for (uint32_t k = (k0 > lim_int ? k0 : lim_int); k < nwin; k++) step(std::true_type{}, k, px.filtered_at((k + 1) << 6));
     }
 
     RowResult res;
@@ -963,7 +927,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
     res.last_unit_bits = 0;
     res.s1 = res.s2 = 0;
     if (kSums) {
-        const uint32_t fl_bits = first_piece ? plit_len(fl) : 0u;
+        const uint32_t fl_bits = plit_len(fl);
         res.bits = row_bits + fl_bits;
         // when the row is a single pixel, 1-pass RGB flushes the filter literal together with it
         // (reference fpng.cpp:1186-1203 vs :1473-1497)
@@ -971,7 +935,7 @@ __device__ __forceinline__ RowResult walk_row(const Job &job, const PackedTables
         const uint32_t la = acc_a % kAdlerMod;
         const uint32_t lw = (uint32_t)((acc_w - acc_j) % kAdlerMod); // every byte weight is positive
         const uint32_t n_mod = (bpl + 1u) % kAdlerMod;
-        const uint32_t fb = first_piece ? filter_byte : 0u; // (the filter byte is the first piece's)
+        const uint32_t fb = filter_byte;
         res.s1 = (wave_sum(la) + fb) % kAdlerMod;
         res.s2 = (wave_sum(lw) + n_mod * fb) % kAdlerMod;
     }
@@ -1057,62 +1021,10 @@ template <typename P> __device__ __forceinline__ void store_be32(P p, uint32_t v
     p[3] = (uint8_t)v;
 }
 
-// ---- direct placement: look-back granules (encode_direct_kernel, further down; scan_kernel places the chunks that kernel deferred) ----
-#ifndef FPNG_DIRECT_ABL // timing-only builds (wrong files!): bit 0 no look-back, bit 1 no placement stores, bit 2 no look behind a piece's first pixel
-#define FPNG_DIRECT_ABL 0
-#endif
-constexpr unsigned long long kLookReady = 1ull << 63;
-constexpr uint32_t kGrpStride = 16; // granules per group record (128 bytes)
-#ifndef FPNG_DIRECT_SPIN_LIMIT
-#define FPNG_DIRECT_SPIN_LIMIT 256
-#endif
-#ifndef FPNG_DIRECT_SLEEP // s_sleep argument between two polls (units of 64 cycles)
-#define FPNG_DIRECT_SLEEP 24
-#endif
-constexpr uint32_t kDirectSpinLimit = FPNG_DIRECT_SPIN_LIMIT; // polls (~0.1 us each) a chunk waits for the chunks in front of it before it is deferred
-__device__ __forceinline__ unsigned long long look_load(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void look_store(unsigned long long *p, unsigned long long v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The sh (1..31) stream bits in front of chunk `id`, top-aligned in the returned word: the last bits of the chunk(s) in front of it
-// (their records; every one of them has been published when this is called), or of the block header.
-__device__ __forceinline__ uint32_t direct_bits_in_front(const Job &job, const unsigned long long *agg, uint32_t id, uint32_t sh, uint32_t first_bit)
-{
-    uint32_t W = 0, have = 0;
-    int64_t j = (int64_t)id - 1;
-    while (have < sh && j >= 0) {
-        unsigned long long a = look_load(&agg[j]);
-        for (uint32_t spins = 0; !(a & kLookReady) && spins < (1u << 16); spins++) a = look_load(&agg[j]); // (published long ago: see the callers; bounded all the same)
-        const uint32_t b = (uint32_t)(a & 0xFFFFFFu), t = (uint32_t)(a >> 24) & 0x7FFFFFFFu;
-        W |= (t << 1) >> have;
-        have += b < 31u ? b : 31u;
-        j--;
-    }
-    if (have < sh) { // the block header's last bits (zlib bits [first_bit - 31, first_bit))
-        const FPNG_GLOBAL uint8_t *hb = (const FPNG_GLOBAL uint8_t *)(uintptr_t)job.table->header;
-        const uint32_t k = first_bit - 31u, b0 = k >> 3;
-        uint64_t v = 0;
-        for (uint32_t i = 0; i < 5; i++) v |= (uint64_t)hb[b0 + i] << (8 * i);
-        const uint32_t t = (uint32_t)(v >> (k & 7u)) & 0x7FFFFFFFu;
-        W |= (t << 1) >> have;
-    }
-    return W;
-}
-
-
 __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const RowInfo *rows, uint64_t *row_off, uint32_t n_jobs,
-                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */, unsigned long long *look, unsigned long long *look_grp, const uint32_t *spill)
+                                         uint64_t (*wsum)[kScanWaves] /* LDS [3][kScanWaves] */)
 {
-    // direct placement (encode_direct_kernel): the records are CHUNKS' (n_pieces per row), the bits are in the file already --
-    // what is left is the sums, the decision, the head of the file in front of the first chunk's first dword, and the look-back
-    // granules' clearing for the scratch set's next submission
-    const bool direct = (job.flags & kJobDirect) != 0;
-    const uint32_t n_rec = direct ? job.n_chunks : job.nrows, rec_per_row = direct ? job.n_pieces : 1u;
+    const uint32_t n_rec = job.nrows;
     const uint32_t t = threadIdx.x, lane = t & 63, wv = uniform(t >> 6);
     const TokenTable *tab = job.table;
     const uint64_t n_filtered = (uint64_t)(job.bpl + 1) * job.nrows;
@@ -1130,7 +1042,6 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         const uint32_t per = (n_rec + kScanBlock - 1) / kScanBlock;
         const uint32_t r0 = t * per < n_rec ? t * per : n_rec, r1 = (r0 + per < n_rec) ? r0 + per : n_rec;
         uint64_t local = 0;
-        uint32_t n_deferred = 0, n_spilled = 0; // direct placement: chunks of this thread's range that encode_direct_kernel left in their spill areas / that overflowed the window
         for (uint32_t rb = r0; rb < r1; rb += 8) { // eight records in flight per round trip
             u32x4 ri[8];
 #pragma unroll
@@ -1141,11 +1052,9 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
                 if (r >= r1) break;
                 const uint32_t s1 = ri[k].y, s2 = ri[k].z; // < 65521
                 local += ri[k].x;
-                n_deferred += ri[k].w & 1u;
-                n_spilled += (ri[k].w >> 1) & 1u;
                 // S2 of the concatenation: every byte of this row is followed by the later rows.  All factors are below
                 // 65521, so the products (and 65520^2 + 65520) fit 32 bits
-                const uint32_t after = ((job.nrows - 1 - r / rec_per_row) % kAdlerMod) * n_row_mod % kAdlerMod; // (a chunk's sums are relative to its ROW's end)
+                const uint32_t after = ((job.nrows - 1 - r) % kAdlerMod) * n_row_mod % kAdlerMod;
                 a_s1 += s1;
                 a_s2 += (s2 + after * s1) % kAdlerMod;
             }
@@ -1153,7 +1062,6 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         uint64_t wave_total;
         const uint64_t excl = wave_exclusive_sum_u64(local, lane, wave_total);
         if (lane == 0) wsum[0][wv] = wave_total;
-        if (t == 0) st.reserved[0] = st.reserved[1] = 0;
         __syncthreads();
         uint64_t before = 0, total = 0;
 #pragma unroll
@@ -1163,62 +1071,7 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
             total += v;
         }
         uint64_t pos = first_bit + before + excl;
-        if (direct) { // (statistics: fpng_amd_debug_peek; thread 0 cleared them in front of the barrier above)
-            if (n_deferred) atomicAdd((unsigned long long *)&st.reserved[0], (unsigned long long)n_deferred);
-            if (n_spilled) atomicAdd((unsigned long long *)&st.reserved[1], (unsigned long long)n_spilled);
-        }
-        if (direct && look && spill) {
-            // ---- deferred chunks (rare: a chunk that did not learn its offset in time, encode_direct_kernel): their offsets are known
-            //      here.  Per round every thread names the next deferred chunk of its range; the workgroup places them one by one, all
-            //      threads on one chunk's dwords.  (Nothing else of the file is touched: the dword a chunk's last bits end in is its
-            //      successor's, which took those bits from the chunk's record.) ----
-            __shared__ uint32_t def_rec[kScanBlock], def_w;
-            __shared__ uint64_t def_pos[kScanBlock];
-            __shared__ uint32_t def_any;
-            const unsigned long long *agg = look + (size_t)job.row_base;
-            gptr_u32 out32 = to_global<gptr_u32>(job.out);
-            const uint64_t cap_dw = job.out_cap >> 2;
-            const uint32_t eob_len_d = tab->lit[256] >> 16;
-            for (uint32_t round = 0;; round++) {
-                if (t == 0) def_any = 0;
-                __syncthreads();
-                def_rec[t] = 0xFFFFFFFFu;
-                if (round < n_deferred) { // this thread's round-th deferred chunk and its offset
-                    uint64_t q = pos;
-                    uint32_t seen = 0;
-                    for (uint32_t r = r0; r < r1; r++) {
-                        const u32x4 ri = rg[r];
-                        if ((ri.w & 1u) && seen++ == round) {
-                            def_rec[t] = r, def_pos[t] = q;
-                            break;
-                        }
-                        q += ri.x;
-                    }
-                    def_any = 1;
-                }
-                __syncthreads();
-                if (!def_any) break;
-                for (uint32_t e = 0; e < kScanBlock; e++) {
-                    const uint32_t rec = def_rec[e];
-                    if (rec == 0xFFFFFFFFu) continue; // (uniform: LDS value)
-                    const bool last = rec + 1 == n_rec;
-                    const uint32_t nbits = rg[rec].x + (last ? eob_len_d : 0u);
-                    const uint64_t P = (uint64_t)job.bit_bias + def_pos[e];
-                    const uint32_t sh = (uint32_t)P & 31u;
-                    const uint64_t D0 = P >> 5, D1 = last ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5);
-                    if (t == 0) def_w = sh ? direct_bits_in_front(job, agg, rec, sh, (uint32_t)first_bit) : 0u;
-                    __syncthreads();
-                    const uint32_t W = def_w;
-                    gptr_cu32 loc = to_global<gptr_cu32>(spill) + job.local_base + (uint64_t)rec * job.local_stride;
-                    for (uint32_t m = t; m < (uint32_t)(D1 - D0); m += kScanBlock) {
-                        const uint32_t hi = loc[m], lo = m ? loc[m - 1] : W;
-                        if (D0 + m < cap_dw) out32[D0 + m] = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        for (uint32_t rb = r0; rb < r1 && !direct; rb += 4) {
+        for (uint32_t rb = r0; rb < r1; rb += 4) {
             uint32_t bits[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) bits[k] = rg[rb + k < r1 ? rb + k : r1 - 1].x;
@@ -1275,7 +1128,6 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         want = want < 4u ? 4u : want;
         uint32_t rl = 12;
         while (rl < 16 && (((span >> rl) + 1 > want) || ((span >> rl) + 1 > job.crc_blocks))) rl++;
-        if (job.force_range_log2 && ((span >> job.force_range_log2) + 1 <= job.crc_blocks)) rl = job.force_range_log2;
         if (!job.whole_png) rl = 16; // row bands: every rank must cut the file into the same ranges (their CRC partials are XOR-ed)
         st.range_log2 = rl;
     }
@@ -1289,30 +1141,20 @@ __device__ __forceinline__ void scan_job(const Job &job, JobState &st, const Row
         for (uint32_t i = t; i < kPngHeaderBytes; i += kScanBlock)
             if (i < 50 || i >= 54) out[i] = job.png_header[i];
     gptr_u8 zl = out + (job.bit_bias >> 3); // zlib byte 0 (only meaningful for the first band / whole image)
-    if (!stored && job.is_first && direct) {
-        // (the first chunk wrote the dword its first bit lies in, with the header's last bits: the head ends in front of it)
-        const uint32_t head_bytes = (uint32_t)((((uint64_t)job.bit_bias + tab->first_token_bit) >> 5) * 4u) - kPngHeaderBytes;
-        for (uint32_t i = t; i < head_bytes; i += kScanBlock) zl[i] = tab->header[i];
-    } else if (!stored && job.is_first) {
+    if (!stored && job.is_first) {
         const uint32_t head_bytes = (tab->header_bits + 7) >> 3; // (the last one holds the pending bits in front of the first token)
         for (uint32_t i = t; i < head_bytes; i += kScanBlock) zl[i] = tab->header[i];
         const uint32_t head_end = kPngHeaderBytes + head_bytes;
         for (uint32_t i = head_end + t; i < ((head_end + 15u) & ~15u); i += kScanBlock) out[i] = 0;
     }
-    if (direct && look) { // the chain's last reader of the granules leaves them zeroed
-        unsigned long long *g = look + (size_t)job.row_base, *gg = look_grp + kGrpStride * (size_t)job.group_base;
-        for (uint32_t i = t; i < n_rec; i += kScanBlock) g[i] = 0ull;
-        for (uint32_t i = t; i < ((n_rec + 63u) >> 6); i += kScanBlock) gg[kGrpStride * (size_t)i] = 0ull, gg[kGrpStride * (size_t)i + 8] = 0ull;
-    }
     if (t == 0 && job.whole_png) store_be32(out + 50, (uint32_t)zlib_size); // IDAT length (reference fpng.cpp:1782)
 }
 
 // scan_kernel: one block per job (whole images; row bands: counting phase and placement phase)
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look,
-                                                             unsigned long long *look_grp, const uint32_t *local)
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const Job *jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
     __shared__ uint64_t wsum[3][kScanWaves];
-    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum, look, look_grp, local);
+    scan_job(jobs[blockIdx.x], states[blockIdx.x], rows, row_off, gridDim.x, wsum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1400,315 +1242,6 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_num_sgpr(80), amdg
     uint32_t bx, by;
     xcd_block_order(bx, by);
     encode_rows_block<C>(arg.job, 0, bx, rows_out, states, local);
-}
-
-// ---------------------------------------------------------------------------------------------
-// encode_direct_kernel (round 5): ONE kernel walks the pixels and writes the file's bits where they belong.
-//
-// encode_rows + assemble move the compressed bytes through HBM three times (local streams out, back in, file out: 1.68 x the
-// step's algorithmic bytes).  What forces the detour is that a row's bit offset is the sum of all earlier rows' bit counts.  Here a
-// row is cut into PIECES whose token bits fit the wave's LDS window (a "chunk" = one piece of one row, one wave): the wave encodes its
-// chunk into the window, publishes the bit count, finds its offset by a DECOUPLED LOOK-BACK over the chunks in front of it (every
-// chunk publishes {bits, its last 31 bits} as soon as it is encoded and {bits up to its end} once it knows them; a chunk waits
-// for lower numbers only, and the hardware starts the workgroups of a grid in rising order -- the argument of dec_unfilter_kernel),
-// and then writes the window, shifted, straight to the file: whole dwords, the first one completed with the last bits of the
-// chunk in front (which it knows from that chunk's record), the one its last bits end in left to the next chunk.  A chunk whose
-// bits do not fit the window spills to its scratch area as the rows of encode_rows do and copies from there (noisy content: no
-// gain, no loss).  What is left for other kernels: scan (totals, Adler, the stored-or-compressed decision, the file's head),
-// the CRC over the finished file (assemble_kernel's direct branch = crc_kernel's arithmetic), finalize.
-// ---------------------------------------------------------------------------------------------
-// Workgroup order: the hardware deals a grid's workgroups round-robin to the 8 XCDs (each with its own L2).  Runs of
-// kDirectGroupBlocks consecutive workgroups (= chunks in file order) go to ONE XCD, so that the rows above a chunk's are L2 hits
-// (all but the first of a run), and the runs go round the XCDs, so that chunks that wait for each other run at about the same time.
-// lin -> logical; the grid is padded to whole rounds of 8 runs (logical numbers past the end leave at once).
-__device__ __forceinline__ uint32_t direct_block_order()
-{
-    const uint32_t lin = blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
-    return ((slot / kDirectGroupBlocks) * 8u + xcd) * kDirectGroupBlocks + slot % kDirectGroupBlocks;
-}
-
-template <int C>
-__device__ __forceinline__ void encode_direct_block(const Job &job, JobState &state, uint32_t jb, RowInfo *rows_out, uint32_t *local, unsigned long long *look,
-                                                    unsigned long long *look_grp)
-{
-    __shared__ PackedTables T;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kRowWaves][kStageDwords + 2 * kWave + 4]; // + dump slots, see sink_put
-    const uint32_t lane = threadIdx.x & 63, wv = uniform(threadIdx.x >> 6), id = jb * kRowWaves + wv;
-    const uint32_t n_chunks = uniform(job.n_chunks), np = uniform(job.n_pieces), w = uniform(job.w);
-    const bool have_chunk = id < n_chunks;
-    const uint32_t r = have_chunk ? id / np : 0u, piece = have_chunk ? id - r * np : 0u;
-    const uint32_t xb = piece * uniform(job.piece_px), xe = (piece + 1 == np) ? w : xb + uniform(job.piece_px);
-    // Everything a chunk must fetch before it can start is asked for at once, in front of the barrier: the tables, the two pixel
-    // windows in front of a piece that starts inside its row, the first token bit.  (A wave's time per chunk is a dozen
-    // microseconds: every dependent round trip to memory that is not hidden costs a fifth of it.)
-    RowWindows<C> pw;
-    typename RowWindows<C>::Raw ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
-    {
-        const uint32_t bpl = uniform(job.bpl);
-        const uint8_t *row = job.rows + (size_t)r * bpl;
-        const bool filter_up = (uniform(job.y0) + r) != 0;
-        pw.init(row, filter_up ? (r ? row - bpl : job.row_above) : nullptr, bpl, lane);
-#if !(FPNG_DIRECT_ABL & 4)
-        if (xb) ra = pw.load_raw(xb - 64), rb = pw.load_raw(xb - 128);
-#endif
-    }
-    const uint64_t first_bit = job.table->first_token_bit;
-    stage_packed_tables<kRowBlock>(T, job.table);
-    __syncthreads();
-    if (!have_chunk) return;
-    const bool last_chunk = id + 1 == n_chunks;
-    const size_t slot = (size_t)job.row_base + id;
-    uint32_t piece_prev_f = 0, piece_carry = 0;
-#if !(FPNG_DIRECT_ABL & 4)
-    if (xb) piece_look_behind<C>(pw, ra, rb, xb, lane, piece_prev_f, piece_carry);
-#endif
-
-    EmitSink sink;
-    sink.stage = stage[wv];
-    gptr_u32 loc = to_global<gptr_u32>(local + job.local_base + (uint64_t)id * job.local_stride); // the chunk's spill area
-    sink.out32 = loc;
-    const uint32_t zero = uniform(job.local_pad); // (a zero the compiler cannot see: encode_rows_block)
-    sink.base_dw = zero;
-    sink.fill = zero;
-    sink.wide = (C == 4);
-    sink_zero_window(sink, lane);
-    wave_lds_fence();
-
-    const RowResult res = walk_row<C, Pass::Encode, true>(job, T, nullptr, r, lane, &sink, xb, xe, piece_prev_f, piece_carry);
-    if (last_chunk) { // end of block symbol behind the last row's tokens (reference fpng.cpp:1564-1567); not part of the record's bits
-        const uint32_t eob = T.lit[256];
-        sink_put<false>(sink, lane == 0 ? (uint64_t)plit_code(eob) : 0ull, lane == 0 ? plit_len(eob) : 0u, sink.fill);
-        sink.fill += plit_len(eob);
-    }
-    wave_lds_fence();
-    // ---- the chunk's stream: dword k of it is stage[k] -- or, if the window overflowed on the way, loc[k] ----
-    const bool spilled = uniform((uint32_t)sink.base_dw) != 0u;
-    const uint32_t nbits = (uint32_t)sink.base_dw * 32u + sink.fill; // (with the end-of-block symbol, if it is here)
-    if (spilled) {
-        sink_flush(sink, lane, true);
-        if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u; // (the dwords behind the last one are read as zeros below; the final flush may or may not have covered them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the wave reads its own stores back: they have left the wave; the loads below go past the caches)
-    }
-    // (spilled is wave-uniform; a spilled stream is read back past the caches -- the rare path)
-    auto sdw = [&](uint32_t k) -> uint32_t { return spilled ? __hip_atomic_load((const uint32_t *)(local + job.local_base + (uint64_t)id * job.local_stride) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sink.stage[k]; };
-    // its last 31 bits, the last one in bit 30 (a chunk of fewer bits: what there is, at the top)
-    uint32_t tail31;
-    if (nbits >= 32) {
-        const uint32_t k = nbits - 31, q = k >> 5, o = k & 31u;
-        const uint32_t lo = uniform(sdw(q)), hi = uniform(sdw(q + 1)); // (q + 1 may lie behind the last dword: zeros there -- the window is cleared, a spill area's slack is written as zeros above)
-        tail31 = (o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo) & 0x7FFFFFFFu;
-    } else
-        tail31 = nbits ? ((uniform(sdw(0)) << (31u - nbits)) & 0x7FFFFFFFu) : 0u;
-    // ---- look-back, two levels, no read-modify-write anywhere.  Per chunk one granule {ready, its last 31 bits, its bits}; per GROUP
-    //      of 64 chunks a 128-byte record with two: the group's bit SUM (written by the NEXT group's first chunk -- its "leader" --
-    //      once it has seen all 64 records) and the bits in FRONT of the group (written by the group's own leader).  A chunk needs
-    //      the records of the chunks of its group in front of it (one load per lane) and its group's prefix; a leader finds that
-    //      prefix by looking back over the groups in front, 64 per round trip = 4096 chunks.  (History, profiles/
-    //      r05_encode_onchip_ab.txt: with chunk granules alone the front of known offsets moved 64 chunks per round trip and job;
-    //      a group counter kept with atomic adds serialised 64 agent-scope atomics per group on one address.) ----
-    unsigned long long *agg = look + (size_t)job.row_base;
-    unsigned long long *grp = look_grp + kGrpStride * (size_t)job.group_base; // group j: grp[16 j] = sum, grp[16 j + 8] = prefix
-    const uint32_t g = id >> 6, k = id & 63u;
-    if (lane == 0) look_store(&agg[id], kLookReady | ((unsigned long long)tail31 << 24) | res.bits);
-    uint64_t excl = 0;
-    bool deferred = false;
-    unsigned long long front = 0; // the record of the chunk right in front (its last bits are wanted below)
-#if FPNG_DIRECT_ABL & 1
-    excl = (uint64_t)id * 21000u; // (timing only: no look-back, chunks at made-up offsets)
-#else
-    {
-        // Polling discipline: a wave re-reads only what it is still missing -- ONE granule while it waits for its group's prefix --
-        // and sleeps about a microsecond between polls.
-        bool g_known = g == 0;            // the group's prefix (gval) is known
-        bool intra_ok = id == 0;          // the records in front, inside the group (k == 0: just the chunk right in front), are in
-        bool prev_sum_ok = g == 0;        // (leading) the group in front is complete and its sum (prev_sum) is known
-        uint64_t gval = 0, gacc = 0, intra = 0, prev_sum = 0;
-        int64_t gbase = (int64_t)g - 2;   // (leading) the nearest group whose record is not yet accounted for (g - 1 comes from its chunks' records)
-        for (uint32_t spins = 0;;) {
-            // (a chunk that has waited long for its group's prefix looks for it itself, like the group's leader: that one may have been deferred)
-            const bool lead = !g_known && (k == 0 || spins >= 48);
-            unsigned long long a = kLookReady, pa = kLookReady, q = 0, gs = 0;
-            if (!intra_ok && lane < k) a = look_load(&agg[(size_t)g * 64u + lane]);
-            if (lead && !prev_sum_ok) pa = look_load(&agg[(size_t)(g - 1) * 64u + lane]); // the 64 records of the group in front
-            if (!g_known) {
-                if (!lead)
-                    q = look_load(&grp[kGrpStride * (size_t)g + 8]);
-                else {
-                    const int64_t j = gbase - lane;
-                    if (j >= 0) {
-                        gs = look_load(&grp[kGrpStride * j]);
-                        q = look_load(&grp[kGrpStride * j + 8]);
-                    } else
-                        gs = kLookReady, q = kLookReady; // (in front of the first group: nothing, and known)
-                }
-            }
-            if (lead && !prev_sum_ok && __ballot((pa & kLookReady) != 0) == ~0ull) {
-                uint64_t total;
-                (void)wave_exclusive_sum_u64((uint64_t)(pa & 0xFFFFFFu), lane, total);
-                prev_sum = total;
-                prev_sum_ok = true;
-                if (lane == 0) look_store(&grp[kGrpStride * (size_t)(g - 1)], kLookReady | prev_sum); // for the leaders further on
-                if (k == 0) { // the chunk right in front is the group's last one
-                    front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pa >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pa, 63);
-                    intra_ok = true;
-                }
-            }
-            if (!intra_ok && k && __ballot((a & kLookReady) != 0) == ~0ull) {
-                uint64_t total;
-                (void)wave_exclusive_sum_u64(lane < k ? (uint64_t)(a & 0xFFFFFFu) : 0ull, lane, total);
-                intra = total;
-                front = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), (int)k - 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, (int)k - 1);
-                intra_ok = true;
-            }
-            if (!g_known) {
-                if (!lead) {
-                    const unsigned long long q0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
-                    if (q0 & kLookReady) g_known = true, gval = q0 & ~kLookReady;
-                } else if (prev_sum_ok) {
-                    const uint64_t qmask = __ballot((q & kLookReady) != 0), smask = __ballot((gs & kLookReady) != 0);
-                    if (qmask) {
-                        const uint32_t L = (uint32_t)__builtin_ctzll(qmask); // the nearest group whose prefix is known
-                        const uint64_t need = L >= 63 ? ~0ull : ((2ull << L) - 1ull); // ... its sum and those of the groups behind it must be known
-                        if ((smask & need) == need) {
-                            const uint64_t part = (lane <= L ? (uint64_t)(gs & ~kLookReady) : 0ull) + (lane == L ? (uint64_t)(q & ~kLookReady) : 0ull);
-                            uint64_t total;
-                            (void)wave_exclusive_sum_u64(part, lane, total);
-                            gval = gacc + total + prev_sum;
-                            g_known = true;
-                            if (lane == 0) look_store(&grp[kGrpStride * (size_t)g + 8], kLookReady | gval);
-                        } else if (spins >= 48) {
-                            // a sum is missing although its group must be complete (its leader-to-be was deferred?): make it from the records
-                            const uint32_t m = (uint32_t)__builtin_ctzll(~smask & need);
-                            const int64_t jm = gbase - (int64_t)m;
-                            const unsigned long long ra = look_load(&agg[(size_t)jm * 64u + lane]);
-                            if (__ballot((ra & kLookReady) != 0) == ~0ull) {
-                                uint64_t total;
-                                (void)wave_exclusive_sum_u64((uint64_t)(ra & 0xFFFFFFu), lane, total);
-                                if (lane == 0) look_store(&grp[kGrpStride * (size_t)jm], kLookReady | total);
-                            }
-                        }
-                    } else if (smask == ~0ull) { // 64 sums, no prefix among them: take them, look further back
-                        uint64_t total;
-                        (void)wave_exclusive_sum_u64((uint64_t)(gs & ~kLookReady), lane, total);
-                        gacc += total;
-                        gbase -= 64;
-                        continue;
-                    }
-                }
-            }
-            if (g_known && intra_ok) {
-                excl = gval + intra;
-                if (!id) front = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(FPNG_DIRECT_SLEEP);
-            if (++spins > kDirectSpinLimit) { // see below
-                deferred = true;
-                break;
-            }
-        }
-    }
-#endif
-    if (deferred) {
-        // The chunks in front have not all reported in time.  A wave that waits holds its place on the compute unit, and with several
-        // such kernels on one GPU (two lanes, several encoders, several processes) waves that wait for each other's unstarted
-        // predecessors could fill it: so nobody waits long.  The chunk goes to its spill area like a row of encode_rows, its record
-        // says so, and scan_kernel -- which knows every offset -- places it (its bit count is published: nobody behind it is held up;
-        // a group whose first chunk is deferred has no prefix written: its other chunks end here too, later groups look past it).
-        if (!spilled) {
-            sink_flush(sink, lane, true);
-            if (lane < 3) loc[((nbits + 31u) >> 5) + lane] = 0u;
-        }
-        if (lane == 0) {
-            RowInfo ri;
-            ri.bits = res.bits, ri.s1 = res.s1, ri.s2 = res.s2, ri.pad = 1u | (spilled ? 2u : 0u);
-            rows_out[slot] = ri;
-            if (last_chunk) state.last_unit_bits = res.last_unit_bits;
-        }
-        return;
-    }
-    // ---- place the bits.  File bit of the chunk's first bit: ----
-    const uint64_t P = (uint64_t)job.bit_bias + first_bit + excl;
-    const uint32_t sh = (uint32_t)P & 31u;
-    const uint64_t D0 = P >> 5;
-    const uint64_t D1 = last_chunk ? ((P + nbits + 31) >> 5) : ((P + nbits) >> 5); // dwords [D0, D1) are this chunk's
-    // the sh bits in front of the chunk, top-aligned: nearly always the last bits of the chunk right in front, whose record the
-    // look-back fetched (fewer than sh bits there, or no chunk in front: direct_bits_in_front() collects them)
-    uint32_t W = 0;
-    if (sh) {
-        const uint32_t fb = (uint32_t)(front & 0xFFFFFFu);
-        if (id && (front & kLookReady) && fb >= sh)
-            W = ((uint32_t)(front >> 24) & 0x7FFFFFFFu) << 1;
-#if !(FPNG_DIRECT_ABL & 1)
-        else
-            W = uniform(direct_bits_in_front(job, agg, id, sh, (uint32_t)first_bit));
-#endif
-    }
-#if !(FPNG_DIRECT_ABL & 2)
-    {
-        // file dword D0 + m = stream dwords m - 1 (its top sh bits) and m (the rest); stream dword -1 = W.  Up to three dwords to the
-        // next 16-byte boundary of the file, then 16 bytes per lane, then what is left.
-        gptr_u32 out32 = to_global<gptr_u32>(job.out);
-        const uint64_t cap_dw = job.out_cap >> 2; // (a stream that outgrows the file's buffer ends as stored blocks: scan_kernel decides, assemble_kernel writes them)
-        const uint32_t nD = (uint32_t)(D1 - D0);
-        auto fdw = [&](uint32_t m, uint32_t lo) -> uint32_t { // lo = stream dword m - 1
-            const uint32_t hi = sdw(m);
-            return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-        };
-        uint32_t head = (4u - ((uint32_t)D0 & 3u)) & 3u;
-        head = head < nD ? head : nD;
-        if (lane < head && D0 + lane < cap_dw) out32[D0 + lane] = fdw(lane, lane ? sdw(lane - 1) : W);
-        const uint32_t nq = (nD - head) >> 2;
-        for (uint32_t q = lane; q < nq; q += kWave) {
-            const uint32_t m0 = head + 4u * q;
-            const uint32_t s0 = m0 ? sdw(m0 - 1) : W, s1 = sdw(m0), s2 = sdw(m0 + 1), s3 = sdw(m0 + 2), s4 = sdw(m0 + 3);
-            u32x4 v;
-            if (sh) {
-                v.x = __builtin_amdgcn_alignbit(s1, s0, 32u - sh), v.y = __builtin_amdgcn_alignbit(s2, s1, 32u - sh);
-                v.z = __builtin_amdgcn_alignbit(s3, s2, 32u - sh), v.w = __builtin_amdgcn_alignbit(s4, s3, 32u - sh);
-            } else
-                v.x = s1, v.y = s2, v.z = s3, v.w = s4;
-            if (D0 + m0 + 4 <= cap_dw) *(gptr_u128)(uintptr_t)(out32 + D0 + m0) = v;
-        }
-        const uint32_t mt = head + 4u * nq + lane;
-        if (mt < nD && D0 + mt < cap_dw) out32[D0 + mt] = fdw(mt, mt ? sdw(mt - 1) : W);
-    }
-#endif
-    if (lane == 0) {
-        RowInfo ri;
-        ri.bits = res.bits;
-        ri.s1 = res.s1;
-        ri.s2 = res.s2;
-        ri.pad = spilled ? 2u : 0u; // (bit 0: deferred, bit 1: the window overflowed -- statistics)
-        rows_out[slot] = ri;
-        if (last_chunk) state.last_unit_bits = res.last_unit_bits;
-    }
-}
-
-#ifndef FPNG_DIRECT_WPE
-#define FPNG_DIRECT_WPE 6
-#endif
-template <int C>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DIRECT_WPE, FPNG_DIRECT_WPE))) void encode_direct_kernel(const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job,
-                                                                                                                          RowInfo *rows_out, JobState *states, uint32_t *local,
-                                                                                                                          unsigned long long *look, unsigned long long *look_grp)
-{
-    const uint32_t b = direct_block_order();
-    if (b >= total_blocks) return;
-    // the job this workgroup belongs to: the last one whose block_base is <= b (blocks_per_job != 0: all jobs have that many -- the
-    // usual batch of equal frames -- and no search's round trips stand in front of the chunk)
-    uint32_t lo = 0, hi = n_jobs;
-    if (blocks_per_job)
-        lo = b / blocks_per_job;
-    else
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (jobs[mid].block_base <= b) lo = mid; else hi = mid;
-        }
-    const uint32_t ji = uniform(lo);
-    const Job &job = jobs[ji];
-    if (job.c != C || !(job.flags & kJobDirect)) return;
-    encode_direct_block<C>(job, states[ji], b - job.block_base, rows_out, local, look, look_grp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2117,10 +1650,8 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(const Job *jobs, JobSt
     const int32_t db = sat(data_begin - range_begin), de = sat(data_end - range_begin); // bytes
     gptr_cu8 base = to_global<gptr_cu8>(job.out) + range_begin;
 
-    // direct placement (encode_direct_kernel): a compressed image's bits are in the file already -- this kernel reads them back for the
-    // CRC (crc_kernel's arithmetic: every piece of the data comes from the file, nothing is gathered); stored outcomes as always
     const bool compressed = uniform(st.mode) == 0u;
-    const bool gather = compressed && !(job.flags & kJobDirect);
+    const bool gather = compressed; // (a band that is to be stored gathers nothing: its bytes are in place, only the CRC is taken)
     if (!compressed && job.whole_png && adler_parts) { // the image fell back to stored blocks: this workgroup writes its range of them
         const size_t slot = (size_t)blockIdx.y * max_crc_blocks + blockIdx.x;
         assemble_stored(job, st, range_begin, range_bytes, db, de, tab, red, tabs, &partials[slot], &adler_parts[2 * slot]);
@@ -2730,32 +2261,6 @@ __global__ __launch_bounds__(kWave) void build_dynamic_kernel(const Job *jobs, u
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// PMC calibration kernels (instrumentation only): stream a buffer of known size with the access
-// widths the encoder uses, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be converted to bytes
-// on gfx950 (MI355X_MICROARCH.md, HBM section: the counters are not in bytes for every width).
-// ---------------------------------------------------------------------------------------------
-template <typename T> __global__ __launch_bounds__(kBlock) void calib_read_kernel(const T *src, size_t n, uint32_t *sink)
-{
-    uint32_t acc = 0;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        if constexpr (sizeof(T) == 16)
-            acc ^= src[i].x ^ src[i].w;
-        else
-            acc ^= (uint32_t)src[i];
-    }
-    if (acc == 0x12345678u) *sink = acc; // keep the loads alive
-}
-template <typename T> __global__ __launch_bounds__(kBlock) void calib_write_kernel(T *dst, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        if constexpr (sizeof(T) == 16)
-            dst[i] = make_uint4((uint32_t)i, 1, 2, 3);
-        else
-            dst[i] = (T)i;
-    }
-}
-
 // Table training, per image of the corpus (one wave each): its histogram adjusted to 16 bits as it enters the reference's block
 // writer (fpng.cpp:868-907 with lit_freq[256] = 1; summed at :751-755, BEFORE the end-of-block count is forced to 1).
 __global__ __launch_bounds__(kWave) void train_accumulate_kernel(const uint32_t *hist_all, unsigned long long *sums)
@@ -2795,20 +2300,9 @@ void launch_hist_first(hipStream_t s, const Job &job, Job *d_job, uint32_t *hist
     arg.job = job;
     hipLaunchKernelGGL(hist_first_kernel, dim3((job.nrows + kHistWaves - 1) / kHistWaves, 1, 1), dim3(kHistBlock), 0, s, arg, d_job, hist);
 }
-void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states, unsigned long long *look,
-                 unsigned long long *look_grp, const uint32_t *local)
+void launch_scan(hipStream_t s, const Job *jobs, uint32_t n_jobs, const RowInfo *rows, uint64_t *row_off, JobState *states)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states, look, look_grp, local);
-}
-void launch_encode_direct(hipStream_t s, const Job *jobs, uint32_t n_jobs, uint32_t total_blocks, uint32_t blocks_per_job, uint32_t chan_mask, RowInfo *rows, JobState *states,
-                          uint32_t *local, unsigned long long *look, unsigned long long *look_grp)
-{
-    // whole rounds of 8 runs of kDirectGroupBlocks workgroups (direct_block_order)
-    const uint32_t round = 8u * kDirectGroupBlocks, grid = (total_blocks + round - 1) / round * round;
-    if (chan_mask & 1u)
-        hipLaunchKernelGGL(encode_direct_kernel<3>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look, look_grp);
-    if (chan_mask & 2u)
-        hipLaunchKernelGGL(encode_direct_kernel<4>, dim3(grid), dim3(kRowBlock), 0, s, jobs, n_jobs, total_blocks, blocks_per_job, rows, states, local, look, look_grp);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_jobs), dim3(kScanBlock), 0, s, jobs, rows, row_off, states);
 }
 void launch_build_dynamic(hipStream_t s, const Job *jobs, uint32_t n_jobs, const uint32_t *hist, TokenTable *tables, uint32_t rezero)
 {
@@ -2861,14 +2355,6 @@ void launch_train_accumulate(hipStream_t s, const uint32_t *hist_all, uint32_t n
 void launch_or_piece(hipStream_t s, uint8_t *dst, const uint8_t *src)
 {
     hipLaunchKernelGGL(or_piece_kernel, dim3(1), dim3(4), 0, s, (uint32_t *)dst, (const uint32_t *)src);
-}
-void launch_calibration(hipStream_t s, int write, uint32_t width, void *buf, size_t bytes, uint32_t *sink)
-{
-    const dim3 grid(256 * 32), block(kBlock); // (every wave slot of the chip taken: the write stream needs that to reach its rate)
-    if (!write && width == 4) hipLaunchKernelGGL(calib_read_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)buf, bytes / 4, sink);
-    if (!write && width == 16) hipLaunchKernelGGL(calib_read_kernel<uint4>, grid, block, 0, s, (const uint4 *)buf, bytes / 16, sink);
-    if (write && width == 4) hipLaunchKernelGGL(calib_write_kernel<uint32_t>, grid, block, 0, s, (uint32_t *)buf, bytes / 4);
-    if (write && width == 16) hipLaunchKernelGGL(calib_write_kernel<uint4>, grid, block, 0, s, (uint4 *)buf, bytes / 16);
 }
 
 } // namespace fpng_amd

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FPNG_AMD_ABI_VERSION 4
+#define FPNG_AMD_ABI_VERSION 5
 
 /* ---- status codes ---- */
 #define FPNG_AMD_OK 0
@@ -106,19 +106,20 @@ uint32_t fpng_amd_adler32_combine(uint32_t adler_x, uint32_t adler_y, uint64_t l
  * reference src/fpng.cpp:1747, + container).  d_out capacities must be >= this. */
 size_t fpng_amd_max_encoded_size(uint32_t w, uint32_t h, uint32_t num_chans);
 
-/* ---- environment knobs (read once per process, for A/B measurements; the defaults are the measured optimum):
- *      FPNG_AMD_LANES=1..4          internal streams that take submissions in turn (default 2; 1 serialises everything)
+/* ---- environment knobs (read once per process; the defaults are the measured optimum; INTEGRATION.md section 8 has the table):
+ *      FPNG_AMD_KEEP_HW_QUEUES=1    the library's constructor leaves GPU_MAX_HW_QUEUES alone (fpng_amd_runtime_info above)
+ *      FPNG_AMD_LANES=1..8          internal streams that take submissions in turn (default: 4 over eight hardware queues, else 2;
+ *                                   1 serialises everything); read when an encoder is created
  *      FPNG_AMD_LOCAL_LIMIT_MB=n    cap on the scratch for the rows' local streams (default 98304); a submission that would
  *                                   need more is refused with FPNG_AMD_ERR_OUT_OF_MEMORY before anything is launched
  *      FPNG_AMD_STAGGER=0|1         2-pass: make a submission's row walk wait for the previous submission's walk
- *                                   (default: on for FPNG_AMD_ENCODE_SLOWER, off otherwise)
- *      FPNG_AMD_JOB_IN_ARGS=0|1     a submission of ONE image hands its job record to the first kernel (each pass) in the kernel
- *                                   arguments instead of uploading it in front of the chain (default 1; 0 = upload as always)
- *      FPNG_AMD_ALWAYS_ORDER=1      put the marker / barrier packets that order a submission behind the caller's stream and behind the
- *                                   scratch set's previous user in front of EVERY chain (default: only when those are still busy)
+ *                                   (default: on for FPNG_AMD_ENCODE_SLOWER with two lanes, off otherwise)
  *      FPNG_AMD_HOST_BANDS=n        fpng_amd_encode_host(): row bands of the streamed upload/encode/download pipeline for every
  *                                   1-pass frame (default: by image size, for page-locked or previously seen buffers; 1 = serial)
- *      FPNG_AMD_TRACE=1             fpng_amd_encode_host(): per-band timeline of the streamed path on stderr ---- */
+ *      FPNG_AMD_DECODE_CPU=1        fpng::fpng_decode_memory never uses the GPU decoder
+ *      FPNG_AMD_DECODE_MAX_ROUNDS=n synchronisation rounds before a file is reported FPNG_AMD_DECODE_UNDECIDED (default 64)
+ *      FPNG_AMD_DECODE_STREAM=0     fpng_amd_decode_host(): upload, decode, download one after the other
+ *      FPNG_AMD_TRACE=1             timelines of the streamed host paths, the sharded path and the decoder on stderr ---- */
 
 /* ---- encoder object: the caller's HIP stream (ordering point) + two internal streams ("lanes") with
  *      reusable device scratch.  Not thread-safe; create one per thread (the reference is re-entrant,
@@ -464,10 +465,6 @@ int fpng_amd_decode_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_D
  * that build_dynamic_kernel left at the head of lane `lane`'s histogram scratch (dst[7] = 0xFEED selects the second page:
  * the phases inside the table builder). */
 int fpng_amd_debug_peek(fpng_amd_encoder *enc, int lane, uint32_t *dst, uint32_t n_words);
-
-/* PMC calibration (instrumentation): stream `bytes` of d_buf once with 4- or 16-byte lanes, reading
- * (write=0) or writing (write=1), so rocprofv3 FETCH_SIZE/WRITE_SIZE can be converted to bytes. */
-int fpng_amd_calibration_stream(fpng_amd_encoder *enc, int write, uint32_t lane_bytes, void *d_buf, size_t bytes);
 
 #ifdef __cplusplus
 }

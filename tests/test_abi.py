@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fpng_amd.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert lib.fpng_amd_abi_version() == 4
+    assert lib.fpng_amd_abi_version() == 5
 
 
 def test_format_tables_self_check(built_lib):

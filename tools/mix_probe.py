@@ -4,8 +4,9 @@
 reads and writes on two streams at once, and compare with the step's 0.47 ms."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, fpng_amd
-enc = fpng_amd.Encoder(device=0, stream="torch")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import torch
+from stream_probe import stream as probe  # (tools/probes/stream_probe.hip; runs on torch's current stream)
 R, W = 1_621_500_000 // 16 * 16, 941_900_000 // 16 * 16
 rbuf = torch.zeros(R, dtype=torch.uint8, device="cuda")
 wbuf = torch.zeros(W, dtype=torch.uint8, device="cuda")
@@ -15,9 +16,9 @@ def run(do_r, do_w, reps=20):
         if k == 3:
             torch.cuda.synchronize(); t0 = time.perf_counter()
         if do_r:
-            with torch.cuda.stream(s1): enc.calibration_stream(rbuf, 0, 16)
+            with torch.cuda.stream(s1): probe(rbuf, 0, 16)
         if do_w:
-            with torch.cuda.stream(s2): enc.calibration_stream(wbuf, 1, 16)
+            with torch.cuda.stream(s2): probe(wbuf, 1, 16)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 tr, tw, tb = run(1, 0), run(0, 1), run(1, 1)
@@ -44,8 +45,8 @@ t = t_of(both); print(f"torch sum || fill_ ({(R+W)/1e9:.3f} GB): {t:.3f} ms = {(
 N32 = w32.numel()
 t = t_of(lambda: torch.arange(N32, out=w32, dtype=torch.int32)); print(f"torch arange(out=) {W/1e9:.3f} GB written: {t:.3f} ms = {W/t/1e9:.2f} TB/s")
 def w4():
-    enc.calibration_stream(wbuf, 1, 4)
+    probe(wbuf, 1, 4)
 t = t_of(w4); print(f"own write kernel, 4-byte lanes: {t:.3f} ms = {W/t/1e9:.2f} TB/s")
 def w16():
-    enc.calibration_stream(wbuf, 1, 16)
+    probe(wbuf, 1, 16)
 t = t_of(w16); print(f"own write kernel, 16-byte lanes: {t:.3f} ms = {W/t/1e9:.2f} TB/s")

@@ -11,7 +11,6 @@ constexpr uint32_t kDecSubBlock = 512;  // subsequences per workgroup of the syn
 #define FPNG_DEC_LEADIN 128
 #endif
 constexpr uint32_t kDecLeadIn = FPNG_DEC_LEADIN; // bits a subsequence's first decode starts early (decode_core.h: sub_first); a multiple of 32
-constexpr uint32_t kDecEmitThreads = 512; // subsequences per workgroup of dec_emit_kernel (divides kDecSubBlock)
 #ifndef FPNG_DEC_UNF_ROWS
 #define FPNG_DEC_UNF_ROWS 48
 #endif
@@ -24,7 +23,8 @@ struct DecJob {
     uint64_t first_bit;       // first row token (behind the dynamic block header)
     uint64_t end_limit_bit;   // (z_bytes - 4) * 8: no token may start here or later
     const uint32_t *lut;      // device: dec::kLutDwords words (decode_core.h)
-    uint8_t *filt;            // device scratch: the filtered stream, h rows of bpl + 1 bytes (the filter byte first), 16-byte aligned
+    uint32_t *win;            // device scratch: h x dec_col_blocks() words, the file's subsequence (counted from its first one) in whose output
+                              // each window of dec_unfilter_kernel's tiles begins (decode_core.h: Window); 0xFFFFFFFF: none
     uint8_t *out;             // device: w * h * dst_c pixels
     uint32_t *segsum;         // device scratch: nseg x ceil(bpl / 4) 8-byte granules {tag, column sum} of dec_unfilter_kernel's look-back
     uint32_t w, h, src_c, dst_c, bpl;
@@ -47,10 +47,17 @@ inline uint32_t dec_col_blocks(uint32_t w, uint32_t src_c, uint32_t dst_c)
     return (src_c == 3 && dst_c == 4) ? (w + 255u) / 256u : ((w * src_c + 3u) / 4u + 255u) / 256u;
 }
 
+// bytes of a row that one column block covers (the first one also holds the row's filter byte: decode_core.h, Window)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t dec_col_block_bytes(uint32_t src_c, uint32_t dst_c) { return (src_c == 3 && dst_c == 4) ? 768u : 1024u; }
+
 struct DecBlockRec {
     uint32_t sum;           // output bytes of its subsequences
     uint32_t first_eob;     // first one that met an end-of-block symbol
     uint32_t first_invalid; // first one whose decode derailed
+    uint32_t first_overflow; // first one that needed more records than it has room for (decode_core.h: kRecCap)
     uint32_t entry_rel;     // where its first subsequence starts, in bits behind the workgroup's first nominal bit
     uint32_t exit_rel;      // where its last subsequence ends, in bits behind the next workgroup's first nominal bit
     uint32_t want_rel;      // dec_chain_kernel: where its first subsequence must start (kDecWantUnknown: ask the workgroup in front)
@@ -99,6 +106,8 @@ struct DecSubArrays {
     uint32_t *tail;   // last four literal bytes
     uint32_t *rel;    // output offset inside its workgroup (exclusive scan of bytes)
     uint32_t *lastpx; // the four literal bytes in front of it
+    uint32_t *eob;    // where its end-of-block symbol ends, in bits behind its nominal first bit (subsequences flagged kSubEob)
+    uint32_t *tok;    // its token records (decode_core.h: rec_chunk_base)
 };
 
 // the kernels work on the workgroups [first_block, first_block + n_blocks) of the batch's subsequences (one group of files);
@@ -113,10 +122,17 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
 // ONE file (jobs[0], a DEVICE pointer whose sub_base the caller knows: passed as first_block of the other launchers), blocks [blk_a, blk_b)
 void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_base_block, uint32_t blk_a, uint32_t blk_b, bool final_piece, uint32_t total_subs, DecSubArrays a,
                               const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry);
+// What the pass that writes the pixels needs of the synchronisation's results: the per-subsequence arrays, the workgroups' output offsets,
+// every file's last subsequence (the one with the stream's end-of-block symbol; sub_limit: subsequences of a file that arrives in
+// pieces which have been placed so far, else 0xFFFFFFFF)
+struct DecPlaced {
+    DecSubArrays a;
+    const uint64_t *block_off;
+    const uint32_t *eob_index; // per file of the launch's `jobs`
+    uint32_t sub_limit;
+};
 // concurrent_status: kernels that may set the file's status bits run next to this launch (no workgroup may then skip its file: dec_unfilter_kernel)
-void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status);
-void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
-                     const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status);
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored);
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status);
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, DecPlaced placed, uint32_t *status, uint32_t epoch, bool any_stored);
 
 } // namespace fpng_amd

@@ -43,7 +43,6 @@ using namespace dec;
 constexpr int kWave = 64;
 constexpr int kDecBlock = 256;
 constexpr int kSubBlock = (int)kDecSubBlock;
-constexpr int kEmitBlock = (int)kDecEmitThreads;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // The token bits a workgroup works on are staged in LDS first (coalesced loads): thread t decodes the kSubBits bits that start
@@ -143,6 +142,28 @@ struct WaveVote {
     }
 };
 
+// ---- token records (decode_core.h): where a subsequence's settling decode leaves what it decoded.  The 64 lanes of a wave write side
+//      by side -- record k of lane l at dword k * 64 + l of the wave's chunk -- and walk in step, so their stores fill whole lines.  What
+//      is not a record (a lookup that was no plain token: the lanes' code is straight-line) goes to the column's spare row. ----
+typedef __attribute__((address_space(1))) uint32_t gu32;
+struct TokOut {
+    gu32 *col; // the subsequence's record 0
+    uint32_t k = 0;
+    __device__ __forceinline__ void put(uint32_t r, bool en)
+    {
+        const uint32_t row = en ? (k < kRecCap ? k : kRecCap) : kRecCap;
+        col[row * kRecLane] = r;
+        k += en ? 1u : 0u;
+    }
+    __device__ __forceinline__ uint32_t count() const { return k; }
+};
+__device__ __forceinline__ TokOut tok_of(uint32_t *tok, uint32_t g)
+{
+    TokOut o;
+    o.col = (gu32 *)(uintptr_t)(tok + rec_chunk_base(g));
+    return o;
+}
+
 // ---- phase maps (decode_core.h) across the threads of a workgroup ----
 __device__ __forceinline__ PhaseMap pm_shfl_up(const PhaseMap &v, int o)
 {
@@ -205,13 +226,13 @@ constexpr uint32_t kSyncDwords = kSubBlock * (kSubBits / 32) + kDecLeadIn / 32 +
 // in its record), and taken up by round 1.  CAND = true: the border rounds -- few workgroups have anything to do in them -- also
 // know the candidate lists.
 template <bool CAND>
-__global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
+__global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void dec_sync_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, uint32_t round,
                                                              DecSubArrays a, DecBlockRec *recs, uint32_t *changed, uint32_t *multi)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
     __shared__ uint32_t bits[slice_slots(kSyncDwords)];
     __shared__ uint32_t s_end[kSubBlock];
-    __shared__ uint32_t red3[3 * (kSubBlock / kWave)];
+    __shared__ uint32_t red3[4 * (kSubBlock / kWave)];
     __shared__ PhaseMap wtail[kSubBlock / kWave + 1];
 #if FPNG_DEC_PAD_LDS // occupancy probe (build variant): LDS nobody uses, so that fewer workgroups share a compute unit
     __shared__ uint32_t pad_lds[FPNG_DEC_PAD_LDS / 4];
@@ -278,16 +299,18 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
         const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
         SubState st;
         st.start = st.end = nominal;
-        st.c.bytes = st.c.lits = st.c.tail = st.c.flags = 0;
+        st.c.bytes = st.c.lits = st.c.tail = st.c.flags = st.c.eob = 0, st.nrec = 0;
         bool dirty = false;
         if (valid) {
             if (!round) {
-                sub_first<VoteAlone>(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st);
+                TokOut rec = tok_of(a.tok, g);
+                sub_first<VoteAlone>(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st, rec);
                 dirty = true;
             } else {
                 const uint32_t v = a.info[g];
-                st.start = nominal + info_start(v), st.end = boundary + info_end(v);
+                st.start = nominal + info_start(v), st.end = boundary + info_end(v), st.nrec = info_nrec(v);
                 st.c.bytes = a.bytes[g], st.c.lits = info_lits(v), st.c.tail = a.tail[g], st.c.flags = info_flags(v);
+                st.c.eob = (st.c.flags & kSubEob) ? nominal + a.eob[g] : 0u;
             }
         }
         want0 += nominal; // (thread 0's nominal: the block's first)
@@ -312,15 +335,16 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             }
             const bool cand_now = CAND && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
             if (!cand_now) {
-                // The threads that must be corrected: 0.04 % of a gradient's subsequences (one in every fifth workgroup: corrected where
-                // it is, both decodes stepped until they meet -- a few tokens), 2 % of a photograph's, more on flat content -- some lane
+                // The threads that must be corrected: 0.04 % of a gradient's subsequences (one in every fifth workgroup: decoded again where
+                // it is, its records written again), 2 % of a photograph's, more on flat content -- some lane
                 // of nearly every wave then, and eight waves each wait for a lane or two.  From kGatherMin of them on they are GATHERED:
                 // their slots are numbered over the workgroup, wave 0 decodes 64 of them per pass, the owners take the results back.
                 // (Measured, 8 x 8K grad / 8 x 11 MP photograph / 8 x 8K stripes, sync ms: in place 0.80 / 0.81 / 0.25; all gathered
                 //  and decoded again 1.01 / 0.65 / 0.13; all gathered and stepped until they meet 1.02 / 1.06 / 0.40.)
                 if (n_need < kGatherMin) {
                     if (need) {
-                        sub_refix<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st);
+                        TokOut rec = tok_of(a.tok, g);
+                        sub_redo<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st, rec);
                         s_end[t] = st.end;
                         dirty = true;
                     }
@@ -346,15 +370,16 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
                         uint32_t *q = redo[t];
                         const uint32_t v = q[0], ot = v >> 5, o_nominal = nominal - t * kSubBits + ot * kSubBits; // (this thread's nominal -> the owner's)
                         SubState r;
-                        sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r);
-                        q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c), q[2] = r.c.bytes, q[3] = r.c.tail;
+                        TokOut rec = tok_of(a.tok, g - t + ot); // (the owner's column: lanes of this pass write to columns of any wave's chunk)
+                        sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r, rec);
+                        q[0] = r.c.eob - o_nominal, q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c, r.nrec), q[2] = r.c.bytes, q[3] = r.c.tail;
                     }
                     __syncthreads();
                     if (mine) {
                         const uint32_t *q = redo[slot - base_slot];
                         const uint32_t v = q[1];
-                        st.start = want, st.end = boundary + info_end(v);
-                        st.c.bytes = q[2], st.c.lits = info_lits(v), st.c.tail = q[3], st.c.flags = info_flags(v);
+                        st.start = want, st.end = boundary + info_end(v), st.nrec = info_nrec(v);
+                        st.c.bytes = q[2], st.c.lits = info_lits(v), st.c.tail = q[3], st.c.flags = info_flags(v), st.c.eob = nominal + q[0];
                         dirty = true;
                     }
                 }
@@ -379,7 +404,8 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
                 const uint32_t start0 = wtail[kSubBlock / kWave].w[0];
                 const uint32_t srel = (valid && t) ? pm_at(gp, start0) : kPhaseUnknown;
                 if (srel != kPhaseUnknown && nominal + srel != st.start) {
-                    sub_redo<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st);
+                    TokOut rec = tok_of(a.tok, g0 + t); // (`g` is the composed map here)
+                    sub_redo<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st, rec);
                     dirty = true;
                 }
                 __syncthreads();
@@ -390,28 +416,31 @@ __global__ __launch_bounds__(kSubBlock, FPNG_DEC_WGS) void dec_sync_kernel(const
             }
         }
         if (dirty && valid) {
-            a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c);
+            a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c, st.nrec);
             a.bytes[g] = st.c.bytes;
             a.tail[g] = st.c.tail;
+            if (st.c.flags & kSubEob) a.eob[g] = st.c.eob - nominal;
         }
         const bool any_dirty = __syncthreads_or(dirty);
         if (!any_dirty) continue;
         // the block's byte count and its first end-of-block / invalid subsequences: wave reductions, then ONE meeting in LDS
         uint32_t sum = valid ? st.c.bytes : 0u;
         uint32_t e = (valid && (st.c.flags & kSubEob)) ? t : (uint32_t)kSubBlock, inv = (valid && (st.c.flags & kSubInvalid)) ? t : (uint32_t)kSubBlock;
+        uint32_t ovf = (valid && (st.c.flags & kSubOverflow)) ? t : (uint32_t)kSubBlock;
 #pragma unroll
         for (int o = 32; o; o >>= 1) {
             sum += (uint32_t)__shfl_xor((int)sum, o, kWave);
             e = min(e, (uint32_t)__shfl_xor((int)e, o, kWave));
             inv = min(inv, (uint32_t)__shfl_xor((int)inv, o, kWave));
+            ovf = min(ovf, (uint32_t)__shfl_xor((int)ovf, o, kWave));
         }
-        if ((t & 63) == 0) red3[(t >> 6) * 3] = sum, red3[(t >> 6) * 3 + 1] = e, red3[(t >> 6) * 3 + 2] = inv;
+        if ((t & 63) == 0) red3[(t >> 6) * 4] = sum, red3[(t >> 6) * 4 + 1] = e, red3[(t >> 6) * 4 + 2] = inv, red3[(t >> 6) * 4 + 3] = ovf;
         __syncthreads();
         if (t == 0) {
-            sum = 0, e = inv = (uint32_t)kSubBlock;
-            for (int q = 0; q < kSubBlock / kWave; q++) sum += red3[q * 3], e = min(e, red3[q * 3 + 1]), inv = min(inv, red3[q * 3 + 2]);
+            sum = 0, e = inv = ovf = (uint32_t)kSubBlock;
+            for (int q = 0; q < kSubBlock / kWave; q++) sum += red3[q * 4], e = min(e, red3[q * 4 + 1]), inv = min(inv, red3[q * 4 + 2]), ovf = min(ovf, red3[q * 4 + 3]);
             DecBlockRec r;
-            r.sum = sum, r.first_eob = e, r.first_invalid = inv;
+            r.sum = sum, r.first_eob = e, r.first_invalid = inv, r.first_overflow = ovf;
             r.entry_rel = st.start - nominal;
             r.exit_rel = s_end[kSubBlock - 1] - (nominal + (uint32_t)kSubBlock * kSubBits); // (a block with fewer subsequences is its file's last)
             const uint32_t known = pm_count(bmap);
@@ -486,8 +515,15 @@ __global__ __launch_bounds__(kDecBlock) void dec_chain_kernel(const DecJob *jobs
 //      behind it is padding and the Adler-32, decoded as garbage by their threads); up to there the chain must hold across the
 //      workgroups' borders and no subsequence may be invalid; exclusive scan of the workgroups' byte counts; the total must be
 //      the filtered image ----
-__global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jobs, const DecBlockRec *recs, const uint32_t *bytes, uint64_t *block_off, uint32_t *status,
-                                                                uint32_t *eob_index)
+// the stream must end 4 bytes (the Adler-32) before the IDAT does: eob_rel = where the end-of-block symbol of the file's subsequence
+// `sub` ends, in bits behind that subsequence's nominal first bit (reference src/fpng.cpp:2331-2340)
+__device__ __forceinline__ uint32_t eob_status(const DecJob &job, uint32_t sub, uint32_t eob_rel)
+{
+    const uint64_t end_bit = job.first_bit + (uint64_t)sub * kSubBits + eob_rel;
+    return kDecSawEob | ((((end_bit + 7) >> 3) + 4 != job.z_bytes) ? kDecBadStream : 0u);
+}
+__global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jobs, const DecBlockRec *recs, const uint32_t *bytes, const uint32_t *eob_rel, uint64_t *block_off,
+                                                                uint32_t *status, uint32_t *eob_index)
 {
     __shared__ uint64_t sums[kDecBlock];
     __shared__ uint32_t red[4];
@@ -513,8 +549,11 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
-        } else if (r.first_invalid <= last_local)
-            bad |= kDecBadStream;
+            if (r.first_overflow < (uint32_t)kSubBlock) bad |= kDecStalled; // (more records than a subsequence has room for: the CPU decoder's file)
+        } else {
+            if (r.first_invalid <= last_local) bad |= kDecBadStream;
+            if (r.first_overflow <= last_local) bad |= kDecStalled;
+        }
     }
     uint32_t tail = 0;
     if (last_blk < nb) {
@@ -524,6 +563,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
     const uint32_t tail_sum = block_sum<kDecBlock / kWave>(tail, red);
     const uint32_t any_bad = block_sum<kDecBlock / kWave>(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
     const uint32_t any_bad2 = block_sum<kDecBlock / kWave>(bad & kDecBadStream, red) ? kDecBadStream : 0u;
+    const uint32_t any_bad3 = block_sum<kDecBlock / kWave>(bad & kDecStalled, red) ? kDecStalled : 0u;
     sums[t] = local;
     __syncthreads();
     if (t == 0) {
@@ -533,8 +573,9 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
             sums[k] = acc;
             acc += v;
         }
-        uint32_t st = any_bad | any_bad2;
+        uint32_t st = any_bad | any_bad2 | any_bad3;
         if (acc + tail_sum != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
+        if (last_blk < nb) st |= eob_status(job, last_blk * kSubBlock + last_local, eob_rel[job.sub_base + last_blk * kSubBlock + last_local]);
         if (st) atomicOr(&status[blockIdx.x], st);
         eob_index[blockIdx.x] = last_blk < nb ? last_blk * kSubBlock + last_local : n;
     }
@@ -549,7 +590,8 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_kernel(const DecJob *jo
 // ---- the same for a file that arrives in pieces (fpng_amd_decode_host's streamed form): the blocks [blk_a, blk_b) of ONE file, on top
 //      of what the pieces in front left in `carry`; `final`: the file's last piece (a stream that has not ended by then never does) ----
 __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJob *jobs, uint32_t blk_a, uint32_t blk_b, uint32_t final_piece, const DecBlockRec *recs,
-                                                                      const uint32_t *bytes, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry)
+                                                                      const uint32_t *bytes, const uint32_t *eob_rel, uint64_t *block_off, uint32_t *status, uint32_t *eob_index,
+                                                                      DecCarry *carry)
 {
     __shared__ uint64_t sums[kDecBlock];
     __shared__ uint32_t red[4];
@@ -575,8 +617,11 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
         if (b < last_blk) {
             local += r.sum;
             if (r.first_invalid < (uint32_t)kSubBlock) bad |= kDecBadStream;
-        } else if (r.first_invalid <= last_local)
-            bad |= kDecBadStream;
+            if (r.first_overflow < (uint32_t)kSubBlock) bad |= kDecStalled;
+        } else {
+            if (r.first_invalid <= last_local) bad |= kDecBadStream;
+            if (r.first_overflow <= last_local) bad |= kDecStalled;
+        }
     }
     uint32_t tail = 0;
     if (last_blk < nb) {
@@ -586,6 +631,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
     const uint32_t tail_sum = block_sum<kDecBlock / kWave>(tail, red);
     const uint32_t any_bad = block_sum<kDecBlock / kWave>(bad & kDecNotConverged, red) ? kDecNotConverged : 0u;
     const uint32_t any_bad2 = block_sum<kDecBlock / kWave>(bad & kDecBadStream, red) ? kDecBadStream : 0u;
+    const uint32_t any_bad3 = block_sum<kDecBlock / kWave>(bad & kDecStalled, red) ? kDecStalled : 0u;
     sums[t] = local;
     __syncthreads();
     if (t == 0) {
@@ -595,11 +641,12 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
             sums[k] = acc;
             acc += v;
         }
-        uint32_t st = any_bad | any_bad2;
+        uint32_t st = any_bad | any_bad2 | any_bad3;
         DecCarry out = in;
         out.bytes = acc + tail_sum;
         if (last_blk < nb) {
             if (out.bytes != (uint64_t)(job.bpl + 1) * job.h) st |= kDecBadStream; // too few or too many pixels
+            st |= eob_status(job, (blk_a + last_blk) * kSubBlock + last_local, eob_rel[job.sub_base + (blk_a + last_blk) * kSubBlock + last_local]);
             eob_index[0] = (blk_a + last_blk) * kSubBlock + last_local;
             out.done = 1;
         } else if (out.bytes > (uint64_t)(job.bpl + 1) * job.h)
@@ -617,7 +664,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_offsets_range_kernel(const DecJ
 
 // ---- dec_subscan_kernel, one workgroup per kDecSubBlock subsequences ----
 __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t total_subs, DecSubArrays a,
-                                                                const uint32_t *status, const uint32_t *eob_index)
+                                                                const uint64_t *block_off, const uint32_t *status, const uint32_t *eob_index)
 {
     __shared__ uint32_t wsum[kSubBlock / kWave];
     const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
@@ -646,103 +693,82 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     const uint32_t *info = a.info + job.sub_base, *tail = a.tail + job.sub_base;
     a.lastpx[g] = lookback_lastpx(
         i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
+    // the windows of dec_unfilter_kernel's tiles whose first byte this subsequence writes: their walk over the records starts here
+    const uint32_t ncb = dec_col_blocks(job.w, job.src_c, job.dst_c), cbw = dec_col_block_bytes(job.src_c, job.dst_c);
+    uint32_t *win = job.win;
+    for_windows_starting_in(block_off[blk] + before, nb, cbw, ncb, job.bpl + 1, job.h, [&](uint32_t y, uint32_t cb) { win[(size_t)y * ncb + cb] = i; });
 }
 
-// ---- the real decode ----
-constexpr uint32_t kEmitDwords = kEmitBlock * (kSubBits / 32) + 8; // (a thread may decode a few tokens into the next workgroup's bits)
-typedef uint32_t __attribute__((aligned(1))) u32_any_t;
+// ---- the pass that writes.  A tile of dec_unfilter_kernel = kUnfRows rows x one block of columns; every row piece ("window",
+//      decode_core.h) is filled in LDS from the token records of the subsequences that cover it: eight threads per row, thread k of
+//      them walks the k-th, (k + 8)-th ... subsequence from the one the window begins in (dec_subscan_kernel left its number), a
+//      record per step, eight records in flight per thread.  A subsequence that straddles two windows is walked for both. ----
+constexpr uint32_t kTilePitch = 1040; // bytes of LDS per row: 3 unused, the filter byte (first column block only), 1024 (768) data bytes, slack
+constexpr uint32_t kRowThreads = 8;   // threads that share a window
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef __attribute__((address_space(3))) u32_any_t lds_u32_any;
-struct StreamSink {
-    __attribute__((address_space(1))) uint32_t *f; // the file's filtered stream (global_store, not flat_store: a flat store also counts as an LDS operation in flight)
-    uint32_t fill_g0 = 0, fill_n = 0, fill_d0 = 0, fill_d1 = 0, fill_d2 = 0; // this thread's long run, waiting for the wave (StreamWriter::run4 / run3)
-    __device__ __forceinline__ void fill(uint32_t g0, uint32_t groups, uint32_t d0, uint32_t d1, uint32_t d2) { fill_g0 = g0, fill_n = groups, fill_d0 = d0, fill_d1 = d1, fill_d2 = d2; }
-    static __device__ __forceinline__ bool any(bool x) { return __ballot(x) != 0; }
-    // The waiting runs, one after the other, each by all threads of the wave that are here: thread k of them stores the groups
-    // k, k + n, ... -- 16 consecutive bytes per thread, a kilobyte per instruction.
-    __device__ __forceinline__ void cooperate()
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct TileRow {
+    lds_u8 *p; // window byte 0
+    __device__ __forceinline__ void put8(uint32_t pos, uint32_t b) { p[pos] = (uint8_t)b; }
+    // bytes [lo, hi) = copies of the C-byte pixel px, byte lo being its byte q: bytes up to a dword boundary, whole dwords (the
+    // pixel rotated: 4 channels one constant, 3 channels a cycle of three), bytes
+    template <int C> __device__ __forceinline__ void fill_c(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
     {
-        uint64_t waiting = __ballot(fill_n != 0);
-        if (!waiting) return;
-        const uint64_t here = __ballot(true);
-        const uint32_t me = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)), n_here = (uint32_t)__popcll(here);
-        do {
-            const int l = __ffsll((unsigned long long)waiting) - 1;
-            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)fill_g0, l), n = (uint32_t)__builtin_amdgcn_readlane((int)fill_n, l);
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d0, l), d1 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d1, l), d2 = (uint32_t)__builtin_amdgcn_readlane((int)fill_d2, l);
-            for (uint32_t i = me; i < n; i += n_here) {
-                const uint32_t m = i % 3u; // the dwords from group g0 on are d0 d1 d2 d0 ...: group i begins with d[4 i % 3] = d[i % 3]
-                const uint32_t a = m == 0 ? d0 : (m == 1 ? d1 : d2), b = m == 0 ? d1 : (m == 1 ? d2 : d0), c = m == 0 ? d2 : (m == 1 ? d0 : d1);
-                store128(g0 + i, a, b, c, a);
-            }
-            waiting &= waiting - 1;
-        } while (waiting);
-        fill_n = 0;
+        const uint64_t wrap = C == 4 ? ((uint64_t)px << 32 | px) : ((uint64_t)(px & 0xFFFFFFu) | (uint64_t)(px & 0xFFFFFFu) << 24 | (uint64_t)px << 48);
+        uint32_t pos = lo;
+        while (pos < hi && (((uint32_t)(uintptr_t)p + pos) & 3u)) {
+            p[pos] = (uint8_t)(wrap >> (8 * q));
+            q = q + 1 == (uint32_t)C ? 0u : q + 1;
+            pos++;
+        }
+        for (; pos + 4 <= hi; pos += 4) {
+            *(lds_u32 *)(p + pos) = (uint32_t)(wrap >> (8 * q));
+            q = C == 4 ? q : (q + 1 == 3u ? 0u : q + 1); // (four bytes on: the same place in a 4-byte pixel, one further in a 3-byte one)
+        }
+        for (; pos < hi; pos++) {
+            p[pos] = (uint8_t)(wrap >> (8 * q));
+            q = q + 1 == (uint32_t)C ? 0u : q + 1;
+        }
     }
-#if defined(FPNG_DEC_EMIT_NOSTORE) // diagnostic builds (fpng_amd/build.py --variant): what the stores cost
-    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { asm volatile("" ::"v"(d), "v"(v)); }
-    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { asm volatile("" ::"v"(g), "v"(a), "v"(b), "v"(c), "v"(d)); }
-#elif defined(FPNG_DEC_EMIT_L2STORE) // ... and what they cost when every one of them hits a line that stays in the L2
-    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d & 0x3FFFu] = v; }
-    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g & 0xFFFu] = u32x4{a, b, c, d}; }
-#elif defined(FPNG_DEC_EMIT_NT) // ... with the non-temporal hint
-    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
-    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+    __device__ __forceinline__ void fill(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
     {
-        __builtin_nontemporal_store(u32x4{a, b, c, d}, (__attribute__((address_space(1))) u32x4 *)f + g);
+        if (c4) fill_c<4>(lo, hi, px, q); else fill_c<3>(lo, hi, px, q);
     }
-#else
-    __device__ __forceinline__ void store32(uint32_t d, uint32_t v) { f[d] = v; }
-    __device__ __forceinline__ void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { ((__attribute__((address_space(1))) u32x4 *)f)[g] = u32x4{a, b, c, d}; }
-#endif
+    bool c4;
 };
-
-__global__ __launch_bounds__(kEmitBlock, FPNG_DEC_WGS) void dec_emit_kernel(const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
-                                                              const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
+// the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks
+template <int C>
+__device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced &pl, uint32_t last, uint32_t y0, uint32_t nrows, uint32_t cb, uint32_t ncb, uint32_t cbw, lds_u8 *tile)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
-    __shared__ uint32_t bits[slice_slots(kEmitDwords)];
-#if FPNG_DEC_PAD_LDS
-    __shared__ uint32_t pad_lds[FPNG_DEC_PAD_LDS / 4];
-    if (total_subs == 0xFFFFFFFFu) pad_lds[threadIdx.x] = n_jobs, status_touch(pad_lds);
-#endif
-    const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
-    const uint32_t *staged = nullptr; // (workgroups are persistent: the table is staged when the file's differs from the one in LDS)
-    LdsBits in = {bits};
-    constexpr uint32_t per_sync = kSubBlock / kEmitBlock; // workgroups of this kernel per workgroup of the synchronisation
-    for (uint32_t bi = blockIdx.x; bi < n_blocks * per_sync; bi += gridDim.x) {
-        const uint32_t g0 = first_block * kSubBlock + bi * kEmitBlock;
-        if (g0 >= total_subs) break;
-        uint32_t local0;
-        const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
-        const uint32_t job_index = (uint32_t)(&job - jobs);
-        if (status[job_index] & ~kDecSawEob) continue; // (uniform: one file per workgroup)
-        const uint32_t last = eob_index[job_index];
-        if (local0 > last) continue; // behind the end of the stream
-        const uint32_t g = g0 + threadIdx.x, i = local0 + threadIdx.x;
-        const bool active = i < job.n_sub && i <= last;
-        const uint64_t nominal0 = job.first_bit + (uint64_t)local0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
-        __syncthreads(); // (the previous block's LDS is free)
-        if (staged != job.lut) stage_lut(job, lut, kEmitBlock), staged = job.lut;
-        stage_bits(job, d0, kEmitDwords, bits, kEmitBlock);
-        __syncthreads();
-        // (threads without a subsequence come along with nothing to write: they help with their wave's long runs)
-        const uint32_t nominal = (uint32_t)(nominal0 - base) + threadIdx.x * kSubBits;
-        const uint32_t stride = job.bpl + 1;
-        const uint64_t off = active ? block_off[g / kSubBlock] + a.rel[g] : 0ull;
-        const uint32_t col = (uint32_t)(off % stride), own = active ? a.bytes[g] : 0u;
-        const bool is_last = active && i == last;
-        const uint32_t pad = (is_last || !active) ? 0u : (0u - ((uint32_t)off + own)) & 15u; // bytes of the following subsequences that complete the last 16-byte group
-        StreamSink sink;
-        sink.f = (__attribute__((address_space(1))) uint32_t *)(uintptr_t)job.filt;
-        uint32_t eob_end = 0;
-        const uint32_t p0 = nominal + (active ? info_start(a.info[g]) : 0u), lastpx = active ? a.lastpx[g] : 0u;
-        uint32_t err = job.src_c == 4 ? walk_emit<4>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end)
-                                      : walk_emit<3>(in, lut, lenof, p0, own, pad, is_last, off, col, lastpx, stride, sink, eob_end);
-        // end of block: the stream must end 4 bytes (the Adler-32) before the IDAT does
-        if ((err & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != job.z_bytes) err |= kDecBadStream;
-        if (err) atomicOr(&status[job_index], err);
+    const uint32_t stride = job.bpl + 1;
+    uint32_t err = 0;
+    for (uint32_t q = threadIdx.x; q < nrows * kRowThreads; q += kDecBlock) {
+        const uint32_t r = q / kRowThreads, k0 = q % kRowThreads;
+        const Window w = window_of(y0 + r, cb, cbw, stride);
+        const uint32_t i0 = job.win[(size_t)(y0 + r) * ncb + cb];
+        if (i0 == 0xFFFFFFFFu) continue; // (a stream that does not cover the image: its status says so)
+        TileRow out;
+        out.p = tile + r * kTilePitch + (cb ? 4u : 3u);
+        out.c4 = C == 4;
+        for (uint32_t i = i0 + k0; i <= last && i < pl.sub_limit; i += kRowThreads) {
+            const uint32_t g = job.sub_base + i;
+            const uint64_t off = pl.block_off[g / kSubBlock] + pl.a.rel[g];
+            if (off >= w.ws + w.wlen) break; // (offsets rise: nothing further on reaches into the window)
+            PlaceState st;
+            st.c = (int32_t)(int64_t)(off - w.ws), st.lastpx = pl.a.lastpx[g], st.err = 0;
+            const uint32_t nrec = min(info_nrec(pl.a.info[g]), kRecCap);
+            const gu32 *col = (const gu32 *)(uintptr_t)(pl.a.tok + rec_chunk_base(g));
+            for (uint32_t k = 0; k < nrec && st.c < (int32_t)w.wlen; k += 8) {
+                uint32_t rr[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) rr[j] = k + j < nrec ? col[(k + j) * kRecLane] : 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) place_one<C>(rr[j], st, w, stride, out);
+            }
+            err |= st.err;
+        }
     }
+    return err;
 }
 
 // ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256), every row read ONCE.  One workgroup per kDecBlock dword
@@ -786,10 +812,11 @@ __device__ __forceinline__ uint32_t gload_u32(const gu8 *base, uint32_t off) { r
 __device__ __forceinline__ void gstore_u32(gu8 *base, uint32_t off, uint32_t v) { *(gu32_any *)(scalar_base(base) + off) = v; }
 __device__ __forceinline__ void gstore_u8(gu8 *base, uint32_t off, uint32_t v) { scalar_base(base)[off] = (uint8_t)v; }
 #ifndef FPNG_DEC_UNF_WAVES
-#define FPNG_DEC_UNF_WAVES 4
+#define FPNG_DEC_UNF_WAVES 3
 #endif
-__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
+__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kUnfRows * kTilePitch];
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
     // cbpre[] = their column blocks' prefix sums.  One workgroup per item, item = workgroup number: an item waits for items with
@@ -819,8 +846,9 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
         // (the file's record, read by every lane, into scalar registers: the compiler keeps what it loads from writable global
         //  memory in vector registers, and every address derived from it would cost a register pair per row)
         DecJob job = jobs[ji];
-        job.filt = (uint8_t *)uni64((uint64_t)(uintptr_t)job.filt), job.out = (uint8_t *)uni64((uint64_t)(uintptr_t)job.out);
+        job.win = (uint32_t *)uni64((uint64_t)(uintptr_t)job.win), job.out = (uint8_t *)uni64((uint64_t)(uintptr_t)job.out);
         job.segsum = (uint32_t *)uni64((uint64_t)(uintptr_t)job.segsum);
+        job.sub_base = uni32(job.sub_base);
         job.w = uni32(job.w), job.h = uni32(job.h), job.bpl = uni32(job.bpl), job.src_c = uni32(job.src_c), job.dst_c = uni32(job.dst_c), job.nseg = uni32(job.nseg), job.mode = uni32(job.mode);
         // (only bits that the kernels in FRONT of this one set decide: every workgroup must come to the same conclusion about a
         //  file, or a later segment would wait for an earlier one that was skipped -- the checks below have bits of their own.
@@ -838,22 +866,29 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
         const uint32_t j4 = widen ? (wave_px / 4) * 3 + lane : cb * kDecBlock + threadIdx.x;
         const bool active = j4 < ncol && (!widen || lane < 48);
         const uint32_t y0 = sg * kUnfRows, nrows = min(kUnfRows, job.h - y0);
-        const size_t stride = (size_t)job.bpl + 1;
+        // ---- the tile's rows, from the token records (all threads; the barrier stands in front of every way out) ----
+        lds_u8 *tile = (lds_u8 *)tile_mem;
+        {
+            const uint32_t ncb = dec_col_blocks(job.w, sc, dc), cbw = dec_col_block_bytes(sc, dc), last_sub = placed.eob_index[ji];
+            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile) : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile);
+            if (err) atomicOr(&status[ji], err);
+        }
+        __syncthreads();
         if (cb == 0 && threadIdx.x == 0) {
             bool bad = false;
-            for (uint32_t k = 0; k < nrows; k++) bad |= job.filt[(size_t)(y0 + k) * stride] != (y0 + k ? 2 : 0);
+            for (uint32_t k = 0; k < nrows; k++) bad |= tile[k * kTilePitch + 3] != (y0 + k ? 2 : 0);
             if (bad) atomicOr(&status[ji], kDecBadFilter);
         }
         if (!widen && !active) return; // (the lanes of a widening wave all stay: they write pixels)
         if (widen && wave_px >= job.w) return;
-        const gu8 *F = (const gu8 *)(uintptr_t)(job.filt + 1 + (size_t)y0 * stride);
         uint32_t v[kUnfRows];
         // (no branch per row: a segment with fewer rows loads its last row again and again -- zeroed below, so that those entries
         //  END UP as copies of the last row's sums, and the stores further down write that row again with the same bytes)
         const uint32_t last = nrows - 1;
         if (active) {
+            const lds_u32 *T = (const lds_u32 *)(tile + 4) + (widen ? wv * 48 + lane : threadIdx.x); // this thread's dword column of the tile
 #pragma unroll
-            for (uint32_t k = 0; k < kUnfRows; k++) v[k] = gload_u32(F + (size_t)min(k, last) * stride, j4 * 4);
+            for (uint32_t k = 0; k < kUnfRows; k++) v[k] = T[min(k, last) * (kTilePitch / 4)];
         }
 #pragma unroll
         for (uint32_t k = 0; k < kUnfRows; k++) v[k] = (k < nrows && active) ? v[k] : 0u;
@@ -1131,30 +1166,26 @@ void launch_dec_offsets(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, uint
                         uint32_t n_group_jobs, DecSubArrays a, const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index)
 {
     const uint32_t j0 = (uint32_t)(group_jobs - jobs);
-    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_group_jobs), dim3(kDecBlock), 0, s, group_jobs, recs, a.bytes, block_off, status + j0, eob_index + j0);
-    hipLaunchKernelGGL(dec_subscan_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, a, status, eob_index);
+    hipLaunchKernelGGL(dec_offsets_kernel, dim3(n_group_jobs), dim3(kDecBlock), 0, s, group_jobs, recs, a.bytes, a.eob, block_off, status + j0, eob_index + j0);
+    hipLaunchKernelGGL(dec_subscan_kernel, dim3(n_blocks), dim3(kSubBlock), 0, s, jobs, n_jobs, first_block, total_subs, a, block_off, status, eob_index);
 }
 void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_base_block, uint32_t blk_a, uint32_t blk_b, bool final_piece, uint32_t total_subs, DecSubArrays a,
                               const DecBlockRec *recs, uint64_t *block_off, uint32_t *status, uint32_t *eob_index, DecCarry *carry)
 {
-    hipLaunchKernelGGL(dec_offsets_range_kernel, dim3(1), dim3(kDecBlock), 0, s, jobs, blk_a, blk_b, final_piece ? 1u : 0u, recs, a.bytes, block_off, status, eob_index, carry);
-    hipLaunchKernelGGL(dec_subscan_kernel, dim3(blk_b - blk_a), dim3(kSubBlock), 0, s, jobs, 1u, sub_base_block + blk_a, total_subs, a, status, eob_index);
-}
-void launch_dec_emit(hipStream_t s, uint32_t resident, const DecJob *jobs, uint32_t n_jobs, uint32_t first_block, uint32_t n_blocks, uint32_t total_subs, DecSubArrays a,
-                     const uint32_t *eob_index, const uint64_t *block_off, uint32_t *status)
-{
-    const uint32_t wgs = n_blocks * (kSubBlock / kEmitBlock);
-    if (wgs) hipLaunchKernelGGL(dec_emit_kernel, dim3(FPNG_DEC_PERSISTENT ? std::min(wgs, resident) : wgs), dim3(kEmitBlock), 0, s, jobs, n_jobs, first_block, n_blocks, total_subs, a, eob_index, block_off, status);
+    hipLaunchKernelGGL(dec_offsets_range_kernel, dim3(1), dim3(kDecBlock), 0, s, jobs, blk_a, blk_b, final_piece ? 1u : 0u, recs, a.bytes, a.eob, block_off, status, eob_index, carry);
+    hipLaunchKernelGGL(dec_subscan_kernel, dim3(blk_b - blk_a), dim3(kSubBlock), 0, s, jobs, 1u, sub_base_block + blk_a, total_subs, a, block_off, status, eob_index);
 }
 // jobs / status: of the group's first file; plan: device arrays (decode_api.cpp); epoch: this launch's (a new one every time; the
 // granules are never cleared)
-void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status)
+void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status)
 {
-    if (n_items) hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, item0, status, epoch, concurrent_status ? 0u : (kDecNotConverged | kDecBadStream));
+    if (n_items)
+        hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, placed, item0, status, epoch,
+                           concurrent_status ? 0u : (kDecNotConverged | kDecBadStream | kDecStalled));
 }
-void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, uint32_t *status, uint32_t epoch, bool any_stored)
+void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, DecPlaced placed, uint32_t *status, uint32_t epoch, bool any_stored)
 {
-    if (plan.total_items) launch_dec_unfilter(s, jobs, plan, 0, plan.total_items, status, epoch, false);
+    if (plan.total_items) launch_dec_unfilter(s, jobs, plan, placed, 0, plan.total_items, status, epoch, false);
     if (!any_stored) return; // (a workgroup that finds its file is not a stored one leaves at once, but n_jobs x 512 of them is not free)
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += 32768) // (the y dimension of a grid holds at most 65535 workgroups)
         hipLaunchKernelGGL(dec_stored_kernel, dim3(512, std::min(32768u, n_jobs - j0)), dim3(kDecBlock), 0, s, jobs + j0, status + j0);

@@ -209,7 +209,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     HeaderMemo memo;
     std::vector<DecJob> jobs;
     std::vector<uint32_t> job_file;
-    size_t z_total = 0, filt_total = 0, seg_total = 0;
+    size_t z_total = 0, win_total = 0, seg_total = 0;
     uint32_t sub_total = 0;
 
     // ---- device-resident files: their first and last bytes come back first (one round trip for the batch) ----
@@ -288,9 +288,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
             sub_total += (j.n_sub + kDecSubBlock - 1) / kDecSubBlock * kDecSubBlock; // whole workgroups per file
             // offsets into the shared scratch (pointers are patched once the buffers exist)
-            const size_t total = ((size_t)j.bpl + 1) * j.h;
-            j.filt = (uint8_t *)(uintptr_t)filt_total;
-            filt_total += ((total + 15) & ~(size_t)15) + 16;
+            j.win = (uint32_t *)(uintptr_t)win_total; // (words, patched below)
+            win_total += (size_t)j.h * dec_col_blocks(j.w, j.src_c, j.dst_c);
             j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
             j.segsum = (uint32_t *)(uintptr_t)seg_total;
             seg_total += (size_t)j.nseg * ((j.bpl + 3) / 4);
@@ -312,7 +311,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     if (!nj) return FPNG_AMD_OK;
 
     // ---- device scratch: one encoder-owned buffer, carved up (kept between calls) ----
-    uint8_t *d_z, *d_filt;
+    uint8_t *d_z;
+    uint32_t *d_win;
     uint32_t *d_status, *d_changed;
     unsigned long long *d_seg;
     uint64_t *d_block_off;
@@ -331,8 +331,10 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve(z_total + 64), o_filt = carve(filt_total + 16), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
-                     o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
+        // (the token records: dec::kRecRows rows of 64 dwords per 64 subsequences, of which a gradient touches 55, a photograph 40)
+        const size_t o_z = carve(z_total + 64), o_win = carve(std::max<size_t>(win_total, 1) * 4), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
+                     o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_eob = carve(subs * 4), o_tok = carve(subs * (size_t)dec::kRecRows * 4),
+                     o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
                      o_luts = carve(std::max<size_t>(lut_keys.size() / 288, 1) * dec::kLutDwords * 4), o_keys = carve(std::max<size_t>(lut_keys.size(), 288)),
                      o_jobs = carve(nj * sizeof(DecJob)), o_plan = carve(((size_t)nj + kMaxGroups) * (sizeof(DecUnfPiece) + 8)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
         if ((rc = e->d_decode.ensure(need))) return rc;
@@ -345,10 +347,12 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         }
         d_seg = e->d_dec_gran.p;
         uint8_t *base = e->d_decode.p;
-        d_z = base + o_z, d_filt = base + o_filt;
+        d_z = base + o_z, d_win = (uint32_t *)(base + o_win);
         d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
-        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint32_t *)(base + o_tok);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
+        // the windows' index: "no subsequence" until dec_subscan_kernel says otherwise (a stream that covers less than the image leaves holes)
+        HIP_TRY(hipMemsetAsync(d_win, 0xFF, std::max<size_t>(win_total, 1) * 4, e->stream));
         d_luts = (uint32_t *)(base + o_luts), d_keys = base + o_keys, d_jobs = (DecJob *)(base + o_jobs), d_status = (uint32_t *)(base + o_status);
         d_plan = base + o_plan;
         setup_ofs = o_jobs, setup_plan = o_plan - o_jobs, setup_len = o_status + (2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4 - o_jobs;
@@ -385,7 +389,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         const Parsed &p = ps[job_file[k]];
         if (!device_data) j.z = d_z + (size_t)(uintptr_t)j.z;
         if (!j.mode) {
-            j.filt = d_filt + (size_t)(uintptr_t)j.filt;
+            j.win = d_win + (size_t)(uintptr_t)j.win;
             j.segsum = (uint32_t *)(d_seg + (size_t)(uintptr_t)j.segsum);
             j.lut = (few_luts ? e->d_lut_cache.p + (size_t)lut_slot[p.lut] * dec::kLutDwords : d_luts + (size_t)p.lut * dec::kLutDwords);
         }
@@ -515,7 +519,6 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         if (nblk) {
             launch_dec_offsets(s, d_jobs, nj, g.blk0, nblk, sub_total, d_jobs + g.j0, g.j1 - g.j0, d_sub, d_recs, d_block_off, d_status, d_eob);
             if ((pe = stamp(g, 2)) != hipSuccess) return pe;
-            launch_dec_emit(s, resident, d_jobs, nj, g.blk0, nblk, sub_total, d_sub, d_eob, d_block_off, d_status);
         } else if ((pe = stamp(g, 2)) != hipSuccess)
             return pe;
         if ((pe = stamp(g, 3)) != hipSuccess) return pe;
@@ -523,7 +526,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         for (uint32_t k = g.j0; k < g.j1; k++) any_stored |= jobs[k].mode != 0;
         // (all groups run on one stream: two un-filter kernels never run at once -- each one's workgroups wait for lower-numbered ones
         //  of their own launch, and two sets of waiting workgroups could keep each other's predecessors off the compute units)
-        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, d_status + g.j0, next_epoch(e), any_stored);
+        const DecPlaced placed = {d_sub, d_block_off, d_eob + g.j0, 0xFFFFFFFFu};
+        launch_dec_finish(s, d_jobs + g.j0, g.j1 - g.j0, g.plan, placed, d_status + g.j0, next_epoch(e), any_stored);
         if ((pe = stamp(g, 4)) != hipSuccess) return pe;
         if (prof && &g == groups.data()) e->dec_prof_recorded = true;
         return hipSuccess;
@@ -665,13 +669,13 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     j.n_sub = (uint32_t)((j.end_limit_bit - j.first_bit + kSubBits - 1) / kSubBits);
     j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
     const uint32_t n_blocks = (j.n_sub + kDecSubBlock - 1) / kDecSubBlock, sub_total = n_blocks * kDecSubBlock;
-    const size_t total = ((size_t)j.bpl + 1) * j.h, col_blocks = dec_col_blocks(j.w, j.src_c, j.dst_c), os = (size_t)p.w * desired;
+    const size_t col_blocks = dec_col_blocks(j.w, j.src_c, j.dst_c), os = (size_t)p.w * desired;
     // ---- scratch ----
-    uint8_t *d_z, *d_filt;
+    uint8_t *d_z;
     DecSubArrays d_sub;
     DecBlockRec *d_recs;
     uint64_t *d_block_off;
-    uint32_t *d_lut, *d_words, *d_status, *d_eob;
+    uint32_t *d_lut, *d_words, *d_status, *d_eob, *d_win;
     DecJob *d_job;
     DecUnfPiece *d_piece;
     DecCarry *d_carry;
@@ -682,8 +686,10 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_z = carve((size_t)p.idat_len + 80), o_filt = carve(((total + 15) & ~(size_t)15) + 32), o_info = carve((size_t)sub_total * 4), o_bytes = carve((size_t)sub_total * 4),
-                     o_tail = carve((size_t)sub_total * 4), o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
+        const size_t n_win = (size_t)j.h * col_blocks;
+        const size_t o_z = carve((size_t)p.idat_len + 80), o_win = carve(n_win * 4), o_info = carve((size_t)sub_total * 4), o_bytes = carve((size_t)sub_total * 4),
+                     o_tail = carve((size_t)sub_total * 4), o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_eob = carve((size_t)sub_total * 4),
+                     o_tok = carve((size_t)sub_total * dec::kRecRows * 4), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
                      o_boff = carve((size_t)n_blocks * 8), o_lut = carve(dec::kLutDwords * 4), o_job = carve(sizeof(DecJob)), o_small = carve(256);
         if ((rc = e->d_decode.ensure(need))) return rc;
         if ((rc = e->d_dec_gran.ensure(std::max<size_t>((size_t)j.nseg * ((j.bpl + 3) / 4), 1)))) return rc;
@@ -692,14 +698,15 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             e->d_dec_gran.fresh = false;
         }
         uint8_t *base = e->d_decode.p;
-        d_z = base + o_z, d_filt = base + o_filt;
+        d_z = base + o_z, d_win = (uint32_t *)(base + o_win);
         d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
-        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint32_t *)(base + o_tok);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff), d_lut = (uint32_t *)(base + o_lut), d_job = (DecJob *)(base + o_job);
+        HIP_TRY(hipMemsetAsync(d_win, 0xFF, n_win * 4, s)); // ("no subsequence": decode_files())
         uint8_t *sm = base + o_small; // status, eob index | carry | unfilter piece | cbpre[2], order[1]
         d_status = (uint32_t *)sm, d_eob = d_status + 1, d_carry = (DecCarry *)(sm + 16), d_piece = (DecUnfPiece *)(sm + 32), d_words = (uint32_t *)(sm + 48);
     }
-    j.z = d_z, j.filt = d_filt, j.lut = d_lut, j.out = e->d_stage_in.p, j.segsum = (uint32_t *)e->d_dec_gran.p;
+    j.z = d_z, j.win = d_win, j.lut = d_lut, j.out = e->d_stage_in.p, j.segsum = (uint32_t *)e->d_dec_gran.p;
     struct Small { // (one upload for the few words the kernels start from)
         uint32_t status, eob;
         uint32_t pad0[2];
@@ -815,7 +822,6 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             if (b > a) {
                 for (uint32_t r = 0; r <= kBorderRounds; r++) launch_dec_sync(s, resident, d_job, 1, a, b - a, sub_total, r, d_sub, d_recs, d_status + 2, d_status + 3);
                 launch_dec_offsets_range(s, d_job, 0, a, b, k + 1 == np, sub_total, d_sub, d_recs, d_block_off, d_status, d_eob, d_carry);
-                launch_dec_emit(s, resident, d_job, 1, a, b - a, sub_total, d_sub, d_eob, d_block_off, d_status);
             }
             HIP_TRY(hipMemcpyAsync(&h_carry[k], d_carry, sizeof(DecCarry), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(ev_carry[k], s));
@@ -829,7 +835,10 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             if (q + 1 == np) segs = j.nseg, rows = p.h;
             else rows = segs * kDecUnfRows;
             if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s_unf, ev_carry[q], 0)); // (piece q's rows are in the filtered stream; the small words went up in front of piece 0)
-            if (segs > segs_done) launch_dec_unfilter(s_unf, d_job, plan, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch, s_unf != s);
+            // (the rows of these segments lie in the output of the subsequences placed so far: the tiles' walks stop there -- what the
+            //  next piece's kernels are writing behind it meanwhile is not theirs to read)
+            const DecPlaced placed = {d_sub, d_block_off, d_eob, blk_end[q] * kDecSubBlock};
+            if (segs > segs_done) launch_dec_unfilter(s_unf, d_job, plan, placed, segs_done * (uint32_t)col_blocks, (segs - segs_done) * (uint32_t)col_blocks, d_status, epoch, s_unf != s);
             segs_done = std::max(segs_done, segs);
             HIP_TRY(hipEventRecord(ev_rows[q], s_unf));
             {

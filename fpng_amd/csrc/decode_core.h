@@ -27,8 +27,20 @@ namespace dec {
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
-constexpr uint32_t kMergeSteps = 24; // sub_refix: tokens stepped one by one before it decodes the subsequence again as a whole
-enum : uint32_t { kSubEob = 1u, kSubInvalid = 4u };
+// TOKEN RECORDS (round 6: every token is decoded ONCE).  The decode that settles a subsequence leaves what it decoded behind, one
+// 32-bit record per lookup, and the pass that writes the pixels (dec_unfilter_kernel) reads records instead of Huffman codes:
+//   a group of literals   n << 26 | the n bytes (first one lowest)          -- the table's entry without its length field
+//   a match               kRecRun | its length in bytes (3..258)
+// A subsequence has room for kRecCap records (its 512 bits in lookups of 2.7 bits and more); one that needs more is flagged and its
+// file left to the CPU decoder (no fpng encoder's output comes near: a record of three literals takes three bits at the very least).
+// Layout in memory: the 64 subsequences of a wave side by side, record k of lane l at dword (k * 64 + l) of the wave's chunk, so that
+// the lanes' stores -- they walk in step, a record per lookup -- fill whole cache lines.
+constexpr uint32_t kRecCap = 192;
+constexpr uint32_t kRecRows = kRecCap + 1;  // + the row that takes what is not a record (and what overflows)
+constexpr uint32_t kRecRun = 1u << 25;      // (= kEntMatch: a table entry of a group of literals never has the bit)
+constexpr uint32_t kRecLane = 64;           // subsequences side by side in a chunk
+FPNG_DEC_HD uint64_t rec_chunk_base(uint32_t g) { return (uint64_t)(g / kRecLane) * (kRecRows * kRecLane) + (g % kRecLane); } // dword index of subsequence g's record 0
+enum : uint32_t { kSubEob = 1u, kSubOverflow = 2u, kSubInvalid = 4u }; // (kSubOverflow: more than kRecCap records)
 enum : uint32_t { kTokLit = 0, kTokMatch = 1, kTokEob = 2, kTokInvalid = 3 };
 
 // (hi:lo) >> sh, 0 <= sh <= 31
@@ -89,6 +101,13 @@ struct SubCount {
     uint32_t lits;  // ... of which literals
     uint32_t tail;  // its last four literal bytes (the most recent one in bits 31..24)
     uint32_t flags; // kSubEob: it met an end-of-block symbol; kSubInvalid: its decode derailed
+    uint32_t eob;   // kSubEob: the position behind that symbol
+};
+// where a walk leaves its records: put(record, enabled) -- a record that is not enabled goes nowhere.  NoRec: a walk that only looks
+// (the lead-in, the phase maps' probes).
+struct NoRec {
+    FPNG_DEC_HD void put(uint32_t, bool) {}
+    FPNG_DEC_HD uint32_t count() const { return 0; }
 };
 
 // When does a lane whose next token needs the general path (fetch()) get it?  On the GPU the lanes of a wave run in lockstep: a
@@ -105,8 +124,8 @@ struct VoteAlone {
 // behind the first token) as straight-line predicated code -- a group of literals that lies wholly in front of the limit and a
 // match are applied -- and what is left (the end of the block, an invalid code, a group that reaches over the limit) takes a
 // single token through fetch(), when the vote says so.
-template <bool Count, class Vote, class Bits>
-FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c)
+template <bool Count, class Vote, class Bits, class Rec>
+FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c, Rec &rec)
 {
     uint32_t lits = c.lits, tail = c.tail, runs = 0, flags = 0;
     const uint32_t lim = limit < data_limit ? limit : data_limit; // (no token may start at or behind data_limit)
@@ -115,9 +134,11 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
         const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u, xb = (e >> 9) & 7u;
         const bool lit = en && n != 0 && L <= room, mt = en && n == 0 && (e & kEntMatch) != 0;
         if (Count) {
+            const uint32_t run = (e & 511u) + ((wk >> L) & ((1u << xb) - 1u));
             lits += lit ? n : 0u;
             tail = funnel(e & 0xFFFFFFu, tail, lit ? 8 * n : 0u);
-            runs += mt ? (e & 511u) + ((wk >> L) & ((1u << xb) - 1u)) : 0u;
+            runs += mt ? run : 0u;
+            rec.put(lit ? (e & 0x0FFFFFFFu) : (kRecRun | run), lit || mt);
         }
         return lit ? L : (mt ? L + xb + 1 : 0u);
     };
@@ -133,14 +154,15 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
             const uint32_t kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
             if (kind >= kTokEob) {
                 flags = kind == kTokEob ? kSubEob : kSubInvalid;
+                if (Count) c.eob = pos + bits;
                 break;
             }
             pos += bits;
             if (Count) {
                 if (kind == kTokLit)
-                    lits += n3, tail = funnel(l3, tail, 8 * n3);
+                    lits += n3, tail = funnel(l3, tail, 8 * n3), rec.put(n3 << 26 | l3, true);
                 else
-                    runs += run;
+                    runs += run, rec.put(kRecRun | run, true);
             }
         }
     }
@@ -154,69 +176,49 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
 struct SubState {
     uint32_t start, end; // first bit of its first token; position behind its last one (its nominal boundary if it is flagged)
     SubCount c;
+    uint32_t nrec;       // records its decode left (more than kRecCap: kSubOverflow is set)
 };
+FPNG_DEC_HD void sub_close(SubState &s, uint32_t boundary, uint32_t e, uint32_t nrec)
+{
+    // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
+    // end-of-block symbols; which one is the true one is settled afterwards (the first one of the chain).
+    s.end = s.c.flags ? boundary : e;
+    s.nrec = nrec < 511u ? nrec : 511u;
+    if (nrec > kRecCap) s.c.flags |= kSubOverflow;
+}
 
 // First decode of a subsequence [nominal, boundary): the decoder starts `lead` bits EARLIER and has, with a probability that
 // tools/sync_stats.c measured (128 bits: all but 0.04 % of the subsequences of a synthetic gradient, 1.8 % of a photograph),
 // fallen into step with the true token sequence when it crosses `nominal`; the first token boundary at or behind `nominal` is
-// the subsequence's start.  Whether it is the true one shows when it is compared with the predecessor's end.
-template <class Vote, class Bits>
-FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, SubState &s)
+// the subsequence's start.  Whether it is the true one shows when it is compared with the predecessor's end.  rec: where the
+// subsequence's own tokens are recorded (the lead-in's are not).
+template <class Vote, class Bits, class Rec>
+FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec)
 {
     uint32_t p = nominal;
     if (lead_start < nominal) {
-        SubCount d = {0, 0, 0, 0};
-        p = walk_count<false, Vote>(in, lut, lenof, lead_start, nominal, data_limit, d);
+        SubCount d = {0, 0, 0, 0, 0};
+        NoRec none;
+        p = walk_count<false, Vote>(in, lut, lenof, lead_start, nominal, data_limit, d, none);
         if (d.flags || p < nominal) p = nominal; // the lead-in derailed: any start is as good as another
     }
     s.start = p;
-    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
-    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, p, boundary, data_limit, s.c);
-    // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
-    // end-of-block symbols; which one is the true one is settled afterwards (the first one of the chain).
-    s.end = s.c.flags ? boundary : e;
+    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = s.c.eob = 0;
+    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, p, boundary, data_limit, s.c, rec);
+    sub_close(s, boundary, e, rec.count());
 }
 
-// The subsequence must start at `want` instead of s.start (its predecessor ended there).  Both decodes -- the old one from
-// s.start, the new one from `want` -- are stepped token by token, the one that lags behind first; where they meet, the rest of the
-// old decode holds, and only the counts in front of that point are exchanged.  No meeting point inside the subsequence (or one
-// so late that the last four literals are not all behind it): decoded again as a whole.
-template <class Vote, class Bits>
-FPNG_DEC_HD void sub_refix(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s)
-{
-    uint32_t A = s.start, B = want;
-    SubCount a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    // (at most kMergeSteps tokens: two decodes that have not met by then rarely will -- a periodic stream keeps them apart for
-    //  good -- and stepping token by token costs several times the group-wise walk that follows)
-    for (uint32_t steps = 0; A != B && steps < kMergeSteps; steps++) {
-        if ((A < B ? A : B) >= boundary) break;
-        if (A < B) {
-            A = walk_count<true, VoteAlone>(in, lut, lenof, A, A + 1, data_limit, a);
-            if (a.flags) break;
-        } else {
-            B = walk_count<true, VoteAlone>(in, lut, lenof, B, B + 1, data_limit, b);
-            if (b.flags) break;
-        }
-    }
-    s.start = want;
-    if (A == B && !a.flags && !b.flags && s.c.lits - a.lits >= 4) {
-        s.c.bytes = s.c.bytes - a.bytes + b.bytes;
-        s.c.lits = s.c.lits - a.lits + b.lits;
-        return; // (end, tail and flags are the old decode's)
-    }
-    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
-    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c);
-    s.end = s.c.flags ? boundary : e;
-}
-
-// ... decoded again as a whole (where the phase maps hand a thread its true start: nearly every thread of the workgroup changes then)
-template <class Vote, class Bits>
-FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s)
+// The subsequence must start at `want` instead of s.start (its predecessor ended there): decoded again as a whole, its records
+// written again from the first one.  (Until round 5 the two decodes were stepped token by token to where they meet and only the
+// counts in front of that point exchanged; records cannot be patched that way -- the new decode may need more of them in front of
+// the meeting point than the old one left room for.)
+template <class Vote, class Bits, class Rec>
+FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec)
 {
     s.start = want;
-    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = 0;
-    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c);
-    s.end = s.c.flags ? boundary : e;
+    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = s.c.eob = 0;
+    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c, rec);
+    sub_close(s, boundary, e, rec.count());
 }
 
 // ---- phase maps: the way out of a PERIODIC stream ----
@@ -283,8 +285,9 @@ FPNG_DEC_HD PhaseMap pm_compose(const PhaseMap &a, const PhaseMap &b)
 template <class Vote, class Bits>
 FPNG_DEC_HD uint32_t sub_probe(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit)
 {
-    SubCount d = {0, 0, 0, 0};
-    const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d);
+    SubCount d = {0, 0, 0, 0, 0};
+    NoRec none;
+    const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d, none);
     return d.flags ? boundary : e;
 }
 // One growing step of a thread's map: every phase the predecessor's map ends in (= a phase this subsequence is entered in: its
@@ -307,211 +310,99 @@ template <class Vote, class Bits>
 FPNG_DEC_HD void pm_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, PhaseMap &map)
 {
     for (uint32_t j = 1; j < kPhases; j++) {
-        SubCount d = {0, 0, 0, 0};
-        const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d);
+        SubCount d = {0, 0, 0, 0, 0};
+        NoRec none;
+        const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d, none);
         if (d.flags || p < nominal || pm_at(map, p - nominal) != kPhaseUnknown) continue;
         pm_set(map, p - nominal, sub_probe<Vote>(in, lut, lenof, p, boundary, data_limit) - boundary);
     }
 }
 
-// per-subsequence record in global memory: start - nominal (0..17) | end - boundary (0..17) << 5 | flags << 10 | literals << 13
-FPNG_DEC_HD uint32_t pack_info(uint32_t start_rel, uint32_t end_rel, const SubCount &c) { return start_rel | end_rel << 5 | c.flags << 10 | c.lits << 13; }
+// per-subsequence word in global memory: start - nominal (0..17) | end - boundary (0..17) << 5 | flags << 10 | literals (at most one
+// per bit: 10 bits) << 13 | records (9 bits) << 23
+FPNG_DEC_HD uint32_t pack_info(uint32_t start_rel, uint32_t end_rel, const SubCount &c, uint32_t nrec) { return start_rel | end_rel << 5 | c.flags << 10 | (c.lits & 1023u) << 13 | nrec << 23; }
 FPNG_DEC_HD uint32_t info_start(uint32_t v) { return v & 31u; }
 FPNG_DEC_HD uint32_t info_end(uint32_t v) { return (v >> 5) & 31u; }
 FPNG_DEC_HD uint32_t info_flags(uint32_t v) { return (v >> 10) & 7u; }
-FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return v >> 13; }
+FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return (v >> 13) & 1023u; }
+FPNG_DEC_HD uint32_t info_nrec(uint32_t v) { return v >> 23; }
 
-// ---- the real decode: one subsequence's tokens into the filtered stream ----
+// ---- the pass that writes: records into WINDOWS of the filtered stream ----
 // The filtered stream = what the reference's decoder consumes row by row (src/fpng.cpp:2255-2262): h rows of 1 filter byte +
-// w * c bytes, kept in exactly this layout (the column kernels read it with unaligned loads).  Every thread stores WHOLE ALIGNED
-// 16-BYTE GROUPS only (Sink::store128(group index, four dwords)): the group in which its output ends is completed with the first
-// bytes of the following subsequences -- it simply decodes on until the group is full -- and a thread whose output starts inside a
-// group leaves that group to the thread in front of it.  No byte stores, nothing is written twice, no store that depends on whose
-// bytes a dword holds.  (Sink::store32 serves the one place where the stream itself ends inside a group.)  4-byte stores from 64
-// lanes whose ranges lie ~150 bytes apart were 64 memory transactions of 4 bytes per instruction, and 6 x the bytes at the fabric.
-enum : uint32_t { kEmitBadStream = 2u, kEmitLeaveToCpu = 16u, kEmitSawEob = 0x100u }; // (= kDecBadStream, kDecStalled, kDecSawEob of decode.h)
-constexpr uint32_t kFillMinDwords = 16, kFillMinPixels3 = 32; // runs from this length on are filled by the wave (StreamWriter::run4 / run3)
-
-template <class Sink> struct StreamWriter {
-    Sink &sink;
-    uint32_t acc;  // bytes not stored yet, the oldest one lowest
-    uint32_t have; // how many (0..3)
-    uint32_t dw;   // stream dword they go to
-    uint32_t q0, q1, q2, q3; // the last whole dwords, the newest in q3: at the end of a 16-byte group they are its four dwords
-    bool skip;     // the group the output starts in belongs to the thread in front (until its end is reached)
-    FPNG_DEC_HD StreamWriter(Sink &s, uint64_t off) : sink(s), acc(0), have((uint32_t)off & 3u), dw((uint32_t)(off >> 2)), q0(0), q1(0), q2(0), q3(0)
-    {
-        skip = ((uint32_t)off & 15u) != 0;
-    }
-    FPNG_DEC_HD void push(uint32_t v, bool full) // a whole dword (where `full`)
-    {
-        q0 = full ? q1 : q0, q1 = full ? q2 : q1, q2 = full ? q3 : q2, q3 = full ? v : q3;
-        const bool gend = full && (dw & 3u) == 3u;
-        if (gend && !skip) sink.store128(dw >> 2, q0, q1, q2, q3);
-        skip = skip && !gend;
-        dw += full;
-    }
-    FPNG_DEC_HD void put(uint32_t bytes, uint32_t n) // n <= 4 bytes, the first one lowest; bytes = 0 where n = 0
-    {
-        const uint32_t sh = 8 * have, lo = acc | (bytes << sh), hi = (bytes >> 8) >> (24 - sh), nh = have + n;
-        const bool full = nh >= 4;
-        push(lo, full);
-        acc = full ? hi : lo;
-        have = nh & 3u;
-    }
-    // npix copies of a 4-byte pixel: the first dword completes the pending bytes, the others are one rotated constant.
-    // A LONG run is not this thread's to write dword by dword -- its wave would wait for it, and on flat content (a screenshot:
-    // a few dozen bytes of tokens stand for kilobytes of pixels) every thread has such runs: the thread writes up to the next
-    // 16-byte group boundary and hands the run's whole groups to Sink::fill(first group, groups, three dwords d0 d1 d2: the
-    // dwords from there on are d0 d1 d2 d0 ...), which the wave's threads store together, 64 groups per instruction
-    // (Sink::cooperate(), called by walk_emit once per iteration).
-    FPNG_DEC_HD void run4(uint32_t px, uint32_t npix)
-    {
-        const uint32_t sh = 8 * have, lo = px << sh, hi = (px >> 8) >> (24 - sh), r = lo | hi;
-        push(acc | lo, true);
-        uint32_t left = npix - 1;
-        if (left >= kFillMinDwords) {
-            while (dw & 3u) push(r, true), left--; // (its last push closed a group: `skip` is off from here)
-            const uint32_t groups = left >> 2;
-            sink.fill(dw >> 2, groups, r, r, r);
-            dw += 4 * groups, left -= 4 * groups;
-            q0 = q1 = q2 = q3 = r;
-        }
-        for (uint32_t j = 0; j < left; j++) push(r, true);
-        acc = hi;
-    }
-    // ... of a 3-byte pixel: the stream repeats every 3 bytes, its dwords every 3 dwords; three groups = 48 bytes = 16 pixels
-    // leave the writer where it was (pending bytes, place inside the pixel)
-    FPNG_DEC_HD void run3(uint32_t px, uint32_t npix)
-    {
-        uint32_t left = npix;
-        if (npix >= kFillMinPixels3) {
-            for (uint32_t k = 0; k < 4; k++) put(px, 3); // (12 bytes: the pending bytes are the run's own from here on)
-            left -= 4;
-            while (dw & 3u) put(px, 3), left--; // (at most 5 pixels; the last push closed a group)
-            uint32_t groups = (3 * left) >> 4;
-            groups -= groups % 3u;
-            // byte 0 of dword dw is the pixel's byte (3 - have) % 3: acc holds the last `have` bytes of a pixel
-            const uint64_t wrap = (uint64_t)px | (uint64_t)px << 24 | (uint64_t)px << 48;
-            const uint32_t ph = (3u - have) % 3u;
-            const uint32_t d0 = (uint32_t)(wrap >> (8 * ph)), d1 = (uint32_t)(wrap >> (8 * ((ph + 1) % 3u))), d2 = (uint32_t)(wrap >> (8 * ((ph + 2) % 3u)));
-            sink.fill(dw >> 2, groups, d0, d1, d2);
-            if (groups) q0 = d2, q1 = d0, q2 = d1, q3 = d2; // (the last group of a multiple of three)
-            dw += 4 * groups, left -= 16 * (groups / 3u);
-        }
-        for (uint32_t k = 0; k < left; k++) put(px, 3);
-    }
-    // Only where the stream ends inside a group: its whole dwords, and the pending bytes (zeros behind them: the buffer is padded).
-    FPNG_DEC_HD void finish()
-    {
-        if (have) push(acc, true), have = 0;
-        const uint32_t m = dw & 3u; // dwords 0..m-1 of the group are in q[4-m]..q3
-        if (skip) return;
-        if (m >= 3) sink.store32(dw - 3, q1);
-        if (m >= 2) sink.store32(dw - 2, q2);
-        if (m >= 1) sink.store32(dw - 1, q3);
-    }
+// w * c bytes.  It is never written to memory as a whole: the kernel that undoes the Up filter (dec_unfilter_kernel) works on tiles
+// of 48 rows x one block of columns, and fills each tile's rows from the records of the subsequences that cover them.  A WINDOW =
+// the bytes of one row that one tile holds: column block cb of row y covers the row's bytes [xw, xe), xw = cb ? 1 + cb * cbw : 0 (the
+// first block also holds the row's filter byte), xe = min(1 + (cb + 1) * cbw, stride); a window never crosses a row end.
+enum : uint32_t { kEmitBadStream = 2u, kEmitLeaveToCpu = 16u }; // (= kDecBadStream, kDecStalled of decode.h)
+struct Window {
+    uint64_t ws;   // stream offset of its first byte
+    uint32_t wlen; // its bytes
+    uint32_t xw;   // column (place in the row, 0 = the filter byte) of its first byte
 };
-
-// The real decode of one subsequence.  The synchronisation has settled where it starts (pos) and how many bytes its tokens stand
-// for (own): the loop is driven by the BYTE count -- `own` bytes plus the `pad` (0..15) first bytes of the following subsequences
-// that complete its last 16-byte group -- so no token has to be compared with a bit limit and a group of literals is simply cut to the
-// bytes still wanted.  off = stream byte of its first output byte, col = that byte's place in its row (0 = the filter byte),
-// lastpx = the four literal bytes in front of it; C = channels in the file; last: the stream's last subsequence (an end-of-block
-// symbol must follow its bytes).  Two predicated lookups per window: literals and matches of exactly ONE pixel (the usual kind on
-// noisy content: length C, no extra bits) are applied in line, everything else takes the branch.  Checked here, token by token:
-// a match repeats whole pixels, starts on a pixel and stays inside its row (reference src/fpng.cpp:2273-2330); that every row
-// starts with its filter literal is checked where the rows are read (dec_unfilter_kernel).  Returns kEmit* flags; eob_end =
-// position behind the end-of-block symbol.
-template <int C, class Bits, class Sink>
-FPNG_DEC_HD uint32_t walk_emit(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t own, uint32_t pad, bool last, uint64_t off, uint32_t col,
-                               uint32_t lastpx, uint32_t stride, Sink &sink, uint32_t &eob_end)
+FPNG_DEC_HD Window window_of(uint32_t y, uint32_t cb, uint32_t cbw, uint32_t stride)
 {
-    StreamWriter<Sink> out(sink, off);
-    const uint32_t bpl = stride - 1;
-    uint32_t todo = own + pad;
-    uint32_t rowleft = stride - col; // bytes up to the end of the row, the next one included (== stride: the next byte is a filter byte)
-    uint32_t err = 0;
-    // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one, or nothing left to do)
-    // (the straight-line part keeps rl = rowleft - 1, 0 .. stride - 1: "wrap at the row's end" is then min(t, t + stride) of
-    //  t = rl - bytes taken -- the unsigned difference is huge exactly when the row ended; the match branch below works on rowleft)
-    uint32_t rl = rowleft - 1;
-    auto take = [&](uint32_t wk) -> uint32_t {
-        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
-        const bool m1 = (e & 0x0FFFFFFFu) == (kEntMatch | (uint32_t)C) && (rl + 1) % C == 0 && rl != bpl - 1 && todo >= (uint32_t)C;
-        const uint32_t nl = n < todo ? n : todo, nb = m1 ? (uint32_t)C : nl;
-        const uint32_t lits = low_bits(e, 8 * nl); // (nl = 0: no byte)
-        out.put(m1 ? (C == 4 ? lastpx : lastpx >> 8) : lits, nb);
-        lastpx = funnel(lits, lastpx, m1 ? 0u : 8 * nl);
-        const uint32_t t = rl - nb, t2 = t + stride;
-        rl = t < t2 ? t : t2;
-        todo -= nb;
-        return nb ? L + (m1 ? 1u : 0u) : 0u;
-    };
-    while (sink.any(todo != 0)) { // (the whole wave stays until its last thread is done: Sink::cooperate() needs them all)
-        const uint32_t w = in.window(pos);
-        const uint32_t ba = take(w);
-        const uint32_t bb = take(w >> ba); // (a first token that was not plain is looked at again, to no effect)
-        pos += ba + bb;
-        if (todo && !bb) { // the token at pos is not a plain one: a match (or the stream ends, or derails, with bytes still owed)
-            rowleft = rl + 1;
-            // Matches that follow one another repeat the same pixel (no literal in between, and none of them may leave its row):
-            // they are written as ONE run -- a flat row of a screenshot is a few dozen maximal matches.
-            const uint32_t px = C == 4 ? lastpx : lastpx >> 8;
-            uint32_t whole = 0; // bytes of the matches that lie wholly inside this thread's bytes
-            bool stop = false;
-            for (;;) {
-                uint32_t n3, l3 = 0, run = 0, bits;
-                const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
-                const bool mine = todo > pad; // (the tokens behind this thread's bytes are their owners' to check)
-                if (kind != kTokMatch) {
-                    // behind a match: an ordinary token, the loop's next iteration takes it; else the stream ends, or derails, with bytes still owed
-                    if (!whole) stop = true, err |= mine ? kEmitBadStream : 0u;
-                    break;
-                }
-                if (mine && (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)) {
-                    stop = true, err |= kEmitBadStream;
-                    break;
-                }
-                // A match at a row's FIRST pixel repeats a pixel of zeros (reference :2268: prev_delta_* start at 0), and so do the
-                // matches behind it until a literal pixel comes -- but "the last literal bytes" this decoder keeps know nothing
-                // of rows.  fpng's encoders never write such a match (a row's first pixel has no left neighbour); a file that
-                // has one is left to the CPU decoder.
-                if (mine && rowleft == bpl) {
-                    stop = true, err |= kEmitLeaveToCpu;
-                    break;
-                }
-                pos += bits;
-                const uint32_t r = run < todo ? run : todo;
-                rowleft -= r;
-                rowleft += (int32_t)rowleft <= 0 ? stride : 0u;
-                todo -= r;
-                if (r == run && mine)
-                    whole += run;
-                else { // the match reaches into (or lies in) the pad: byte by byte
-                    if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
-                    whole = 0;
-                    for (uint32_t k = 0; k < r; k++) out.put((px >> (8 * (k % C))) & 255u, 1);
-                    break;
-                }
-                if (!todo || rowleft == stride) break; // (a row ended: a filter literal must follow)
-            }
-            if (whole) C == 4 ? out.run4(px, whole >> 2) : out.run3(px, whole / 3u);
-            rl = rowleft - 1;
-            if (stop) break;
+    Window w;
+    w.xw = cb ? 1u + cb * cbw : 0u;
+    const uint32_t xe = 1u + (cb + 1u) * cbw < stride ? 1u + (cb + 1u) * cbw : stride;
+    w.wlen = xe - w.xw;
+    w.ws = (uint64_t)y * stride + w.xw;
+    return w;
+}
+// Every window whose FIRST byte lies in the stream bytes [off, off + bytes) -- the output of one subsequence -- is handed to
+// mark(y, cb): that subsequence is where the window's walk starts (dec_subscan_kernel writes the index the tiles read).
+template <class Mark> FPNG_DEC_HD void for_windows_starting_in(uint64_t off, uint32_t bytes, uint32_t cbw, uint32_t ncb, uint32_t stride, uint32_t h, const Mark &mark)
+{
+    if (!bytes) return;
+    uint32_t y = (uint32_t)(off / stride);
+    const uint32_t x = (uint32_t)(off - (uint64_t)y * stride);
+    // first window start at or behind column x of row y: 0, then 1 + cb * cbw
+    uint32_t cb = x == 0 ? 0u : (x - 1u + cbw - 1u) / cbw;
+    if (x != 0 && cb == 0) cb = 1; // (x = 1: the start "1 + 0 * cbw" is not a window start -- block 0 starts at the filter byte)
+    const uint64_t end = off + bytes;
+    for (; y < h; y++, cb = 0) {
+        for (; cb < ncb; cb++) {
+            const uint64_t ws = (uint64_t)y * stride + (cb ? 1u + cb * cbw : 0u);
+            if (ws >= end) return;
+            mark(y, cb);
         }
-        sink.cooperate();
     }
-    if (last && !err) { // the end-of-block symbol
-        uint32_t n3, l3 = 0, run = 0, bits;
-        const uint32_t kind = fetch(in.window(pos), lut, lenof, 64u, n3, l3, run, bits);
-        if (kind == kTokEob)
-            err |= kEmitSawEob, eob_end = pos + bits;
-        else
-            err |= kEmitBadStream;
+}
+
+// One record applied to a window.  c: window position of the record's first byte (negative: in front of the window); out.put8(pos,
+// byte) / out.fill(lo, hi, px, q): the bytes [lo, hi) are copies of the C-byte pixel px, byte lo being the pixel's byte q.  Checked for
+// the runs that START in this window (every run starts in exactly one): a match repeats whole pixels, starts on a pixel, stays inside
+// its row (reference src/fpng.cpp:2273-2330); one at a row's FIRST pixel would repeat a pixel of zeros (:2268, prev_delta_* start at
+// 0) -- "the last literal bytes" know nothing of rows, no fpng encoder writes such a match, the file is left to the CPU decoder.
+// That every row starts with its filter literal is checked where the rows are read (dec_unfilter_kernel).
+struct PlaceState {
+    int32_t c;       // window position of the next output byte
+    uint32_t lastpx; // the last four literal bytes (the most recent one highest)
+    uint32_t err;    // kEmit* flags
+};
+template <int C, class Out> FPNG_DEC_HD void place_one(uint32_t r, PlaceState &s, const Window &w, uint32_t stride, Out &out)
+{
+    const uint32_t n = (r >> 26) & 3u;
+    if (n) {
+        const uint32_t b0 = r & 255u, b1 = (r >> 8) & 255u, b2 = (r >> 16) & 255u;
+        if ((uint32_t)s.c < w.wlen) out.put8((uint32_t)s.c, b0);
+        if (n > 1 && (uint32_t)(s.c + 1) < w.wlen) out.put8((uint32_t)(s.c + 1), b1);
+        if (n > 2 && (uint32_t)(s.c + 2) < w.wlen) out.put8((uint32_t)(s.c + 2), b2);
+        s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n);
+        s.c += (int32_t)n;
+    } else if (r & kRecRun) {
+        const uint32_t run = r & (kRecRun - 1u), bpl = stride - 1;
+        if ((uint32_t)s.c < w.wlen) {
+            const uint32_t rowleft = stride - (w.xw + (uint32_t)s.c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
+            if (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)
+                s.err |= kEmitBadStream;
+            else if (rowleft == bpl)
+                s.err |= kEmitLeaveToCpu;
+        }
+        const int32_t e = s.c + (int32_t)run;
+        const int32_t lo = s.c > 0 ? s.c : 0, hi = e < (int32_t)w.wlen ? e : (int32_t)w.wlen;
+        if (lo < hi) out.fill((uint32_t)lo, (uint32_t)hi, C == 4 ? s.lastpx : s.lastpx >> 8, (uint32_t)(lo - s.c) % C);
+        s.c = e;
     }
-    out.finish();
-    return err;
 }
 
 // The four literal bytes in front of subsequence g: collected backwards over its predecessors' (literal count, tail) records.

@@ -22,32 +22,35 @@ struct HostBits { // positions relative to dword `d0` of the (zero padded) strea
     const uint32_t *dw;
     uint32_t window(uint32_t pos) const { return funnel(dw[(pos >> 5) + 1], dw[pos >> 5], pos & 31u); }
 };
-struct HostSink { // the filtered stream; every dword may be stored once
-    uint8_t *f;
-    size_t ndw;
+// a subsequence's token records (decode.hip: TokOut): at most kRecCap are kept, all are counted
+struct HostRec {
+    std::vector<uint32_t> *v;
+    uint32_t k = 0;
+    void put(uint32_t r, bool en)
+    {
+        if (!en) return;
+        if (k < kRecCap) (*v)[k] = r;
+        k++;
+    }
+    uint32_t count() const { return k; }
+};
+// a window of the filtered stream (decode.hip: TileRow); every byte may be written once
+struct HostRow {
+    uint8_t *p;
     std::vector<bool> *written;
+    size_t base; // index of p[0] in *written
     bool *fault;
-    void store32(uint32_t d, uint32_t v)
+    void put8(uint32_t pos, uint32_t b)
     {
-        if (d >= ndw || (*written)[d]) {
-            *fault = true;
-            return;
-        }
-        (*written)[d] = true;
-        memcpy(f + 4 * (size_t)d, &v, 4);
+        if ((*written)[base + pos]) *fault = true;
+        (*written)[base + pos] = true;
+        p[pos] = (uint8_t)b;
     }
-    void store128(uint32_t g, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+    uint32_t C;
+    void fill(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
     {
-        store32(4 * g, a), store32(4 * g + 1, b), store32(4 * g + 2, c), store32(4 * g + 3, d);
+        for (uint32_t pos = lo; pos < hi; pos++, q = (q + 1) % C) put8(pos, (px >> (8 * q)) & 255u);
     }
-    // (a long run's whole groups: on the GPU left to the wave, here stored at once)
-    void fill(uint32_t g0, uint32_t groups, uint32_t d0, uint32_t d1, uint32_t d2)
-    {
-        const uint32_t d[3] = {d0, d1, d2};
-        for (uint32_t i = 0; i < groups; i++) store128(g0 + i, d[(4 * i) % 3], d[(4 * i + 1) % 3], d[(4 * i + 2) % 3], d[(4 * i + 3) % 3]);
-    }
-    static bool any(bool x) { return x; }
-    static void cooperate() {}
 };
 
 } // namespace
@@ -86,9 +89,10 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         first_bit += 8 * z_shift, end_limit += 8 * z_shift;
         const uint8_t *lenof = (const uint8_t *)(lut.data() + kLutEntries);
         const uint32_t n_sub = (uint32_t)((end_limit - first_bit + kSubBits - 1) / kSubBits), nb = (n_sub + sub_block - 1) / sub_block;
-        std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub);
+        std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub), eob_rel(n_sub, 0);
+        std::vector<std::vector<uint32_t>> tok(n_sub, std::vector<uint32_t>(kRecCap, 0)); // the records the settling decode of every subsequence leaves
         struct Rec {
-            uint32_t sum, first_eob, first_invalid, entry_rel, exit_rel, want_rel;
+            uint32_t sum, first_eob, first_invalid, first_overflow, entry_rel, exit_rel, want_rel;
             PhaseMap bmap;
             uint32_t left;
         };
@@ -120,12 +124,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             for (uint32_t t = 0; t < nthreads; t++) {
                 const uint32_t i = local0 + t, nominal = nominal_of(t), boundary = nominal + kSubBits;
                 if (!round) {
-                    sub_first<VoteAlone>(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t]);
+                    HostRec rec = {&tok[i]};
+                    sub_first<VoteAlone>(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t], rec);
                     dirty[t] = true;
                 } else {
                     const uint32_t v = info[i];
-                    st[t].start = nominal + info_start(v), st[t].end = boundary + info_end(v);
+                    st[t].start = nominal + info_start(v), st[t].end = boundary + info_end(v), st[t].nrec = info_nrec(v);
                     st[t].c.bytes = bytes[i], st[t].c.lits = info_lits(v), st[t].c.tail = tail[i], st[t].c.flags = info_flags(v);
+                    st[t].c.eob = (st[t].c.flags & kSubEob) ? nominal + eob_rel[i] : 0u;
                 }
                 s_end[t] = st[t].end;
             }
@@ -151,13 +157,12 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 }
                 const bool cand_now = round && !cand_done && (it >= kRefixRounds || (cand_first && it >= 1)); // (thread 0 takes its wanted start in step 0)
                 if (!cand_now) {
-                    // (the kernel gathers them into one wave and decodes them again from four on, else corrects them in place)
+                    // (the kernel gathers them into one wave from four on, else decodes them again where they are)
+                    (void)n_need;
                     for (uint32_t t = 0; t < nthreads; t++)
                         if (want[t] != st[t].start) {
-                            if (n_need >= 4)
-                                sub_redo<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
-                            else
-                                sub_refix<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t]);
+                            HostRec rec = {&tok[local0 + t]};
+                            sub_redo<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t], rec);
                             s_end[t] = st[t].end;
                             dirty[t] = true;
                             if (!ever[t]) ever[t] = true, fixed_subs++;
@@ -189,7 +194,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     if (srel == kPhaseUnknown) continue;
                     const uint32_t ws = nominal_of(t) + srel;
                     if (ws == st[t].start) continue;
-                    sub_redo<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t]);
+                    HostRec rec = {&tok[local0 + t]};
+                    sub_redo<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t], rec);
                     dirty[t] = true;
                     if (!ever[t]) ever[t] = true, fixed_subs++;
                 }
@@ -200,18 +206,21 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             for (uint32_t t = 0; t < nthreads; t++)
                 if (dirty[t]) {
                     const uint32_t i = local0 + t, nominal = nominal_of(t);
-                    info[i] = pack_info(st[t].start - nominal, st[t].end - (nominal + kSubBits), st[t].c);
-                    if (info_start(info[i]) != st[t].start - nominal || info_end(info[i]) != st[t].end - (nominal + kSubBits) || info_lits(info[i]) != st[t].c.lits)
+                    info[i] = pack_info(st[t].start - nominal, st[t].end - (nominal + kSubBits), st[t].c, st[t].nrec);
+                    if (info_start(info[i]) != st[t].start - nominal || info_end(info[i]) != st[t].end - (nominal + kSubBits) || info_lits(info[i]) != st[t].c.lits ||
+                        info_nrec(info[i]) != st[t].nrec || info_flags(info[i]) != st[t].c.flags)
                         throw 1; // a field of the record overflowed
                     bytes[i] = st[t].c.bytes, tail[i] = st[t].c.tail;
+                    if (st[t].c.flags & kSubEob) eob_rel[i] = st[t].c.eob - nominal;
                     any_dirty = true;
                 }
             if (!any_dirty) return false;
-            Rec r = {0, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, pm_none(), unsettled};
+            Rec r = {0, sub_block, sub_block, sub_block, st[0].start - nominal_of(0), 0, kUnknown, pm_none(), unsettled};
             for (uint32_t t = 0; t < nthreads; t++) {
                 r.sum += st[t].c.bytes;
                 if ((st[t].c.flags & kSubEob) && r.first_eob == sub_block) r.first_eob = t;
                 if ((st[t].c.flags & kSubInvalid) && r.first_invalid == sub_block) r.first_invalid = t;
+                if ((st[t].c.flags & kSubOverflow) && r.first_overflow == sub_block) r.first_overflow = t;
             }
             r.exit_rel = nthreads == sub_block ? s_end[sub_block - 1] - (nominal_of(0) + sub_block * kSubBits) : 0u;
             r.bmap = (pm_count(bmap) || unsettled) ? bmap : pm_one(r.entry_rel, r.exit_rel);
@@ -223,6 +232,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         } catch (int) {
             return -1002;
         }
+        // (from here on `throw 3`: dec_subscan_kernel's windows)
         // ---- dec_chain_kernel: every block's true entry as far as the blocks' maps tell it (a block whose map does not know the phase
         //      it is entered in hands on its present exit: the neighbour's word, as before) ----
         auto block_fn = [&](uint32_t b, uint32_t x) {
@@ -292,19 +302,27 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
             if (b < last_blk) {
                 acc += recs[b].sum;
                 if (recs[b].first_invalid < sub_block) status |= 2;
-            } else if (recs[b].first_invalid <= last_local)
-                status |= 2;
+                if (recs[b].first_overflow < sub_block) status |= 16;
+            } else {
+                if (recs[b].first_invalid <= last_local) status |= 2;
+                if (recs[b].first_overflow <= last_local) status |= 16;
+            }
         }
         if (last_blk < nb)
             for (uint32_t k = 0; k <= last_local; k++) acc += bytes[last_blk * sub_block + k];
         else
             status |= 2;
         if (acc != total) status |= 2;
-        if (status & 1) return FPNG_AMD_DECODE_UNDECIDED;
-        if (status) return 1; // FPNG_DECODE_NOT_FPNG
         const uint32_t eob_index = last_blk * sub_block + last_local;
-        // ---- dec_subscan_kernel ----
-        std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0);
+        // the stream must end 4 bytes (the Adler-32) before the IDAT does (eob_status() of decode.hip)
+        if (last_blk < nb && ((first_bit + (uint64_t)eob_index * kSubBits + eob_rel[eob_index] + 7) >> 3) + 4 != z_bytes) status |= 2;
+        if (status & (1 | 16)) return FPNG_AMD_DECODE_UNDECIDED; // (decode_api.cpp: not converged / left to the CPU decoder go first)
+        if (status) return 1; // FPNG_DECODE_NOT_FPNG
+        // ---- dec_subscan_kernel: offsets, the literal bytes in front, and the windows (decode_core.h) that begin in each subsequence's output ----
+        // (the kernel's tiles: column blocks of 1024 bytes, 768 where 3-channel rows become 4-channel pixels)
+        const uint32_t cbw = (c == 3 && desired == 4) ? 768u : 1024u, ncb = (bpl + cbw - 1) / cbw;
+        std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0), win((size_t)h * ncb, 0xFFFFFFFFu);
+        try {
         for (uint32_t b = 0; b <= last_blk; b++) {
             uint32_t before = 0;
             for (uint32_t t = 0; t < sub_block; t++) {
@@ -313,38 +331,47 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 rel[i] = before;
                 lastpx[i] = lookback_lastpx(
                     i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
+                for_windows_starting_in(block_off[b] + before, bytes[i], cbw, ncb, stride, h, [&](uint32_t y, uint32_t cb) {
+                    if (win[(size_t)y * ncb + cb] != 0xFFFFFFFFu) throw 3; // two subsequences claim one window
+                    win[(size_t)y * ncb + cb] = i;
+                });
                 before += bytes[i];
             }
         }
-        // ---- dec_emit_kernel: one thread per subsequence, whole aligned dwords of the stream ----
+        } catch (int) {
+            return -1007; // two subsequences claim one window
+        }
+        // ---- dec_unfilter_kernel's tiles, first half: every window filled from the records of the subsequences that cover it, thread k of
+        //      the window's eight taking the k-th, (k + 8)-th ... subsequence from the one the window begins in ----
         uint32_t err = 0;
         bool fault = false;
-        const size_t ndw = (total + 3) / 4;
-        std::vector<bool> written((ndw + 3) / 4 * 4, false);
-        HostSink sink = {filt.data(), ndw, &written, &fault};
-        for (uint32_t i = 0; i < n_sub && i <= eob_index; i++) {
-            const uint64_t off = block_off[i / sub_block] + rel[i];
-            // (the kernel stages a workgroup's bits from its first subsequence's nominal bit on; workgroups of emit_block threads)
-            const uint32_t emit_block = sub_block > 1 ? sub_block / 2 : 1, c0 = i / emit_block * emit_block;
-            const uint64_t nominal0 = first_bit + (uint64_t)c0 * kSubBits, d0 = nominal0 >> 5, base = d0 << 5;
-            HostBits in = {zdw.data() + d0};
-            const uint32_t nominal = (uint32_t)(nominal0 - base) + (i - c0) * kSubBits;
-            const uint32_t col = (uint32_t)(off % stride), own = bytes[i];
-            const bool is_last = i == eob_index;
-            const uint32_t pad = is_last ? 0u : (0u - ((uint32_t)off + own)) & 15u;
-            uint32_t eob_end = 0;
-            const uint32_t p0 = nominal + info_start(info[i]);
-            const uint32_t fl = c == 4 ? walk_emit<4>(in, lut.data(), lenof, p0, own, pad, is_last, off, col, lastpx[i], stride, sink, eob_end)
-                                       : walk_emit<3>(in, lut.data(), lenof, p0, own, pad, is_last, off, col, lastpx[i], stride, sink, eob_end);
-            if ((fl & kEmitSawEob) && ((base + eob_end + 7) >> 3) + 4 != z_bytes) err |= 2;
-            err |= fl;
-        }
+        std::vector<bool> written(total, false);
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t cb = 0; cb < ncb; cb++) {
+                const Window wd = window_of(y, cb, cbw, stride);
+                const uint32_t i0 = win[(size_t)y * ncb + cb];
+                if (i0 == 0xFFFFFFFFu) return -1005; // (the stream covers the image: every window begins somewhere)
+                HostRow row = {filt.data() + wd.ws, &written, (size_t)wd.ws, &fault, c};
+                for (uint32_t k0 = 0; k0 < 8; k0++)
+                    for (uint32_t i = i0 + k0; i <= eob_index; i += 8) {
+                        const uint64_t off = block_off[i / sub_block] + rel[i];
+                        if (off >= wd.ws + wd.wlen) break;
+                        PlaceState ps;
+                        ps.c = (int32_t)(int64_t)(off - wd.ws), ps.lastpx = lastpx[i], ps.err = 0;
+                        const uint32_t nrec = std::min(info_nrec(info[i]), kRecCap);
+                        for (uint32_t k = 0; k < nrec && ps.c < (int32_t)wd.wlen; k += 8)
+                            for (uint32_t j = 0; j < 8; j++) { // (the kernel loads eight records at a time; behind the last one: zeros)
+                                const uint32_t r = k + j < nrec ? tok[i][k + j] : 0u;
+                                if (c == 4) place_one<4>(r, ps, wd, stride, row); else place_one<3>(r, ps, wd, stride, row);
+                            }
+                        err |= ps.err;
+                    }
+            }
         if (fault) return -1004;
         if (err & kEmitLeaveToCpu) return FPNG_AMD_DECODE_UNDECIDED; // (decode_api.cpp: kDecStalled goes first -- a match at a row's first pixel is the CPU decoder's)
         if (err & 2) return 1;
-        if (!(err & kEmitSawEob)) return 1;
-        for (size_t d = 0; d < ndw; d++)
-            if (!written[d]) return -1005; // a dword of the stream nobody stored
+        for (uint64_t d = 0; d < total; d++)
+            if (!written[d]) return -1005; // a byte of the stream nobody wrote
     }
     // ---- Up filter undone, channel conversion (dec_unfilter_kernel) ----
     std::vector<uint8_t> prev(bpl, 0), cur(bpl);

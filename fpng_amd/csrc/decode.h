@@ -103,11 +103,10 @@ struct DecCarry {
 struct DecSubArrays {
     uint32_t *info;   // dec::pack_info
     uint32_t *bytes;  // output bytes
-    uint32_t *tail;   // last four literal bytes
     uint32_t *rel;    // output offset inside its workgroup (exclusive scan of bytes)
-    uint32_t *lastpx; // the four literal bytes in front of it
+    uint32_t *lastpx; // the four literal bytes in front of it (decode_core.h: lookback_lastpx, over the records)
     uint32_t *eob;    // where its end-of-block symbol ends, in bits behind its nominal first bit (subsequences flagged kSubEob)
-    uint32_t *tok;    // its token records (decode_core.h: rec_chunk_base)
+    uint64_t *tok;    // its token records, two to an entry (decode_core.h: rec_index)
 };
 
 // the kernels work on the workgroups [first_block, first_block + n_blocks) of the batch's subsequences (one group of files);
@@ -134,5 +133,8 @@ struct DecPlaced {
 // concurrent_status: kernels that may set the file's status bits run next to this launch (no workgroup may then skip its file: dec_unfilter_kernel)
 void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, DecPlaced placed, uint32_t *status, uint32_t epoch, bool any_stored);
+#ifdef FPNG_DEC_TILE_TIMING
+void dec_dump_tile_times(const char *path, uint32_t n_items); // (diagnostic build: dec_unfilter_kernel's per-tile time stamps of the last launch)
+#endif
 
 } // namespace fpng_amd

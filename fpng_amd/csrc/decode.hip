@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 namespace fpng_amd {
 
@@ -142,25 +144,26 @@ struct WaveVote {
     }
 };
 
-// ---- token records (decode_core.h): where a subsequence's settling decode leaves what it decoded.  The 64 lanes of a wave write side
-//      by side -- record k of lane l at dword k * 64 + l of the wave's chunk -- and walk in step, so their stores fill whole lines.  What
-//      is not a record (a lookup that was no plain token: the lanes' code is straight-line) goes to the column's spare row. ----
-typedef __attribute__((address_space(1))) uint32_t gu32;
+// ---- token records (decode_core.h): where a subsequence's settling decode leaves what it decoded, an 8-byte entry per step of the
+//      walk.  The 64 lanes of a wave write side by side -- entry k of lane l at 8-byte word k * 64 + l of the wave's chunk -- and
+//      walk in step, so their stores fill whole lines.  A step that decoded nothing plain leaves its (empty) entry where the next
+//      step's will go. ----
+typedef __attribute__((address_space(1))) uint64_t gu64e;
 struct TokOut {
-    gu32 *col; // the subsequence's record 0
+    gu64e *col; // the subsequence's entry 0 (decode_core.h: rec_index)
     uint32_t k = 0;
-    __device__ __forceinline__ void put(uint32_t r, bool en)
+    __device__ __forceinline__ void put2(uint32_t a, uint32_t b)
     {
-        const uint32_t row = en ? (k < kRecCap ? k : kRecCap) : kRecCap;
-        col[row * kRecLane] = r;
-        k += en ? 1u : 0u;
+        const uint32_t kk = k < kRecCap ? k : kRecCap;
+        col[(kk >> 2) * 256u + (kk & 3u) * 8u] = (uint64_t)b << 32 | a;
+        k += (a | b) ? 1u : 0u;
     }
     __device__ __forceinline__ uint32_t count() const { return k; }
 };
-__device__ __forceinline__ TokOut tok_of(uint32_t *tok, uint32_t g)
+__device__ __forceinline__ TokOut tok_of(uint64_t *tok, uint32_t g)
 {
     TokOut o;
-    o.col = (gu32 *)(uintptr_t)(tok + rec_chunk_base(g));
+    o.col = (gu64e *)(uintptr_t)(tok + rec_index(g, 0));
     return o;
 }
 
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
         SubState st;
         st.start = st.end = nominal;
-        st.c.bytes = st.c.lits = st.c.tail = st.c.flags = st.c.eob = 0, st.nrec = 0;
+        st.c.bytes = st.c.flags = st.c.eob = 0, st.nrec = 0;
         bool dirty = false;
         if (valid) {
             if (!round) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
             } else {
                 const uint32_t v = a.info[g];
                 st.start = nominal + info_start(v), st.end = boundary + info_end(v), st.nrec = info_nrec(v);
-                st.c.bytes = a.bytes[g], st.c.lits = info_lits(v), st.c.tail = a.tail[g], st.c.flags = info_flags(v);
+                st.c.bytes = a.bytes[g], st.c.flags = info_flags(v);
                 st.c.eob = (st.c.flags & kSubEob) ? nominal + a.eob[g] : 0u;
             }
         }
@@ -372,14 +375,14 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                         SubState r;
                         TokOut rec = tok_of(a.tok, g - t + ot); // (the owner's column: lanes of this pass write to columns of any wave's chunk)
                         sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r, rec);
-                        q[0] = r.c.eob - o_nominal, q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c, r.nrec), q[2] = r.c.bytes, q[3] = r.c.tail;
+                        q[0] = r.c.eob - o_nominal, q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c, r.nrec), q[2] = r.c.bytes;
                     }
                     __syncthreads();
                     if (mine) {
                         const uint32_t *q = redo[slot - base_slot];
                         const uint32_t v = q[1];
                         st.start = want, st.end = boundary + info_end(v), st.nrec = info_nrec(v);
-                        st.c.bytes = q[2], st.c.lits = info_lits(v), st.c.tail = q[3], st.c.flags = info_flags(v), st.c.eob = nominal + q[0];
+                        st.c.bytes = q[2], st.c.flags = info_flags(v), st.c.eob = nominal + q[0];
                         dirty = true;
                     }
                 }
@@ -418,7 +421,6 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (dirty && valid) {
             a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c, st.nrec);
             a.bytes[g] = st.c.bytes;
-            a.tail[g] = st.c.tail;
             if (st.c.flags & kSubEob) a.eob[g] = st.c.eob - nominal;
         }
         const bool any_dirty = __syncthreads_or(dirty);
@@ -669,15 +671,21 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     __shared__ uint32_t wsum[kSubBlock / kWave];
     const uint32_t blk = first_block + blockIdx.x, g0 = blk * kSubBlock;
     if (g0 >= total_subs) return;
+    // (everything this thread will want from memory is asked for at once, in front of the questions whose answers decide whether it
+    //  is wanted: the kernel is a chain of round trips otherwise -- 14 400 workgroups of it for 8 x 8K)
+    const uint32_t t = threadIdx.x, g = g0 + t, lane = t & 63, wv = t >> 6;
+    const uint64_t *mine = a.tok + rec_index(g, 0);
+    const uint32_t nb_l = a.bytes[g], info_l = a.info[g];
+    const uint64_t e0_l = mine[0], e1_l = mine[8], boff_l = block_off[blk]; // (entries 0 and 1)
     uint32_t local0;
     const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
     const uint32_t job_index = (uint32_t)(&job - jobs);
     if (status[job_index] & ~kDecSawEob) return;
     const uint32_t last = eob_index[job_index];
     if (local0 > last) return; // behind the end of the stream
-    const uint32_t t = threadIdx.x, g = g0 + t, i = local0 + t, lane = t & 63, wv = t >> 6;
+    const uint32_t i = local0 + t;
     const bool active = i < job.n_sub && i <= last;
-    const uint32_t nb = active ? a.bytes[g] : 0u;
+    const uint32_t nb = active ? nb_l : 0u;
     uint32_t incl = nb;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
@@ -690,30 +698,62 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     for (uint32_t q = 0; q < wv; q++) before += wsum[q];
     if (!active) return;
     a.rel[g] = before;
-    const uint32_t *info = a.info + job.sub_base, *tail = a.tail + job.sub_base;
-    a.lastpx[g] = lookback_lastpx(
-        i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
+    const uint32_t *info = a.info + job.sub_base;
+    const uint64_t *tok = a.tok;
+    const uint32_t sb = job.sub_base;
+    {
+        const uint32_t nent = info_nrec(info_l);
+        const bool need = nent && needs_lastpx(e0_l, e1_l, nent);
+        a.lastpx[g] = need ? lookback_lastpx(
+                                 i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[rec_index(sb + k, e)]; })
+                           : 0u;
+    }
     // the windows of dec_unfilter_kernel's tiles whose first byte this subsequence writes: their walk over the records starts here
     const uint32_t ncb = dec_col_blocks(job.w, job.src_c, job.dst_c), cbw = dec_col_block_bytes(job.src_c, job.dst_c);
     uint32_t *win = job.win;
-    for_windows_starting_in(block_off[blk] + before, nb, cbw, ncb, job.bpl + 1, job.h, [&](uint32_t y, uint32_t cb) { win[(size_t)y * ncb + cb] = i; });
+    if (nb) for_windows_starting_in(boff_l + before, nb, cbw, ncb, job.bpl + 1, job.h, [&](uint32_t y, uint32_t cb) { win[(size_t)y * ncb + cb] = i; });
 }
 
+#ifdef FPNG_DEC_TILE_TIMING // diagnostic build (fpng_amd/build.py --variant tile_timing): when does a tile start, have its rows, know its carry, end?
+__device__ unsigned long long g_tile_times[8 * 65536];
+#define FPNG_TILE_STAMP(k) do { if (threadIdx.x == 0 && item0 + blockIdx.x < 65536) g_tile_times[8 * (item0 + blockIdx.x) + (k)] = wall_clock64(); } while (0) // (by workgroup number)
+#else
+#define FPNG_TILE_STAMP(k) do { } while (0)
+#endif
 // ---- the pass that writes.  A tile of dec_unfilter_kernel = kUnfRows rows x one block of columns; every row piece ("window",
 //      decode_core.h) is filled in LDS from the token records of the subsequences that cover it: eight threads per row, thread k of
 //      them walks the k-th, (k + 8)-th ... subsequence from the one the window begins in (dec_subscan_kernel left its number), a
 //      record per step, eight records in flight per thread.  A subsequence that straddles two windows is walked for both. ----
-constexpr uint32_t kTilePitch = 1040; // bytes of LDS per row: 3 unused, the filter byte (first column block only), 1024 (768) data bytes, slack
+constexpr uint32_t kTilePitch = 1040; // bytes of LDS per row: 7 of slack, the filter byte (first column block only), 1024 (768) data bytes, 8 of slack
+constexpr uint32_t kTileData = 8;     // where a row's data bytes begin (a dword boundary)
 constexpr uint32_t kRowThreads = 8;   // threads that share a window
+constexpr uint32_t kUnfBlock = 512;   // threads of dec_unfilter_kernel: kUnfRows x kRowThreads of them fill the tile, kDecBlock of them own a dword column
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t __attribute__((aligned(1))) u32_any_t;
+typedef __attribute__((address_space(3))) u32_any_t lds_u32_any; // (a dword at any byte address: the hardware takes it)
 struct TileRow {
-    lds_u8 *p; // window byte 0
-    __device__ __forceinline__ void put8(uint32_t pos, uint32_t b) { p[pos] = (uint8_t)b; }
+    lds_u8 *row; // the row's first byte in the tile: a byte nobody reads, where stores that go nowhere go
+    uint32_t a0; // window byte 0 stands a0 bytes behind it (kTileData - 1: the window begins with the filter byte, else kTileData)
+    bool c4;
+    __device__ __forceinline__ void put8c(uint32_t pos, uint32_t b, bool cond) { row[cond ? a0 + pos : 0u] = (uint8_t)b; }
+    // A group of literals that begins inside the window, written as ONE dword at its (any) byte address: its bytes and, behind them,
+    // up to three bytes that are not its own -- they lie where this thread's NEXT records go (which overwrite them), behind the
+    // window (the row's slack), or on the first bytes of the next subsequence, whose thread writes those again when the wave has
+    // finished the round (fill_tile).  Where `ok` is false the dword goes to the row's last eight bytes, which nobody reads.
+    __device__ __forceinline__ void put_wide(uint32_t c, uint32_t r, bool ok) { *(lds_u32_any *)(row + (ok ? a0 + c : kTilePitch - 8u)) = r; }
+    // ... the same without a question: the position is CLAMPED to [-4, wlen] -- a record in front of the window or behind it lands in
+    // the four bytes of slack on that side, one that straddles an edge puts its inner bytes where they belong
+    __device__ __forceinline__ void put_clamped(int32_t c, uint32_t wlen, uint32_t v)
+    {
+        const int32_t lo = c < -4 ? -4 : c, pos = lo > (int32_t)wlen ? (int32_t)wlen : lo;
+        *(lds_u32_any *)(row + a0 + pos) = v;
+    }
     // bytes [lo, hi) = copies of the C-byte pixel px, byte lo being its byte q: bytes up to a dword boundary, whole dwords (the
     // pixel rotated: 4 channels one constant, 3 channels a cycle of three), bytes
     template <int C> __device__ __forceinline__ void fill_c(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
     {
+        lds_u8 *p = row + a0;
         const uint64_t wrap = C == 4 ? ((uint64_t)px << 32 | px) : ((uint64_t)(px & 0xFFFFFFu) | (uint64_t)(px & 0xFFFFFFu) << 24 | (uint64_t)px << 48);
         uint32_t pos = lo;
         while (pos < hi && (((uint32_t)(uintptr_t)p + pos) & 3u)) {
@@ -734,38 +774,99 @@ struct TileRow {
     {
         if (c4) fill_c<4>(lo, hi, px, q); else fill_c<3>(lo, hi, px, q);
     }
-    bool c4;
 };
+// place_one() of decode_core.h for a wave.  The straight-line form: a record is ONE dword store at its position, clamped to the
+// window and the four bytes of slack on either side of it (TileRow::put_clamped) -- a group of literals: its bytes and, behind them,
+// up to three that are not its own (they lie where this thread's next records go, which overwrite them; behind the window; or on the
+// first bytes of the next subsequence, whose thread writes those again when the wave has finished the round: fill_tile); nothing: four
+// zeros, to the same effect; a match of ONE pixel (noisy content has one in a few hundred tokens, i.e. some lane of a wave in every
+// fourth step): the pixel; a match that lies outside the window: the pixel, into the slack.  Only a longer match that touches some
+// lane's window sends the wave through the general form.
+template <int C> __device__ __forceinline__ void place_lean(uint32_t r, PlaceState &s, const Window &w, uint32_t stride, TileRow &out)
+{
+    const bool isrun = (r & kRecRun) != 0;
+    const uint32_t n = (r >> 26) & 3u;
+    uint32_t len = n, data = r;
+    if (__builtin_amdgcn_ballot_w64(isrun) != 0) {
+        const uint32_t rl = r & 0xFFFFFFu, c = (uint32_t)s.c;
+        if (__builtin_amdgcn_ballot_w64(isrun && rl != (uint32_t)C && s.c + (int32_t)rl > 0 && s.c < (int32_t)w.wlen) != 0) {
+            place_one<C>(r, s, w, stride, out);
+            return;
+        }
+        if (isrun) {
+            if (c < w.wlen) { // a one-pixel match that begins in the window: the reference's checks (place_one)
+                const uint32_t rowleft = stride - (w.xw + c), bpl = stride - 1;
+                if (rowleft % C != 0 || rowleft > bpl || rl > rowleft)
+                    s.err |= kEmitBadStream;
+                else if (rowleft == bpl)
+                    s.err |= kEmitLeaveToCpu;
+            }
+            len = rl, data = C == 4 ? s.lastpx : s.lastpx >> 8;
+        }
+    }
+    out.put_clamped(s.c, w.wlen, data);
+    s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n); // (a match: n = 0, nothing moves)
+    s.c += (int32_t)len;
+}
 // the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks
 template <int C>
-__device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced &pl, uint32_t last, uint32_t y0, uint32_t nrows, uint32_t cb, uint32_t ncb, uint32_t cbw, lds_u8 *tile)
+__device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced &pl, uint32_t last, uint32_t y0, uint32_t nrows, uint32_t cb, uint32_t ncb, uint32_t cbw, lds_u8 *tile,
+                                              uint32_t item0)
 {
     const uint32_t stride = job.bpl + 1;
     uint32_t err = 0;
-    for (uint32_t q = threadIdx.x; q < nrows * kRowThreads; q += kDecBlock) {
+    for (uint32_t q = threadIdx.x; q < nrows * kRowThreads; q += kUnfBlock) {
         const uint32_t r = q / kRowThreads, k0 = q % kRowThreads;
         const Window w = window_of(y0 + r, cb, cbw, stride);
         const uint32_t i0 = job.win[(size_t)(y0 + r) * ncb + cb];
         if (i0 == 0xFFFFFFFFu) continue; // (a stream that does not cover the image: its status says so)
         TileRow out;
-        out.p = tile + r * kTilePitch + (cb ? 4u : 3u);
-        out.c4 = C == 4;
+        out.row = tile + r * kTilePitch, out.a0 = cb ? kTileData : kTileData - 1u, out.c4 = C == 4;
         for (uint32_t i = i0 + k0; i <= last && i < pl.sub_limit; i += kRowThreads) {
             const uint32_t g = job.sub_base + i;
             const uint64_t off = pl.block_off[g / kSubBlock] + pl.a.rel[g];
             if (off >= w.ws + w.wlen) break; // (offsets rise: nothing further on reaches into the window)
             PlaceState st;
             st.c = (int32_t)(int64_t)(off - w.ws), st.lastpx = pl.a.lastpx[g], st.err = 0;
-            const uint32_t nrec = min(info_nrec(pl.a.info[g]), kRecCap);
-            const gu32 *col = (const gu32 *)(uintptr_t)(pl.a.tok + rec_chunk_base(g));
-            for (uint32_t k = 0; k < nrec && st.c < (int32_t)w.wlen; k += 8) {
-                uint32_t rr[8];
+            const PlaceState st0 = st;
+            FPNG_TILE_STAMP(5);
+            const uint32_t nent = min(info_nrec(pl.a.info[g]), kRecCap);
+            const gu64e *col = (const gu64e *)(uintptr_t)(pl.a.tok + rec_index(g, 0));
+            constexpr uint32_t kBatch = 16; // entries in flight per thread
+            for (uint32_t k = 0; k < nent && st.c < (int32_t)w.wlen; k += kBatch) {
+                uint64_t rr[kBatch];
+                // (all loads of a batch in flight, none behind a branch, their addresses one base and constants: what lies behind the
+                //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway; the scratch ends with kBatch spare
+                //  rows -- is read and counts as nothing)
+                const gu64e *ck = col + (size_t)(k >> 2) * 256u; // (k is a multiple of kBatch: whole blocks of four entries)
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) rr[j] = k + j < nrec ? col[(k + j) * kRecLane] : 0u;
+                for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) place_one<C>(rr[j], st, w, stride, out);
+                for (uint32_t j = 0; j < kBatch; j++) rr[j] = k + j < nent ? rr[j] : 0ull;
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) {
+                    place_lean<C>((uint32_t)rr[j], st, w, stride, out);
+                    place_lean<C>((uint32_t)(rr[j] >> 32), st, w, stride, out);
+                }
             }
             err |= st.err;
+            FPNG_TILE_STAMP(6);
+            // The wave has written this round's subsequences -- the lanes of a row walk neighbours, in step -- and the dword stores of
+            // the one in front may have left up to four bytes on this one's first bytes (place_lean): its first four entries (four
+            // bytes at the least) once more, byte for byte, as far as the first four bytes go.
+            if (st0.c >= 0 && nent) {
+                Window wf = w;
+                wf.wlen = min(w.wlen, (uint32_t)st0.c + 4u);
+                PlaceState sf = st0;
+                uint64_t e4[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) e4[j] = col[min(j, nent - 1) * 8u];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    if (j < nent) place_one<C>((uint32_t)e4[j], sf, wf, stride, out), place_one<C>((uint32_t)(e4[j] >> 32), sf, wf, stride, out);
+                }
+            }
+            FPNG_TILE_STAMP(7);
         }
     }
     return err;
@@ -811,12 +912,11 @@ __device__ __forceinline__ gu8 *scalar_base(const gu8 *p)
 __device__ __forceinline__ uint32_t gload_u32(const gu8 *base, uint32_t off) { return *(const gu32_any *)(scalar_base(base) + off); }
 __device__ __forceinline__ void gstore_u32(gu8 *base, uint32_t off, uint32_t v) { *(gu32_any *)(scalar_base(base) + off) = v; }
 __device__ __forceinline__ void gstore_u8(gu8 *base, uint32_t off, uint32_t v) { scalar_base(base)[off] = (uint8_t)v; }
-#ifndef FPNG_DEC_UNF_WAVES
-#define FPNG_DEC_UNF_WAVES 3
-#endif
-__global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_DEC_UNF_WAVES, FPNG_DEC_UNF_WAVES))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
+// (three workgroups of eight waves per compute unit: the tiles' LDS)
+__global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kUnfRows * kTilePitch];
+    FPNG_TILE_STAMP(0);
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
     // cbpre[] = their column blocks' prefix sums.  One workgroup per item, item = workgroup number: an item waits for items with
@@ -828,7 +928,12 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
     // and leaves the file to the CPU decoder (FPNG_AMD_DECODE_UNDECIDED).
     constexpr uint32_t kSpinLimit = 1u << 20;
     {
-        const uint32_t item = item0 + blockIdx.x; // (item0: a later launch for the same files, fpng_amd_decode_host's streamed form)
+        // Which item?  The hardware deals a grid's workgroups to the eight XCDs in turn, and neighbouring items -- the column blocks of
+        // one band of rows -- read the same blocks of token records where their windows meet: inside every run of 64 workgroups the
+        // numbers are dealt so that eight neighbours share an XCD, i.e. an L2.  (Items still wait for lower numbers only; the order of
+        // the runs is the grid's.)
+        const uint32_t b = blockIdx.x, b_run = b & ~63u;
+        const uint32_t item = item0 + (b_run + 64u <= gridDim.x ? b_run + ((b & 7u) << 3) + ((b >> 3) & 7u) : b); // (item0: a later launch for the same files, fpng_amd_decode_host's streamed form)
         if (item >= plan.total_items) return;
         uint32_t lo = 0, hi = plan.n_pieces;
         while (hi - lo > 1) {
@@ -870,35 +975,36 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
         lds_u8 *tile = (lds_u8 *)tile_mem;
         {
             const uint32_t ncb = dec_col_blocks(job.w, sc, dc), cbw = dec_col_block_bytes(sc, dc), last_sub = placed.eob_index[ji];
-            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile) : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile);
+            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, item0) : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, item0);
             if (err) atomicOr(&status[ji], err);
         }
         __syncthreads();
+        FPNG_TILE_STAMP(1);
+        if (threadIdx.x >= (uint32_t)kDecBlock) return; // (the tile is filled: from here on a thread per dword column)
         if (cb == 0 && threadIdx.x == 0) {
             bool bad = false;
-            for (uint32_t k = 0; k < nrows; k++) bad |= tile[k * kTilePitch + 3] != (y0 + k ? 2 : 0);
+            for (uint32_t k = 0; k < nrows; k++) bad |= tile[k * kTilePitch + kTileData - 1] != (y0 + k ? 2 : 0);
             if (bad) atomicOr(&status[ji], kDecBadFilter);
         }
         if (!widen && !active) return; // (the lanes of a widening wave all stay: they write pixels)
         if (widen && wave_px >= job.w) return;
-        uint32_t v[kUnfRows];
-        // (no branch per row: a segment with fewer rows loads its last row again and again -- zeroed below, so that those entries
-        //  END UP as copies of the last row's sums, and the stores further down write that row again with the same bytes)
-        const uint32_t last = nrows - 1;
-        if (active) {
-            const lds_u32 *T = (const lds_u32 *)(tile + 4) + (widen ? wv * 48 + lane : threadIdx.x); // this thread's dword column of the tile
-#pragma unroll
-            for (uint32_t k = 0; k < kUnfRows; k++) v[k] = T[min(k, last) * (kTilePitch / 4)];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kUnfRows; k++) v[k] = (k < nrows && active) ? v[k] : 0u;
+        // ---- the columns' running sums, in place: row k of the tile becomes the sum of its rows 0 .. k (every thread its own dword
+        //      column; eight rows in flight).  The rows stay in LDS -- until round 6 a thread held its 48 of them in registers, which
+        //      is what kept the kernel at four waves per SIMD. ----
+        lds_u32 *T = (lds_u32 *)(tile + kTileData) + (widen ? wv * 48 + lane : threadIdx.x); // this thread's dword column of the tile
+        constexpr uint32_t P = kTilePitch / 4;
         uint32_t p = 0;
+        if (active) {
+            for (uint32_t k = 0; k < nrows; k += 8) {
+                uint32_t t8[8];
 #pragma unroll
-        for (uint32_t k = 0; k < kUnfRows; k++) {
-            p = add_bytes(p, v[k]);
-            asm("" : "+v"(p)); // (ONE register per row: the compiler otherwise keeps every sum as the two halves add_bytes() joins and joins them where they are stored)
-            v[k] = p;
+                for (uint32_t q = 0; q < 8; q++) t8[q] = T[min(k + q, nrows - 1) * P];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++)
+                    if (k + q < nrows) p = add_bytes(p, t8[q]), T[(k + q) * P] = p;
+            }
         }
+        FPNG_TILE_STAMP(2);
         gu64 *gran = (gu64 *)(uintptr_t)job.segsum + j4;
         uint32_t carry = 0;
         if (active && (sg + 1 < job.nseg || sg)) { // (a file of one segment publishes nothing)
@@ -929,33 +1035,28 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
         }
         // ---- the pixels.  Dword stores at any byte address (rows of 3-channel pixels start anywhere; the hardware takes
         //      unaligned dwords, as it does for the loads above); bytes only where a row ends inside a dword ----
+        FPNG_TILE_STAMP(3);
         const size_t os = (size_t)job.w * dc;
         gu8 *orow = (gu8 *)(uintptr_t)(job.out + (size_t)y0 * os);
-#pragma unroll
-        for (uint32_t k = 0; k < kUnfRows; k++) {
-            v[k] = add_bytes(carry, v[k]);
-            asm("" : "+v"(v[k]));
-        }
+        auto row_sum = [&](uint32_t k) { return active ? add_bytes(carry, T[k * P]) : 0u; }; // the pixels' bytes of row k, this thread's four
         if (sc == dc) {
             const uint32_t nb = min(4u, job.bpl - j4 * 4);
             if (nb == 4) {
-#pragma unroll
-                for (uint32_t k = 0; k < kUnfRows; k++)
-                    gstore_u32(orow + (size_t)min(k, last) * os, j4 * 4, v[k]);
+                for (uint32_t k = 0; k < nrows; k++) gstore_u32(orow + (size_t)k * os, j4 * 4, row_sum(k));
             } else {
-#pragma unroll
-                for (uint32_t k = 0; k < kUnfRows; k++)
-                    for (uint32_t b = 0; b < nb; b++) gstore_u8(orow + (size_t)min(k, last) * os, j4 * 4 + b, v[k] >> (8 * b));
+                for (uint32_t k = 0; k < nrows; k++) {
+                    const uint32_t v = row_sum(k);
+                    for (uint32_t b = 0; b < nb; b++) gstore_u8(orow + (size_t)k * os, j4 * 4 + b, v >> (8 * b));
+                }
             }
         } else if (widen) {
             // lane L's pixel = bytes 3L .. 3L + 2 of the wave's 192: in the dwords of lanes 3L / 4 and the next one
             const uint32_t src = (3u * lane) >> 2, sh = (3u * lane) & 3u;
             const bool st = wave_px + lane < job.w;
-#pragma unroll
-            for (uint32_t k = 0; k < kUnfRows; k++) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v[k]), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src + 1) << 2), (int)v[k]);
-                if (st) gstore_u32(orow + (size_t)min(k, last) * os, (wave_px + lane) * 4, funnel(hi, lo, 8 * sh) | 0xFF000000u);
-                __builtin_amdgcn_sched_barrier(0); // (row by row: gathering all rows first costs a register per row and lane)
+            for (uint32_t k = 0; k < nrows; k++) {
+                const uint32_t v = row_sum(k);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src + 1) << 2), (int)v);
+                if (st) gstore_u32(orow + (size_t)k * os, (wave_px + lane) * 4, funnel(hi, lo, 8 * sh) | 0xFF000000u);
             }
         } else {
             // 4 -> 3 channels: the wave's 64 pixels are 48 dwords; lane L < 48 builds dword L = bytes 4L .. 4L + 3 of the 192
@@ -968,22 +1069,15 @@ __global__ __launch_bounds__(kDecBlock) __attribute__((amdgpu_waves_per_eu(FPNG_
                 const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)acc), b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((p0 + 1) & 63u) << 2), (int)acc);
                 return funnel((b & 0xFFFFFFu) >> 8, (a & 0xFFFFFFu) | (b << 24), 8 * r); // (b's 24 bits : a's 24 bits) >> 8 r
             };
-#pragma unroll
-            for (uint32_t k = 0; k < kUnfRows; k++) {
-                const uint32_t d = dword(v[k]);
-                if (nb == 4) gstore_u32(orow + (size_t)min(k, last) * os, off, d);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (__builtin_amdgcn_ballot_w64(nb - 1u < 3u)) { // the row ends inside some lane's dword (all lanes come along: they are the gather's sources)
-#pragma unroll
-                for (uint32_t k = 0; k < kUnfRows; k++) {
-                    const uint32_t d = dword(v[k]);
-                    if (nb - 1u < 3u)
-                        for (uint32_t q = 0; q < nb; q++) gstore_u8(orow + (size_t)min(k, last) * os, off + q, d >> (8 * q));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            const bool ragged = __builtin_amdgcn_ballot_w64(nb - 1u < 3u) != 0; // the row ends inside some lane's dword (all lanes come along: they are the gather's sources)
+            for (uint32_t k = 0; k < nrows; k++) {
+                const uint32_t d = dword(row_sum(k));
+                if (nb == 4) gstore_u32(orow + (size_t)k * os, off, d);
+                if (ragged && nb - 1u < 3u)
+                    for (uint32_t q = 0; q < nb; q++) gstore_u8(orow + (size_t)k * os, off + q, d >> (8 * q));
             }
         }
+        FPNG_TILE_STAMP(4);
     }
 }
 
@@ -1108,7 +1202,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_build_lut_kernel(const uint8_t 
         else if (s1 == 256)
             ent = l1 << 28;
         else if (s1 > 256)
-            ent = l1 << 28 | kEntMatch | (uint32_t)kLenExtra[s1 - 257] << 9 | kLenBase[s1 - 257];
+            ent = l1 << 28 | kEntMatch | (kLenExtra[s1 - 257] ? 0u : kEntSimple) | (uint32_t)kLenExtra[s1 - 257] << 9 | kLenBase[s1 - 257];
         else {
             uint32_t L = l1, n = 1, lits = s1;
             while (n < 3) { // the next code is whole if its length fits into the index bits that are left
@@ -1117,7 +1211,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_build_lut_kernel(const uint8_t 
                 lits |= s2 << (8 * n);
                 n++, L += l2;
             }
-            ent = L << 28 | n << 26 | lits;
+            ent = L << 28 | n << 26 | kEntSimple | lits;
         }
         lut[k] = ent;
     }
@@ -1180,9 +1274,21 @@ void launch_dec_offsets_range(hipStream_t s, const DecJob *jobs, uint32_t sub_ba
 void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status)
 {
     if (n_items)
-        hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kDecBlock), 0, s, jobs, plan, placed, item0, status, epoch,
+        hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kUnfBlock), 0, s, jobs, plan, placed, item0, status, epoch,
                            concurrent_status ? 0u : (kDecNotConverged | kDecBadStream | kDecStalled));
 }
+#ifdef FPNG_DEC_TILE_TIMING
+void dec_dump_tile_times(const char *path, uint32_t n_items)
+{
+    std::vector<unsigned long long> t(8 * (size_t)std::min(n_items, 65536u));
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_tile_times), t.size() * 8) != hipSuccess) return;
+    if (FILE *f = fopen(path, "w")) {
+        for (size_t i = 0; i < t.size() / 8; i++) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
+        fclose(f);
+    }
+}
+#endif
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, DecPlaced placed, uint32_t *status, uint32_t epoch, bool any_stored)
 {
     if (plan.total_items) launch_dec_unfilter(s, jobs, plan, placed, 0, plan.total_items, status, epoch, false);

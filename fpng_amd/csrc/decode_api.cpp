@@ -84,7 +84,7 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
         else if (s1 == 256)
             ent = l1 << 28;
         else if (s1 > 256)
-            ent = l1 << 28 | dec::kEntMatch | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257];
+            ent = l1 << 28 | dec::kEntMatch | (len_extra[s1 - 257] ? 0u : dec::kEntSimple) | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257];
         else {
             uint32_t L = l1, n = 1, lits = s1;
             while (n < 3) { // the next code is whole if its length fits into the index bits that are left
@@ -93,7 +93,7 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
                 lits |= s2 << (8 * n);
                 n++, L += l2;
             }
-            ent = L << 28 | n << 26 | lits;
+            ent = L << 28 | n << 26 | dec::kEntSimple | lits;
         }
         lut[k] = ent;
     }
@@ -331,9 +331,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        // (the token records: dec::kRecRows rows of 64 dwords per 64 subsequences, of which a gradient touches 55, a photograph 40)
+        // (the token records: dec::kRecRows rows of 64 8-byte entries per 64 subsequences -- 16 x the files' bytes, of which a gradient touches a fifth)
         const size_t o_z = carve(z_total + 64), o_win = carve(std::max<size_t>(win_total, 1) * 4), o_info = carve(subs * 4), o_bytes = carve(subs * 4),
-                     o_tail = carve(subs * 4), o_rel = carve(subs * 4), o_last = carve(subs * 4), o_eob = carve(subs * 4), o_tok = carve(subs * (size_t)dec::kRecRows * 4),
+                     o_rel = carve(subs * 4), o_last = carve(subs * 4), o_eob = carve(subs * 4), o_tok = carve((subs * (size_t)dec::kRecRows + 32 * dec::kRecLane) * 8),
                      o_recs = carve(blocks * sizeof(DecBlockRec)), o_boff = carve(blocks * 8),
                      o_luts = carve(std::max<size_t>(lut_keys.size() / 288, 1) * dec::kLutDwords * 4), o_keys = carve(std::max<size_t>(lut_keys.size(), 288)),
                      o_jobs = carve(nj * sizeof(DecJob)), o_plan = carve(((size_t)nj + kMaxGroups) * (sizeof(DecUnfPiece) + 8)), o_status = carve((2 * (size_t)nj + 1 + 2 * kMaxGroups) * 4);
@@ -348,8 +348,8 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         d_seg = e->d_dec_gran.p;
         uint8_t *base = e->d_decode.p;
         d_z = base + o_z, d_win = (uint32_t *)(base + o_win);
-        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
-        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint32_t *)(base + o_tok);
+        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint64_t *)(base + o_tok);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff);
         // the windows' index: "no subsequence" until dec_subscan_kernel says otherwise (a stream that covers less than the image leaves holes)
         HIP_TRY(hipMemsetAsync(d_win, 0xFF, std::max<size_t>(win_total, 1) * 4, e->stream));
@@ -589,6 +589,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (trace_t) fprintf(stderr, "[decode] +%.0f us: done\n", since());
+#ifdef FPNG_DEC_TILE_TIMING
+    if (const char *tp = getenv("FPNG_AMD_TILE_TIMES")) dec_dump_tile_times(tp, groups[0].plan.total_items);
+#endif
     static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)
@@ -688,8 +691,8 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
         };
         const size_t n_win = (size_t)j.h * col_blocks;
         const size_t o_z = carve((size_t)p.idat_len + 80), o_win = carve(n_win * 4), o_info = carve((size_t)sub_total * 4), o_bytes = carve((size_t)sub_total * 4),
-                     o_tail = carve((size_t)sub_total * 4), o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_eob = carve((size_t)sub_total * 4),
-                     o_tok = carve((size_t)sub_total * dec::kRecRows * 4), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
+                     o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_eob = carve((size_t)sub_total * 4),
+                     o_tok = carve(((size_t)sub_total * dec::kRecRows + 32 * dec::kRecLane) * 8), o_recs = carve(n_blocks * sizeof(DecBlockRec)),
                      o_boff = carve((size_t)n_blocks * 8), o_lut = carve(dec::kLutDwords * 4), o_job = carve(sizeof(DecJob)), o_small = carve(256);
         if ((rc = e->d_decode.ensure(need))) return rc;
         if ((rc = e->d_dec_gran.ensure(std::max<size_t>((size_t)j.nseg * ((j.bpl + 3) / 4), 1)))) return rc;
@@ -699,8 +702,8 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
         }
         uint8_t *base = e->d_decode.p;
         d_z = base + o_z, d_win = (uint32_t *)(base + o_win);
-        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes), d_sub.tail = (uint32_t *)(base + o_tail);
-        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint32_t *)(base + o_tok);
+        d_sub.info = (uint32_t *)(base + o_info), d_sub.bytes = (uint32_t *)(base + o_bytes);
+        d_sub.rel = (uint32_t *)(base + o_rel), d_sub.lastpx = (uint32_t *)(base + o_last), d_sub.eob = (uint32_t *)(base + o_eob), d_sub.tok = (uint64_t *)(base + o_tok);
         d_recs = (DecBlockRec *)(base + o_recs), d_block_off = (uint64_t *)(base + o_boff), d_lut = (uint32_t *)(base + o_lut), d_job = (DecJob *)(base + o_job);
         HIP_TRY(hipMemsetAsync(d_win, 0xFF, n_win * 4, s)); // ("no subsequence": decode_files())
         uint8_t *sm = base + o_small; // status, eob index | carry | unfilter piece | cbpre[2], order[1]

@@ -10,6 +10,9 @@
 //   n == 0, bit 25 set:   a match length symbol: bits 8..0 base length (3..258), bits 11..9 number of extra bits (0..5); L covers
 //                         the symbol's code only (the extra bits and the 1-bit distance code follow in the stream)
 //   n == 0, bit 25 clear: end of block
+//   bit 24 (kEntSimple):  a token the walks take in their straight-line part: a group of literals, or a match WITHOUT extra bits
+//                         (lengths 3 .. 10: one, two, three pixels -- the matches of noisy content); every other match, like the end
+//                         of the block, goes through fetch()
 // Behind the 4096 entries: lenof[256], the code length of every literal byte value -- a group of literals is taken apart with it
 // where token granularity matters (the hand-over between two subsequences must not depend on how the literals were grouped).
 #pragma once
@@ -27,19 +30,35 @@ namespace dec {
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
-// TOKEN RECORDS (round 6: every token is decoded ONCE).  The decode that settles a subsequence leaves what it decoded behind, one
-// 32-bit record per lookup, and the pass that writes the pixels (dec_unfilter_kernel) reads records instead of Huffman codes:
+constexpr uint32_t kEntSimple = 1u << 24;
+// TOKEN RECORDS (round 6: every token is decoded ONCE).  The decode that settles a subsequence leaves what it decoded behind, and the
+// pass that writes the pixels (dec_unfilter_kernel) reads records instead of Huffman codes.  A record is 32 bits:
 //   a group of literals   n << 26 | the n bytes (first one lowest)          -- the table's entry without its length field
-//   a match               kRecRun | its length in bytes (3..258)
-// A subsequence has room for kRecCap records (its 512 bits in lookups of 2.7 bits and more); one that needs more is flagged and its
-// file left to the CPU decoder (no fpng encoder's output comes near: a record of three literals takes three bits at the very least).
-// Layout in memory: the 64 subsequences of a wave side by side, record k of lane l at dword (k * 64 + l) of the wave's chunk, so that
-// the lanes' stores -- they walk in step, a record per lookup -- fill whole cache lines.
-constexpr uint32_t kRecCap = 192;
-constexpr uint32_t kRecRows = kRecCap + 1;  // + the row that takes what is not a record (and what overflows)
+//   a match               kRecRun | its length in bytes (3..258) in bits 23..0 (bit 24 means nothing: a table entry's kEntSimple may stand there)
+//   0                     nothing
+// and an ENTRY is two of them -- what one step of the walk (two lookups) decoded, stored with one 8-byte store; a token that takes the
+// walk's general path is an entry of its own.  A subsequence has room for kRecCap entries (its 512 bits in steps of four bits and
+// more); one that needs more is flagged and its file left to the CPU decoder (no fpng encoder's output comes near: a step of two
+// groups of three literals takes six bits at the very least).
+// LAYOUT in memory, made for both sides.  The writers are the 64 lanes of a wave, one subsequence each, walking in step: entry k of
+// all of them at once.  The readers (dec_unfilter_kernel's tiles) are EIGHT neighbouring subsequences at a time -- eight lanes per
+// row of a tile, the tile's rows far apart in the stream -- reading their entries k, k + 1, ... in batches.  So a chunk (64
+// subsequences) is cut into blocks of 4 entries x 8 subsequences = 256 bytes: entry k of subsequence l (of the chunk) is 8-byte word
+//     (k / 4) * 256 + (l / 8) * 32 + (k % 4) * 8 + l % 8
+// -- a wave's store of one entry fills eight 64-byte pieces, four steps fill the eight 256-byte blocks whole; a reader's eight lanes
+// find four consecutive entries in one block: whole 128-byte lines in both directions.  (Round 6's first layout, entry k of lane l at
+// k * 64 + l, had the readers use 64 bytes of every line they fetched, the other half going to another tile on another XCD: 7 GB
+// fetched for 1.6 GB of entries, profiles/r06_decode_once_ab.txt.)
+constexpr uint32_t kRecCap = 128;
+constexpr uint32_t kRecRows = kRecCap + 4;  // + the entry that takes what overflows (a whole block of four)
 constexpr uint32_t kRecRun = 1u << 25;      // (= kEntMatch: a table entry of a group of literals never has the bit)
-constexpr uint32_t kRecLane = 64;           // subsequences side by side in a chunk
-FPNG_DEC_HD uint64_t rec_chunk_base(uint32_t g) { return (uint64_t)(g / kRecLane) * (kRecRows * kRecLane) + (g % kRecLane); } // dword index of subsequence g's record 0
+constexpr uint32_t kRecLane = 64;           // subsequences in a chunk
+constexpr uint32_t kRecChunk = kRecRows * kRecLane; // 8-byte words of a chunk
+FPNG_DEC_HD uint64_t rec_index(uint32_t g, uint32_t k) // 8-byte-word index of entry k of subsequence g
+{
+    const uint32_t l = g % kRecLane;
+    return (uint64_t)(g / kRecLane) * kRecChunk + (k >> 2) * 256u + (l >> 3) * 32u + (k & 3u) * 8u + (l & 7u);
+}
 enum : uint32_t { kSubEob = 1u, kSubOverflow = 2u, kSubInvalid = 4u }; // (kSubOverflow: more than kRecCap records)
 enum : uint32_t { kTokLit = 0, kTokMatch = 1, kTokEob = 2, kTokInvalid = 3 };
 
@@ -98,15 +117,13 @@ FPNG_DEC_HD uint32_t fetch(uint32_t w, const uint32_t *lut, const uint8_t *lenof
 // what a subsequence's decode leaves behind
 struct SubCount {
     uint32_t bytes; // output bytes of its tokens
-    uint32_t lits;  // ... of which literals
-    uint32_t tail;  // its last four literal bytes (the most recent one in bits 31..24)
     uint32_t flags; // kSubEob: it met an end-of-block symbol; kSubInvalid: its decode derailed
     uint32_t eob;   // kSubEob: the position behind that symbol
 };
-// where a walk leaves its records: put(record, enabled) -- a record that is not enabled goes nowhere.  NoRec: a walk that only looks
-// (the lead-in, the phase maps' probes).
+// where a walk leaves its records: put2(a, b) -- one step's two records, an entry unless both are nothing.  NoRec: a walk that only
+// looks (the lead-in, the phase maps' probes).
 struct NoRec {
-    FPNG_DEC_HD void put(uint32_t, bool) {}
+    FPNG_DEC_HD void put2(uint32_t, uint32_t) {}
     FPNG_DEC_HD uint32_t count() const { return 0; }
 };
 
@@ -127,26 +144,29 @@ struct VoteAlone {
 template <bool Count, class Vote, class Bits, class Rec>
 FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c, Rec &rec)
 {
-    uint32_t lits = c.lits, tail = c.tail, runs = 0, flags = 0;
+    uint32_t bytes = 0, flags = 0;
     const uint32_t lim = limit < data_limit ? limit : data_limit; // (no token may start at or behind data_limit)
-    // one token at the window's first bit if it is a plain one; returns the bits it took (0: not a plain one)
-    auto take = [&](uint32_t wk, uint32_t room, bool en) -> uint32_t {
-        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u, xb = (e >> 9) & 7u;
-        const bool lit = en && n != 0 && L <= room, mt = en && n == 0 && (e & kEntMatch) != 0;
+    // one token at the window's first bit if it is a SIMPLE one (kEntSimple: a group of literals that lies wholly in front of the limit,
+    // a match without extra bits); returns the bits it took (0: not one of those); r: its record = the table's entry without its
+    // length field.  (Until round 6 every match was taken here, its extra bits cut out of the window in straight-line code for
+    // every lane and both lookups: 125 vector instructions a step where this form has half; a match with extra bits now costs its
+    // lane the general path -- fetch() -- and is rare where steps are many.)
+    auto take = [&](uint32_t wk, uint32_t room, bool en, uint32_t &r) -> uint32_t {
+        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
+        const bool ok = en && (e & kEntSimple) != 0 && (n == 0 || L <= room);
         if (Count) {
-            const uint32_t run = (e & 511u) + ((wk >> L) & ((1u << xb) - 1u));
-            lits += lit ? n : 0u;
-            tail = funnel(e & 0xFFFFFFu, tail, lit ? 8 * n : 0u);
-            runs += mt ? run : 0u;
-            rec.put(lit ? (e & 0x0FFFFFFFu) : (kRecRun | run), lit || mt);
+            bytes += ok ? (n ? n : (e & 511u)) : 0u;
+            r = ok ? (e & 0x0FFFFFFFu) : 0u;
         }
-        return lit ? L : (mt ? L + xb + 1 : 0u);
+        return ok ? L + (n == 0 ? 1u : 0u) : 0u;
     };
     while (pos < lim) {
         const uint32_t w = in.window(pos), room = lim - pos;
-        const uint32_t ba = take(w, room, true);
+        uint32_t ra = 0, rb = 0;
+        const uint32_t ba = take(w, room, true, ra);
         const bool en_b = ba != 0 && ba <= 14 && ba < room; // (the second token starts inside, with 18 valid bits in the window)
-        const uint32_t bb = take(w >> ba, room - ba, en_b);
+        const uint32_t bb = take(w >> ba, room - ba, en_b, rb);
+        if (Count) rec.put2(ra, rb);
         pos += ba + bb;
         const bool waiting = pos < lim && (ba == 0 || (en_b && bb == 0)); // the token at pos is not a plain one
         if (Vote::go(waiting)) {
@@ -160,15 +180,15 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
             pos += bits;
             if (Count) {
                 if (kind == kTokLit)
-                    lits += n3, tail = funnel(l3, tail, 8 * n3), rec.put(n3 << 26 | l3, true);
+                    bytes += n3, rec.put2(n3 << 26 | l3, 0u);
                 else
-                    runs += run, rec.put(kRecRun | run, true);
+                    bytes += run, rec.put2(kRecRun | run, 0u);
             }
         }
     }
     if (!flags && pos < limit) flags = kSubInvalid; // ran off the data without an end-of-block symbol
     c.flags = flags;
-    if (Count) c.bytes += (lits - c.lits) + runs, c.lits = lits, c.tail = tail;
+    if (Count) c.bytes += bytes;
     return pos;
 }
 
@@ -176,14 +196,14 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
 struct SubState {
     uint32_t start, end; // first bit of its first token; position behind its last one (its nominal boundary if it is flagged)
     SubCount c;
-    uint32_t nrec;       // records its decode left (more than kRecCap: kSubOverflow is set)
+    uint32_t nrec;       // entries its decode left (more than kRecCap: kSubOverflow is set)
 };
 FPNG_DEC_HD void sub_close(SubState &s, uint32_t boundary, uint32_t e, uint32_t nrec)
 {
     // A decode that derailed or met an end-of-block symbol hands over on the nominal boundary: speculative decodes meet FALSE
     // end-of-block symbols; which one is the true one is settled afterwards (the first one of the chain).
     s.end = s.c.flags ? boundary : e;
-    s.nrec = nrec < 511u ? nrec : 511u;
+    s.nrec = nrec < 1023u ? nrec : 1023u;
     if (nrec > kRecCap) s.c.flags |= kSubOverflow;
 }
 
@@ -197,13 +217,13 @@ FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *l
 {
     uint32_t p = nominal;
     if (lead_start < nominal) {
-        SubCount d = {0, 0, 0, 0, 0};
+        SubCount d = {0, 0, 0};
         NoRec none;
         p = walk_count<false, Vote>(in, lut, lenof, lead_start, nominal, data_limit, d, none);
         if (d.flags || p < nominal) p = nominal; // the lead-in derailed: any start is as good as another
     }
     s.start = p;
-    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = s.c.eob = 0;
+    s.c.bytes = s.c.flags = s.c.eob = 0;
     const uint32_t e = walk_count<true, Vote>(in, lut, lenof, p, boundary, data_limit, s.c, rec);
     sub_close(s, boundary, e, rec.count());
 }
@@ -216,7 +236,7 @@ template <class Vote, class Bits, class Rec>
 FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec)
 {
     s.start = want;
-    s.c.bytes = s.c.lits = s.c.tail = s.c.flags = s.c.eob = 0;
+    s.c.bytes = s.c.flags = s.c.eob = 0;
     const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c, rec);
     sub_close(s, boundary, e, rec.count());
 }
@@ -285,7 +305,7 @@ FPNG_DEC_HD PhaseMap pm_compose(const PhaseMap &a, const PhaseMap &b)
 template <class Vote, class Bits>
 FPNG_DEC_HD uint32_t sub_probe(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit)
 {
-    SubCount d = {0, 0, 0, 0, 0};
+    SubCount d = {0, 0, 0};
     NoRec none;
     const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d, none);
     return d.flags ? boundary : e;
@@ -310,7 +330,7 @@ template <class Vote, class Bits>
 FPNG_DEC_HD void pm_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, PhaseMap &map)
 {
     for (uint32_t j = 1; j < kPhases; j++) {
-        SubCount d = {0, 0, 0, 0, 0};
+        SubCount d = {0, 0, 0};
         NoRec none;
         const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d, none);
         if (d.flags || p < nominal || pm_at(map, p - nominal) != kPhaseUnknown) continue;
@@ -318,14 +338,12 @@ FPNG_DEC_HD void pm_seed(const Bits &in, const uint32_t *lut, const uint8_t *len
     }
 }
 
-// per-subsequence word in global memory: start - nominal (0..17) | end - boundary (0..17) << 5 | flags << 10 | literals (at most one
-// per bit: 10 bits) << 13 | records (9 bits) << 23
-FPNG_DEC_HD uint32_t pack_info(uint32_t start_rel, uint32_t end_rel, const SubCount &c, uint32_t nrec) { return start_rel | end_rel << 5 | c.flags << 10 | (c.lits & 1023u) << 13 | nrec << 23; }
+// per-subsequence word in global memory: start - nominal (0..17) | end - boundary (0..17) << 5 | flags << 10 | entries (10 bits) << 13
+FPNG_DEC_HD uint32_t pack_info(uint32_t start_rel, uint32_t end_rel, const SubCount &c, uint32_t nrec) { return start_rel | end_rel << 5 | c.flags << 10 | nrec << 13; }
 FPNG_DEC_HD uint32_t info_start(uint32_t v) { return v & 31u; }
 FPNG_DEC_HD uint32_t info_end(uint32_t v) { return (v >> 5) & 31u; }
 FPNG_DEC_HD uint32_t info_flags(uint32_t v) { return (v >> 10) & 7u; }
-FPNG_DEC_HD uint32_t info_lits(uint32_t v) { return (v >> 13) & 1023u; }
-FPNG_DEC_HD uint32_t info_nrec(uint32_t v) { return v >> 23; }
+FPNG_DEC_HD uint32_t info_nrec(uint32_t v) { return (v >> 13) & 1023u; }
 
 // ---- the pass that writes: records into WINDOWS of the filtered stream ----
 // The filtered stream = what the reference's decoder consumes row by row (src/fpng.cpp:2255-2262): h rows of 1 filter byte +
@@ -353,7 +371,7 @@ FPNG_DEC_HD Window window_of(uint32_t y, uint32_t cb, uint32_t cbw, uint32_t str
 template <class Mark> FPNG_DEC_HD void for_windows_starting_in(uint64_t off, uint32_t bytes, uint32_t cbw, uint32_t ncb, uint32_t stride, uint32_t h, const Mark &mark)
 {
     if (!bytes) return;
-    uint32_t y = (uint32_t)(off / stride);
+    uint32_t y = (off >> 32) ? (uint32_t)(off / stride) : (uint32_t)off / stride; // (a 32-bit division wherever the image is under 4 GB)
     const uint32_t x = (uint32_t)(off - (uint64_t)y * stride);
     // first window start at or behind column x of row y: 0, then 1 + cb * cbw
     uint32_t cb = x == 0 ? 0u : (x - 1u + cbw - 1u) / cbw;
@@ -368,12 +386,14 @@ template <class Mark> FPNG_DEC_HD void for_windows_starting_in(uint64_t off, uin
     }
 }
 
-// One record applied to a window.  c: window position of the record's first byte (negative: in front of the window); out.put8(pos,
-// byte) / out.fill(lo, hi, px, q): the bytes [lo, hi) are copies of the C-byte pixel px, byte lo being the pixel's byte q.  Checked for
-// the runs that START in this window (every run starts in exactly one): a match repeats whole pixels, starts on a pixel, stays inside
-// its row (reference src/fpng.cpp:2273-2330); one at a row's FIRST pixel would repeat a pixel of zeros (:2268, prev_delta_* start at
-// 0) -- "the last literal bytes" know nothing of rows, no fpng encoder writes such a match, the file is left to the CPU decoder.
-// That every row starts with its filter literal is checked where the rows are read (dec_unfilter_kernel).
+// One record applied to a window.  c: window position of the record's first byte (negative: in front of the window); out.put8c(pos,
+// byte, cond): the byte goes to window position pos if cond (the literal part is straight-line code: a record without literals, or
+// bytes outside the window, are stores that go nowhere); out.fill(lo, hi, px, q): the bytes [lo, hi) are copies of the C-byte pixel
+// px, byte lo being the pixel's byte q.  Checked for the runs that START in this window (every run starts in exactly one): a match
+// repeats whole pixels, starts on a pixel, stays inside its row (reference src/fpng.cpp:2273-2330); one at a row's FIRST pixel would
+// repeat a pixel of zeros (:2268, prev_delta_* start at 0) -- "the last literal bytes" know nothing of rows, no fpng encoder writes
+// such a match, the file is left to the CPU decoder.  That every row starts with its filter literal is checked where the rows are
+// read (dec_unfilter_kernel).
 struct PlaceState {
     int32_t c;       // window position of the next output byte
     uint32_t lastpx; // the last four literal bytes (the most recent one highest)
@@ -381,18 +401,16 @@ struct PlaceState {
 };
 template <int C, class Out> FPNG_DEC_HD void place_one(uint32_t r, PlaceState &s, const Window &w, uint32_t stride, Out &out)
 {
-    const uint32_t n = (r >> 26) & 3u;
-    if (n) {
-        const uint32_t b0 = r & 255u, b1 = (r >> 8) & 255u, b2 = (r >> 16) & 255u;
-        if ((uint32_t)s.c < w.wlen) out.put8((uint32_t)s.c, b0);
-        if (n > 1 && (uint32_t)(s.c + 1) < w.wlen) out.put8((uint32_t)(s.c + 1), b1);
-        if (n > 2 && (uint32_t)(s.c + 2) < w.wlen) out.put8((uint32_t)(s.c + 2), b2);
-        s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n);
-        s.c += (int32_t)n;
-    } else if (r & kRecRun) {
-        const uint32_t run = r & (kRecRun - 1u), bpl = stride - 1;
-        if ((uint32_t)s.c < w.wlen) {
-            const uint32_t rowleft = stride - (w.xw + (uint32_t)s.c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
+    const uint32_t n = (r >> 26) & 3u, c = (uint32_t)s.c; // (c + j < wlen as unsigned numbers: also "not in front of the window")
+    out.put8c(c, r & 255u, n > 0 && c < w.wlen);
+    out.put8c(c + 1, (r >> 8) & 255u, n > 1 && c + 1 < w.wlen);
+    out.put8c(c + 2, (r >> 16) & 255u, n > 2 && c + 2 < w.wlen);
+    s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n);
+    s.c += (int32_t)n;
+    if (!n && (r & kRecRun)) {
+        const uint32_t run = r & 0xFFFFFFu, bpl = stride - 1;
+        if (c < w.wlen) {
+            const uint32_t rowleft = stride - (w.xw + c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
             if (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)
                 s.err |= kEmitBadStream;
             else if (rowleft == bpl)
@@ -405,19 +423,42 @@ template <int C, class Out> FPNG_DEC_HD void place_one(uint32_t r, PlaceState &s
     }
 }
 
-// The four literal bytes in front of subsequence g: collected backwards over its predecessors' (literal count, tail) records.
-// info(k) / tail(k): records of the file's subsequence k.
-template <class Info, class Tail> FPNG_DEC_HD uint32_t lookback_lastpx(uint32_t g, const Info &info, const Tail &tail)
+// Does a subsequence's walk ever look at the literal bytes in front of it?  Only if a match comes before four literal bytes of its
+// own -- on photographic content next to never, and then the look back (below: loads all over the records) can be left out.
+// e0, e1: its first two entries (the lanes of a wave read theirs side by side).
+FPNG_DEC_HD bool needs_lastpx(uint64_t e0, uint64_t e1, uint32_t nent)
+{
+    uint32_t lits = 0;
+    const uint32_t r[4] = {(uint32_t)e0, (uint32_t)(e0 >> 32), nent > 1 ? (uint32_t)e1 : 0u, nent > 1 ? (uint32_t)(e1 >> 32) : 0u};
+    for (int q = 0; q < 4; q++) {
+        if (r[q] & kRecRun) return lits < 4;
+        lits += (r[q] >> 26) & 3u;
+    }
+    return lits < 4 && nent > 2; // (two entries at most and no match among them: nothing ever asks)
+}
+
+// The four literal bytes in front of subsequence g (what a match at its very beginning repeats): collected backwards over the
+// records of the subsequences in front of it -- matches carry no bytes of their own, so usually the last two or three records of
+// the subsequence just in front.  nent(k): entries of the file's subsequence k (at most kRecCap of them were kept); entry(k, e):
+// its entry e as (first record) | (second record) << 32.
+template <class Nent, class Entry> FPNG_DEC_HD uint32_t lookback_lastpx(uint32_t g, const Nent &nent, const Entry &entry)
 {
     uint32_t v = 0, got = 0; // got bytes collected, the most recent one in bits 31..24
     while (g > 0 && got < 4) {
         g--;
-        const uint32_t l = info_lits(info(g));
-        if (!l) continue;
-        const uint32_t m = l < 4 - got ? l : 4 - got;                 // take its m most recent bytes
-        const uint64_t top = (uint64_t)tail(g) >> (32 - 8 * m);       // (m = 4: the whole word)
-        v |= (uint32_t)(top << (32 - 8 * (got + m)));
-        got += m;
+        uint32_t ne = nent(g);
+        ne = ne < kRecCap ? ne : kRecCap;
+        while (ne > 0 && got < 4) {
+            const uint64_t en = entry(g, --ne);
+            for (int half = 1; half >= 0 && got < 4; half--) {
+                const uint32_t r = (uint32_t)(en >> (32 * half)), n = (r >> 26) & 3u;
+                if (!n) continue;
+                const uint32_t m = n < 4 - got ? n : 4 - got;                                // take its m most recent bytes
+                const uint32_t top = ((r & 0xFFFFFFu) << (8 * (4 - n))) >> (32 - 8 * m);      // (its n bytes top-aligned, the upper m of them)
+                v |= top << (32 - 8 * (got + m));
+                got += m;
+            }
+        }
     }
     return v;
 }

@@ -22,14 +22,14 @@ struct HostBits { // positions relative to dword `d0` of the (zero padded) strea
     const uint32_t *dw;
     uint32_t window(uint32_t pos) const { return funnel(dw[(pos >> 5) + 1], dw[pos >> 5], pos & 31u); }
 };
-// a subsequence's token records (decode.hip: TokOut): at most kRecCap are kept, all are counted
+// a subsequence's token records (decode.hip: TokOut): an entry of two per step of the walk; at most kRecCap are kept, all are counted
 struct HostRec {
-    std::vector<uint32_t> *v;
+    std::vector<uint64_t> *v;
     uint32_t k = 0;
-    void put(uint32_t r, bool en)
+    void put2(uint32_t a, uint32_t b)
     {
-        if (!en) return;
-        if (k < kRecCap) (*v)[k] = r;
+        if (!(a | b)) return;
+        if (k < kRecCap) (*v)[k] = (uint64_t)b << 32 | a;
         k++;
     }
     uint32_t count() const { return k; }
@@ -40,6 +40,10 @@ struct HostRow {
     std::vector<bool> *written;
     size_t base; // index of p[0] in *written
     bool *fault;
+    void put8c(uint32_t pos, uint32_t b, bool cond)
+    {
+        if (cond) put8(pos, b);
+    }
     void put8(uint32_t pos, uint32_t b)
     {
         if ((*written)[base + pos]) *fault = true;
@@ -89,8 +93,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         first_bit += 8 * z_shift, end_limit += 8 * z_shift;
         const uint8_t *lenof = (const uint8_t *)(lut.data() + kLutEntries);
         const uint32_t n_sub = (uint32_t)((end_limit - first_bit + kSubBits - 1) / kSubBits), nb = (n_sub + sub_block - 1) / sub_block;
-        std::vector<uint32_t> info(n_sub), bytes(n_sub), tail(n_sub), eob_rel(n_sub, 0);
-        std::vector<std::vector<uint32_t>> tok(n_sub, std::vector<uint32_t>(kRecCap, 0)); // the records the settling decode of every subsequence leaves
+        std::vector<uint32_t> info(n_sub), bytes(n_sub), eob_rel(n_sub, 0);
+        std::vector<std::vector<uint64_t>> tok(n_sub, std::vector<uint64_t>(kRecCap, 0)); // the entries the settling decode of every subsequence leaves
         struct Rec {
             uint32_t sum, first_eob, first_invalid, first_overflow, entry_rel, exit_rel, want_rel;
             PhaseMap bmap;
@@ -130,7 +134,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 } else {
                     const uint32_t v = info[i];
                     st[t].start = nominal + info_start(v), st[t].end = boundary + info_end(v), st[t].nrec = info_nrec(v);
-                    st[t].c.bytes = bytes[i], st[t].c.lits = info_lits(v), st[t].c.tail = tail[i], st[t].c.flags = info_flags(v);
+                    st[t].c.bytes = bytes[i], st[t].c.flags = info_flags(v);
                     st[t].c.eob = (st[t].c.flags & kSubEob) ? nominal + eob_rel[i] : 0u;
                 }
                 s_end[t] = st[t].end;
@@ -207,10 +211,10 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 if (dirty[t]) {
                     const uint32_t i = local0 + t, nominal = nominal_of(t);
                     info[i] = pack_info(st[t].start - nominal, st[t].end - (nominal + kSubBits), st[t].c, st[t].nrec);
-                    if (info_start(info[i]) != st[t].start - nominal || info_end(info[i]) != st[t].end - (nominal + kSubBits) || info_lits(info[i]) != st[t].c.lits ||
-                        info_nrec(info[i]) != st[t].nrec || info_flags(info[i]) != st[t].c.flags)
+                    if (info_start(info[i]) != st[t].start - nominal || info_end(info[i]) != st[t].end - (nominal + kSubBits) || info_nrec(info[i]) != st[t].nrec ||
+                        info_flags(info[i]) != st[t].c.flags)
                         throw 1; // a field of the record overflowed
-                    bytes[i] = st[t].c.bytes, tail[i] = st[t].c.tail;
+                    bytes[i] = st[t].c.bytes;
                     if (st[t].c.flags & kSubEob) eob_rel[i] = st[t].c.eob - nominal;
                     any_dirty = true;
                 }
@@ -329,8 +333,11 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 const uint32_t i = b * sub_block + t;
                 if (i >= n_sub || i > eob_index) break;
                 rel[i] = before;
-                lastpx[i] = lookback_lastpx(
-                    i, [&](uint32_t k) { return info[k]; }, [&](uint32_t k) { return tail[k]; });
+                const uint32_t nent_i = info_nrec(info[i]);
+                lastpx[i] = (nent_i && needs_lastpx(tok[i][0], tok[i][1], nent_i))
+                                ? lookback_lastpx(
+                                      i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[k][e]; })
+                                : 0xDEADBEEFu; // (never looked at: a walk that did would write wrong pixels here)
                 for_windows_starting_in(block_off[b] + before, bytes[i], cbw, ncb, stride, h, [&](uint32_t y, uint32_t cb) {
                     if (win[(size_t)y * ncb + cb] != 0xFFFFFFFFu) throw 3; // two subsequences claim one window
                     win[(size_t)y * ncb + cb] = i;
@@ -358,11 +365,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                         if (off >= wd.ws + wd.wlen) break;
                         PlaceState ps;
                         ps.c = (int32_t)(int64_t)(off - wd.ws), ps.lastpx = lastpx[i], ps.err = 0;
-                        const uint32_t nrec = std::min(info_nrec(info[i]), kRecCap);
-                        for (uint32_t k = 0; k < nrec && ps.c < (int32_t)wd.wlen; k += 8)
-                            for (uint32_t j = 0; j < 8; j++) { // (the kernel loads eight records at a time; behind the last one: zeros)
-                                const uint32_t r = k + j < nrec ? tok[i][k + j] : 0u;
-                                if (c == 4) place_one<4>(r, ps, wd, stride, row); else place_one<3>(r, ps, wd, stride, row);
+                        const uint32_t nent = std::min(info_nrec(info[i]), kRecCap);
+                        for (uint32_t k = 0; k < nent && ps.c < (int32_t)wd.wlen; k += 8)
+                            for (uint32_t j = 0; j < 8; j++) { // (the kernel loads eight entries at a time; behind the last one: zeros)
+                                const uint64_t en = k + j < nent ? tok[i][k + j] : 0ull;
+                                for (int half = 0; half < 2; half++) {
+                                    const uint32_t r = (uint32_t)(en >> (32 * half));
+                                    if (c == 4) place_one<4>(r, ps, wd, stride, row); else place_one<3>(r, ps, wd, stride, row);
+                                }
                             }
                         err |= ps.err;
                     }

@@ -36,23 +36,21 @@ struct DecJob {
     uint32_t z_shift;         // bytes between z (rounded down to a dword) and the stream's first byte; the bit positions above count from z
 };
 
-// what the synchronisation leaves per workgroup of kDecSubBlock subsequences (indices inside the workgroup, kDecSubBlock = none)
-// Column blocks of dec_unfilter_kernel for one file: a workgroup of kDecBlock threads covers kDecBlock dword columns of the filtered
-// rows -- or, where 3-channel rows become 4-channel pixels, 4 waves x 48 dword columns = 256 whole pixels (see the kernel).
+// Column blocks of dec_unfilter_kernel for one file: 256 PIXELS of the file's rows each -- 256 dword columns of 4-byte pixels, or
+// 4 waves x 48 dword columns of 3-byte ones (see the kernel) -- so that a match, which repeats whole pixels, is whole pixels in
+// every block it touches.
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline uint32_t dec_col_blocks(uint32_t w, uint32_t src_c, uint32_t dst_c)
-{
-    return (src_c == 3 && dst_c == 4) ? (w + 255u) / 256u : ((w * src_c + 3u) / 4u + 255u) / 256u;
-}
+inline uint32_t dec_col_blocks(uint32_t w, uint32_t /*src_c*/, uint32_t /*dst_c*/) { return (w + 255u) / 256u; }
 
 // bytes of a row that one column block covers (the first one also holds the row's filter byte: decode_core.h, Window)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline uint32_t dec_col_block_bytes(uint32_t src_c, uint32_t dst_c) { return (src_c == 3 && dst_c == 4) ? 768u : 1024u; }
+inline uint32_t dec_col_block_bytes(uint32_t src_c, uint32_t /*dst_c*/) { return 256u * src_c; }
 
+// what the synchronisation leaves per workgroup of kDecSubBlock subsequences (indices inside the workgroup, kDecSubBlock = none)
 struct DecBlockRec {
     uint32_t sum;           // output bytes of its subsequences
     uint32_t first_eob;     // first one that met an end-of-block symbol

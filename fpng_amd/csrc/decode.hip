@@ -721,155 +721,160 @@ __device__ unsigned long long g_tile_times[8 * 65536];
 #define FPNG_TILE_STAMP(k) do { } while (0)
 #endif
 // ---- the pass that writes.  A tile of dec_unfilter_kernel = kUnfRows rows x one block of columns; every row piece ("window",
-//      decode_core.h) is filled in LDS from the token records of the subsequences that cover it: eight threads per row, thread k of
-//      them walks the k-th, (k + 8)-th ... subsequence from the one the window begins in (dec_subscan_kernel left its number), a
-//      record per step, eight records in flight per thread.  A subsequence that straddles two windows is walked for both. ----
-constexpr uint32_t kTilePitch = 1040; // bytes of LDS per row: 7 of slack, the filter byte (first column block only), 1024 (768) data bytes, 8 of slack
-constexpr uint32_t kTileData = 8;     // where a row's data bytes begin (a dword boundary)
-constexpr uint32_t kRowThreads = 8;   // threads that share a window
-constexpr uint32_t kUnfBlock = 512;   // threads of dec_unfilter_kernel: kUnfRows x kRowThreads of them fill the tile, kDecBlock of them own a dword column
+//      decode_core.h) is filled in LDS from the token records of the subsequences that cover it.  The WALKS of a tile -- (window,
+//      subsequence that reaches into it) pairs, some four hundred -- are numbered through (a prefix sum over the rows' counts) and
+//      dealt to the threads one each: no lane idles because its row has seven subsequences where another has nine.  A walk writes
+//      its subsequence's bytes with exact stores and only marks the pixels of long matches (decode_core.h: walk_apply, walk_record);
+//      when all walks have ended the marked pixels are filled, a lane per pixel (propagate_matches).  A subsequence that straddles
+//      two windows is walked for both. ----
+constexpr uint32_t kUnfRows = kDecUnfRows;
+constexpr uint32_t kTileData = 16;    // where a row's data bytes begin in its LDS row (a dword boundary; the filter byte of the first column block just in front)
+constexpr uint32_t kTilePitch = kTileData + 1024 + 8; // bytes of LDS per row: slack of eight bytes on either side of the window (decode_core.h: Out::put64)
+constexpr uint32_t kUnfBlock = 512;   // threads of dec_unfilter_kernel: all of them walk and fill matches, kDecBlock of them own a dword column
+constexpr uint32_t kRowMaskWords = 8; // a row's bitmap of marked pixels: 256 pixels
+constexpr uint32_t kMaxWalksPerRow = 64; // (a subsequence puts out 39 bytes at the very least: a window of 1024 has 28 walks at most)
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t __attribute__((aligned(1))) u32_any_t;
-typedef __attribute__((address_space(3))) u32_any_t lds_u32_any; // (a dword at any byte address: the hardware takes it)
-struct TileRow {
-    lds_u8 *row; // the row's first byte in the tile: a byte nobody reads, where stores that go nowhere go
-    uint32_t a0; // window byte 0 stands a0 bytes behind it (kTileData - 1: the window begins with the filter byte, else kTileData)
-    bool c4;
-    __device__ __forceinline__ void put8c(uint32_t pos, uint32_t b, bool cond) { row[cond ? a0 + pos : 0u] = (uint8_t)b; }
-    // A group of literals that begins inside the window, written as ONE dword at its (any) byte address: its bytes and, behind them,
-    // up to three bytes that are not its own -- they lie where this thread's NEXT records go (which overwrite them), behind the
-    // window (the row's slack), or on the first bytes of the next subsequence, whose thread writes those again when the wave has
-    // finished the round (fill_tile).  Where `ok` is false the dword goes to the row's last eight bytes, which nobody reads.
-    __device__ __forceinline__ void put_wide(uint32_t c, uint32_t r, bool ok) { *(lds_u32_any *)(row + (ok ? a0 + c : kTilePitch - 8u)) = r; }
-    // ... the same without a question: the position is CLAMPED to [-4, wlen] -- a record in front of the window or behind it lands in
-    // the four bytes of slack on that side, one that straddles an edge puts its inner bytes where they belong
-    __device__ __forceinline__ void put_clamped(int32_t c, uint32_t wlen, uint32_t v)
+typedef uint64_t __attribute__((aligned(1))) u64_any_t;
+typedef __attribute__((address_space(3))) u32_any_t lds_u32_any; // (a dword / two at any byte address: the hardware takes it)
+typedef __attribute__((address_space(3))) u64_any_t lds_u64_any;
+struct TileOut {
+    lds_u8 *win0; // where window byte 0 stands in the tile
+    lds_u32 *bm;  // the row's bitmap
+    lds_u32 *epx; // the row's entry pixel (a tail's upper half)
+    __device__ __forceinline__ void put64(int32_t pos, uint64_t v) { *(lds_u64_any *)(win0 + pos) = v; }
+    __device__ __forceinline__ void entry_px(uint32_t th) { *epx = th; }
+    __device__ __forceinline__ void mark(uint32_t lo, uint32_t hi)
     {
-        const int32_t lo = c < -4 ? -4 : c, pos = lo > (int32_t)wlen ? (int32_t)wlen : lo;
-        *(lds_u32_any *)(row + a0 + pos) = v;
-    }
-    // bytes [lo, hi) = copies of the C-byte pixel px, byte lo being its byte q: bytes up to a dword boundary, whole dwords (the
-    // pixel rotated: 4 channels one constant, 3 channels a cycle of three), bytes
-    template <int C> __device__ __forceinline__ void fill_c(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
-    {
-        lds_u8 *p = row + a0;
-        const uint64_t wrap = C == 4 ? ((uint64_t)px << 32 | px) : ((uint64_t)(px & 0xFFFFFFu) | (uint64_t)(px & 0xFFFFFFu) << 24 | (uint64_t)px << 48);
-        uint32_t pos = lo;
-        while (pos < hi && (((uint32_t)(uintptr_t)p + pos) & 3u)) {
-            p[pos] = (uint8_t)(wrap >> (8 * q));
-            q = q + 1 == (uint32_t)C ? 0u : q + 1;
-            pos++;
+        while (lo < hi) {
+            const uint32_t d = lo >> 5, end = min(hi, (d + 1u) << 5), width = end - lo;
+            const uint32_t mask = width == 32u ? 0xFFFFFFFFu : ((1u << width) - 1u) << (lo & 31u);
+            __hip_atomic_fetch_or(bm + d, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lo = end;
         }
-        for (; pos + 4 <= hi; pos += 4) {
-            *(lds_u32 *)(p + pos) = (uint32_t)(wrap >> (8 * q));
-            q = C == 4 ? q : (q + 1 == 3u ? 0u : q + 1); // (four bytes on: the same place in a 4-byte pixel, one further in a 3-byte one)
-        }
-        for (; pos < hi; pos++) {
-            p[pos] = (uint8_t)(wrap >> (8 * q));
-            q = q + 1 == (uint32_t)C ? 0u : q + 1;
-        }
-    }
-    __device__ __forceinline__ void fill(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
-    {
-        if (c4) fill_c<4>(lo, hi, px, q); else fill_c<3>(lo, hi, px, q);
     }
 };
-// place_one() of decode_core.h for a wave.  The straight-line form: a record is ONE dword store at its position, clamped to the
-// window and the four bytes of slack on either side of it (TileRow::put_clamped) -- a group of literals: its bytes and, behind them,
-// up to three that are not its own (they lie where this thread's next records go, which overwrite them; behind the window; or on the
-// first bytes of the next subsequence, whose thread writes those again when the wave has finished the round: fill_tile); nothing: four
-// zeros, to the same effect; a match of ONE pixel (noisy content has one in a few hundred tokens, i.e. some lane of a wave in every
-// fourth step): the pixel; a match that lies outside the window: the pixel, into the slack.  Only a longer match that touches some
-// lane's window sends the wave through the general form.
-template <int C> __device__ __forceinline__ void place_lean(uint32_t r, PlaceState &s, const Window &w, uint32_t stride, TileRow &out)
-{
-    const bool isrun = (r & kRecRun) != 0;
-    const uint32_t n = (r >> 26) & 3u;
-    uint32_t len = n, data = r;
-    if (__builtin_amdgcn_ballot_w64(isrun) != 0) {
-        const uint32_t rl = r & 0xFFFFFFu, c = (uint32_t)s.c;
-        if (__builtin_amdgcn_ballot_w64(isrun && rl != (uint32_t)C && s.c + (int32_t)rl > 0 && s.c < (int32_t)w.wlen) != 0) {
-            place_one<C>(r, s, w, stride, out);
-            return;
-        }
-        if (isrun) {
-            if (c < w.wlen) { // a one-pixel match that begins in the window: the reference's checks (place_one)
-                const uint32_t rowleft = stride - (w.xw + c), bpl = stride - 1;
-                if (rowleft % C != 0 || rowleft > bpl || rl > rowleft)
-                    s.err |= kEmitBadStream;
-                else if (rowleft == bpl)
-                    s.err |= kEmitLeaveToCpu;
-            }
-            len = rl, data = C == 4 ? s.lastpx : s.lastpx >> 8;
-        }
-    }
-    out.put_clamped(s.c, w.wlen, data);
-    s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n); // (a match: n = 0, nothing moves)
-    s.c += (int32_t)len;
-}
-// the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks
+#ifndef FPNG_DEC_FILL_BATCH
+#define FPNG_DEC_FILL_BATCH 16
+#endif
+// the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks.  s_first[r]:
+// number of the first walk of row r (s_first[nrows]: all of them), s_i0[r]: the subsequence it walks.
 template <int C>
 __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced &pl, uint32_t last, uint32_t y0, uint32_t nrows, uint32_t cb, uint32_t ncb, uint32_t cbw, lds_u8 *tile,
-                                              uint32_t item0)
+                                              lds_u32 *bm, lds_u32 *epx, uint32_t *s_first, uint32_t *s_i0, uint32_t item0)
 {
-    const uint32_t stride = job.bpl + 1;
+    const uint32_t t = threadIdx.x, stride = job.bpl + 1;
+    if (t < (uint32_t)kWave) { // the rows' walks: from the subsequence a window begins in to the one the NEXT window (of the stream) begins in
+        uint32_t cnt = 0, i0 = 0;
+        if (t < nrows) {
+            const size_t wi = (size_t)(y0 + t) * ncb + cb;
+            const uint32_t a = job.win[wi];
+            uint32_t b = wi + 1 < (size_t)job.h * ncb ? job.win[wi + 1] : 0xFFFFFFFFu; // (none: the window nobody begins in -- behind the stream's end, or not placed yet)
+            b = min(b, min(last, pl.sub_limit - 1u));
+            if (a != 0xFFFFFFFFu && a <= b) cnt = min(b - a + 1u, kMaxWalksPerRow), i0 = a;
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, kWave);
+            if ((int)t >= o) incl += up;
+        }
+        if (t == 0) s_first[0] = 0;
+        s_first[t + 1] = incl, s_i0[t] = i0;
+    }
+    for (uint32_t k = t; k < kUnfRows * kRowMaskWords; k += kUnfBlock) bm[k] = 0;
+    __syncthreads();
+    FPNG_TILE_STAMP(5);
+    const uint32_t total = s_first[nrows];
     uint32_t err = 0;
-    for (uint32_t q = threadIdx.x; q < nrows * kRowThreads; q += kUnfBlock) {
-        const uint32_t r = q / kRowThreads, k0 = q % kRowThreads;
+    for (uint32_t q0 = 0; q0 < total; q0 += kUnfBlock) {
+        const uint32_t q = q0 + t;
+        bool live = q < total;
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) {
+            const uint32_t m = r + step;
+            if (m < nrows && s_first[min(m, kUnfRows)] <= q) r = m;
+        }
+        const uint32_t i = live ? s_i0[r] + (q - s_first[r]) : 0u;
         const Window w = window_of(y0 + r, cb, cbw, stride);
-        const uint32_t i0 = job.win[(size_t)(y0 + r) * ncb + cb];
-        if (i0 == 0xFFFFFFFFu) continue; // (a stream that does not cover the image: its status says so)
-        TileRow out;
-        out.row = tile + r * kTilePitch, out.a0 = cb ? kTileData : kTileData - 1u, out.c4 = C == 4;
-        for (uint32_t i = i0 + k0; i <= last && i < pl.sub_limit; i += kRowThreads) {
-            const uint32_t g = job.sub_base + i;
-            const uint64_t off = pl.block_off[g / kSubBlock] + pl.a.rel[g];
-            if (off >= w.ws + w.wlen) break; // (offsets rise: nothing further on reaches into the window)
-            PlaceState st;
-            st.c = (int32_t)(int64_t)(off - w.ws), st.lastpx = pl.a.lastpx[g], st.err = 0;
-            const PlaceState st0 = st;
-            FPNG_TILE_STAMP(5);
-            const uint32_t nent = min(info_nrec(pl.a.info[g]), kRecCap);
-            const gu64e *col = (const gu64e *)(uintptr_t)(pl.a.tok + rec_index(g, 0));
-            constexpr uint32_t kBatch = 16; // entries in flight per thread
-            for (uint32_t k = 0; k < nent && st.c < (int32_t)w.wlen; k += kBatch) {
-                uint64_t rr[kBatch];
-                // (all loads of a batch in flight, none behind a branch, their addresses one base and constants: what lies behind the
-                //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway; the scratch ends with kBatch spare
-                //  rows -- is read and counts as nothing)
-                const gu64e *ck = col + (size_t)(k >> 2) * 256u; // (k is a multiple of kBatch: whole blocks of four entries)
+        TileOut out;
+        out.win0 = tile + r * kTilePitch + (cb ? kTileData : kTileData - 1u), out.bm = bm + r * kRowMaskWords, out.epx = epx + r;
+        const uint32_t g = job.sub_base + i;
+        const uint64_t off = pl.block_off[g / kSubBlock] + pl.a.rel[g];
+        const uint32_t th0 = pl.a.lastpx[g], info = pl.a.info[g];
+        live = live && off < w.ws + w.wlen; // (offsets rise: a subsequence that begins behind the window has nothing for it)
+        WalkState st;
+        st.c = st.c0 = live ? (int32_t)(int64_t)(off - w.ws) : (int32_t)w.wlen; // (a lane without a walk: its stores go to the slack behind the row)
+        st.tl = 0, st.th = th0, st.err = 0;
+        const uint32_t nent = live ? min(info_nrec(info), kRecCap) : 0u;
+        const gu64e *col = (const gu64e *)(uintptr_t)(pl.a.tok + rec_index(g, 0));
+        constexpr uint32_t kBatch = FPNG_DEC_FILL_BATCH; // entries in flight per thread
+        for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < nent && st.c < (int32_t)w.wlen) != 0; k += kBatch) {
+            uint64_t rr[kBatch];
+            // (all loads of a batch in flight, none behind a branch, their addresses one base and constants: what lies behind the
+            //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing)
+            const gu64e *ck = col + (size_t)(k >> 2) * 256u; // (k is a multiple of kBatch: whole blocks of four entries)
 #pragma unroll
-                for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
+            for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
 #pragma unroll
-                for (uint32_t j = 0; j < kBatch; j++) rr[j] = k + j < nent ? rr[j] : 0ull;
-#pragma unroll
-                for (uint32_t j = 0; j < kBatch; j++) {
-                    place_lean<C>((uint32_t)rr[j], st, w, stride, out);
-                    place_lean<C>((uint32_t)(rr[j] >> 32), st, w, stride, out);
+            for (uint32_t j = 0; j < kBatch; j++) {
+                const uint64_t en = k + j < nent ? rr[j] : 0ull;
+                const uint32_t a = (uint32_t)en, b = (uint32_t)(en >> 32);
+                if (__builtin_amdgcn_ballot_w64(!entry_plain<C>(a, b)) == 0)
+                    walk_entry_plain<C>(a, b, st, w, stride, out);
+                else
+                    walk_entry<C>(en, st, w, stride, out);
+            }
+        }
+        err |= st.err;
+    }
+    FPNG_TILE_STAMP(6);
+    return err;
+}
+// The pixels that the walks marked -- long matches -- take the value of the nearest unmarked pixel to their left in their row (an
+// unmarked pixel is a literal one, or a short match's, written by a walk; none in the window: the row's entry pixel).  Items of
+// (row, 64 pixels); a wave looks at its items' bitmaps at once (a lane each) and then works through those that have marked pixels.
+template <int C> __device__ __forceinline__ void propagate_matches(lds_u8 *tile, const lds_u32 *bm, const lds_u32 *epx, uint32_t nrows)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    constexpr uint32_t kWaves = kUnfBlock / kWave, kItems = kUnfRows * 4, kPerWave = (kItems + kWaves - 1) / kWaves;
+    static_assert(kPerWave <= (uint32_t)kWave, "a lane per item");
+    uint32_t mlo = 0, mhi = 0;
+    {
+        const uint32_t it = wv + kWaves * lane, row = it >> 2, grp = it & 3u;
+        if (lane < kPerWave && row < nrows) mlo = bm[row * kRowMaskWords + grp * 2], mhi = bm[row * kRowMaskWords + grp * 2 + 1];
+    }
+    uint64_t todo = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0);
+    while (todo) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t M = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
+        const uint32_t it = wv + kWaves * j, row = it >> 2, grp = it & 3u;
+        int32_t fsrc = -1; // the nearest unmarked pixel in front of this group
+        if (M & 1ull) {
+            for (uint32_t gg = grp; gg-- > 0;) {
+                const uint64_t mg = ~((uint64_t)bm[row * kRowMaskWords + gg * 2 + 1] << 32 | bm[row * kRowMaskWords + gg * 2]);
+                if (mg) {
+                    fsrc = (int32_t)(64u * gg + 63u - (uint32_t)__builtin_clzll(mg));
+                    break;
                 }
             }
-            err |= st.err;
-            FPNG_TILE_STAMP(6);
-            // The wave has written this round's subsequences -- the lanes of a row walk neighbours, in step -- and the dword stores of
-            // the one in front may have left up to four bytes on this one's first bytes (place_lean): its first four entries (four
-            // bytes at the least) once more, byte for byte, as far as the first four bytes go.
-            if (st0.c >= 0 && nent) {
-                Window wf = w;
-                wf.wlen = min(w.wlen, (uint32_t)st0.c + 4u);
-                PlaceState sf = st0;
-                uint64_t e4[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) e4[j] = col[min(j, nent - 1) * 8u];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    if (j < nent) place_one<C>((uint32_t)e4[j], sf, wf, stride, out), place_one<C>((uint32_t)(e4[j] >> 32), sf, wf, stride, out);
-                }
-            }
-            FPNG_TILE_STAMP(7);
+        }
+        const uint64_t z = ~M & ((1ull << lane) - 1ull);
+        const int32_t src = z ? (int32_t)(64u * grp + 63u - (uint32_t)__builtin_clzll(z)) : fsrc;
+        if ((M >> lane) & 1ull) {
+            lds_u8 *rowp = tile + row * kTilePitch + kTileData;
+            uint32_t v = tail_px<C>(epx[row]);
+            if (src >= 0) v = C == 4 ? ((lds_u32 *)rowp)[src] : *(lds_u32_any *)(rowp + 3 * src);
+            const uint32_t p = 64u * grp + lane;
+            if (C == 4)
+                ((lds_u32 *)rowp)[p] = v;
+            else
+                rowp[3 * p] = (uint8_t)v, rowp[3 * p + 1] = (uint8_t)(v >> 8), rowp[3 * p + 2] = (uint8_t)(v >> 16);
         }
     }
-    return err;
 }
 
 // ---- Up filter undone: out[y] = out[y-1] + filtered[y] (bytes, mod 256), every row read ONCE.  One workgroup per kDecBlock dword
@@ -881,7 +886,6 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
 //      tickets are drawn in the order the workgroups start -- then writes the pixels, 3 <-> 4 channels on the way out.  The rows sit
 //      in the filtered stream at a stride of bpl + 1 bytes: unaligned dword loads.  The filter literal in front of every row must be
 //      0, then 2 = Up (reference src/fpng.cpp:2255-2259): one lane of the first column block looks. ----
-constexpr uint32_t kUnfRows = kDecUnfRows;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)
 {
@@ -916,6 +920,8 @@ __device__ __forceinline__ void gstore_u8(gu8 *base, uint32_t off, uint32_t v) {
 __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void dec_unfilter_kernel(const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t *status, uint32_t epoch, uint32_t skip_mask)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kUnfRows * kTilePitch];
+    __shared__ uint32_t mask_mem[kUnfRows * kRowMaskWords], epx_mem[kUnfRows]; // the rows' marked pixels (long matches), their entry pixels
+    __shared__ uint32_t s_first[kWave + 1], s_i0[kWave];                        // the tile's walks (fill_tile)
     FPNG_TILE_STAMP(0);
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
@@ -963,20 +969,25 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (job.mode != 0 || (status[ji] & skip_mask)) return;
         const uint32_t ncol = (job.bpl + 3) / 4;
         const uint32_t sc = job.src_c, dc = job.dst_c, lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-        // Which dword column is this thread's?  Normally workgroup-thread t has column cb * 256 + t.  Where 3-channel rows become
-        // 4-channel pixels, a wave takes 48 dword columns = 192 bytes = 64 WHOLE pixels (its lanes 48..63 hold no column) and
-        // every lane writes one pixel, gathered from two lanes' dwords -- dword stores instead of a byte at a time.
-        const bool widen = sc == 3 && dc == 4;
-        const uint32_t wave_px = (cb * (kDecBlock / kWave) + wv) * kWave; // (widen: the wave's first pixel)
-        const uint32_t j4 = widen ? (wave_px / 4) * 3 + lane : cb * kDecBlock + threadIdx.x;
-        const bool active = j4 < ncol && (!widen || lane < 48);
+        // Which dword column is this thread's?  Rows of 4-byte pixels: workgroup-thread t has column cb * 256 + t.  Rows of 3-byte
+        // pixels: a wave takes 48 dword columns = 192 bytes = 64 WHOLE pixels (its lanes 48..63 hold no column), a column block is
+        // 256 pixels either way; where such rows become 4-channel pixels every lane writes one pixel, gathered from two lanes'
+        // dwords -- dword stores instead of a byte at a time.
+        const bool three = sc == 3, widen = three && dc == 4;
+        const uint32_t wave_px = (cb * (kDecBlock / kWave) + wv) * kWave; // (the wave's first pixel)
+        const uint32_t j4 = three ? (wave_px / 4) * 3 + lane : cb * kDecBlock + threadIdx.x;
+        const bool active = j4 < ncol && (!three || lane < 48) && threadIdx.x < (uint32_t)kDecBlock;
         const uint32_t y0 = sg * kUnfRows, nrows = min(kUnfRows, job.h - y0);
-        // ---- the tile's rows, from the token records (all threads; the barrier stands in front of every way out) ----
+        // ---- the tile's rows, from the token records (all threads; the barriers stand in front of every way out) ----
         lds_u8 *tile = (lds_u8 *)tile_mem;
         {
             const uint32_t ncb = dec_col_blocks(job.w, sc, dc), cbw = dec_col_block_bytes(sc, dc), last_sub = placed.eob_index[ji];
-            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, item0) : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, item0);
+            lds_u32 *bm = (lds_u32 *)mask_mem, *epx = (lds_u32 *)epx_mem;
+            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, item0)
+                                         : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, item0);
             if (err) atomicOr(&status[ji], err);
+            __syncthreads();
+            if (sc == 4) propagate_matches<4>(tile, bm, epx, nrows); else propagate_matches<3>(tile, bm, epx, nrows);
         }
         __syncthreads();
         FPNG_TILE_STAMP(1);
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         // ---- the columns' running sums, in place: row k of the tile becomes the sum of its rows 0 .. k (every thread its own dword
         //      column; eight rows in flight).  The rows stay in LDS -- until round 6 a thread held its 48 of them in registers, which
         //      is what kept the kernel at four waves per SIMD. ----
-        lds_u32 *T = (lds_u32 *)(tile + kTileData) + (widen ? wv * 48 + lane : threadIdx.x); // this thread's dword column of the tile
+        lds_u32 *T = (lds_u32 *)(tile + kTileData) + (three ? wv * 48 + lane : threadIdx.x); // this thread's dword column of the tile
         constexpr uint32_t P = kTilePitch / 4;
         uint32_t p = 0;
         if (active) {

@@ -386,41 +386,114 @@ template <class Mark> FPNG_DEC_HD void for_windows_starting_in(uint64_t off, uin
     }
 }
 
-// One record applied to a window.  c: window position of the record's first byte (negative: in front of the window); out.put8c(pos,
-// byte, cond): the byte goes to window position pos if cond (the literal part is straight-line code: a record without literals, or
-// bytes outside the window, are stores that go nowhere); out.fill(lo, hi, px, q): the bytes [lo, hi) are copies of the C-byte pixel
-// px, byte lo being the pixel's byte q.  Checked for the runs that START in this window (every run starts in exactly one): a match
-// repeats whole pixels, starts on a pixel, stays inside its row (reference src/fpng.cpp:2273-2330); one at a row's FIRST pixel would
-// repeat a pixel of zeros (:2268, prev_delta_* start at 0) -- "the last literal bytes" know nothing of rows, no fpng encoder writes
-// such a match, the file is left to the CPU decoder.  That every row starts with its filter literal is checked where the rows are
-// read (dec_unfilter_kernel).
-struct PlaceState {
-    int32_t c;       // window position of the next output byte
-    uint32_t lastpx; // the last four literal bytes (the most recent one highest)
+// ---- the walk over a subsequence's records that fills one window (dec_unfilter_kernel's tiles; tests/cpp/decode_emul.cpp) ----
+// EXACT STORES.  The walk keeps the last eight output bytes (the "tail": tl, th -- the most recent byte highest in th) and every
+// step stores the eight bytes that END at the step's last byte: all of them true output, whatever the step added (0 .. 7 bytes), so no
+// store ever leaves a byte that is not the stream's -- with two exceptions, both inside the walk's own territory: (a) a store never
+// begins in front of the subsequence's first byte (c0: the bytes in front are another walk's); in the subsequence's first eight
+// bytes it begins there, shifted, and leaves zeros on bytes that this walk's next steps write; (b) the bytes of a LONG match (more
+// than eight bytes) are not written at all: the walk marks the match's pixels in the window's bitmap, and when every walk of the tile
+// has ended the marked pixels take the value of the nearest unmarked pixel to their left (a match repeats the pixel in front of it:
+// reference src/fpng.cpp:2273-2330) -- all pixels of all long matches at once, a lane each, instead of one lane writing 258 bytes.
+// The tail's older bytes may then stand for bytes of such a match (stale): they land on marked pixels only.  So walks never write a
+// byte of another walk's territory, and the order in which the lanes of a wave -- or two waves -- store does not matter.
+// A pixel the window's FIRST data byte belongs to may be marked too (a match that began in the window to the left): the walk whose
+// match covers that byte hands its pixel over (Out::entry_px), the source of the window's leading marked pixels.
+// Out (decode.hip: TileOut; the emulator: HostOut):  put64(pos, v) -- eight bytes at window position pos in [-8, wlen] (eight bytes
+// of slack on either side); mark(lo, hi) -- pixels [lo, hi) of the window are a long match's; entry_px(th) -- see above.
+// Checked for the matches that START in this window (every match starts in exactly one): a match repeats whole pixels, starts on a
+// pixel, stays inside its row (reference src/fpng.cpp:2273-2330); one at a row's FIRST pixel would repeat a pixel of zeros (:2268,
+// prev_delta_* start at 0) -- "the last literal bytes" know nothing of rows, no fpng encoder writes such a match, the file is left
+// to the CPU decoder.  That every row starts with its filter literal is checked where the rows are read (dec_unfilter_kernel).
+struct WalkState {
+    int32_t c, c0;   // window position of the next output byte; of the subsequence's first byte
+    uint32_t tl, th; // the tail
     uint32_t err;    // kEmit* flags
 };
-template <int C, class Out> FPNG_DEC_HD void place_one(uint32_t r, PlaceState &s, const Window &w, uint32_t stride, Out &out)
+FPNG_DEC_HD uint64_t shr64(uint64_t v, uint32_t s) { return v >> (s & 63u); }
+FPNG_DEC_HD uint64_t shl64(uint64_t v, uint32_t s) { return v << (s & 63u); }
+// n (0 .. 7) bytes d (first one lowest; n == 0: d == 0) are the walk's next output
+template <class Out> FPNG_DEC_HD void walk_apply(WalkState &s, uint32_t n, uint64_t d, const Window &w, Out &out)
 {
-    const uint32_t n = (r >> 26) & 3u, c = (uint32_t)s.c; // (c + j < wlen as unsigned numbers: also "not in front of the window")
-    out.put8c(c, r & 255u, n > 0 && c < w.wlen);
-    out.put8c(c + 1, (r >> 8) & 255u, n > 1 && c + 1 < w.wlen);
-    out.put8c(c + 2, (r >> 16) & 255u, n > 2 && c + 2 < w.wlen);
-    s.lastpx = funnel(r & 0xFFFFFFu, s.lastpx, 8 * n);
-    s.c += (int32_t)n;
-    if (!n && (r & kRecRun)) {
-        const uint32_t run = r & 0xFFFFFFu, bpl = stride - 1;
-        if (c < w.wlen) {
-            const uint32_t rowleft = stride - (w.xw + c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
-            if (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)
-                s.err |= kEmitBadStream;
-            else if (rowleft == bpl)
-                s.err |= kEmitLeaveToCpu;
+    const uint32_t sh = 8u * n;
+    const uint64_t ta = shr64((uint64_t)s.th << 32 | s.tl, sh) | shl64(d, 64u - sh);
+    s.tl = (uint32_t)ta, s.th = (uint32_t)(ta >> 32);
+    const int32_t e = s.c + (int32_t)n, e8 = e - 8, start = e8 > s.c0 ? e8 : s.c0;
+    const uint64_t v = shr64(ta, 8u * (uint32_t)(start - e8)); // (start - e8 == 8: nothing of this subsequence yet -- whatever is stored lies where its first steps write)
+    const int32_t lo = start < -8 ? -8 : start, pos = lo > (int32_t)w.wlen ? (int32_t)w.wlen : lo;
+    out.put64(pos, v);
+    s.c = e;
+}
+// the pixel a match repeats, and k copies of it (C * k <= 8) as output bytes
+template <int C> FPNG_DEC_HD uint32_t tail_px(uint32_t th) { return C == 4 ? th : th >> 8; }
+// Is the entry (a, b) one for the straight-line step -- each record nothing, a group of literals, or a match of ONE pixel, seven
+// bytes at most together?
+template <int C> FPNG_DEC_HD bool entry_plain(uint32_t a, uint32_t b)
+{
+    const bool ra = (a & kRecRun) != 0, rb = (b & kRecRun) != 0;
+    const bool oka = !ra || (a & 0xFFFFFFu) == (uint32_t)C, okb = !rb || (b & 0xFFFFFFu) == (uint32_t)C;
+    return oka && okb && !(C == 4 && ra && rb);
+}
+// ... the straight-line step for such an entry: both records become bytes (a match of one pixel: the tail's pixel), one store.
+// The reference's checks for a match that begins in the window (see walk_record): a one-pixel match cannot leave its row if it
+// starts on a pixel, so that is all there is to look at.
+template <int C, class Out> FPNG_DEC_HD void walk_entry_plain(uint32_t a, uint32_t b, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    const bool ra = (a & kRecRun) != 0, rb = (b & kRecRun) != 0;
+    const uint32_t na = ra ? (uint32_t)C : (a >> 26) & 3u, da = ra ? tail_px<C>(s.th) : a & 0xFFFFFFu;
+    const uint32_t th1 = funnel(da, s.th, (8u * na) & 31u); // the tail's upper half behind a (four bytes from a 4-byte pixel: as it was)
+    const uint32_t nb = rb ? (uint32_t)C : (b >> 26) & 3u, db = rb ? tail_px<C>(th1) : b & 0xFFFFFFu;
+    if (ra | rb) {
+        const uint32_t ca = (uint32_t)s.c, cb2 = ca + na, bpl = stride - 1; // (as unsigned numbers: "not in front of the window" too)
+        uint32_t bad = 0;
+        if (ra && ca < w.wlen) {
+            const uint32_t rowleft = stride - (w.xw + ca);
+            bad |= (rowleft % C != 0 || rowleft > bpl) ? kEmitBadStream : (rowleft == bpl ? kEmitLeaveToCpu : 0u);
         }
-        const int32_t e = s.c + (int32_t)run;
-        const int32_t lo = s.c > 0 ? s.c : 0, hi = e < (int32_t)w.wlen ? e : (int32_t)w.wlen;
-        if (lo < hi) out.fill((uint32_t)lo, (uint32_t)hi, C == 4 ? s.lastpx : s.lastpx >> 8, (uint32_t)(lo - s.c) % C);
-        s.c = e;
+        if (rb && cb2 < w.wlen) {
+            const uint32_t rowleft = stride - (w.xw + cb2);
+            bad |= (rowleft % C != 0 || rowleft > bpl) ? kEmitBadStream : (rowleft == bpl ? kEmitLeaveToCpu : 0u);
+        }
+        s.err |= bad;
     }
+    walk_apply(s, na + nb, (uint64_t)da | shl64(db, 8u * na), w, out);
+}
+// ... and one record in full.  fb: window position of the window's first DATA byte (1 where it begins with the row's filter byte).
+template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    if (!(r & kRecRun)) {
+        const uint32_t n = (r >> 26) & 3u;
+        if (n) walk_apply(s, n, r & 0xFFFFFFu, w, out);
+        return;
+    }
+    const uint32_t run = r & 0xFFFFFFu, c = (uint32_t)s.c, bpl = stride - 1;
+    if (c < w.wlen) { // the match begins in this window
+        const uint32_t rowleft = stride - (w.xw + c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
+        if (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)
+            s.err |= kEmitBadStream;
+        else if (rowleft == bpl)
+            s.err |= kEmitLeaveToCpu;
+    }
+    const uint32_t px = tail_px<C>(s.th);
+    if (run <= 8u && run % C == 0) { // one or two pixels: output bytes like any others
+        const uint64_t one = C == 4 ? px : (px & 0xFFFFFFu);
+        walk_apply(s, (uint32_t)C, one, w, out);
+        if (run > (uint32_t)C) walk_apply(s, (uint32_t)C, one, w, out);
+        return;
+    }
+    // a long match (or one no fpng encoder writes: the status says so): its pixels are marked
+    const int32_t fb = w.xw ? 0 : 1, e = s.c + (int32_t)run;
+    const int32_t lo = s.c > fb ? s.c : fb, hi = e < (int32_t)w.wlen ? e : (int32_t)w.wlen;
+    if (lo < hi) {
+        if (s.c <= fb) out.entry_px(s.th); // (it covers the window's first data byte)
+        out.mark((uint32_t)(lo - fb) / C, ((uint32_t)(hi - fb) + C - 1) / C);
+    }
+    s.c = e;
+}
+template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    walk_record<C>((uint32_t)en, s, w, stride, out);
+    walk_record<C>((uint32_t)(en >> 32), s, w, stride, out);
 }
 
 // Does a subsequence's walk ever look at the literal bytes in front of it?  Only if a match comes before four literal bytes of its

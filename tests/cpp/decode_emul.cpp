@@ -34,26 +34,28 @@ struct HostRec {
     }
     uint32_t count() const { return k; }
 };
-// a window of the filtered stream (decode.hip: TileRow); every byte may be written once
-struct HostRow {
-    uint8_t *p;
-    std::vector<bool> *written;
-    size_t base; // index of p[0] in *written
-    bool *fault;
-    void put8c(uint32_t pos, uint32_t b, bool cond)
+// a window of the filtered stream in a tile (decode.hip: TileOut): eight bytes of slack on either side; every store of a walk must
+// stay inside the walk's own territory -- the bytes of its subsequence -- or outside the window
+struct HostOut {
+    uint8_t *win0;              // window byte 0
+    std::vector<bool> *marked;  // the window's pixels that a long match covers
+    uint32_t *epx;
+    bool *has_epx, *fault;
+    int32_t wlen, own_lo, own_hi; // the walk's territory in window positions
+    void put64(int32_t pos, uint64_t v)
     {
-        if (cond) put8(pos, b);
+        if (pos < -8 || pos > wlen) *fault = true;
+        for (int q = 0; q < 8; q++) {
+            const int32_t x = pos + q;
+            if (x >= 0 && x < wlen && (x < own_lo || x >= own_hi)) *fault = true; // another walk's byte
+            win0[x] = (uint8_t)(v >> (8 * q));
+        }
     }
-    void put8(uint32_t pos, uint32_t b)
+    void entry_px(uint32_t th) { *epx = th, *has_epx = true; }
+    void mark(uint32_t lo, uint32_t hi)
     {
-        if ((*written)[base + pos]) *fault = true;
-        (*written)[base + pos] = true;
-        p[pos] = (uint8_t)b;
-    }
-    uint32_t C;
-    void fill(uint32_t lo, uint32_t hi, uint32_t px, uint32_t q)
-    {
-        for (uint32_t pos = lo; pos < hi; pos++, q = (q + 1) % C) put8(pos, (px >> (8 * q)) & 255u);
+        if (hi > marked->size()) *fault = true;
+        for (uint32_t p = lo; p < hi && p < marked->size(); p++) (*marked)[p] = true;
     }
 };
 
@@ -323,8 +325,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         if (status & (1 | 16)) return FPNG_AMD_DECODE_UNDECIDED; // (decode_api.cpp: not converged / left to the CPU decoder go first)
         if (status) return 1; // FPNG_DECODE_NOT_FPNG
         // ---- dec_subscan_kernel: offsets, the literal bytes in front, and the windows (decode_core.h) that begin in each subsequence's output ----
-        // (the kernel's tiles: column blocks of 1024 bytes, 768 where 3-channel rows become 4-channel pixels)
-        const uint32_t cbw = (c == 3 && desired == 4) ? 768u : 1024u, ncb = (bpl + cbw - 1) / cbw;
+        // (the kernel's tiles: column blocks of 256 pixels)
+        const uint32_t cbw = 256u * c, ncb = (w + 255u) / 256u;
         std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0), win((size_t)h * ncb, 0xFFFFFFFFu);
         try {
         for (uint32_t b = 0; b <= last_blk; b++) {
@@ -348,40 +350,62 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         } catch (int) {
             return -1007; // two subsequences claim one window
         }
-        // ---- dec_unfilter_kernel's tiles, first half: every window filled from the records of the subsequences that cover it, thread k of
-        //      the window's eight taking the k-th, (k + 8)-th ... subsequence from the one the window begins in ----
+        // ---- dec_unfilter_kernel's tiles, first half: every window filled from the records of the subsequences that reach into it -- from
+        //      the one it begins in to the one the next window begins in, a walk each (decode_core.h) -- then the pixels of the long matches ----
         uint32_t err = 0;
         bool fault = false;
-        std::vector<bool> written(total, false);
+        std::vector<uint8_t> tile(8 + cbw + 1 + 8);
         for (uint32_t y = 0; y < h; y++)
             for (uint32_t cb = 0; cb < ncb; cb++) {
                 const Window wd = window_of(y, cb, cbw, stride);
-                const uint32_t i0 = win[(size_t)y * ncb + cb];
+                const size_t wi = (size_t)y * ncb + cb;
+                const uint32_t i0 = win[wi];
                 if (i0 == 0xFFFFFFFFu) return -1005; // (the stream covers the image: every window begins somewhere)
-                HostRow row = {filt.data() + wd.ws, &written, (size_t)wd.ws, &fault, c};
-                for (uint32_t k0 = 0; k0 < 8; k0++)
-                    for (uint32_t i = i0 + k0; i <= eob_index; i += 8) {
-                        const uint64_t off = block_off[i / sub_block] + rel[i];
-                        if (off >= wd.ws + wd.wlen) break;
-                        PlaceState ps;
-                        ps.c = (int32_t)(int64_t)(off - wd.ws), ps.lastpx = lastpx[i], ps.err = 0;
-                        const uint32_t nent = std::min(info_nrec(info[i]), kRecCap);
-                        for (uint32_t k = 0; k < nent && ps.c < (int32_t)wd.wlen; k += 8)
-                            for (uint32_t j = 0; j < 8; j++) { // (the kernel loads eight entries at a time; behind the last one: zeros)
-                                const uint64_t en = k + j < nent ? tok[i][k + j] : 0ull;
-                                for (int half = 0; half < 2; half++) {
-                                    const uint32_t r = (uint32_t)(en >> (32 * half));
-                                    if (c == 4) place_one<4>(r, ps, wd, stride, row); else place_one<3>(r, ps, wd, stride, row);
-                                }
-                            }
-                        err |= ps.err;
+                uint32_t i1 = wi + 1 < (size_t)h * ncb ? win[wi + 1] : 0xFFFFFFFFu;
+                i1 = std::min(i1, eob_index);
+                std::fill(tile.begin(), tile.end(), (uint8_t)0xCD);
+                const uint32_t fb = cb ? 0u : 1u, npx = (wd.wlen - fb) / c;
+                std::vector<bool> marked(npx, false);
+                uint32_t epx = 0;
+                bool has_epx = false;
+                int32_t covered = 0; // window bytes [0, covered) belong to walks so far
+                for (uint32_t i = i0; i <= i1; i++) {
+                    const uint64_t off = block_off[i / sub_block] + rel[i];
+                    if (off >= wd.ws + wd.wlen) break;
+                    WalkState ws;
+                    ws.c = ws.c0 = (int32_t)(int64_t)(off - wd.ws), ws.tl = 0, ws.th = lastpx[i], ws.err = 0;
+                    if (i == i0 ? ws.c > 0 : ws.c != covered) return -1005; // a gap between two walks
+                    HostOut out = {tile.data() + 8, &marked, &epx, &has_epx, &fault, (int32_t)wd.wlen, ws.c0, ws.c0 + (int32_t)std::min<uint64_t>(bytes[i], 1u << 30)};
+                    const uint32_t nent = std::min(info_nrec(info[i]), kRecCap);
+                    for (uint32_t k = 0; k < nent; k++) { // (the kernel goes on to the end of its batch of entries: behind the window's end every store lands in the slack)
+                        const uint64_t en = tok[i][k];
+                        // (the kernel takes the straight-line step when the entries of ALL lanes of the wave allow it: both forms must do the same)
+                        if (c == 4) {
+                            if (entry_plain<4>((uint32_t)en, (uint32_t)(en >> 32)) && ((k ^ i) & 1)) walk_entry_plain<4>((uint32_t)en, (uint32_t)(en >> 32), ws, wd, stride, out);
+                            else walk_entry<4>(en, ws, wd, stride, out);
+                        } else {
+                            if (entry_plain<3>((uint32_t)en, (uint32_t)(en >> 32)) && ((k ^ i) & 1)) walk_entry_plain<3>((uint32_t)en, (uint32_t)(en >> 32), ws, wd, stride, out);
+                            else walk_entry<3>(en, ws, wd, stride, out);
+                        }
                     }
+                    if (ws.c != out.own_hi) return -1008; // the records do not add up to the subsequence's byte count
+                    covered = ws.c;
+                    err |= ws.err;
+                }
+                if (covered < (int32_t)wd.wlen) return -1005; // a byte of the window nobody wrote
+                // the long matches' pixels (decode.hip: propagate_matches): the nearest unmarked pixel to the left, else the entry pixel
+                uint8_t *data = tile.data() + 8 + fb;
+                for (uint32_t p = 0; p < npx; p++) {
+                    if (!marked[p]) continue;
+                    if (p == 0 && !has_epx && !(err & (2u | kEmitLeaveToCpu))) return -1009; // a window that begins inside a match nobody handed over
+                    const uint32_t px = c == 4 ? epx : epx >> 8;
+                    for (uint32_t q = 0; q < c; q++) data[(size_t)p * c + q] = p ? data[(size_t)(p - 1) * c + q] : (uint8_t)(px >> (8 * q));
+                }
+                memcpy(filt.data() + wd.ws, tile.data() + 8, wd.wlen);
             }
         if (fault) return -1004;
         if (err & kEmitLeaveToCpu) return FPNG_AMD_DECODE_UNDECIDED; // (decode_api.cpp: kDecStalled goes first -- a match at a row's first pixel is the CPU decoder's)
         if (err & 2) return 1;
-        for (uint64_t d = 0; d < total; d++)
-            if (!written[d]) return -1005; // a byte of the stream nobody wrote
     }
     // ---- Up filter undone, channel conversion (dec_unfilter_kernel) ----
     std::vector<uint8_t> prev(bpl, 0), cur(bpl);

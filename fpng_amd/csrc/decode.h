@@ -23,8 +23,9 @@ struct DecJob {
     uint64_t first_bit;       // first row token (behind the dynamic block header)
     uint64_t end_limit_bit;   // (z_bytes - 4) * 8: no token may start here or later
     const uint32_t *lut;      // device: dec::kLutDwords words (decode_core.h)
-    uint32_t *win;            // device scratch: h x dec_col_blocks() words, the file's subsequence (counted from its first one) in whose output
-                              // each window of dec_unfilter_kernel's tiles begins (decode_core.h: Window); 0xFFFFFFFF: none
+    uint32_t *win;            // device scratch: h x dec_col_blocks() x dec::kWinWords words: for each window of dec_unfilter_kernel's tiles (decode_core.h:
+                              // Window) the file's subsequence (counted from its first one) in whose output it begins, 0xFFFFFFFF: none; and where
+                              // that subsequence's walk may begin (decode_core.h: Resume)
     uint8_t *out;             // device: w * h * dst_c pixels
     uint32_t *segsum;         // device scratch: nseg x ceil(bpl / 4) 8-byte granules {tag, column sum} of dec_unfilter_kernel's look-back
     uint32_t w, h, src_c, dst_c, bpl;

@@ -701,17 +701,31 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     const uint32_t *info = a.info + job.sub_base;
     const uint64_t *tok = a.tok;
     const uint32_t sb = job.sub_base;
-    {
-        const uint32_t nent = info_nrec(info_l);
-        const bool need = nent && needs_lastpx(e0_l, e1_l, nent);
-        a.lastpx[g] = need ? lookback_lastpx(
-                                 i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[rec_index(sb + k, e)]; })
-                           : 0u;
-    }
-    // the windows of dec_unfilter_kernel's tiles whose first byte this subsequence writes: their walk over the records starts here
-    const uint32_t ncb = dec_col_blocks(job.w, job.src_c, job.dst_c), cbw = dec_col_block_bytes(job.src_c, job.dst_c);
+    const uint32_t nent = info_nrec(info_l);
+    const bool need = nent && needs_lastpx(e0_l, e1_l, nent);
+    const uint32_t lastpx = need ? lookback_lastpx(
+                                       i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[rec_index(sb + k, e)]; })
+                                 : 0u;
+    a.lastpx[g] = lastpx;
+    // the windows of dec_unfilter_kernel's tiles whose first byte this subsequence writes: their walk over the records starts here --
+    // at its first record, or (a subsequence that covers many windows: decode_core.h, resume points) at the entry that reaches the window
+    const uint32_t ncb = dec_col_blocks(job.w, job.src_c, job.dst_c), cbw = dec_col_block_bytes(job.src_c, job.dst_c), stride = job.bpl + 1;
     uint32_t *win = job.win;
-    if (nb) for_windows_starting_in(boff_l + before, nb, cbw, ncb, job.bpl + 1, job.h, [&](uint32_t y, uint32_t cb) { win[(size_t)y * ncb + cb] = i; });
+    if (nb) {
+        const uint64_t off = boff_l + before;
+        const bool big = nb >= kResumeMinBytes;
+        const uint32_t ncap = min(nent, kRecCap);
+        ResumeWalk rw = resume_begin(lastpx);
+        for_windows_starting_in(off, nb, cbw, ncb, stride, job.h, [&](uint32_t y, uint32_t cb) {
+            uint4 v = make_uint4(i, kNoResume, 0u, 0u);
+            if (big) {
+                const uint32_t d = (uint32_t)((uint64_t)y * stride + (cb ? 1u + cb * cbw : 0u) - off);
+                resume_seek(rw, d, ncap, [&](uint32_t k) { return tok[rec_index(g, k)]; });
+                v.y = rw.sk, v.z = rw.sc - d, v.w = rw.sth;
+            }
+            *(uint4 *)(win + ((size_t)y * ncb + cb) * kWinWords) = v;
+        });
+    }
 }
 
 #ifdef FPNG_DEC_TILE_TIMING // diagnostic build (fpng_amd/build.py --variant tile_timing): when does a tile start, have its rows, know its carry, end?
@@ -769,8 +783,8 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         uint32_t cnt = 0, i0 = 0;
         if (t < nrows) {
             const size_t wi = (size_t)(y0 + t) * ncb + cb;
-            const uint32_t a = job.win[wi];
-            uint32_t b = wi + 1 < (size_t)job.h * ncb ? job.win[wi + 1] : 0xFFFFFFFFu; // (none: the window nobody begins in -- behind the stream's end, or not placed yet)
+            const uint32_t a = job.win[wi * kWinWords];
+            uint32_t b = wi + 1 < (size_t)job.h * ncb ? job.win[(wi + 1) * kWinWords] : 0xFFFFFFFFu; // (none: the window nobody begins in -- behind the stream's end, or not placed yet)
             b = min(b, min(last, pl.sub_limit - 1u));
             if (a != 0xFFFFFFFFu && a <= b) cnt = min(b - a + 1u, kMaxWalksPerRow), i0 = a;
         }
@@ -804,29 +818,44 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         const uint32_t g = job.sub_base + i;
         const uint64_t off = pl.block_off[g / kSubBlock] + pl.a.rel[g];
         const uint32_t th0 = pl.a.lastpx[g], info = pl.a.info[g];
+        // (a row's first walk: the window's resume point, if its subsequence left one)
+        const bool first = live && q == s_first[r];
+        uint4 rs = make_uint4(0u, kNoResume, 0u, 0u);
+        if (first) rs = *(const uint4 *)(job.win + ((size_t)(y0 + r) * ncb + cb) * kWinWords);
+        const bool resumed = first && rs.y != kNoResume;
         live = live && off < w.ws + w.wlen; // (offsets rise: a subsequence that begins behind the window has nothing for it)
         WalkState st;
-        st.c = st.c0 = live ? (int32_t)(int64_t)(off - w.ws) : (int32_t)w.wlen; // (a lane without a walk: its stores go to the slack behind the row)
-        st.tl = 0, st.th = th0, st.err = 0;
-        const uint32_t nent = live ? min(info_nrec(info), kRecCap) : 0u;
+        st.c = st.c0 = resumed ? (int32_t)rs.z : (live ? (int32_t)(int64_t)(off - w.ws) : (int32_t)w.wlen); // (a lane without a walk: its stores go to the slack behind the row)
+        // (a resumed walk's stores may begin in front of the entry it begins with: those bytes -- stale ones of the tail -- lie in front of
+        //  the window; held back to that entry's first byte, a store would leave zeros BEHIND a subsequence that ends within eight bytes)
+        if (resumed) st.c0 -= 8;
+        st.tl = 0, st.th = resumed ? rs.w : th0, st.err = 0;
+        const uint32_t nent = live ? min(info_nrec(info), kRecCap) : 0u, kstart = resumed ? rs.y : 0u;
         const gu64e *col = (const gu64e *)(uintptr_t)(pl.a.tok + rec_index(g, 0));
         constexpr uint32_t kBatch = FPNG_DEC_FILL_BATCH; // entries in flight per thread
-        for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < nent && st.c < (int32_t)w.wlen) != 0; k += kBatch) {
+        static_assert(kResumeAlign % kBatch == 0, "a resumed walk begins with a whole batch");
+        uint32_t k = kstart; // (every lane at its own: a resumed walk begins further on)
+        for (;;) {
+            const bool act = k < nent && st.c < (int32_t)w.wlen;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
             uint64_t rr[kBatch];
             // (all loads of a batch in flight, none behind a branch, their addresses one base and constants: what lies behind the
-            //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing)
-            const gu64e *ck = col + (size_t)(k >> 2) * 256u; // (k is a multiple of kBatch: whole blocks of four entries)
+            //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing; a lane
+            //  that has ended stays where it is)
+            const gu64e *ck = col + (size_t)(k >> 2) * 256u;
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
+            const uint32_t left = act ? nent - k : 0u; // entries of this batch that count
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) {
-                const uint64_t en = k + j < nent ? rr[j] : 0ull;
+                const uint64_t en = j < left ? rr[j] : 0ull;
                 const uint32_t a = (uint32_t)en, b = (uint32_t)(en >> 32);
                 if (__builtin_amdgcn_ballot_w64(!entry_plain<C>(a, b)) == 0)
                     walk_entry_plain<C>(a, b, st, w, stride, out);
                 else
                     walk_entry<C>(en, st, w, stride, out);
             }
+            k += act ? kBatch : 0u;
         }
         err |= st.err;
     }

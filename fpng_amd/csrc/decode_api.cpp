@@ -289,7 +289,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
             sub_total += (j.n_sub + kDecSubBlock - 1) / kDecSubBlock * kDecSubBlock; // whole workgroups per file
             // offsets into the shared scratch (pointers are patched once the buffers exist)
             j.win = (uint32_t *)(uintptr_t)win_total; // (words, patched below)
-            win_total += (size_t)j.h * dec_col_blocks(j.w, j.src_c, j.dst_c);
+            win_total += (size_t)j.h * dec_col_blocks(j.w, j.src_c, j.dst_c) * dec::kWinWords;
             j.nseg = (p.h + kDecUnfRows - 1) / kDecUnfRows;
             j.segsum = (uint32_t *)(uintptr_t)seg_total;
             seg_total += (size_t)j.nseg * ((j.bpl + 3) / 4);
@@ -689,7 +689,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             need += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t n_win = (size_t)j.h * col_blocks;
+        const size_t n_win = (size_t)j.h * col_blocks * dec::kWinWords;
         const size_t o_z = carve((size_t)p.idat_len + 80), o_win = carve(n_win * 4), o_info = carve((size_t)sub_total * 4), o_bytes = carve((size_t)sub_total * 4),
                      o_rel = carve((size_t)sub_total * 4), o_last = carve((size_t)sub_total * 4), o_eob = carve((size_t)sub_total * 4),
                      o_tok = carve(((size_t)sub_total * dec::kRecRows + 32 * dec::kRecLane) * 8), o_recs = carve(n_blocks * sizeof(DecBlockRec)),

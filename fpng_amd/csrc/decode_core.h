@@ -496,6 +496,42 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &
     walk_record<C>((uint32_t)(en >> 32), s, w, stride, out);
 }
 
+// ---- resume points.  A subsequence whose output covers many windows (long matches: flat content -- eleven windows of an 8K row
+// and more) would be walked from its first record for each of them, a lane alone skipping forty entries.  dec_subscan_kernel,
+// which sees every subsequence once, walks such a subsequence's records once and leaves each window that begins in its output the
+// place where that window's walk may begin: the first entry that reaches into the window, where that entry's output begins
+// (relative to the window's first byte: <= 0), the tail's upper half there.  A window's words (DecJob::win): subsequence, entry
+// (kNoResume: from the subsequence's first record, its offset and tail as the synchronisation left them), position, tail. ----
+constexpr uint32_t kWinWords = 4, kNoResume = 0xFFFFFFFFu;
+constexpr uint32_t kResumeMinBytes = 2048; // output bytes of a subsequence from which on its windows get resume points
+constexpr uint32_t kResumeAlign = 16;      // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches)
+struct ResumeWalk {
+    uint32_t k, c, th;    // the next entry; output bytes of the entries in front of it; the tail's upper half there
+    uint32_t sk, sc, sth; // ... the same at the last entry whose number is a multiple of kResumeAlign
+};
+FPNG_DEC_HD ResumeWalk resume_begin(uint32_t th) { return ResumeWalk{0u, 0u, th, 0u, 0u, th}; }
+// the walk moves on to the first entry that ends behind byte d of the subsequence's output (d rises from call to call); the resume
+// point for a window that begins at byte d: entry sk, whose output begins sc - d bytes from the window's first (<= 0), tail sth
+template <class Entry> FPNG_DEC_HD void resume_seek(ResumeWalk &s, uint32_t d, uint32_t nent, const Entry &entry)
+{
+    for (; s.k < nent; s.k++) {
+        if (!(s.k & (kResumeAlign - 1u))) s.sk = s.k, s.sc = s.c, s.sth = s.th;
+        const uint64_t en = entry(s.k);
+        uint32_t nbytes = 0, th = s.th;
+        for (int half = 0; half < 2; half++) {
+            const uint32_t r = (uint32_t)(en >> (32 * half));
+            if (r & kRecRun)
+                nbytes += r & 0xFFFFFFu; // (a match leaves the tail's pixel as it is)
+            else {
+                const uint32_t n = (r >> 26) & 3u;
+                nbytes += n, th = funnel(r & 0xFFFFFFu, th, 8 * n);
+            }
+        }
+        if (s.c + nbytes > d) break;
+        s.c += nbytes, s.th = th;
+    }
+}
+
 // Does a subsequence's walk ever look at the literal bytes in front of it?  Only if a match comes before four literal bytes of its
 // own -- on photographic content next to never, and then the look back (below: loads all over the records) can be left out.
 // e0, e1: its first two entries (the lanes of a wave read theirs side by side).

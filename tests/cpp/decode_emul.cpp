@@ -328,6 +328,10 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
         // (the kernel's tiles: column blocks of 256 pixels)
         const uint32_t cbw = 256u * c, ncb = (w + 255u) / 256u;
         std::vector<uint32_t> rel(n_sub, 0), lastpx(n_sub, 0), win((size_t)h * ncb, 0xFFFFFFFFu);
+        struct ResumePoint {
+            uint32_t k, crel, th;
+        };
+        std::vector<ResumePoint> resume((size_t)h * ncb, ResumePoint{kNoResume, 0, 0});
         try {
         for (uint32_t b = 0; b <= last_blk; b++) {
             uint32_t before = 0;
@@ -340,9 +344,19 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                                 ? lookback_lastpx(
                                       i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[k][e]; })
                                 : 0xDEADBEEFu; // (never looked at: a walk that did would write wrong pixels here)
-                for_windows_starting_in(block_off[b] + before, bytes[i], cbw, ncb, stride, h, [&](uint32_t y, uint32_t cb) {
+                // (a subsequence that covers many windows leaves each of them a resume point: decode_core.h; the emulator's threshold is
+                //  low -- small test images have small windows' worth of flat rows)
+                const bool big = bytes[i] >= std::min<uint32_t>(kResumeMinBytes, 2 * cbw);
+                ResumeWalk rw = resume_begin(lastpx[i] == 0xDEADBEEFu ? 0u : lastpx[i]);
+                const uint64_t off_i = block_off[b] + before;
+                for_windows_starting_in(off_i, bytes[i], cbw, ncb, stride, h, [&](uint32_t y, uint32_t cb) {
                     if (win[(size_t)y * ncb + cb] != 0xFFFFFFFFu) throw 3; // two subsequences claim one window
                     win[(size_t)y * ncb + cb] = i;
+                    if (big) {
+                        const uint32_t d = (uint32_t)((uint64_t)y * stride + (cb ? 1u + cb * cbw : 0u) - off_i);
+                        resume_seek(rw, d, std::min(nent_i, kRecCap), [&](uint32_t k) { return tok[i][k]; });
+                        resume[(size_t)y * ncb + cb] = ResumePoint{rw.sk, rw.sc - d, rw.sth};
+                    }
                 });
                 before += bytes[i];
             }
@@ -375,9 +389,14 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     WalkState ws;
                     ws.c = ws.c0 = (int32_t)(int64_t)(off - wd.ws), ws.tl = 0, ws.th = lastpx[i], ws.err = 0;
                     if (i == i0 ? ws.c > 0 : ws.c != covered) return -1005; // a gap between two walks
-                    HostOut out = {tile.data() + 8, &marked, &epx, &has_epx, &fault, (int32_t)wd.wlen, ws.c0, ws.c0 + (int32_t)std::min<uint64_t>(bytes[i], 1u << 30)};
+                    const int32_t own_lo = ws.c0, own_hi = ws.c0 + (int32_t)std::min<uint64_t>(bytes[i], 1u << 30);
+                    uint32_t kstart = 0;
+                    if (i == i0 && resume[wi].k != kNoResume) // the window's first walk begins at its resume point
+                        kstart = resume[wi].k, ws.c = (int32_t)resume[wi].crel, ws.c0 = ws.c - 8, ws.th = resume[wi].th; // (c0: decode.hip, fill_tile)
+                    if (i == i0 && ws.c > 0) return -1005;
+                    HostOut out = {tile.data() + 8, &marked, &epx, &has_epx, &fault, (int32_t)wd.wlen, own_lo, own_hi};
                     const uint32_t nent = std::min(info_nrec(info[i]), kRecCap);
-                    for (uint32_t k = 0; k < nent; k++) { // (the kernel goes on to the end of its batch of entries: behind the window's end every store lands in the slack)
+                    for (uint32_t k = kstart; k < nent; k++) { // (the kernel goes on to the end of its batch of entries: behind the window's end every store lands in the slack)
                         const uint64_t en = tok[i][k];
                         // (the kernel takes the straight-line step when the entries of ALL lanes of the wave allow it: both forms must do the same)
                         if (c == 4) {
@@ -388,7 +407,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                             else walk_entry<3>(en, ws, wd, stride, out);
                         }
                     }
-                    if (ws.c != out.own_hi) return -1008; // the records do not add up to the subsequence's byte count
+                    if (ws.c != own_hi) return -1008; // the records do not add up to the subsequence's byte count
                     covered = ws.c;
                     err |= ws.err;
                 }

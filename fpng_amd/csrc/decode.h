@@ -80,6 +80,7 @@ struct DecUnfPlan {
     const uint32_t *cbpre; // n_files + 1
     const uint32_t *order; // n_files: indices into the group's jobs
     uint32_t n_pieces, total_items;
+    uint32_t n_files, pad_; // files of the order (cbpre holds n_files + 1 words)
 };
 
 // a device-resident file (dec_fetch_kernel gathers the heads and tails of a batch's files for the host's container walk)

@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 namespace fpng_amd {
@@ -770,7 +771,7 @@ struct TileOut {
     }
 };
 #ifndef FPNG_DEC_FILL_BATCH
-#define FPNG_DEC_FILL_BATCH 16
+#define FPNG_DEC_FILL_BATCH 8
 #endif
 // the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks.  s_first[r]:
 // number of the first walk of row r (s_first[nrows]: all of them), s_i0[r]: the subsequence it walks.
@@ -825,7 +826,7 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         const bool resumed = first && rs.y != kNoResume;
         live = live && off < w.ws + w.wlen; // (offsets rise: a subsequence that begins behind the window has nothing for it)
         WalkState st;
-        st.c = st.c0 = resumed ? (int32_t)rs.z : (live ? (int32_t)(int64_t)(off - w.ws) : (int32_t)w.wlen); // (a lane without a walk: its stores go to the slack behind the row)
+        st.c = st.c0 = resumed ? (int32_t)rs.z : (live ? (int32_t)(int64_t)(off - w.ws) : (int32_t)w.wlen + 8); // (a lane without a walk: its stores go to the slack behind the row)
         // (a resumed walk's stores may begin in front of the entry it begins with: those bytes -- stale ones of the tail -- lie in front of
         //  the window; held back to that entry's first byte, a store would leave zeros BEHIND a subsequence that ends within eight bytes)
         if (resumed) st.c0 -= 8;
@@ -835,13 +836,14 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         constexpr uint32_t kBatch = FPNG_DEC_FILL_BATCH; // entries in flight per thread
         static_assert(kResumeAlign % kBatch == 0, "a resumed walk begins with a whole batch");
         uint32_t k = kstart; // (every lane at its own: a resumed walk begins further on)
-        for (;;) {
-            const bool act = k < nent && st.c < (int32_t)w.wlen;
-            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+        // one batch: its entries loaded (all loads in flight, none behind a branch, their addresses one base and constants: what lies
+        // behind the subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing; a
+        // lane that has ended stays where it is), then walked: all lanes' entries without a match (three steps in four of a
+        // gradient, nine in ten of a photograph) -- two groups of literals, one store; one-pixel matches among them -- the same with the
+        // tail's pixel for the match; anything else -- record by record.  hold: walk_apply (the first batch: a walk's first eight bytes)
+        auto batch = [&](auto hold, bool act) {
+            constexpr bool Hold = decltype(hold)::value;
             uint64_t rr[kBatch];
-            // (all loads of a batch in flight, none behind a branch, their addresses one base and constants: what lies behind the
-            //  subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing; a lane
-            //  that has ended stays where it is)
             const gu64e *ck = col + (size_t)(k >> 2) * 256u;
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
@@ -850,11 +852,27 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
             for (uint32_t j = 0; j < kBatch; j++) {
                 const uint64_t en = j < left ? rr[j] : 0ull;
                 const uint32_t a = (uint32_t)en, b = (uint32_t)(en >> 32);
-                if (__builtin_amdgcn_ballot_w64(!entry_plain<C>(a, b)) == 0)
-                    walk_entry_plain<C>(a, b, st, w, stride, out);
+                if (__builtin_amdgcn_ballot_w64(((a | b) & kRecRun) != 0) == 0)
+                    walk_entry_literals<Hold>(a, b, st, w, out);
+                else if (__builtin_amdgcn_ballot_w64(!entry_plain<C>(a, b)) == 0)
+                    walk_entry_plain<C, Hold>(a, b, st, w, stride, out);
                 else
                     walk_entry<C>(en, st, w, stride, out);
             }
+        };
+        static_assert(kResumeAlign % kBatch == 0, "a resumed walk begins with a whole batch");
+        {
+            const bool act = k < nent && st.c < (int32_t)w.wlen;
+            if (__builtin_amdgcn_ballot_w64(act) != 0) {
+                batch(std::true_type{}, act);
+                k += act ? kBatch : 0u;
+            }
+        }
+        for (;;) {
+            const bool act = k < nent && st.c < (int32_t)w.wlen;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+            if (!act) st.c = (int32_t)w.wlen + 8; // (a lane that has ended stores into the slack from now on: its subsequence may have been shorter than a store)
+            batch(std::false_type{}, act);
             k += act ? kBatch : 0u;
         }
         err |= st.err;
@@ -970,19 +988,40 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const uint32_t b = blockIdx.x, b_run = b & ~63u;
         const uint32_t item = item0 + (b_run + 64u <= gridDim.x ? b_run + ((b & 7u) << 3) + ((b >> 3) & 7u) : b); // (item0: a later launch for the same files, fpng_amd_decode_host's streamed form)
         if (item >= plan.total_items) return;
-        uint32_t lo = 0, hi = plan.n_pieces;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (plan.pieces[mid].item0 <= item) lo = mid; else hi = mid;
+        // (which piece, which file: the lists are short -- eight files, one piece -- and a binary search over them in memory is a chain of
+        //  round trips in front of everything else the tile does: the lanes of a wave look at an element each, all at once)
+        const uint32_t l64 = threadIdx.x & (kWave - 1);
+        DecUnfPiece pc;
+        uint32_t per_seg, fidx, cb0;
+        if (plan.n_pieces <= (uint32_t)kWave && plan.n_files < (uint32_t)kWave) {
+            const bool hasp = l64 < plan.n_pieces, hasf = l64 <= plan.n_files;
+            const DecUnfPiece mine = plan.pieces[hasp ? l64 : 0u];
+            const uint32_t cbl = plan.cbpre[hasf ? l64 : 0u];
+            const uint32_t pi = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hasp && mine.item0 <= item)) - 1u; // (pieces rise; the first one begins at item 0)
+            pc.item0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.item0, (int)pi), pc.seg0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.seg0, (int)pi);
+            pc.alive = (uint32_t)__builtin_amdgcn_readlane((int)mine.alive, (int)pi), pc.pad_ = 0;
+            per_seg = (uint32_t)__builtin_amdgcn_readlane((int)cbl, (int)pc.alive);
+            const uint32_t within0 = (item - pc.item0) % per_seg;
+            fidx = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(l64 < pc.alive && cbl <= within0)) - 1u;
+            cb0 = (uint32_t)__builtin_amdgcn_readlane((int)cbl, (int)fidx);
+        } else {
+            uint32_t lo = 0, hi = plan.n_pieces;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (plan.pieces[mid].item0 <= item) lo = mid; else hi = mid;
+            }
+            pc = plan.pieces[lo];
+            per_seg = plan.cbpre[pc.alive];
+            const uint32_t within0 = (item - pc.item0) % per_seg;
+            lo = 0, hi = pc.alive;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (plan.cbpre[mid] <= within0) lo = mid; else hi = mid;
+            }
+            fidx = lo, cb0 = plan.cbpre[lo];
         }
-        const DecUnfPiece pc = plan.pieces[lo];
-        const uint32_t per_seg = plan.cbpre[pc.alive], rel = item - pc.item0, sg = uni32(pc.seg0 + rel / per_seg), within = rel % per_seg;
-        lo = 0, hi = pc.alive;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (plan.cbpre[mid] <= within) lo = mid; else hi = mid;
-        }
-        const uint32_t ji = uni32(plan.order[lo]), cb = uni32(within - plan.cbpre[lo]);
+        const uint32_t rel = item - pc.item0, sg = uni32(pc.seg0 + rel / per_seg), within = rel % per_seg;
+        const uint32_t ji = uni32(plan.order[fidx]), cb = uni32(within - cb0);
         // (the file's record, read by every lane, into scalar registers: the compiler keeps what it loads from writable global
         //  memory in vector registers, and every address derived from it would cost a register pair per row)
         DecJob job = jobs[ji];

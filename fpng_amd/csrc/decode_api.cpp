@@ -498,7 +498,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
                 }
             }
             g.plan.pieces = d_pieces + p0, g.plan.n_pieces = (uint32_t)(pieces.size() - p0), g.plan.total_items = item;
-            g.plan.cbpre = d_words + w0, g.plan.order = d_words + w0 + m + 1;
+            g.plan.cbpre = d_words + w0, g.plan.order = d_words + w0 + m + 1, g.plan.n_files = m, g.plan.pad_ = 0;
         }
         if (!pieces.empty()) std::memcpy(h_setup + setup_plan, pieces.data(), pieces.size() * sizeof(DecUnfPiece));
         if (!words.empty()) std::memcpy(h_setup + setup_plan + ((size_t)nj + kMaxGroups) * sizeof(DecUnfPiece), words.data(), words.size() * 4);
@@ -722,7 +722,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
     HIP_TRY(hipMemcpyAsync(d_lut, lut.data(), dec::kLutDwords * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_job, &j, sizeof j, hipMemcpyHostToDevice, s));
     DecUnfPlan plan;
-    plan.pieces = d_piece, plan.cbpre = d_words, plan.order = d_words + 2, plan.n_pieces = 1, plan.total_items = j.nseg * (uint32_t)col_blocks;
+    plan.pieces = d_piece, plan.cbpre = d_words, plan.order = d_words + 2, plan.n_pieces = 1, plan.total_items = j.nseg * (uint32_t)col_blocks, plan.n_files = 1, plan.pad_ = 0;
     const uint32_t epoch = next_epoch(e); // (one epoch for all of this file's unfilter launches: later segments look back at earlier launches' sums)
     // ---- pieces: whole blocks of subsequences; a piece's kernels read up to 64 bytes behind its last block (a token's window, the pad) ----
     constexpr uint32_t kMaxPieces = 16;

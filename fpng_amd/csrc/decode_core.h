@@ -412,14 +412,16 @@ struct WalkState {
 };
 FPNG_DEC_HD uint64_t shr64(uint64_t v, uint32_t s) { return v >> (s & 63u); }
 FPNG_DEC_HD uint64_t shl64(uint64_t v, uint32_t s) { return v << (s & 63u); }
-// n (0 .. 7) bytes d (first one lowest; n == 0: d == 0) are the walk's next output
-template <class Out> FPNG_DEC_HD void walk_apply(WalkState &s, uint32_t n, uint64_t d, const Window &w, Out &out)
+// n (0 .. 7) bytes d (first one lowest; n == 0: d == 0) are the walk's next output.  Hold = false: the caller knows that the walk is
+// eight bytes and more into its subsequence (every entry holds a byte at least: behind a subsequence's first eight entries) -- the
+// store begins eight bytes in front of the step's end, no question.
+template <bool Hold = true, class Out> FPNG_DEC_HD void walk_apply(WalkState &s, uint32_t n, uint64_t d, const Window &w, Out &out)
 {
     const uint32_t sh = 8u * n;
     const uint64_t ta = shr64((uint64_t)s.th << 32 | s.tl, sh) | shl64(d, 64u - sh);
     s.tl = (uint32_t)ta, s.th = (uint32_t)(ta >> 32);
-    const int32_t e = s.c + (int32_t)n, e8 = e - 8, start = e8 > s.c0 ? e8 : s.c0;
-    const uint64_t v = shr64(ta, 8u * (uint32_t)(start - e8)); // (start - e8 == 8: nothing of this subsequence yet -- whatever is stored lies where its first steps write)
+    const int32_t e = s.c + (int32_t)n, e8 = e - 8, start = (Hold && s.c0 > e8) ? s.c0 : e8;
+    const uint64_t v = Hold ? shr64(ta, 8u * (uint32_t)(start - e8)) : ta; // (start - e8 == 8: nothing of this subsequence yet -- whatever is stored lies where its first steps write)
     const int32_t lo = start < -8 ? -8 : start, pos = lo > (int32_t)w.wlen ? (int32_t)w.wlen : lo;
     out.put64(pos, v);
     s.c = e;
@@ -437,7 +439,7 @@ template <int C> FPNG_DEC_HD bool entry_plain(uint32_t a, uint32_t b)
 // ... the straight-line step for such an entry: both records become bytes (a match of one pixel: the tail's pixel), one store.
 // The reference's checks for a match that begins in the window (see walk_record): a one-pixel match cannot leave its row if it
 // starts on a pixel, so that is all there is to look at.
-template <int C, class Out> FPNG_DEC_HD void walk_entry_plain(uint32_t a, uint32_t b, WalkState &s, const Window &w, uint32_t stride, Out &out)
+template <int C, bool Hold = true, class Out> FPNG_DEC_HD void walk_entry_plain(uint32_t a, uint32_t b, WalkState &s, const Window &w, uint32_t stride, Out &out)
 {
     const bool ra = (a & kRecRun) != 0, rb = (b & kRecRun) != 0;
     const uint32_t na = ra ? (uint32_t)C : (a >> 26) & 3u, da = ra ? tail_px<C>(s.th) : a & 0xFFFFFFu;
@@ -456,7 +458,13 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry_plain(uint32_t a, uint32
         }
         s.err |= bad;
     }
-    walk_apply(s, na + nb, (uint64_t)da | shl64(db, 8u * na), w, out);
+    walk_apply<Hold>(s, na + nb, (uint64_t)da | shl64(db, 8u * na), w, out);
+}
+// ... and for an entry without a match (nearly all of them): two groups of literals, six bytes at most
+template <bool Hold = true, class Out> FPNG_DEC_HD void walk_entry_literals(uint32_t a, uint32_t b, WalkState &s, const Window &w, Out &out)
+{
+    const uint32_t na = (a >> 26) & 3u, nb = (b >> 26) & 3u;
+    walk_apply<Hold>(s, na + nb, (uint64_t)(a & 0xFFFFFFu) | shl64(b & 0xFFFFFFu, 8u * na), w, out);
 }
 // ... and one record in full.  fb: window position of the window's first DATA byte (1 where it begins with the row's filter byte).
 template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &s, const Window &w, uint32_t stride, Out &out)

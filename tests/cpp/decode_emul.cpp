@@ -398,14 +398,23 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     const uint32_t nent = std::min(info_nrec(info[i]), kRecCap);
                     for (uint32_t k = kstart; k < nent; k++) { // (the kernel goes on to the end of its batch of entries: behind the window's end every store lands in the slack)
                         const uint64_t en = tok[i][k];
-                        // (the kernel takes the straight-line step when the entries of ALL lanes of the wave allow it: both forms must do the same)
-                        if (c == 4) {
-                            if (entry_plain<4>((uint32_t)en, (uint32_t)(en >> 32)) && ((k ^ i) & 1)) walk_entry_plain<4>((uint32_t)en, (uint32_t)(en >> 32), ws, wd, stride, out);
-                            else walk_entry<4>(en, ws, wd, stride, out);
-                        } else {
-                            if (entry_plain<3>((uint32_t)en, (uint32_t)(en >> 32)) && ((k ^ i) & 1)) walk_entry_plain<3>((uint32_t)en, (uint32_t)(en >> 32), ws, wd, stride, out);
-                            else walk_entry<3>(en, ws, wd, stride, out);
-                        }
+                        const uint32_t a = (uint32_t)en, b2 = (uint32_t)(en >> 32);
+                        // (the kernel takes a straight-line step when the entries of ALL lanes of the wave allow it -- all forms must do the
+                        //  same -- and drops walk_apply's hold-back behind a walk's first batch of eight entries)
+                        const bool hold = k - kstart < 8, lits = !((a | b2) & kRecRun) && ((k ^ i) & 2);
+                        const bool plain = (c == 4 ? entry_plain<4>(a, b2) : entry_plain<3>(a, b2)) && ((k ^ i) & 1);
+                        if (lits) {
+                            if (hold) walk_entry_literals<true>(a, b2, ws, wd, out); else walk_entry_literals<false>(a, b2, ws, wd, out);
+                        } else if (plain) {
+                            if (c == 4) {
+                                if (hold) walk_entry_plain<4, true>(a, b2, ws, wd, stride, out); else walk_entry_plain<4, false>(a, b2, ws, wd, stride, out);
+                            } else {
+                                if (hold) walk_entry_plain<3, true>(a, b2, ws, wd, stride, out); else walk_entry_plain<3, false>(a, b2, ws, wd, stride, out);
+                            }
+                        } else if (c == 4)
+                            walk_entry<4>(en, ws, wd, stride, out);
+                        else
+                            walk_entry<3>(en, ws, wd, stride, out);
                     }
                     if (ws.c != own_hi) return -1008; // the records do not add up to the subsequence's byte count
                     covered = ws.c;

@@ -9,7 +9,7 @@ t0 = a[:, 1].min()
 us = (a[:, 1:] - t0) / 100.0
 print(f"{len(a)} tiles; kernel span {us[:, 4].max():.1f} us")
 if a.shape[1] >= 9:
-    for name, x in (("  start -> first walk begins", us[:, 5] - us[:, 0]), ("  first walk: its records", us[:, 6] - us[:, 5]), ("  first walk: first bytes again", us[:, 7] - us[:, 6]), ("  -> barrier", us[:, 1] - us[:, 7])):
+    for name, x in (("  start -> walks dealt (barrier)", us[:, 5] - us[:, 0]), ("  thread 0's walks", us[:, 6] - us[:, 5]), ("  -> barrier, long matches, barrier", us[:, 1] - us[:, 6])):
         print(f"  {name:32s} mean {x.mean():8.2f} us  p50 {np.percentile(x, 50):8.2f}  p90 {np.percentile(x, 90):8.2f}")
 for name, x in (("fill (start -> rows there)", us[:, 1] - us[:, 0]), ("column sums", us[:, 2] - us[:, 1]), ("look-back", us[:, 3] - us[:, 2]), ("pixels out", us[:, 4] - us[:, 3]), ("whole tile", us[:, 4] - us[:, 0])):
     print(f"  {name:28s} mean {x.mean():8.2f} us  p10 {np.percentile(x, 10):8.2f}  p50 {np.percentile(x, 50):8.2f}  p90 {np.percentile(x, 90):8.2f}  max {x.max():8.2f}")

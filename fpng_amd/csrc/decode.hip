@@ -717,11 +717,25 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
         const bool big = nb >= kResumeMinBytes;
         const uint32_t ncap = min(nent, kRecCap);
         ResumeWalk rw = resume_begin(lastpx);
+        // (the walk's entries four at a time -- a block of the records' layout, four loads in flight: one at a time is a round trip each)
+        uint64_t e4[4] = {0, 0, 0, 0};
+        uint32_t e4_at = 0xFFFFFFFFu;
+        const uint64_t *mine0 = tok + rec_index(g, 0);
+        auto entry_at = [&](uint32_t k) {
+            if ((k >> 2) != e4_at) {
+                e4_at = k >> 2;
+                const uint64_t *blk4 = mine0 + (size_t)e4_at * 256u;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) e4[q] = blk4[q * 8u];
+            }
+            const uint32_t q = k & 3u;
+            return q == 0 ? e4[0] : (q == 1 ? e4[1] : (q == 2 ? e4[2] : e4[3]));
+        };
         for_windows_starting_in(off, nb, cbw, ncb, stride, job.h, [&](uint32_t y, uint32_t cb) {
             uint4 v = make_uint4(i, kNoResume, 0u, 0u);
             if (big) {
                 const uint32_t d = (uint32_t)((uint64_t)y * stride + (cb ? 1u + cb * cbw : 0u) - off);
-                resume_seek(rw, d, ncap, [&](uint32_t k) { return tok[rec_index(g, k)]; });
+                resume_seek(rw, d, ncap, entry_at);
                 v.y = rw.sk, v.z = rw.sc - d, v.w = rw.sth;
             }
             *(uint4 *)(win + ((size_t)y * ncb + cb) * kWinWords) = v;
@@ -771,7 +785,7 @@ struct TileOut {
     }
 };
 #ifndef FPNG_DEC_FILL_BATCH
-#define FPNG_DEC_FILL_BATCH 8
+#define FPNG_DEC_FILL_BATCH 4
 #endif
 // the rows [y0, y0 + nrows) of column block cb of `job` into `tile`; returns the kEmit* flags of this thread's walks.  s_first[r]:
 // number of the first walk of row r (s_first[nrows]: all of them), s_i0[r]: the subsequence it walks.
@@ -837,16 +851,18 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         static_assert(kResumeAlign % kBatch == 0, "a resumed walk begins with a whole batch");
         uint32_t k = kstart; // (every lane at its own: a resumed walk begins further on)
         // one batch: its entries loaded (all loads in flight, none behind a branch, their addresses one base and constants: what lies
-        // behind the subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing; a
-        // lane that has ended stays where it is), then walked: all lanes' entries without a match (three steps in four of a
+        // behind the subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing;
+        // the NEXT batch's loads are issued in front of this one's walk), then walked: all lanes' entries without a match (three steps in four of a
         // gradient, nine in ten of a photograph) -- two groups of literals, one store; one-pixel matches among them -- the same with the
-        // tail's pixel for the match; anything else -- record by record.  hold: walk_apply (the first batch: a walk's first eight bytes)
+        // tail's pixel for the match; long matches only (flat content) -- their pixels marked; anything else -- record by record.  hold: walk_apply (the first batch: a walk's first eight bytes)
+        uint64_t rr[kBatch], nx[kBatch]; // the batch at hand, the next one (on its way while this one is walked)
+        auto load = [&](uint64_t (&dst)[kBatch], uint32_t kk) {
+            const gu64e *ck = col + (size_t)(kk >> 2) * 256u;
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; j++) dst[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
+        };
         auto batch = [&](auto hold, bool act) {
             constexpr bool Hold = decltype(hold)::value;
-            uint64_t rr[kBatch];
-            const gu64e *ck = col + (size_t)(k >> 2) * 256u;
-#pragma unroll
-            for (uint32_t j = 0; j < kBatch; j++) rr[j] = ck[(j >> 2) * 256u + (j & 3u) * 8u];
             const uint32_t left = act ? nent - k : 0u; // entries of this batch that count
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) {
@@ -856,24 +872,28 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
                     walk_entry_literals<Hold>(a, b, st, w, out);
                 else if (__builtin_amdgcn_ballot_w64(!entry_plain<C>(a, b)) == 0)
                     walk_entry_plain<C, Hold>(a, b, st, w, stride, out);
+                else if (__builtin_amdgcn_ballot_w64(!entry_long_matches(a, b)) == 0)
+                    walk_entry_long<C>(a, b, st, w, stride, out);
                 else
                     walk_entry<C>(en, st, w, stride, out);
             }
         };
         static_assert(kResumeAlign % kBatch == 0, "a resumed walk begins with a whole batch");
-        {
-            const bool act = k < nent && st.c < (int32_t)w.wlen;
-            if (__builtin_amdgcn_ballot_w64(act) != 0) {
-                batch(std::true_type{}, act);
-                k += act ? kBatch : 0u;
-            }
-        }
-        for (;;) {
+        load(rr, k);
+        for (uint32_t it = 0;; it++) {
             const bool act = k < nent && st.c < (int32_t)w.wlen;
             if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-            if (!act) st.c = (int32_t)w.wlen + 8; // (a lane that has ended stores into the slack from now on: its subsequence may have been shorter than a store)
-            batch(std::false_type{}, act);
-            k += act ? kBatch : 0u;
+            const uint32_t knext = k + (act ? kBatch : 0u); // (a lane that has ended stays where it is)
+            load(nx, knext);
+            if (it * kBatch < 8u) // (a walk's first eight entries: eight bytes at least)
+                batch(std::true_type{}, act);
+            else {
+                if (!act) st.c = (int32_t)w.wlen + 8; // (a lane that has ended stores into the slack from now on: its subsequence may have been shorter than a store)
+                batch(std::false_type{}, act);
+            }
+            k = knext;
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; j++) rr[j] = nx[j];
         }
         err |= st.err;
     }
@@ -883,11 +903,24 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
 // The pixels that the walks marked -- long matches -- take the value of the nearest unmarked pixel to their left in their row (an
 // unmarked pixel is a literal one, or a short match's, written by a walk; none in the window: the row's entry pixel).  Items of
 // (row, 64 pixels); a wave looks at its items' bitmaps at once (a lane each) and then works through those that have marked pixels.
-template <int C> __device__ __forceinline__ void propagate_matches(lds_u8 *tile, const lds_u32 *bm, const lds_u32 *epx, uint32_t nrows)
+template <int C> __device__ __forceinline__ void propagate_matches(lds_u8 *tile, const lds_u32 *bm, const lds_u32 *epx, uint32_t nrows, uint32_t *s_front)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     constexpr uint32_t kWaves = kUnfBlock / kWave, kItems = kUnfRows * 4, kPerWave = (kItems + kWaves - 1) / kWaves;
     static_assert(kPerWave <= (uint32_t)kWave, "a lane per item");
+    // (per row, by a thread each: the nearest unmarked pixel in front of the row's second, third and fourth 64 pixels -- number + 1, 0:
+    //  none -- 9 bits each: what an item whose first pixels are marked would otherwise look for through the bitmaps in front of it)
+    if (threadIdx.x < nrows) {
+        const lds_u32 *m = bm + threadIdx.x * kRowMaskWords;
+        uint32_t last = 0, packed = 0;
+        for (uint32_t gg = 0; gg < 3; gg++) {
+            const uint64_t free = ~((uint64_t)m[gg * 2 + 1] << 32 | m[gg * 2]);
+            if (free) last = 64u * gg + 64u - (uint32_t)__builtin_clzll(free);
+            packed |= last << (9u * gg);
+        }
+        s_front[threadIdx.x] = packed;
+    }
+    __syncthreads();
     uint32_t mlo = 0, mhi = 0;
     {
         const uint32_t it = wv + kWaves * lane, row = it >> 2, grp = it & 3u;
@@ -899,16 +932,7 @@ template <int C> __device__ __forceinline__ void propagate_matches(lds_u8 *tile,
         todo &= todo - 1;
         const uint64_t M = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
         const uint32_t it = wv + kWaves * j, row = it >> 2, grp = it & 3u;
-        int32_t fsrc = -1; // the nearest unmarked pixel in front of this group
-        if (M & 1ull) {
-            for (uint32_t gg = grp; gg-- > 0;) {
-                const uint64_t mg = ~((uint64_t)bm[row * kRowMaskWords + gg * 2 + 1] << 32 | bm[row * kRowMaskWords + gg * 2]);
-                if (mg) {
-                    fsrc = (int32_t)(64u * gg + 63u - (uint32_t)__builtin_clzll(mg));
-                    break;
-                }
-            }
-        }
+        const int32_t fsrc = grp ? (int32_t)((s_front[row] >> (9u * (grp - 1u))) & 511u) - 1 : -1; // the nearest unmarked pixel in front of this group
         const uint64_t z = ~M & ((1ull << lane) - 1ull);
         const int32_t src = z ? (int32_t)(64u * grp + 63u - (uint32_t)__builtin_clzll(z)) : fsrc;
         if ((M >> lane) & 1ull) {
@@ -1055,7 +1079,7 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                                          : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, item0);
             if (err) atomicOr(&status[ji], err);
             __syncthreads();
-            if (sc == 4) propagate_matches<4>(tile, bm, epx, nrows); else propagate_matches<3>(tile, bm, epx, nrows);
+            if (sc == 4) propagate_matches<4>(tile, bm, epx, nrows, s_i0); else propagate_matches<3>(tile, bm, epx, nrows, s_i0);
         }
         __syncthreads();
         FPNG_TILE_STAMP(1);

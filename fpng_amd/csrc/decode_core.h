@@ -466,30 +466,23 @@ template <bool Hold = true, class Out> FPNG_DEC_HD void walk_entry_literals(uint
     const uint32_t na = (a >> 26) & 3u, nb = (b >> 26) & 3u;
     walk_apply<Hold>(s, na + nb, (uint64_t)(a & 0xFFFFFFu) | shl64(b & 0xFFFFFFu, 8u * na), w, out);
 }
-// ... and one record in full.  fb: window position of the window's first DATA byte (1 where it begins with the row's filter byte).
-template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &s, const Window &w, uint32_t stride, Out &out)
+// the reference's checks for a match of `run` bytes that begins at the walk's position, if that lies in this window
+template <int C> FPNG_DEC_HD void match_checks(uint32_t run, WalkState &s, const Window &w, uint32_t stride)
 {
-    if (!(r & kRecRun)) {
-        const uint32_t n = (r >> 26) & 3u;
-        if (n) walk_apply(s, n, r & 0xFFFFFFu, w, out);
-        return;
-    }
-    const uint32_t run = r & 0xFFFFFFu, c = (uint32_t)s.c, bpl = stride - 1;
-    if (c < w.wlen) { // the match begins in this window
+    const uint32_t c = (uint32_t)s.c, bpl = stride - 1;
+    if (c < w.wlen) {
         const uint32_t rowleft = stride - (w.xw + c); // bytes up to the end of the row, this one included (== stride: a filter byte stands here)
         if (rowleft % C != 0 || rowleft > bpl || run > rowleft || run % C != 0)
             s.err |= kEmitBadStream;
         else if (rowleft == bpl)
             s.err |= kEmitLeaveToCpu;
     }
-    const uint32_t px = tail_px<C>(s.th);
-    if (run <= 8u && run % C == 0) { // one or two pixels: output bytes like any others
-        const uint64_t one = C == 4 ? px : (px & 0xFFFFFFu);
-        walk_apply(s, (uint32_t)C, one, w, out);
-        if (run > (uint32_t)C) walk_apply(s, (uint32_t)C, one, w, out);
-        return;
-    }
-    // a long match (or one no fpng encoder writes: the status says so): its pixels are marked
+}
+// a LONG match (more than eight bytes -- or one no fpng encoder writes: the status says so): its pixels are marked.  fb: window
+// position of the window's first DATA byte (1 where it begins with the row's filter byte).
+template <int C, class Out> FPNG_DEC_HD void walk_long_match(uint32_t run, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    match_checks<C>(run, s, w, stride);
     const int32_t fb = w.xw ? 0 : 1, e = s.c + (int32_t)run;
     const int32_t lo = s.c > fb ? s.c : fb, hi = e < (int32_t)w.wlen ? e : (int32_t)w.wlen;
     if (lo < hi) {
@@ -497,6 +490,36 @@ template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &
         out.mark((uint32_t)(lo - fb) / C, ((uint32_t)(hi - fb) + C - 1) / C);
     }
     s.c = e;
+}
+// ... and one record in full
+template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    if (!(r & kRecRun)) {
+        const uint32_t n = (r >> 26) & 3u;
+        if (n) walk_apply(s, n, r & 0xFFFFFFu, w, out);
+        return;
+    }
+    const uint32_t run = r & 0xFFFFFFu;
+    if (run <= 8u && run % C == 0) { // one or two pixels: output bytes like any others
+        match_checks<C>(run, s, w, stride);
+        const uint32_t px = tail_px<C>(s.th);
+        const uint64_t one = C == 4 ? px : (px & 0xFFFFFFu);
+        walk_apply(s, (uint32_t)C, one, w, out);
+        if (run > (uint32_t)C) walk_apply(s, (uint32_t)C, one, w, out);
+        return;
+    }
+    walk_long_match<C>(run, s, w, stride, out);
+}
+// Flat content: every step two matches of 258 bytes.  Is the entry one of long matches only (each record nothing or one)?
+FPNG_DEC_HD bool entry_long_matches(uint32_t a, uint32_t b)
+{
+    const bool oka = !a || ((a & kRecRun) && (a & 0xFFFFFFu) > 8u), okb = !b || ((b & kRecRun) && (b & 0xFFFFFFu) > 8u);
+    return oka && okb;
+}
+template <int C, class Out> FPNG_DEC_HD void walk_entry_long(uint32_t a, uint32_t b, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    if (a) walk_long_match<C>(a & 0xFFFFFFu, s, w, stride, out);
+    if (b) walk_long_match<C>(b & 0xFFFFFFu, s, w, stride, out);
 }
 template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &s, const Window &w, uint32_t stride, Out &out)
 {
@@ -512,7 +535,7 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &
 // (kNoResume: from the subsequence's first record, its offset and tail as the synchronisation left them), position, tail. ----
 constexpr uint32_t kWinWords = 4, kNoResume = 0xFFFFFFFFu;
 constexpr uint32_t kResumeMinBytes = 2048; // output bytes of a subsequence from which on its windows get resume points
-constexpr uint32_t kResumeAlign = 16;      // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches)
+constexpr uint32_t kResumeAlign = 8;       // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches)
 struct ResumeWalk {
     uint32_t k, c, th;    // the next entry; output bytes of the entries in front of it; the tail's upper half there
     uint32_t sk, sc, sth; // ... the same at the last entry whose number is a multiple of kResumeAlign

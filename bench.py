@@ -152,7 +152,10 @@ def committed_traffic(kernel, tag):
             if len(f) in (5, 7) and f[0] == kernel:  # (round 6 on: + launches per step, megabytes per step; the first five columns are ONE launch's)
                 import hashlib
                 # (the file's content hash goes along: a summary from another tree cannot pass for this one's unnoticed)
-                return int((float(f[2]) + float(f[4])) * 1e6), os.path.relpath(path, ROOT) + "#sha256=" + hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
+                # (a kernel that is launched several times per step -- dec_sync_kernel: round 0 and two border rounds -- is timed as ONE
+                #  phase by the library: its bytes are the step's too, the last column)
+                mb = float(f[6]) if len(f) == 7 else float(f[2]) + float(f[4])
+                return int(mb * 1e6), os.path.relpath(path, ROOT) + "#sha256=" + hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
     return None, None
 
 

@@ -704,9 +704,20 @@ __global__ __launch_bounds__(kSubBlock) void dec_subscan_kernel(const DecJob *jo
     const uint32_t sb = job.sub_base;
     const uint32_t nent = info_nrec(info_l);
     const bool need = nent && needs_lastpx(e0_l, e1_l, nent);
-    const uint32_t lastpx = need ? lookback_lastpx(
-                                       i, [&](uint32_t k) { return info_nrec(info[k]); }, [&](uint32_t k, uint32_t e) { return tok[rec_index(sb + k, e)]; })
-                                 : 0u;
+    // (the look back reads entries from a subsequence's last one down: the four of a block of the records' layout in one round trip)
+    uint64_t lb4[4] = {0, 0, 0, 0};
+    uint32_t lb_sub = 0xFFFFFFFFu, lb_at = 0xFFFFFFFFu;
+    auto lookback_entry = [&](uint32_t k, uint32_t e) {
+        if (k != lb_sub || (e >> 2) != lb_at) {
+            lb_sub = k, lb_at = e >> 2;
+            const uint64_t *blk4 = tok + rec_index(sb + k, 0) + (size_t)lb_at * 256u;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) lb4[q] = blk4[q * 8u];
+        }
+        const uint32_t q = e & 3u;
+        return q == 0 ? lb4[0] : (q == 1 ? lb4[1] : (q == 2 ? lb4[2] : lb4[3]));
+    };
+    const uint32_t lastpx = need ? lookback_lastpx(i, [&](uint32_t k) { return info_nrec(info[k]); }, lookback_entry) : 0u;
     a.lastpx[g] = lastpx;
     // the windows of dec_unfilter_kernel's tiles whose first byte this subsequence writes: their walk over the records starts here --
     // at its first record, or (a subsequence that covers many windows: decode_core.h, resume points) at the entry that reaches the window

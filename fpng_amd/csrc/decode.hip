@@ -303,19 +303,28 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const uint32_t data_limit = lim64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)lim64;
         SubState st;
         st.start = st.end = nominal;
-        st.c.bytes = st.c.flags = st.c.eob = 0, st.nrec = 0;
+        st.c.bytes = st.c.flags = st.c.eob = st.c.gen = 0, st.nrec = 0;
         bool dirty = false;
-        if (valid) {
-            if (!round) {
+        // Which form of the walk (decode_core.h: walk_count)?  The first decode: the lean one unless the lead-ins of four lanes of the
+        // wave and more met a match with extra bits -- then the stream is one of matches (UI content, tiles, flat rows), and the rich
+        // one.  Every correction, here and in the border rounds, takes the rich one: few subsequences of a gradient are corrected,
+        // nearly all of a periodic stream of matches are, again and again.
+        constexpr bool kRichRedo = true;
+        if (!round) {
+            uint32_t p0 = nominal, gen = 0;
+            if (valid && i) p0 = sub_lead<VoteAlone>(in, lut, lenof, nominal - kDecLeadIn, nominal, data_limit, gen);
+            const bool rich = __popcll(__ballot(valid && gen != 0)) >= 4;
+            if (valid) {
                 TokOut rec = tok_of(a.tok, g);
-                sub_first<VoteAlone>(in, lut, lenof, i ? nominal - kDecLeadIn : nominal, nominal, boundary, data_limit, st, rec);
+                sub_main<VoteAlone>(in, lut, lenof, p0, boundary, data_limit, st, rec, rich);
                 dirty = true;
-            } else {
-                const uint32_t v = a.info[g];
-                st.start = nominal + info_start(v), st.end = boundary + info_end(v), st.nrec = info_nrec(v);
-                st.c.bytes = a.bytes[g], st.c.flags = info_flags(v);
-                st.c.eob = (st.c.flags & kSubEob) ? nominal + a.eob[g] : 0u;
             }
+        }
+        if (valid && round) {
+            const uint32_t v = a.info[g];
+            st.start = nominal + info_start(v), st.end = boundary + info_end(v), st.nrec = info_nrec(v);
+            st.c.bytes = a.bytes[g], st.c.flags = info_flags(v);
+            st.c.eob = (st.c.flags & kSubEob) ? nominal + a.eob[g] : 0u;
         }
         want0 += nominal; // (thread 0's nominal: the block's first)
         s_end[t] = st.end;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (n_need < kGatherMin) {
                     if (need) {
                         TokOut rec = tok_of(a.tok, g);
-                        sub_redo<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st, rec);
+                        sub_redo<VoteAlone>(in, lut, lenof, want, boundary, data_limit, st, rec, kRichRedo);
                         s_end[t] = st.end;
                         dirty = true;
                     }
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                         const uint32_t v = q[0], ot = v >> 5, o_nominal = nominal - t * kSubBits + ot * kSubBits; // (this thread's nominal -> the owner's)
                         SubState r;
                         TokOut rec = tok_of(a.tok, g - t + ot); // (the owner's column: lanes of this pass write to columns of any wave's chunk)
-                        sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r, rec);
+                        sub_redo<VoteAlone>(in, lut, lenof, o_nominal + (v & 31u), o_nominal + kSubBits, data_limit, r, rec, kRichRedo);
                         q[0] = r.c.eob - o_nominal, q[1] = pack_info(v & 31u, r.end - (o_nominal + kSubBits), r.c, r.nrec), q[2] = r.c.bytes;
                     }
                     __syncthreads();
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                 const uint32_t srel = (valid && t) ? pm_at(gp, start0) : kPhaseUnknown;
                 if (srel != kPhaseUnknown && nominal + srel != st.start) {
                     TokOut rec = tok_of(a.tok, g0 + t); // (`g` is the composed map here)
-                    sub_redo<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st, rec);
+                    sub_redo<VoteAlone>(in, lut, lenof, nominal + srel, boundary, data_limit, st, rec, kRichRedo);
                     dirty = true;
                 }
                 __syncthreads();

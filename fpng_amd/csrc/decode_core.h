@@ -119,6 +119,7 @@ struct SubCount {
     uint32_t bytes; // output bytes of its tokens
     uint32_t flags; // kSubEob: it met an end-of-block symbol; kSubInvalid: its decode derailed
     uint32_t eob;   // kSubEob: the position behind that symbol
+    uint32_t gen;   // matches that took the general path (a walk without Rich: matches with extra bits)
 };
 // where a walk leaves its records: put2(a, b) -- one step's two records, an entry unless both are nothing.  NoRec: a walk that only
 // looks (the lead-in, the phase maps' probes).
@@ -141,24 +142,34 @@ struct VoteAlone {
 // behind the first token) as straight-line predicated code -- a group of literals that lies wholly in front of the limit and a
 // match are applied -- and what is left (the end of the block, an invalid code, a group that reaches over the limit) takes a
 // single token through fetch(), when the vote says so.
-template <bool Count, class Vote, class Bits, class Rec>
+template <bool Count, bool Rich, class Vote, class Bits, class Rec>
 FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t pos, uint32_t limit, uint32_t data_limit, SubCount &c, Rec &rec)
 {
     uint32_t bytes = 0, flags = 0;
     const uint32_t lim = limit < data_limit ? limit : data_limit; // (no token may start at or behind data_limit)
-    // one token at the window's first bit if it is a SIMPLE one (kEntSimple: a group of literals that lies wholly in front of the limit,
-    // a match without extra bits); returns the bits it took (0: not one of those); r: its record = the table's entry without its
-    // length field.  (Until round 6 every match was taken here, its extra bits cut out of the window in straight-line code for
-    // every lane and both lookups: 125 vector instructions a step where this form has half; a match with extra bits now costs its
-    // lane the general path -- fetch() -- and is rare where steps are many.)
+    // one token at the window's first bit if it is one the straight-line part takes: a group of literals that lies wholly in front of
+    // the limit, or a match; returns the bits it took (0: not one of those); r: its record.  A match WITH extra bits (rare in
+    // gradients and photographs, frequent where flat runs end at block edges: UI content, tiles) has its length completed under a
+    // branch of its own in the RICH form of the walk; in the lean form it goes through fetch(), a token to itself and an iteration
+    // of the loop.  Which form: the caller's choice -- the lean one is 4 .. 9 % faster where such matches are rare (the branch sits in
+    // the chain lookup -> bits -> next lookup), the rich one 1.3 .. 3 x faster where they are frequent (profiles/r08_sync_matches_ab.txt);
+    // dec_sync_kernel looks at what the lead-ins of a wave met.  (Round 5's form cut the extra bits out of the window for every lane
+    // and both lookups: 125 vector instructions a step.)
     auto take = [&](uint32_t wk, uint32_t room, bool en, uint32_t &r) -> uint32_t {
         const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
-        const bool ok = en && (e & kEntSimple) != 0 && (n == 0 || L <= room);
-        if (Count) {
-            bytes += ok ? (n ? n : (e & 511u)) : 0u;
-            r = ok ? (e & 0x0FFFFFFFu) : 0u;
+        bool ok = en && (e & kEntSimple) != 0 && (n == 0 || L <= room);
+        uint32_t len = e & 511u, bits = L + (n == 0 ? 1u : 0u);
+        if (Rich && en && (e & (kEntMatch | kEntSimple)) == kEntMatch) {
+            const uint32_t xb = (e >> 9) & 7u; // (18 bits at most with the code and the distance bit: the window has them, see en_b)
+            len += (wk >> L) & ((1u << xb) - 1u);
+            bits += xb;
+            ok = true;
         }
-        return ok ? L + (n == 0 ? 1u : 0u) : 0u;
+        if (Count) {
+            bytes += ok ? (n ? n : len) : 0u;
+            r = ok ? (n ? (e & 0x0FFFFFFFu) : (kRecRun | len)) : 0u;
+        }
+        return ok ? bits : 0u;
     };
     while (pos < lim) {
         const uint32_t w = in.window(pos), room = lim - pos;
@@ -184,6 +195,7 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
                 else
                     bytes += run, rec.put2(kRecRun | run, 0u);
             }
+            c.gen += kind == kTokMatch ? 1u : 0u;
         }
     }
     if (!flags && pos < limit) flags = kSubInvalid; // ran off the data without an end-of-block symbol
@@ -210,35 +222,45 @@ FPNG_DEC_HD void sub_close(SubState &s, uint32_t boundary, uint32_t e, uint32_t 
 // First decode of a subsequence [nominal, boundary): the decoder starts `lead` bits EARLIER and has, with a probability that
 // tools/sync_stats.c measured (128 bits: all but 0.04 % of the subsequences of a synthetic gradient, 1.8 % of a photograph),
 // fallen into step with the true token sequence when it crosses `nominal`; the first token boundary at or behind `nominal` is
-// the subsequence's start.  Whether it is the true one shows when it is compared with the predecessor's end.  rec: where the
-// subsequence's own tokens are recorded (the lead-in's are not).
-template <class Vote, class Bits, class Rec>
-FPNG_DEC_HD void sub_first(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec)
+// the subsequence's start.  Whether it is the true one shows when it is compared with the predecessor's end.
+// sub_lead: the lead-in (the lean walk; gen: the matches it met that a rich walk would have taken in its stride) -> the start;
+// sub_main: the subsequence's own tokens, recorded in rec, with the walk the caller chose.
+template <class Vote, class Bits>
+FPNG_DEC_HD uint32_t sub_lead(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t data_limit, uint32_t &gen)
 {
-    uint32_t p = nominal;
-    if (lead_start < nominal) {
-        SubCount d = {0, 0, 0};
-        NoRec none;
-        p = walk_count<false, Vote>(in, lut, lenof, lead_start, nominal, data_limit, d, none);
-        if (d.flags || p < nominal) p = nominal; // the lead-in derailed: any start is as good as another
+    // (in two halves: a decoder that is not in step yet decodes noise, matches of every kind among it -- what the second half meets
+    //  says something about the stream)
+    NoRec none;
+    uint32_t p = lead_start;
+    const uint32_t mid = nominal - lead_start > 64u ? nominal - 64u : lead_start;
+    if (p < mid) {
+        SubCount d = {0, 0, 0, 0};
+        p = walk_count<false, false, Vote>(in, lut, lenof, p, mid, data_limit, d, none);
+        if (d.flags || p < mid) p = mid;
     }
-    s.start = p;
-    s.c.bytes = s.c.flags = s.c.eob = 0;
-    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, p, boundary, data_limit, s.c, rec);
+    SubCount d = {0, 0, 0, 0};
+    p = walk_count<false, false, Vote>(in, lut, lenof, p, nominal, data_limit, d, none);
+    gen = d.gen;
+    return (d.flags || p < nominal) ? nominal : p; // (the lead-in derailed: any start is as good as another)
+}
+template <class Vote, class Bits, class Rec>
+FPNG_DEC_HD void sub_main(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec, bool rich)
+{
+    s.start = start;
+    s.c.bytes = s.c.flags = s.c.eob = s.c.gen = 0;
+    const uint32_t e = rich ? walk_count<true, true, Vote>(in, lut, lenof, start, boundary, data_limit, s.c, rec)
+                            : walk_count<true, false, Vote>(in, lut, lenof, start, boundary, data_limit, s.c, rec);
     sub_close(s, boundary, e, rec.count());
 }
 
 // The subsequence must start at `want` instead of s.start (its predecessor ended there): decoded again as a whole, its records
 // written again from the first one.  (Until round 5 the two decodes were stepped token by token to where they meet and only the
-// counts in front of that point exchanged; records cannot be patched that way -- the new decode may need more of them in front of
-// the meeting point than the old one left room for.)
+// counts in front of that point exchanged; records cannot be patched that way -- the new decode may need more of them in front of the
+// meeting point than the old one left room for.)
 template <class Vote, class Bits, class Rec>
-FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec)
+FPNG_DEC_HD void sub_redo(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t want, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec, bool rich)
 {
-    s.start = want;
-    s.c.bytes = s.c.flags = s.c.eob = 0;
-    const uint32_t e = walk_count<true, Vote>(in, lut, lenof, want, boundary, data_limit, s.c, rec);
-    sub_close(s, boundary, e, rec.count());
+    sub_main<Vote>(in, lut, lenof, want, boundary, data_limit, s, rec, rich);
 }
 
 // ---- phase maps: the way out of a PERIODIC stream ----
@@ -305,9 +327,9 @@ FPNG_DEC_HD PhaseMap pm_compose(const PhaseMap &a, const PhaseMap &b)
 template <class Vote, class Bits>
 FPNG_DEC_HD uint32_t sub_probe(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit)
 {
-    SubCount d = {0, 0, 0};
+    SubCount d = {0, 0, 0, 0};
     NoRec none;
-    const uint32_t e = walk_count<false, Vote>(in, lut, lenof, start, boundary, data_limit, d, none);
+    const uint32_t e = walk_count<false, true, Vote>(in, lut, lenof, start, boundary, data_limit, d, none); // (the rich walk: periodic streams are streams of matches)
     return d.flags ? boundary : e;
 }
 // One growing step of a thread's map: every phase the predecessor's map ends in (= a phase this subsequence is entered in: its
@@ -330,9 +352,9 @@ template <class Vote, class Bits>
 FPNG_DEC_HD void pm_seed(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t lead_start, uint32_t nominal, uint32_t boundary, uint32_t data_limit, PhaseMap &map)
 {
     for (uint32_t j = 1; j < kPhases; j++) {
-        SubCount d = {0, 0, 0};
+        SubCount d = {0, 0, 0, 0};
         NoRec none;
-        const uint32_t p = walk_count<false, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d, none);
+        const uint32_t p = walk_count<false, true, Vote>(in, lut, lenof, lead_start + j, nominal, data_limit, d, none);
         if (d.flags || p < nominal || pm_at(map, p - nominal) != kPhaseUnknown) continue;
         pm_set(map, p - nominal, sub_probe<Vote>(in, lut, lenof, p, boundary, data_limit) - boundary);
     }

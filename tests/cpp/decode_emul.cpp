@@ -131,7 +131,11 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                 const uint32_t i = local0 + t, nominal = nominal_of(t), boundary = nominal + kSubBits;
                 if (!round) {
                     HostRec rec = {&tok[i]};
-                    sub_first<VoteAlone>(in, lut.data(), lenof, i ? nominal - lead_in : nominal, nominal, boundary, data_limit, st[t], rec);
+                    // (the kernel chooses the walk's form by what the lead-ins of a wave met: here by the thread's own, and by its number
+                    //  where it met nothing -- both forms must settle on the same tokens)
+                    uint32_t p0 = nominal, gen = 0;
+                    if (i) p0 = sub_lead<VoteAlone>(in, lut.data(), lenof, nominal - lead_in, nominal, data_limit, gen);
+                    sub_main<VoteAlone>(in, lut.data(), lenof, p0, boundary, data_limit, st[t], rec, gen != 0 || (i & 1));
                     dirty[t] = true;
                 } else {
                     const uint32_t v = info[i];
@@ -168,7 +172,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     for (uint32_t t = 0; t < nthreads; t++)
                         if (want[t] != st[t].start) {
                             HostRec rec = {&tok[local0 + t]};
-                            sub_redo<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t], rec);
+                            sub_redo<VoteAlone>(in, lut.data(), lenof, want[t], nominal_of(t) + kSubBits, data_limit, st[t], rec, (t ^ it) & 1);
                             s_end[t] = st[t].end;
                             dirty[t] = true;
                             if (!ever[t]) ever[t] = true, fixed_subs++;
@@ -201,7 +205,7 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                     const uint32_t ws = nominal_of(t) + srel;
                     if (ws == st[t].start) continue;
                     HostRec rec = {&tok[local0 + t]};
-                    sub_redo<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t], rec);
+                    sub_redo<VoteAlone>(in, lut.data(), lenof, ws, nominal_of(t) + kSubBits, data_limit, st[t], rec, true);
                     dirty[t] = true;
                     if (!ever[t]) ever[t] = true, fixed_subs++;
                 }

@@ -233,15 +233,15 @@ FPNG_DEC_HD uint32_t sub_lead(const Bits &in, const uint32_t *lut, const uint8_t
     NoRec none;
     uint32_t p = lead_start;
     const uint32_t mid = nominal - lead_start > 64u ? nominal - 64u : lead_start;
-    if (p < mid) {
+    for (uint32_t half = 0; half < 2; half++) { // (one body of the walk for both halves)
+        const uint32_t to = half ? nominal : mid;
+        if (p >= to && !half) continue;
         SubCount d = {0, 0, 0, 0};
-        p = walk_count<false, false, Vote>(in, lut, lenof, p, mid, data_limit, d, none);
-        if (d.flags || p < mid) p = mid;
+        p = walk_count<false, false, Vote>(in, lut, lenof, p, to, data_limit, d, none);
+        if (d.flags || p < to) p = to; // (it derailed: any start is as good as another)
+        gen = d.gen;
     }
-    SubCount d = {0, 0, 0, 0};
-    p = walk_count<false, false, Vote>(in, lut, lenof, p, nominal, data_limit, d, none);
-    gen = d.gen;
-    return (d.flags || p < nominal) ? nominal : p; // (the lead-in derailed: any start is as good as another)
+    return p;
 }
 template <class Vote, class Bits, class Rec>
 FPNG_DEC_HD void sub_main(const Bits &in, const uint32_t *lut, const uint8_t *lenof, uint32_t start, uint32_t boundary, uint32_t data_limit, SubState &s, Rec &rec, bool rich)

@@ -4,28 +4,33 @@
 //
 // An fpng stream is ONE Huffman-coded bit string with no restart points, but Huffman decoders SELF-SYNCHRONISE: started at a
 // wrong bit, a decoder falls into step with the true token sequence after a few dozen bits.  So the token bits are cut into
-// subsequences of kSubBits bits, one thread each (the per-thread logic lives in decode_core.h, which also compiles for the host):
+// subsequences of kSubBits bits, one thread each (the per-thread logic lives in decode_core.h, which also compiles for the host),
+// and EVERY TOKEN IS DECODED ONCE (round 6): the decode that settles a subsequence leaves token records, the pass that writes reads them.
 //   dec_build_lut_kernel the lookup table of every distinct set of code lengths (decode_core.h: up to three literals per lookup)
 //   dec_sync_kernel     round 0 (<false>), one workgroup per kDecSubBlock subsequences, their bits and the lookup table staged in
 //                       LDS: every thread starts kDecLeadIn bits EARLY, takes the first token boundary at or behind its nominal
-//                       first bit as its start and counts its tokens' output bytes; then, still inside the workgroup, every thread
-//                       whose predecessor ended elsewhere than it started is corrected -- a few where they are, from four on
-//                       gathered into one wave and decoded again -- until nothing changes, three steps at most: a workgroup that
-//                       still changes then (a periodic stream) is marked and left to round 1.  Rounds 1.. (<true>, persistent
-//                       workgroups): the same across workgroup borders -- a workgroup whose first thread starts where the previous
-//                       workgroup's last one ended is passed over -- plus the PHASE MAPS that settle periodic streams.
+//                       first bit as its start, decodes its tokens -- their output bytes counted, what they are left behind as
+//                       records (an 8-byte entry per step of the walk) -- then, still inside the workgroup, every thread whose
+//                       predecessor ended elsewhere than it started is corrected -- a few where they are, from four on gathered
+//                       into one wave, decoded again, their records written again -- until nothing changes, three steps at most:
+//                       a workgroup that still changes then (a periodic stream) is marked and left to round 1.  Rounds 1..
+//                       (<true>, persistent workgroups): the same across workgroup borders -- a workgroup whose first thread
+//                       starts where the previous workgroup's last one ended is passed over -- plus the PHASE MAPS that settle
+//                       periodic streams.
 //   dec_chain_kernel    in front of rounds 2..: the workgroups' phase maps composed along every file -> the entry each workgroup
 //                       must take (leaves at once unless some map has more than one pair)
 //   dec_offsets_kernel  per file: the first end-of-block symbol of the chain ends the stream; up to there the chain must hold and
 //                       no subsequence may be invalid; exclusive scan of the workgroups' byte counts; the total must be the image
-//   dec_subscan_kernel  per workgroup of subsequences: output offset of every subsequence and the four literal bytes in front of
-//                       it (what a match at its very beginning repeats)
-//   dec_emit_kernel     decodes again, now for real, one thread per subsequence: literals and the runs of repeated pixels go
-//                       into the filtered stream as whole aligned dwords (a thread completes its last dword with the next
-//                       subsequence's first bytes); every rule of the reference's decoder is checked (filter literal 0 then 2,
-//                       matches whole pixels inside a row, the stream ends 4 bytes before the IDAT does)
-//   dec_unfilter_kernel the Up filter undone in one pass: one thread per dword column and segment of kDecUnfRows rows, the sums of
-//                       the segments above through a decoupled look-back; channel count conversion; the rows' filter literals
+//   dec_subscan_kernel  per workgroup of subsequences: output offset of every subsequence, the four literal bytes in front of it
+//                       (what a match at its very beginning repeats), and for every WINDOW (a row x 256 pixels: a row of a tile of
+//                       the pass that writes) that begins in a subsequence's output: the subsequence, and -- flat content -- where in
+//                       its records the window's walk may begin
+//   dec_unfilter_kernel the pass that writes, one workgroup per tile of kDecUnfRows rows x 256 pixels: the tile's rows filled in LDS
+//                       from the records (a walk per (window, subsequence) pair, dealt one per thread; exact stores; the pixels of
+//                       long matches marked and filled a lane each) -- every rule of the reference's decoder checked (filter
+//                       literal 0 then 2, matches whole pixels inside a row; that the stream ends 4 bytes before the IDAT does:
+//                       dec_offsets_kernel) -- then the Up filter undone in the same pass: a thread per dword column, the sums of
+//                       the segments above through a decoupled look-back; channel count conversion
 //   dec_stored_kernel   files that are stored blocks (reference fpng.cpp:2107-2207): a strided copy
 #include "decode.h"
 #include "decode_core.h"
@@ -122,28 +127,9 @@ template <int WAVES> __device__ __forceinline__ uint32_t block_sum(uint32_t v, u
     return r;
 }
 
-// decode_core.h: a lane whose next token needs the general path waits until eight lanes of its wave wait, or all that are still
-// at work
-#ifndef FPNG_DEC_VOTE
-#define FPNG_DEC_VOTE 1
-#endif
 #ifndef FPNG_DEC_PERSISTENT // 1: a few workgroups per compute unit loop over the blocks; 0: one workgroup per block
 #define FPNG_DEC_PERSISTENT 0
 #endif
-#ifndef FPNG_DEC_WGS // workgroups per compute unit the register allocation of the two decoding kernels aims at
-#define FPNG_DEC_WGS 1
-#endif
-struct WaveVote {
-    static __device__ __forceinline__ bool go(bool waiting)
-    {
-#if FPNG_DEC_VOTE
-        const uint64_t m = __ballot(waiting);
-        return waiting && (__popcll(m) >= 8 || m == __ballot(true));
-#else
-        return waiting;
-#endif
-    }
-};
 
 // ---- token records (decode_core.h): where a subsequence's settling decode leaves what it decoded, an 8-byte entry per step of the
 //      walk.  The 64 lanes of a wave write side by side -- entry k of lane l at 8-byte word k * 64 + l of the wave's chunk -- and
@@ -975,7 +961,7 @@ template <int C> __device__ __forceinline__ void propagate_matches(lds_u8 *tile,
 //      sum, | 2: the sum of everything down to its last row), so the value is its own flag and no fence is needed
 //      (cdna_hip_programming.md, publish/consume recipe R2); a workgroup only ever waits for workgroups with a LOWER ticket, and
 //      tickets are drawn in the order the workgroups start -- then writes the pixels, 3 <-> 4 channels on the way out.  The rows sit
-//      in the filtered stream at a stride of bpl + 1 bytes: unaligned dword loads.  The filter literal in front of every row must be
+//      in the tile (LDS), filled from the token records (above).  The filter literal in front of every row must be
 //      0, then 2 = Up (reference src/fpng.cpp:2255-2259): one lane of the first column block looks. ----
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)

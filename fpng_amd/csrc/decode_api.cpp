@@ -194,7 +194,7 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
     hipStream_t s = e->stream;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-    const uint32_t resident = (uint32_t)std::max(cus, 1) * 3; // persistent workgroups of dec_sync_kernel / dec_emit_kernel: their LDS lets three share a compute unit
+    const uint32_t resident = (uint32_t)std::max(cus, 1) * 3; // persistent workgroups of dec_sync_kernel's border rounds: their LDS lets three share a compute unit
     uint32_t max_rounds = kMaxRounds;
     if (const char *mr = getenv("FPNG_AMD_DECODE_MAX_ROUNDS")) max_rounds = (uint32_t)std::max(0, atoi(mr)); // (0: every dynamic file is left to the CPU decoder -- tests)
     static const bool trace_t = getenv("FPNG_AMD_TRACE") != nullptr;
@@ -837,7 +837,7 @@ int decode_host_streamed(fpng_amd_encoder *e, const uint8_t *png, const Parsed &
             uint32_t segs = rows / kDecUnfRows; // whole segments only -- or, behind the last piece, everything
             if (q + 1 == np) segs = j.nseg, rows = p.h;
             else rows = segs * kDecUnfRows;
-            if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s_unf, ev_carry[q], 0)); // (piece q's rows are in the filtered stream; the small words went up in front of piece 0)
+            if (s_unf != s) HIP_TRY(hipStreamWaitEvent(s_unf, ev_carry[q], 0)); // (piece q's rows are in the records of the subsequences placed so far; the small words went up in front of piece 0)
             // (the rows of these segments lie in the output of the subsequences placed so far: the tiles' walks stop there -- what the
             //  next piece's kernels are writing behind it meanwhile is not theirs to read)
             const DecPlaced placed = {d_sub, d_block_off, d_eob, blk_end[q] * kDecSubBlock};

@@ -128,11 +128,10 @@ struct NoRec {
     FPNG_DEC_HD uint32_t count() const { return 0; }
 };
 
-// When does a lane whose next token needs the general path (fetch()) get it?  On the GPU the lanes of a wave run in lockstep: a
-// token that is rare for one lane (a long match, a group of literals that reaches over the limit) turns up in SOME lane of the
-// wave almost every iteration, and the whole wave walks through the general path each time.  So such a lane waits -- the
-// straight-line part of the loop does nothing for it -- until eight lanes wait or no lane can go on (WaveVote, decode.hip).
-// On the host every lane is alone.
+// When does a lane whose next token needs the general path (fetch()) get it?  At once (VoteAlone): the lanes of a wave that do not
+// need it wait for those that do, as the SIMT machine has it.  (Rounds 4-5 also had a wave-wide vote -- such a lane waited until
+// eight lanes waited or no lane could go on -- which lost to this on every content once the walk's straight-line part took the
+// frequent tokens; the parameter stays: the walks are written against it.)
 struct VoteAlone {
     static FPNG_DEC_HD bool go(bool waiting) { return waiting; }
 };

@@ -456,7 +456,8 @@ int fpng_amd_encoder_set_profiling(fpng_amd_encoder *enc, int enabled);
 int fpng_amd_encoder_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_PHASES]);
 const char *fpng_amd_encoder_phase_names(fpng_amd_encoder *enc);
 /* ... and of the last fpng_amd_decode_batch*() call (first group of files) while profiling was enabled:
- *      "sync,offsets,emit,unfilter" = dec_sync_kernel (all rounds), dec_offsets_kernel + dec_subscan_kernel, dec_emit_kernel,
+ *      "sync,offsets,emit,unfilter" = dec_sync_kernel (all rounds), dec_offsets_kernel + dec_subscan_kernel, nothing (the slot of
+ *      round 5's dec_emit_kernel: since round 6 every token is decoded once, by the synchronisation; it reads a few microseconds),
  *      dec_unfilter_kernel + dec_stored_kernel (fpng_amd/csrc/decode.hip). */
 #define FPNG_AMD_NUM_DECODE_PHASES 4
 int fpng_amd_decode_last_phase_ms(fpng_amd_encoder *enc, float ms[FPNG_AMD_NUM_DECODE_PHASES]);

@@ -860,7 +860,8 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         // behind the subsequence's last entry -- rows that the wave's other lanes mostly need anyway -- is read and counts as nothing;
         // the NEXT batch's loads are issued in front of this one's walk), then walked: all lanes' entries without a match (three steps in four of a
         // gradient, nine in ten of a photograph) -- two groups of literals, one store; one-pixel matches among them -- the same with the
-        // tail's pixel for the match; long matches only (flat content) -- their pixels marked; anything else -- record by record.  hold: walk_apply (the first batch: a walk's first eight bytes)
+        // tail's pixel for the match; long matches only (flat content) -- their pixels marked; long matches between those (dithered
+        // panels) -- marked, the rest one store; anything else (matches of two pixels) -- record by record.  hold: walk_apply (the first batch: a walk's first eight bytes)
         uint64_t rr[kBatch], nx[kBatch]; // the batch at hand, the next one (on its way while this one is walked)
         auto load = [&](uint64_t (&dst)[kBatch], uint32_t kk) {
             const gu64e *ck = col + (size_t)(kk >> 2) * 256u;
@@ -880,6 +881,8 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
                     walk_entry_plain<C, Hold>(a, b, st, w, stride, out);
                 else if (__builtin_amdgcn_ballot_w64(!entry_long_matches(a, b)) == 0)
                     walk_entry_long<C>(a, b, st, w, stride, out);
+                else if (__builtin_amdgcn_ballot_w64(!entry_mixed<C>(a, b)) == 0)
+                    walk_entry_mixed<C>(a, b, st, w, stride, out);
                 else
                     walk_entry<C>(en, st, w, stride, out);
             }

@@ -542,6 +542,18 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry_long(uint32_t a, uint32_
     if (a) walk_long_match<C>(a & 0xFFFFFFu, s, w, stride, out);
     if (b) walk_long_match<C>(b & 0xFFFFFFu, s, w, stride, out);
 }
+// Long matches BETWEEN literals (dithered panels, tiles whose runs end in a few literal pixels): each record nothing, a group of
+// literals, a one-pixel match, or a long match.  The long ones are marked where they stand in the entry's order, what is left is the
+// plain entry's one store.
+FPNG_DEC_HD bool record_long_match(uint32_t r) { return (r & kRecRun) && (r & 0xFFFFFFu) > 8u; }
+template <int C> FPNG_DEC_HD bool entry_mixed(uint32_t a, uint32_t b) { return entry_plain<C>(record_long_match(a) ? 0u : a, record_long_match(b) ? 0u : b); }
+template <int C, class Out> FPNG_DEC_HD void walk_entry_mixed(uint32_t a, uint32_t b, WalkState &s, const Window &w, uint32_t stride, Out &out)
+{
+    const bool la = record_long_match(a), lb = record_long_match(b);
+    if (la) walk_long_match<C>(a & 0xFFFFFFu, s, w, stride, out);
+    walk_entry_plain<C, true>(la ? 0u : a, lb ? 0u : b, s, w, stride, out); // (nothing left: the tail's eight bytes once more -- true ones, or a long match's: marked)
+    if (lb) walk_long_match<C>(b & 0xFFFFFFu, s, w, stride, out);
+}
 template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &s, const Window &w, uint32_t stride, Out &out)
 {
     walk_record<C>((uint32_t)en, s, w, stride, out);
@@ -556,7 +568,7 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &
 // (kNoResume: from the subsequence's first record, its offset and tail as the synchronisation left them), position, tail. ----
 constexpr uint32_t kWinWords = 4, kNoResume = 0xFFFFFFFFu;
 constexpr uint32_t kResumeMinBytes = 2048; // output bytes of a subsequence from which on its windows get resume points
-constexpr uint32_t kResumeAlign = 8;       // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches)
+constexpr uint32_t kResumeAlign = 4;       // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches of four)
 struct ResumeWalk {
     uint32_t k, c, th;    // the next entry; output bytes of the entries in front of it; the tail's upper half there
     uint32_t sk, sc, sth; // ... the same at the last entry whose number is a multiple of kResumeAlign

@@ -417,6 +417,8 @@ extern "C" int fpng_emul_decode(const uint8_t *png, uint32_t size, uint32_t desi
                             }
                         } else if (entry_long_matches(a, b2) && ((k ^ i) & 4)) {
                             if (c == 4) walk_entry_long<4>(a, b2, ws, wd, stride, out); else walk_entry_long<3>(a, b2, ws, wd, stride, out);
+                        } else if ((c == 4 ? entry_mixed<4>(a, b2) : entry_mixed<3>(a, b2)) && ((k ^ i) & 8)) {
+                            if (c == 4) walk_entry_mixed<4>(a, b2, ws, wd, stride, out); else walk_entry_mixed<3>(a, b2, ws, wd, stride, out);
                         } else if (c == 4)
                             walk_entry<4>(en, ws, wd, stride, out);
                         else

@@ -101,6 +101,7 @@ DROPIN_VARIANTS = {"nocrc"}
 VARIANTS = {"nocrc": ["FPNG_DISABLE_DECODE_CRC32_CHECKS=1"],  # the reference's fuzzing switch (src/fpng.cpp:50-53): libfpng_amd_nocrc.so + libfpng_nocrc.so
             "timing": ["FPNG_BUILD_TIMING"],  # cycle counters inside build_dynamic_kernel (tools/build_timing.py, profiles/r05_table_builder.txt)
             "dec_pad27k": ["FPNG_DEC_PAD_LDS=27648"],  # decoder occupancy probe: two workgroups per compute unit instead of three (profiles/r05_decode_occupancy.txt)
+            "sync_timing": ["FPNG_DEC_SYNC_TIMING"],  # dec_sync_kernel<false> stamps every workgroup: start / bits staged / first wave decoded / all decoded / corrected / end (FPNG_AMD_SYNC_TIMES=<file>; tools/gpu_sync_times.sh)
             "tile_timing": ["FPNG_DEC_TILE_TIMING"],  # dec_unfilter_kernel stamps every tile's start / rows there / carry known / end (FPNG_AMD_TILE_TIMES=<file>; profiles/r06y_tile_times.txt, r07b_tile_times.txt; tools/gpu_tile_times.sh)
             "rows4_w8": ["FPNG_ROWS_WPE4=8"]}  # the 4-channel row walk at eight waves per SIMD on wide rows too (profiles/r05_rows_w6.txt; the product: seven)
 

@@ -133,6 +133,9 @@ struct DecPlaced {
 // concurrent_status: kernels that may set the file's status bits run next to this launch (no workgroup may then skip its file: dec_unfilter_kernel)
 void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, DecPlaced placed, uint32_t item0, uint32_t n_items, uint32_t *status, uint32_t epoch, bool concurrent_status);
 void launch_dec_finish(hipStream_t s, const DecJob *jobs, uint32_t n_jobs, DecUnfPlan plan, DecPlaced placed, uint32_t *status, uint32_t epoch, bool any_stored);
+#ifdef FPNG_DEC_SYNC_TIMING
+void dec_dump_sync_times(const char *path, uint32_t n_blocks); // (diagnostic build: dec_sync_kernel<false>'s per-workgroup time stamps of the last launch)
+#endif
 #ifdef FPNG_DEC_TILE_TIMING
 void dec_dump_tile_times(const char *path, uint32_t n_items); // (diagnostic build: dec_unfilter_kernel's per-tile time stamps of the last launch)
 #endif

@@ -52,6 +52,12 @@ constexpr int kWave = 64;
 constexpr int kDecBlock = 256;
 constexpr int kSubBlock = (int)kDecSubBlock;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef FPNG_DEC_SYNC_TIMING // diagnostic build (fpng_amd/build.py --variant sync_timing): where does a workgroup of round 0 spend its time?
+__device__ unsigned long long g_sync_times[8 * 65536];
+#define FPNG_SYNC_STAMP(k) do { if (!CAND && threadIdx.x == 0 && blockIdx.x < 65536) g_sync_times[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define FPNG_SYNC_STAMP(k) do { } while (0)
+#endif
 
 // The token bits a workgroup works on are staged in LDS first (coalesced loads): thread t decodes the kSubBits bits that start
 // kSubBits / 32 dwords behind thread t-1's, so straight from global memory every load instruction of a wave would touch 64
@@ -74,21 +80,52 @@ struct LdsBits {
     }
 };
 
-__device__ __forceinline__ void stage_lut(const DecJob &job, uint32_t *lut, int threads)
+// (Both stagings ask for EVERYTHING first and store afterwards: a loop of load -> wait -> store is a chain of round trips to memory --
+//  seventeen of them for the bits, 22 us of a workgroup's 50, tools/gpu_sync_times.sh -- where one, or three, will do.)
+template <int THREADS> __device__ __forceinline__ void stage_lut(const DecJob &job, uint32_t *lut)
 {
     const u32x4 *src = (const u32x4 *)job.lut;
-    for (int i = threadIdx.x; i < (int)(kLutDwords / 4); i += threads) ((u32x4 *)lut)[i] = src[i];
+    constexpr int kVec = (int)(kLutDwords / 4), kPer = (kVec + THREADS - 1) / THREADS, kFlight = 2;
+#pragma unroll 1
+    for (int q0 = 0; q0 < kPer; q0 += kFlight) {
+        u32x4 v[kFlight];
+#pragma unroll
+        for (int q = 0; q < kFlight; q++) {
+            const int i = (int)threadIdx.x + (q0 + q) * THREADS;
+            v[q] = src[i < kVec ? i : kVec - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < kFlight; q++) {
+            const int i = (int)threadIdx.x + (q0 + q) * THREADS;
+            if (i < kVec) ((u32x4 *)lut)[i] = v[q];
+        }
+    }
 }
-// dwords [d0, d0 + count) of the file's zlib stream
-__device__ __forceinline__ void stage_bits(const DecJob &job, uint64_t d0, uint32_t count, uint32_t *bits, int threads)
+// dwords [d0, d0 + COUNT) of the file's zlib stream
+template <int THREADS, uint32_t COUNT> __device__ __forceinline__ void stage_bits(const DecJob &job, uint64_t d0, uint32_t *bits)
 {
     const uint64_t n_dw = (job.z_bytes + 16) >> 2;
     const uint32_t *w = (const uint32_t *)job.z;
-    for (uint32_t d = threadIdx.x; d < count; d += threads) {
-        const uint32_t v = (d0 + d < n_dw) ? w[d0 + d] : 0u;
-        const uint32_t sl = slice_slot(d);
-        bits[sl] = v;
-        if (d && !(d & 31u)) bits[sl - 1] = v; // the copy behind the 32 dwords in front
+    constexpr uint32_t kPer = (COUNT + THREADS - 1) / THREADS, kFlight = 5; // (loads in flight per thread: the kernel has few registers to spare)
+#pragma unroll 1
+    for (uint32_t q0 = 0; q0 < kPer; q0 += kFlight) {
+        uint32_t v[kFlight];
+#pragma unroll
+        for (uint32_t q = 0; q < kFlight; q++) {
+            const uint32_t d = threadIdx.x + (q0 + q) * THREADS;
+            const bool in = d < COUNT && d0 + d < n_dw;
+            v[q] = w[in ? d0 + d : 0];
+            v[q] = in ? v[q] : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kFlight; q++) {
+            const uint32_t d = threadIdx.x + (q0 + q) * THREADS;
+            if (d < COUNT) {
+                const uint32_t sl = slice_slot(d);
+                bits[sl] = v[q];
+                if (d && !(d & 31u)) bits[sl - 1] = v[q]; // the copy behind the 32 dwords in front
+            }
+        }
     }
 }
 
@@ -228,6 +265,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     __shared__ uint32_t pad_lds[FPNG_DEC_PAD_LDS / 4];
     if (total_subs == 0xFFFFFFFFu) pad_lds[threadIdx.x] = round, status_touch(pad_lds);
 #endif
+    FPNG_SYNC_STAMP(0);
     const uint8_t *lenof = (const uint8_t *)(lut + kLutEntries);
     const uint32_t *staged = nullptr; // the table in LDS (workgroups are persistent: 1-pass files of one channel count share theirs)
     const uint32_t t = threadIdx.x;
@@ -280,9 +318,10 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
         const uint64_t d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
         __syncthreads(); // (the previous block's LDS is free)
-        if (staged != job.lut) stage_lut(job, lut, kSubBlock), staged = job.lut;
-        stage_bits(job, d0, kSyncDwords, bits, kSubBlock);
+        if (staged != job.lut) stage_lut<kSubBlock>(job, lut), staged = job.lut;
+        stage_bits<kSubBlock, kSyncDwords>(job, d0, bits);
         __syncthreads();
+        FPNG_SYNC_STAMP(1);
         LdsBits in = {bits};
         const uint32_t nominal = (uint32_t)(first_nominal - base) + t * kSubBits, boundary = nominal + kSubBits;
         const uint64_t lim64 = job.end_limit_bit - base;
@@ -312,6 +351,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
             st.c.bytes = a.bytes[g], st.c.flags = info_flags(v);
             st.c.eob = (st.c.flags & kSubEob) ? nominal + a.eob[g] : 0u;
         }
+        FPNG_SYNC_STAMP(2);
         want0 += nominal; // (thread 0's nominal: the block's first)
         s_end[t] = st.end;
         bool cand_done = false;
@@ -319,6 +359,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         PhaseMap bmap = pm_none();
         for (uint32_t it = 0;; it++) {
             __syncthreads();
+            if (it == 0) FPNG_SYNC_STAMP(3);
             uint32_t want = st.start;
             if (t)
                 want = s_end[t - 1];
@@ -414,6 +455,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                 bmap = wtail[kSubBlock / kWave];
             }
         }
+        FPNG_SYNC_STAMP(4);
         if (dirty && valid) {
             a.info[g] = pack_info(st.start - nominal, st.end - boundary, st.c, st.nrec);
             a.bytes[g] = st.c.bytes;
@@ -448,6 +490,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
             if (round) atomicOr(changed, 1u);
             if (CAND && known > 1) atomicOr(multi, 1u); // (dec_chain_kernel has something to do from now on)
         }
+        FPNG_SYNC_STAMP(5);
     }
 }
 
@@ -1389,6 +1432,18 @@ void launch_dec_unfilter(hipStream_t s, const DecJob *jobs, DecUnfPlan plan, Dec
         hipLaunchKernelGGL(dec_unfilter_kernel, dim3(n_items), dim3(kUnfBlock), 0, s, jobs, plan, placed, item0, status, epoch,
                            concurrent_status ? 0u : (kDecNotConverged | kDecBadStream | kDecStalled));
 }
+#ifdef FPNG_DEC_SYNC_TIMING
+void dec_dump_sync_times(const char *path, uint32_t n_blocks)
+{
+    std::vector<unsigned long long> t(8 * (size_t)std::min(n_blocks, 65536u));
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_sync_times), t.size() * 8) != hipSuccess) return;
+    if (FILE *f = fopen(path, "w")) {
+        for (size_t i = 0; i < t.size() / 8; i++) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5]);
+        fclose(f);
+    }
+}
+#endif
 #ifdef FPNG_DEC_TILE_TIMING
 void dec_dump_tile_times(const char *path, uint32_t n_items)
 {

@@ -592,6 +592,9 @@ int decode_files(fpng_amd_encoder *e, const fpng_amd_png *files, uint32_t n, uin
 #ifdef FPNG_DEC_TILE_TIMING
     if (const char *tp = getenv("FPNG_AMD_TILE_TIMES")) dec_dump_tile_times(tp, groups[0].plan.total_items);
 #endif
+#ifdef FPNG_DEC_SYNC_TIMING
+    if (const char *tp = getenv("FPNG_AMD_SYNC_TIMES")) dec_dump_sync_times(tp, groups[0].blk1 - groups[0].blk0);
+#endif
     static const bool trace = getenv("FPNG_AMD_TRACE") != nullptr;
     for (uint32_t k = 0; k < nj; k++) {
         if (trace)

@@ -82,10 +82,10 @@ struct LdsBits {
 
 // (Both stagings ask for EVERYTHING first and store afterwards: a loop of load -> wait -> store is a chain of round trips to memory --
 //  seventeen of them for the bits, 22 us of a workgroup's 50, tools/gpu_sync_times.sh -- where one, or three, will do.)
-template <int THREADS> __device__ __forceinline__ void stage_lut(const DecJob &job, uint32_t *lut)
+template <int THREADS, int FLIGHT> __device__ __forceinline__ void stage_lut(const DecJob &job, uint32_t *lut)
 {
     const u32x4 *src = (const u32x4 *)job.lut;
-    constexpr int kVec = (int)(kLutDwords / 4), kPer = (kVec + THREADS - 1) / THREADS, kFlight = 2;
+    constexpr int kVec = (int)(kLutDwords / 4), kPer = (kVec + THREADS - 1) / THREADS, kFlight = FLIGHT; // (vectors in flight per thread: what the kernel's registers allow)
 #pragma unroll 1
     for (int q0 = 0; q0 < kPer; q0 += kFlight) {
         u32x4 v[kFlight];
@@ -137,6 +137,17 @@ __device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t
         if (jobs[mid].sub_base <= g) lo = mid; else hi = mid;
     }
     local = g - jobs[lo].sub_base;
+    return jobs[lo];
+}
+// ... the same by the lanes of a wave at once (a batch has few files; the binary search is a chain of round trips to memory in front
+// of everything a workgroup does)
+__device__ __forceinline__ const DecJob &job_of_sub_wave(const DecJob *jobs, uint32_t n_jobs, uint32_t g, uint32_t &local)
+{
+    if (n_jobs > (uint32_t)kWave) return job_of_sub(jobs, n_jobs, g, local);
+    const uint32_t l = threadIdx.x & (kWave - 1);
+    const uint32_t base = jobs[l < n_jobs ? l : 0u].sub_base;
+    const uint32_t lo = (uint32_t)__popcll(__ballot(l < n_jobs && base <= g)) - 1u; // (bases rise, the first one is 0)
+    local = g - (uint32_t)__builtin_amdgcn_readlane((int)base, (int)lo);
     return jobs[lo];
 }
 template <int WAVES> __device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, WAVES words
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (g0 >= total_subs) break;
         // all subsequences of a workgroup's block belong to one file (sub_base is padded to kSubBlock by the host)
         uint32_t local0;
-        const DecJob &job = job_of_sub(jobs, n_jobs, g0, local0);
+        const DecJob &job = CAND ? job_of_sub(jobs, n_jobs, g0, local0) : job_of_sub_wave(jobs, n_jobs, g0, local0); // (round 0: every workgroup asks)
         const uint32_t g = g0 + t, i = local0 + t;
         const bool valid = i < job.n_sub;
         uint32_t want0 = 0;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const uint64_t first_nominal = job.first_bit + (uint64_t)local0 * kSubBits;
         const uint64_t d0 = (first_nominal - lead0) >> 5, base = d0 << 5;
         __syncthreads(); // (the previous block's LDS is free)
-        if (staged != job.lut) stage_lut<kSubBlock>(job, lut), staged = job.lut;
+        if (staged != job.lut) stage_lut<kSubBlock, CAND ? 2 : 3>(job, lut), staged = job.lut;
         stage_bits<kSubBlock, kSyncDwords>(job, d0, bits);
         __syncthreads();
         FPNG_SYNC_STAMP(1);

@@ -80,9 +80,21 @@ struct LdsBits {
     }
 };
 
+struct SyncJob { // what dec_sync_kernel reads of a file's record
+    uint64_t first_bit, end_limit_bit, z_bytes;
+    const uint8_t *z;
+    const uint32_t *lut;
+    uint32_t n_sub;
+};
+__device__ __forceinline__ SyncJob sync_job_of(const DecJob &j)
+{
+    SyncJob r;
+    r.first_bit = j.first_bit, r.end_limit_bit = j.end_limit_bit, r.z_bytes = j.z_bytes, r.z = j.z, r.lut = j.lut, r.n_sub = j.n_sub;
+    return r;
+}
 // (Both stagings ask for EVERYTHING first and store afterwards: a loop of load -> wait -> store is a chain of round trips to memory --
 //  seventeen of them for the bits, 22 us of a workgroup's 50, tools/gpu_sync_times.sh -- where one, or three, will do.)
-template <int THREADS, int FLIGHT> __device__ __forceinline__ void stage_lut(const DecJob &job, uint32_t *lut)
+template <int THREADS, int FLIGHT> __device__ __forceinline__ void stage_lut(const SyncJob &job, uint32_t *lut)
 {
     const u32x4 *src = (const u32x4 *)job.lut;
     constexpr int kVec = (int)(kLutDwords / 4), kPer = (kVec + THREADS - 1) / THREADS, kFlight = FLIGHT; // (vectors in flight per thread: what the kernel's registers allow)
@@ -102,7 +114,7 @@ template <int THREADS, int FLIGHT> __device__ __forceinline__ void stage_lut(con
     }
 }
 // dwords [d0, d0 + COUNT) of the file's zlib stream
-template <int THREADS, uint32_t COUNT> __device__ __forceinline__ void stage_bits(const DecJob &job, uint64_t d0, uint32_t *bits)
+template <int THREADS, uint32_t COUNT> __device__ __forceinline__ void stage_bits(const SyncJob &job, uint64_t d0, uint32_t *bits)
 {
     const uint64_t n_dw = (job.z_bytes + 16) >> 2;
     const uint32_t *w = (const uint32_t *)job.z;
@@ -139,16 +151,23 @@ __device__ __forceinline__ const DecJob &job_of_sub(const DecJob *jobs, uint32_t
     local = g - jobs[lo].sub_base;
     return jobs[lo];
 }
-// ... the same by the lanes of a wave at once (a batch has few files; the binary search is a chain of round trips to memory in front
-// of everything a workgroup does)
-__device__ __forceinline__ const DecJob &job_of_sub_wave(const DecJob *jobs, uint32_t n_jobs, uint32_t g, uint32_t &local)
+// ... the same by the lanes of a wave at once, and what dec_sync_kernel wants of the file's record with it (a batch has few files; the
+// binary search and then the record's fields are a chain of round trips to memory in front of everything a workgroup does: here one)
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) { return (uint64_t)rl32((uint32_t)(v >> 32), lane) << 32 | rl32((uint32_t)v, lane); }
+__device__ __forceinline__ SyncJob job_of_sub_wave(const DecJob *jobs, uint32_t n_jobs, uint32_t g, uint32_t &local)
 {
-    if (n_jobs > (uint32_t)kWave) return job_of_sub(jobs, n_jobs, g, local);
+    if (n_jobs > (uint32_t)kWave) return sync_job_of(job_of_sub(jobs, n_jobs, g, local));
     const uint32_t l = threadIdx.x & (kWave - 1);
-    const uint32_t base = jobs[l < n_jobs ? l : 0u].sub_base;
+    const DecJob &mine = jobs[l < n_jobs ? l : 0u];
+    const uint32_t base = mine.sub_base, n_sub = mine.n_sub;
+    const uint64_t first_bit = mine.first_bit, end_limit_bit = mine.end_limit_bit, z_bytes = mine.z_bytes, z = (uint64_t)(uintptr_t)mine.z, lut = (uint64_t)(uintptr_t)mine.lut;
     const uint32_t lo = (uint32_t)__popcll(__ballot(l < n_jobs && base <= g)) - 1u; // (bases rise, the first one is 0)
-    local = g - (uint32_t)__builtin_amdgcn_readlane((int)base, (int)lo);
-    return jobs[lo];
+    local = g - rl32(base, lo);
+    SyncJob r;
+    r.n_sub = rl32(n_sub, lo), r.first_bit = rl64(first_bit, lo), r.end_limit_bit = rl64(end_limit_bit, lo), r.z_bytes = rl64(z_bytes, lo);
+    r.z = (const uint8_t *)(uintptr_t)rl64(z, lo), r.lut = (const uint32_t *)(uintptr_t)rl64(lut, lo);
+    return r;
 }
 template <int WAVES> __device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red) // red: LDS, WAVES words
 {
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(kSubBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (g0 >= total_subs) break;
         // all subsequences of a workgroup's block belong to one file (sub_base is padded to kSubBlock by the host)
         uint32_t local0;
-        const DecJob &job = CAND ? job_of_sub(jobs, n_jobs, g0, local0) : job_of_sub_wave(jobs, n_jobs, g0, local0); // (round 0: every workgroup asks)
+        const SyncJob job = CAND ? sync_job_of(job_of_sub(jobs, n_jobs, g0, local0)) : job_of_sub_wave(jobs, n_jobs, g0, local0); // (round 0, where every workgroup asks: fetched with the search)
         const uint32_t g = g0 + t, i = local0 + t;
         const bool valid = i < job.n_sub;
         uint32_t want0 = 0;
@@ -1079,11 +1098,11 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         //  round trips in front of everything else the tile does: the lanes of a wave look at an element each, all at once)
         const uint32_t l64 = threadIdx.x & (kWave - 1);
         DecUnfPiece pc;
-        uint32_t per_seg, fidx, cb0;
+        uint32_t per_seg, fidx, cb0, ji_w = 0xFFFFFFFFu;
         if (plan.n_pieces <= (uint32_t)kWave && plan.n_files < (uint32_t)kWave) {
             const bool hasp = l64 < plan.n_pieces, hasf = l64 <= plan.n_files;
             const DecUnfPiece mine = plan.pieces[hasp ? l64 : 0u];
-            const uint32_t cbl = plan.cbpre[hasf ? l64 : 0u];
+            const uint32_t cbl = plan.cbpre[hasf ? l64 : 0u], ordl = plan.order[l64 < plan.n_files ? l64 : 0u];
             const uint32_t pi = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hasp && mine.item0 <= item)) - 1u; // (pieces rise; the first one begins at item 0)
             pc.item0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.item0, (int)pi), pc.seg0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.seg0, (int)pi);
             pc.alive = (uint32_t)__builtin_amdgcn_readlane((int)mine.alive, (int)pi), pc.pad_ = 0;
@@ -1091,6 +1110,7 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
             const uint32_t within0 = (item - pc.item0) % per_seg;
             fidx = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(l64 < pc.alive && cbl <= within0)) - 1u;
             cb0 = (uint32_t)__builtin_amdgcn_readlane((int)cbl, (int)fidx);
+            ji_w = (uint32_t)__builtin_amdgcn_readlane((int)ordl, (int)fidx);
         } else {
             uint32_t lo = 0, hi = plan.n_pieces;
             while (hi - lo > 1) {
@@ -1108,7 +1128,7 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
             fidx = lo, cb0 = plan.cbpre[lo];
         }
         const uint32_t rel = item - pc.item0, sg = uni32(pc.seg0 + rel / per_seg), within = rel % per_seg;
-        const uint32_t ji = uni32(plan.order[fidx]), cb = uni32(within - cb0);
+        const uint32_t ji = ji_w != 0xFFFFFFFFu ? ji_w : uni32(plan.order[fidx]), cb = uni32(within - cb0);
         // (the file's record, read by every lane, into scalar registers: the compiler keeps what it loads from writable global
         //  memory in vector registers, and every address derived from it would cost a register pair per row)
         DecJob job = jobs[ji];

@@ -4,8 +4,10 @@
   decoder's host side prepares (fpng_amd_decode_plan: container checks, block header, the lookup table): subsequences of 512 token
   bits decoded from a lead-in in front of their nominal first bits, corrections inside a workgroup until every subsequence starts
   where its predecessor ended, rounds across workgroup borders, the stream's end = the FIRST end-of-block symbol of the chain,
-  output offsets, the literal bytes in front of every subsequence, tiles of the filtered stream decoded for real, the Up filter
-  undone.  Workgroup size, lead-in and tile size are parameters there: small ones put many borders and seams into small images.
+  output offsets, the literal bytes in front of every subsequence, the token RECORDS every settling decode leaves, the windows of
+  the filtered stream filled from them (every store of every walk checked against the walk's territory, long matches marked and
+  filled, resume points, every form of the walk's step), the Up filter undone.  Workgroup size and lead-in are parameters there:
+  small ones put many borders and seams into small images.
   It must reproduce the pixels, and the status codes of the CPU decoder / the reference on damaged files.
 * a few lines of Python decode a stream token by token with the same table: that pins the table's FORMAT (code bits << 28 |
   literal count << 26 | up to three literal bytes; match: bit 25, base length, extra bit count; then the literals' code lengths).

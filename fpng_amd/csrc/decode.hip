@@ -1386,9 +1386,9 @@ __global__ __launch_bounds__(kDecBlock) void dec_build_lut_kernel(const uint8_t 
         if (!l1 || s1 > 285)
             ent = 0;
         else if (s1 == 256)
-            ent = l1 << 28;
+            ent = kEntEob | l1 << 12;
         else if (s1 > 256)
-            ent = l1 << 28 | kEntMatch | (kLenExtra[s1 - 257] ? 0u : kEntSimple) | (uint32_t)kLenExtra[s1 - 257] << 9 | kLenBase[s1 - 257];
+            ent = kLenExtra[s1 - 257] ? kEntMatch | l1 << 12 | (uint32_t)kLenExtra[s1 - 257] << 9 | kLenBase[s1 - 257] : (l1 + 1) << 28 | kEntMatch | kLenBase[s1 - 257];
         else {
             uint32_t L = l1, n = 1, lits = s1;
             while (n < 3) { // the next code is whole if its length fits into the index bits that are left
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(kDecBlock) void dec_build_lut_kernel(const uint8_t 
                 lits |= s2 << (8 * n);
                 n++, L += l2;
             }
-            ent = L << 28 | n << 26 | kEntSimple | lits;
+            ent = L << 28 | n << 26 | lits;
         }
         lut[k] = ent;
     }

@@ -82,9 +82,9 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
         if (!l1 || s1 > 285)
             ent = 0;
         else if (s1 == 256)
-            ent = l1 << 28;
+            ent = dec::kEntEob | l1 << 12;
         else if (s1 > 256)
-            ent = l1 << 28 | dec::kEntMatch | (len_extra[s1 - 257] ? 0u : dec::kEntSimple) | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257];
+            ent = len_extra[s1 - 257] ? dec::kEntMatch | l1 << 12 | (uint32_t)len_extra[s1 - 257] << 9 | len_base[s1 - 257] : (l1 + 1) << 28 | dec::kEntMatch | len_base[s1 - 257];
         else {
             uint32_t L = l1, n = 1, lits = s1;
             while (n < 3) { // the next code is whole if its length fits into the index bits that are left
@@ -93,7 +93,7 @@ void build_multi_lut(const uint32_t *table, const uint8_t sizes[288], uint32_t *
                 lits |= s2 << (8 * n);
                 n++, L += l2;
             }
-            ent = L << 28 | n << 26 | dec::kEntSimple | lits;
+            ent = L << 28 | n << 26 | lits;
         }
         lut[k] = ent;
     }

@@ -3,16 +3,19 @@
 // tools/sync_stats.c measured the numbers the constants come from.  Reference: src/fpng.cpp:2209-2901 decodes the same streams
 // serially, one token at a time; here a stream is cut into subsequences of kSubBits token bits that are decoded independently.
 //
-// THE LOOKUP TABLE (built on the host, decode_api.cpp: build_multi_lut).  Index = the next 12 stream bits, one 32-bit entry:
-//   bits 31..28  L: code bits this entry consumes (1..12); 0 = no such code
+// THE LOOKUP TABLE (built on the host, decode_api.cpp: build_multi_lut, or by dec_build_lut_kernel).  Index = the next 12 stream
+// bits, one 32-bit entry.  A SIMPLE token -- a group of literals, or a match WITHOUT extra bits (lengths 3 .. 10 and 258: one, two,
+// three pixels, the matches of noisy content; whole runs) -- has:
+//   bits 31..28  the stream bits it takes, ALL of them (1..13: a match's 1-bit distance code -- "the previous pixel", reference
+//                src/fpng.cpp:2301 -- included); 0: not a simple token
 //   bits 27..26  n: number of LITERALS decoded at once (1..3: as many whole literal codes as fit into the 12 bits, at most 3);
-//                   their byte values in bits 7..0, 15..8, 23..16 (first one lowest)
-//   n == 0, bit 25 set:   a match length symbol: bits 8..0 base length (3..258), bits 11..9 number of extra bits (0..5); L covers
-//                         the symbol's code only (the extra bits and the 1-bit distance code follow in the stream)
-//   n == 0, bit 25 clear: end of block
-//   bit 24 (kEntSimple):  a token the walks take in their straight-line part: a group of literals, or a match WITHOUT extra bits
-//                         (lengths 3 .. 10: one, two, three pixels -- the matches of noisy content); every other match, like the end
-//                         of the block, goes through fetch()
+//                their byte values in bits 7..0, 15..8, 23..16 (first one lowest)
+//   n == 0:      bit 25 (kEntMatch) set, bits 8..0 the match's length
+// -- the entry without its upper four bits is the token's RECORD (below).  Every other token:
+//   a match with extra bits: kEntMatch, bits 8..0 base length (11..227), bits 11..9 number of extra bits (1..5), bits 15..12 the
+//                length symbol's code bits (the extra bits and the 1-bit distance code follow in the stream)
+//   the end of the block:    kEntEob, bits 15..12 its code bits
+//   no such code:            0
 // Behind the 4096 entries: lenof[256], the code length of every literal byte value -- a group of literals is taken apart with it
 // where token granularity matters (the hand-over between two subsequences must not depend on how the literals were grouped).
 #pragma once
@@ -30,11 +33,12 @@ namespace dec {
 constexpr uint32_t kLutEntries = 4096;
 constexpr uint32_t kLutDwords = kLutEntries + 64; // + lenof[256]
 constexpr uint32_t kEntMatch = 1u << 25;
-constexpr uint32_t kEntSimple = 1u << 24;
+constexpr uint32_t kEntEob = 1u << 24;
+constexpr uint32_t kEntSimpleMin = 1u << 28; // (an entry at or above it is a simple token's)
 // TOKEN RECORDS (round 6: every token is decoded ONCE).  The decode that settles a subsequence leaves what it decoded behind, and the
 // pass that writes the pixels (dec_unfilter_kernel) reads records instead of Huffman codes.  A record is 32 bits:
 //   a group of literals   n << 26 | the n bytes (first one lowest)          -- the table's entry without its length field
-//   a match               kRecRun | its length in bytes (3..258) in bits 23..0 (bit 24 means nothing: a table entry's kEntSimple may stand there)
+//   a match               kRecRun | its length in bytes (3..258) in bits 23..0
 //   0                     nothing
 // and an ENTRY is two of them -- what one step of the walk (two lookups) decoded, stored with one 8-byte store; a token that takes the
 // walk's general path is an entry of its own.  A subsequence has room for kRecCap entries (its 512 bits in steps of four bits and
@@ -87,14 +91,12 @@ FPNG_DEC_HD uint32_t low_bits(uint32_t v, uint32_t bits)
 // front of that bit.  Out: n literal bytes in `lits` (kTokLit), `run` bytes (kTokMatch); bits consumed.
 FPNG_DEC_HD uint32_t fetch(uint32_t w, const uint32_t *lut, const uint8_t *lenof, uint32_t room, uint32_t &n, uint32_t &lits, uint32_t &run, uint32_t &bits)
 {
-    const uint32_t e = lut[w & (kLutEntries - 1)];
-    const uint32_t L = e >> 28;
+    const uint32_t e = lut[w & (kLutEntries - 1)], adv = e >> 28;
     n = (e >> 26) & 3u;
-    bits = L;
-    if (!L) return kTokInvalid;
+    bits = adv;
     if (n) {
         lits = e & 0xFFFFFFu;
-        if (L > room) { // the group reaches over the stopping bit: token by token
+        if (adv > room) { // the group reaches over the stopping bit: token by token
             uint32_t k = 0, used = 0;
             do {
                 used += lenof[(lits >> (8 * k)) & 255u];
@@ -106,12 +108,13 @@ FPNG_DEC_HD uint32_t fetch(uint32_t w, const uint32_t *lut, const uint8_t *lenof
         return kTokLit;
     }
     if (e & kEntMatch) {
-        const uint32_t xb = (e >> 9) & 7u;
+        const uint32_t L = adv ? adv - 1u : (e >> 12) & 15u, xb = (e >> 9) & 7u;
         run = (e & 511u) + ((w >> L) & ((1u << xb) - 1u));
         bits = L + xb + 1; // extra bits + the 1-bit distance code ("the previous pixel": reference src/fpng.cpp:2301)
         return kTokMatch;
     }
-    return kTokEob;
+    bits = (e >> 12) & 15u;
+    return (e & kEntEob) ? kTokEob : kTokInvalid;
 }
 
 // what a subsequence's decode leaves behind
@@ -136,6 +139,9 @@ struct VoteAlone {
     static FPNG_DEC_HD bool go(bool waiting) { return waiting; }
 };
 
+FPNG_DEC_HD uint32_t ent_out_bytes(uint32_t e) { return ((e >> 26) & 3u) + ((e & kEntMatch) ? (e & 511u) : 0u); } // a simple token's output bytes (0: none)
+constexpr uint32_t kFastRoom = 26; // (a simple token takes 13 bits at most)
+
 // Decodes the tokens that start in [pos, limit) (positions: bits relative to the staged slice); returns the position behind the
 // last one.  Written for the SIMT machine: one iteration reads a 32-bit window and does TWO lookups (the second one on the bits
 // behind the first token) as straight-line predicated code -- a group of literals that lies wholly in front of the limit and a
@@ -155,13 +161,13 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
     // dec_sync_kernel looks at what the lead-ins of a wave met.  (Round 5's form cut the extra bits out of the window for every lane
     // and both lookups: 125 vector instructions a step.)
     auto take = [&](uint32_t wk, uint32_t room, bool en, uint32_t &r) -> uint32_t {
-        const uint32_t e = lut[wk & (kLutEntries - 1)], L = e >> 28, n = (e >> 26) & 3u;
-        bool ok = en && (e & kEntSimple) != 0 && (n == 0 || L <= room);
-        uint32_t len = e & 511u, bits = L + (n == 0 ? 1u : 0u);
-        if (Rich && en && (e & (kEntMatch | kEntSimple)) == kEntMatch) {
-            const uint32_t xb = (e >> 9) & 7u; // (18 bits at most with the code and the distance bit: the window has them, see en_b)
+        const uint32_t e = lut[wk & (kLutEntries - 1)], adv = e >> 28, n = (e >> 26) & 3u;
+        bool ok = en && adv != 0 && (n == 0 || adv <= room);
+        uint32_t len = e & 511u, bits = adv;
+        if (Rich && en && !adv && (e & kEntMatch)) {
+            const uint32_t L = (e >> 12) & 15u, xb = (e >> 9) & 7u; // (18 bits at most with the code and the distance bit: the window has them, see en_b)
             len += (wk >> L) & ((1u << xb) - 1u);
-            bits += xb;
+            bits = L + xb + 1u;
             ok = true;
         }
         if (Count) {
@@ -170,7 +176,33 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
         }
         return ok ? bits : 0u;
     };
+    bool stuck = false; // (the lean form's fast steps: the token at pos is known not to be a simple one)
     while (pos < lim) {
+        if (!Rich) {
+            // FAST steps of the lean form, while the position is kFastRoom bits and more in front of the limit -- nearly all of a
+            // subsequence: two simple tokens end in front of the limit whatever they are, so a step is two lookups, two adds and the
+            // record's store, no question asked.  A lane whose next token is not a simple one leaves for the careful step below.
+            // (Round 6 measured this loop twice: with the staging loop in front of it -- half of a workgroup's time without a vector
+            //  instruction -- it bought 1 .. 4 %, profiles/r06x_sync_fastloop_ab.txt; behind the staging's fix the decode is what a
+            //  workgroup does, profiles/r14_sync_fastloop_ab.txt.)
+            for (;;) {
+                if (!(pos + kFastRoom <= lim) || stuck) break;
+                const uint32_t w = in.window(pos);
+                uint32_t ea = lut[w & (kLutEntries - 1)];
+                ea = ea >= kEntSimpleMin ? ea : 0u;
+                const uint32_t ba = ea >> 28;
+                uint32_t eb = lut[(w >> ba) & (kLutEntries - 1)]; // (ba == 0: the same entry again, masked again)
+                eb = eb >= kEntSimpleMin ? eb : 0u;
+                const uint32_t bb = eb >> 28;
+                if (Count) {
+                    bytes += ent_out_bytes(ea) + ent_out_bytes(eb);
+                    rec.put2(ea & 0x0FFFFFFFu, eb & 0x0FFFFFFFu);
+                }
+                pos += ba + bb;
+                stuck = bb == 0; // (the token now at pos is not a simple one)
+            }
+            if (!(pos < lim)) break;
+        }
         const uint32_t w = in.window(pos), room = lim - pos;
         uint32_t ra = 0, rb = 0;
         const uint32_t ba = take(w, room, true, ra);
@@ -179,6 +211,7 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
         if (Count) rec.put2(ra, rb);
         pos += ba + bb;
         const bool waiting = pos < lim && (ba == 0 || (en_b && bb == 0)); // the token at pos is not a plain one
+        stuck = waiting;
         if (Vote::go(waiting)) {
             uint32_t n3, l3 = 0, run = 0, bits;
             const uint32_t kind = fetch(in.window(pos), lut, lenof, lim - pos, n3, l3, run, bits);
@@ -188,6 +221,7 @@ FPNG_DEC_HD uint32_t walk_count(const Bits &in, const uint32_t *lut, const uint8
                 break;
             }
             pos += bits;
+            stuck = false;
             if (Count) {
                 if (kind == kTokLit)
                     bytes += n3, rec.put2(n3 << 26 | l3, 0u);

@@ -523,15 +523,16 @@ extern "C" long long fpng_emul_tokenize(const uint8_t *png, uint32_t size, long 
         if (n >= cap) return -3;
         const uint64_t d = pos >> 5;
         const uint32_t w = funnel(zdw[d + 1], zdw[d], (uint32_t)(pos & 31));
-        const uint32_t e = lut[w & (kLutEntries - 1)], L = e >> 28, nl = (e >> 26) & 3u;
-        if (!L) return -2;
+        // (decode_core.h: a simple token's entry holds ALL the bits it takes in its upper four, any other its code bits in 15..12)
+        const uint32_t e = lut[w & (kLutEntries - 1)], adv = e >> 28, nl = (e >> 26) & 3u;
+        if (!e) return -2;
         bitpos[n] = pos;
         if (nl) {
             const uint32_t b = e & 255u;
             kind[n] = 0, value[n] = (uint16_t)b, aux[n] = 0;
             pos += lenof[b];
         } else if (e & kEntMatch) {
-            const uint32_t xb = (e >> 9) & 7u;
+            const uint32_t L = adv ? adv - 1u : (e >> 12) & 15u, xb = (e >> 9) & 7u;
             kind[n] = 1, value[n] = (uint16_t)((e & 511u) + ((w >> L) & ((1u << xb) - 1u))), aux[n] = (uint8_t)((w >> (L + xb)) & 1u);
             pos += L + xb + 1;
         } else {

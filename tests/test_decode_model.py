@@ -9,8 +9,9 @@
   filled, resume points, every form of the walk's step), the Up filter undone.  Workgroup size and lead-in are parameters there:
   small ones put many borders and seams into small images.
   It must reproduce the pixels, and the status codes of the CPU decoder / the reference on damaged files.
-* a few lines of Python decode a stream token by token with the same table: that pins the table's FORMAT (code bits << 28 |
-  literal count << 26 | up to three literal bytes; match: bit 25, base length, extra bit count; then the literals' code lengths).
+* a few lines of Python decode a stream token by token with the same table: that pins the table's FORMAT (a simple token: all its
+  bits << 28 | literal count << 26 | up to three literal bytes, or bit 25 | match length; other tokens: code bits << 12, a match's
+  base length and extra bit count, bit 24 for the end of the block; then the literals' code lengths; token_mutator.entry_code_bits).
 
 The kernels themselves are held against the CPU decoder and the reference decoder by tests/test_gpu_decode.py."""
 import ctypes as C
@@ -21,6 +22,7 @@ import numpy as np
 import pytest
 
 import dropin
+import token_mutator
 from cpu_ref import fuzz_image, have_ref, oracle, ref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -351,7 +353,7 @@ def _serial_decode(png):
         assert pos < limit
         wnd = (zint >> pos) & 0xFFFFFFFF
         e = int(lut[wnd & 4095])
-        L, n = e >> 28, (e >> 26) & 3
+        L, n = token_mutator.entry_code_bits(e), (e >> 26) & 3
         assert L, "no such code"
         if n:
             lits = [(e >> (8 * k)) & 255 for k in range(n)]

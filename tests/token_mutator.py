@@ -10,6 +10,19 @@ import zlib
 import numpy as np
 
 
+
+def entry_code_bits(e):
+    """Code bits of the token a table entry stands for (fpng_amd/csrc/decode_core.h): a simple token -- a group of literals, a match
+    without extra bits -- holds ALL the bits it takes in its upper four (a match's 1-bit distance code included), every other token
+    its code bits in bits 15..12; 0: no such code."""
+    adv, n = e >> 28, (e >> 26) & 3
+    if n:
+        return adv
+    if e & (1 << 25):
+        return adv - 1 if adv else (e >> 12) & 15
+    return (e >> 12) & 15
+
+
 class Stream:
     """tokens of a dynamic-block fpng file: ('lit', byte) | ('match', length, dist_bit) | ('eob',)"""
 
@@ -23,7 +36,7 @@ class Stream:
         self.lit_code, self.len_syms, self.eob = {}, {}, None
         for i in range(4096):
             e = int(lut[i])
-            L, n = e >> 28, (e >> 26) & 3
+            L, n = entry_code_bits(e), (e >> 26) & 3
             if not L:
                 continue
             if n:
@@ -42,7 +55,7 @@ class Stream:
             assert pos < limit
             wnd = (self.zint >> pos) & 0xFFFFFFFF
             e = int(lut[wnd & 4095])
-            L, n = e >> 28, (e >> 26) & 3
+            L, n = entry_code_bits(e), (e >> 26) & 3
             assert L
             if n:
                 b = e & 255
@@ -223,7 +236,7 @@ class LargeStream:
         self.lit_code, self.len_syms, self.eob = {}, {}, None
         for i in range(4096):
             e = int(lut[i])
-            L, n = e >> 28, (e >> 26) & 3
+            L, n = entry_code_bits(e), (e >> 26) & 3
             if not L:
                 continue
             if n:

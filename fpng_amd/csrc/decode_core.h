@@ -470,10 +470,12 @@ FPNG_DEC_HD uint64_t shl64(uint64_t v, uint32_t s) { return v << (s & 63u); }
 // n (0 .. 7) bytes d (first one lowest; n == 0: d == 0) are the walk's next output.  Hold = false: the caller knows that the walk is
 // eight bytes and more into its subsequence (every entry holds a byte at least: behind a subsequence's first eight entries) -- the
 // store begins eight bytes in front of the step's end, no question.
-template <bool Hold = true, class Out> FPNG_DEC_HD void walk_apply(WalkState &s, uint32_t n, uint64_t d, const Window &w, Out &out)
+// Wide: n may be 8 (a match of two 4-byte pixels), the whole tail is new then.
+template <bool Hold = true, bool Wide = false, class Out> FPNG_DEC_HD void walk_apply(WalkState &s, uint32_t n, uint64_t d, const Window &w, Out &out)
 {
     const uint32_t sh = 8u * n;
-    const uint64_t ta = shr64((uint64_t)s.th << 32 | s.tl, sh) | shl64(d, 64u - sh);
+    uint64_t ta = shr64((uint64_t)s.th << 32 | s.tl, sh) | shl64(d, 64u - sh);
+    if (Wide) ta = n >= 8u ? d : ta;
     s.tl = (uint32_t)ta, s.th = (uint32_t)(ta >> 32);
     const int32_t e = s.c + (int32_t)n, e8 = e - 8, start = (Hold && s.c0 > e8) ? s.c0 : e8;
     const uint64_t v = Hold ? shr64(ta, 8u * (uint32_t)(start - e8)) : ta; // (start - e8 == 8: nothing of this subsequence yet -- whatever is stored lies where its first steps write)
@@ -547,23 +549,21 @@ template <int C, class Out> FPNG_DEC_HD void walk_long_match(uint32_t run, WalkS
     s.c = e;
 }
 // ... and one record in full
+// (a group of literals and a match of one or two pixels -- output bytes like any others, the pixel once or twice -- share ONE store:
+//  dithered panels are two-pixel matches between literals, entry after entry, in some lane of every wave)
 template <int C, class Out> FPNG_DEC_HD void walk_record(uint32_t r, WalkState &s, const Window &w, uint32_t stride, Out &out)
 {
-    if (!(r & kRecRun)) {
-        const uint32_t n = (r >> 26) & 3u;
-        if (n) walk_apply(s, n, r & 0xFFFFFFu, w, out);
-        return;
-    }
+    const bool isrun = (r & kRecRun) != 0;
     const uint32_t run = r & 0xFFFFFFu;
-    if (run <= 8u && run % C == 0) { // one or two pixels: output bytes like any others
-        match_checks<C>(run, s, w, stride);
-        const uint32_t px = tail_px<C>(s.th);
-        const uint64_t one = C == 4 ? px : (px & 0xFFFFFFu);
-        walk_apply(s, (uint32_t)C, one, w, out);
-        if (run > (uint32_t)C) walk_apply(s, (uint32_t)C, one, w, out);
+    if (isrun && !(run <= 8u && run % C == 0)) {
+        walk_long_match<C>(run, s, w, stride, out);
         return;
     }
-    walk_long_match<C>(run, s, w, stride, out);
+    if (isrun) match_checks<C>(run, s, w, stride);
+    const uint64_t one = C == 4 ? tail_px<C>(s.th) : (tail_px<C>(s.th) & 0xFFFFFFu);
+    const uint64_t rep = run > (uint32_t)C ? (one | one << (8 * C)) : one;
+    const uint32_t n = isrun ? run : (r >> 26) & 3u;
+    if (n) walk_apply<true, C == 4>(s, n, isrun ? rep : (uint64_t)(r & 0xFFFFFFu), w, out);
 }
 // Flat content: every step two matches of 258 bytes.  Is the entry one of long matches only (each record nothing or one)?
 FPNG_DEC_HD bool entry_long_matches(uint32_t a, uint32_t b)
@@ -601,7 +601,7 @@ template <int C, class Out> FPNG_DEC_HD void walk_entry(uint64_t en, WalkState &
 // (relative to the window's first byte: <= 0), the tail's upper half there.  A window's words (DecJob::win): subsequence, entry
 // (kNoResume: from the subsequence's first record, its offset and tail as the synchronisation left them), position, tail. ----
 constexpr uint32_t kWinWords = 4, kNoResume = 0xFFFFFFFFu;
-constexpr uint32_t kResumeMinBytes = 2048; // output bytes of a subsequence from which on its windows get resume points
+constexpr uint32_t kResumeMinBytes = 2048; // output bytes of a subsequence from which on its windows get resume points (1024, 512: no different, profiles/r15_dither_notes.txt)
 constexpr uint32_t kResumeAlign = 4;       // a resume point is an entry whose number is a multiple of this (the tiles read entries in batches of four)
 struct ResumeWalk {
     uint32_t k, c, th;    // the next entry; output bytes of the entries in front of it; the tail's upper half there

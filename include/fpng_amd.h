@@ -421,9 +421,11 @@ int fpng_amd_decode_host(fpng_amd_encoder *enc, const void *png, uint32_t size, 
  * kernels' per-thread code on the CPU against it): result (container status, geometry; status 0 = the stream's shape is acceptable so
  * far), mode (0 = one dynamic block, 1 = stored blocks), the IDAT chunk's offset and payload length, the first row token's bit and
  * the bit no token may start at or behind (both counted from the zlib stream's first byte = png + idat_ofs + 8), and the kernels'
- * lookup table, FPNG_AMD_DECODE_LUT_WORDS words (fpng_amd/csrc/decode_core.h): lut[next 12 bits] = code bits consumed << 28 |
- * number of literals (1..3) << 26 | their byte values (first lowest); or, literals 0: bit 25 set = a match (base length in bits
- * 8..0, extra bit count in bits 11..9), clear = end of block; 0 = no such code; then 64 words = the literals' code lengths. */
+ * lookup table, FPNG_AMD_DECODE_LUT_WORDS words (fpng_amd/csrc/decode_core.h): lut[next 12 bits] = for a group of literals or a
+ * match without extra bits: ALL the stream bits it takes << 28 | number of literals (1..3) << 26 | their byte values (first
+ * lowest), or literals 0: bit 25 set, the match's length in bits 8..0; top four bits 0: a match with extra bits (bit 25, base
+ * length in bits 8..0, extra bit count in bits 11..9, the length symbol's code bits in bits 15..12), the end of the block (bit 24,
+ * code bits in bits 15..12), or 0 = no such code; then 64 words = the literals' code lengths. */
 #define FPNG_AMD_DECODE_LUT_WORDS 4160
 int fpng_amd_decode_plan(const void *png, uint32_t size, fpng_amd_decode_result *result, uint32_t *mode, uint32_t *idat_ofs,
                          uint32_t *idat_len, uint64_t *first_bit, uint64_t *end_limit_bit, uint32_t *lut);

@@ -209,6 +209,24 @@ def synth_image(kind, w, h, num_chans, seed=12345):
     return out.reshape(h, w, num_chans)
 
 
+class DecodeBatch:
+    """What Encoder.make_decode_batch() returns: the files, the output tensors and the C arrays of one fpng_amd_decode_batch_device() call."""
+
+    def __init__(self, pngs, outs, arr, res, desired_chans):
+        self.pngs, self.outs, self.arr, self.res, self.desired_chans = pngs, outs, arr, res, desired_chans
+
+    def statuses(self):
+        """status of every file after the last call (one numpy view of the result records, no loop over them)"""
+        return np.frombuffer(self.res, dtype=np.int32).reshape(-1, 4)[:, 3]
+
+    def results(self):
+        """list of (status, uint8 CUDA tensor (h, w, desired_chans) or None, channels_in_file)"""
+        out, d = [], self.desired_chans
+        for r, t in zip(self.res, self.outs):
+            out.append((r.status, t.view(-1)[: r.w * r.h * d].view(r.h, r.w, d) if r.status == 0 else None, r.channels_in_file))
+        return out
+
+
 class Encoder:
     """Reusable device scratch + the HIP stream submissions are ordered against (one Encoder per thread).
     `stream="torch"` (default): every submit() is ordered behind the work already enqueued on torch's CURRENT
@@ -369,10 +387,10 @@ class Encoder:
             out.append((r.status, outs[i][: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
         return out
 
-    def decode_device(self, pngs, desired_chans, dims, outs=None):
-        """fpng_amd_decode_batch_device: list of uint8 CUDA tensors holding whole fpng-written files (e.g. the encoder's outputs) ->
-        list of (status, uint8 CUDA tensor (h, w, desired_chans) or None, channels_in_file).  dims: list of (w, h) (sizes the
-        output tensors; the files' bytes stay on the device); outs: optional preallocated uint8 CUDA tensors to decode into."""
+    def make_decode_batch(self, pngs, desired_chans, dims, outs=None):
+        """Descriptor (fpng_amd_png_in[n] + the result records) for decode_device().  Build it once when the same device buffers are
+        decoded repeatedly: a call then costs one C call, as make_batch() does for submit() -- filling the array takes Python about
+        3 us a file, as long as the GPU needs for a 512 x 512 one."""
         n = len(pngs)
         arr = (_lib.PngIn * n)()
         res = (_lib.DecodeResult * n)()
@@ -385,14 +403,18 @@ class Encoder:
             arr[i].size = p.numel()
             arr[i].d_pixels = t.data_ptr()
             arr[i].pixels_cap = t.numel()
+        return DecodeBatch(list(pngs), made, arr, res, desired_chans)
+
+    def decode_device(self, pngs, desired_chans=None, dims=None, outs=None, results=True):
+        """fpng_amd_decode_batch_device: list of uint8 CUDA tensors holding whole fpng-written files (e.g. the encoder's outputs) ->
+        list of (status, uint8 CUDA tensor (h, w, desired_chans) or None, channels_in_file).  dims: list of (w, h) (sizes the
+        output tensors; the files' bytes stay on the device); outs: optional preallocated uint8 CUDA tensors to decode into.
+        pngs may be a make_decode_batch() descriptor (the other arguments are then its own); results=False: the call returns the
+        descriptor, whose statuses() / results() can be asked later."""
+        batch = pngs if isinstance(pngs, DecodeBatch) else self.make_decode_batch(pngs, desired_chans, dims, outs)
         self._sync_stream()
-        check(self.lib.fpng_amd_decode_batch_device(self.h, arr, n, desired_chans, res))
-        out = []
-        for i in range(n):
-            r = res[i]
-            ok = r.status == 0
-            out.append((r.status, made[i].view(-1)[: r.w * r.h * desired_chans].view(r.h, r.w, desired_chans) if ok else None, r.channels_in_file))
-        return out
+        check(self.lib.fpng_amd_decode_batch_device(self.h, batch.arr, len(batch.arr), batch.desired_chans, batch.res))
+        return batch.results() if results else batch
 
     def last_decode_phase_ms(self):
         """{"sync", "offsets", "emit", "unfilter"} -> ms of the last decode call's kernels (first group of files), measured with HIP

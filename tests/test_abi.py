@@ -101,6 +101,30 @@ def test_decode_entry_points_reject_bad_arguments_before_touching_the_gpu(built_
     assert "null" in lib.fpng_amd_last_error().decode().lower() or lib.fpng_amd_last_error()
 
 
+def test_decode_descriptor_reads_its_result_records_without_a_loop(built_lib):
+    """fpng_amd.api.DecodeBatch (Encoder.make_decode_batch): statuses() is a view of the fpng_amd_decode_result records the C call
+    fills -- field order and size as include/fpng_amd.h declares them -- and results() hands out views of the output tensors."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from fpng_amd import _lib
+    from fpng_amd.api import DecodeBatch
+    assert C.sizeof(_lib.DecodeResult) == 16 and _lib.DecodeResult.status.offset == 12
+    n = 5
+    res = (_lib.DecodeResult * n)()
+    outs = [torch.arange(6 * 4 * 3, dtype=torch.uint8) for _ in range(n)]
+    for i in range(n):
+        res[i].w, res[i].h, res[i].channels_in_file, res[i].status = 6, 4, 3 + (i & 1), (0, 3, 64, 0, 1)[i]
+    db = DecodeBatch([None] * n, outs, (_lib.PngIn * n)(), res, 3)
+    assert list(db.statuses()) == [0, 3, 64, 0, 1]
+    res[1].status = 0  # (a view, not a copy)
+    assert list(db.statuses()) == [0, 0, 64, 0, 1]
+    got = db.results()
+    assert [st for st, _, _ in got] == [0, 0, 64, 0, 1] and [cf for _, _, cf in got] == [3, 4, 3, 4, 3]
+    assert got[2][1] is None and got[4][1] is None and tuple(got[0][1].shape) == (4, 6, 3)
+    assert np.array_equal(got[3][1].numpy().reshape(-1), np.arange(72, dtype=np.uint8))
+
+
 def _raw_crc(data):
     """CRC-32 with init 0 and no final xor (what the kernels' partials are made of): crc32 is affine in the message."""
     return zlib.crc32(data) ^ zlib.crc32(bytes(len(data)))
